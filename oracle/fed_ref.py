@@ -1,0 +1,56 @@
+"""Oracle (test infrastructure only): FedAvg aggregation and the train/test
+loops of federated/fed_run.py on CPU."""
+import torch
+
+
+def communication_fedavg(server_model, models, client_weights):
+    """federated/fed_run.py:400-414 (the branch every non-fedbn mode takes,
+    SURVEY.md 3.5).  For each key: 'num_batches_tracked' -> server takes client
+    0's value and the clients keep their own; otherwise server = sum_i w_i *
+    client_i (accumulated in client order) and every client is overwritten."""
+    with torch.no_grad():
+        ssd = server_model.state_dict()
+        for key in ssd.keys():
+            if 'num_batches_tracked' in key:
+                ssd[key].data.copy_(models[0].state_dict()[key])
+            else:
+                temp = torch.zeros_like(ssd[key])
+                for ci in range(len(client_weights)):
+                    temp += client_weights[ci] * models[ci].state_dict()[key]
+                ssd[key].data.copy_(temp)
+                for ci in range(len(client_weights)):
+                    models[ci].state_dict()[key].data.copy_(ssd[key])
+    return server_model, models
+
+
+def train_epoch(model, loader, lr, loss_fun):
+    """federated/fed_run.py:31-88 without logging/device moves: returns
+    (train_loss, train_acc) = (sum loss / n_batches, correct / num_data)."""
+    model.train()
+    num_data, correct, loss_all, it = 0, 0, 0.0, -1
+    for it, (img, lab) in enumerate(loader):
+        for p in model.parameters():
+            p.grad = None
+        logit = model(img)
+        loss = loss_fun(logit, lab)
+        loss_all += loss.item()
+        correct += int((logit.max(dim=1)[1] == lab).sum())
+        num_data += img.size(0)
+        loss.backward()
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(p.grad, alpha=-lr)   # torch.optim.SGD._single_tensor_sgd form
+    return loss_all / (it + 1), float(correct) / num_data
+
+
+def test_epoch(model, loader, loss_fun):
+    """federated/fed_run.py:214-259 (IN_test off): eval-mode forward."""
+    model.eval()
+    num_data, correct, loss_all, it = 0, 0, 0.0, -1
+    with torch.no_grad():
+        for it, (img, lab) in enumerate(loader):
+            logit = model(img)
+            loss_all += loss_fun(logit, lab).item()
+            correct += int((logit.max(dim=1)[1] == lab).sum())
+            num_data += img.size(0)
+    return loss_all / (it + 1), float(correct) / num_data

@@ -1,0 +1,175 @@
+"""Oracle (test infrastructure only): the per-client ResNet on CPU, fp32.
+
+Restates nets/resnet.py:132-191 (ResNet: stem, _make_layer, AvgPool2d(7),
+class_classifier, kaiming fan_out init :149-154) with plain torch.nn.  The
+residual blocks are NOT in /root/reference: nets/resnet.py:3 imports
+BasicBlock / Bottleneck from torchvision.models.resnet (requirements.txt:7
+``torchvision>=0.8.1``, un-vendored, not installed here).  They are restated
+below from torchvision's published definition (conv1x1 -> BN -> ReLU ->
+conv3x3(stride) -> BN -> ReLU -> conv1x1 -> BN -> (+downsample(x)) -> ReLU,
+expansion 4, stride on the 3x3 conv; BasicBlock: conv3x3(stride) -> BN -> ReLU
+-> conv3x3 -> BN -> (+identity) -> ReLU), which is also the structure the
+reference's own commented-out BottleneckMeta/BasicBlockMeta show at
+nets/resnet.py:28-130.  Parity of the block arithmetic is therefore
+"unpinned" by the reference; the stem/_make_layer/head/forward are pinned by
+running the reference's ResNet class with these blocks injected
+(tools/make_golden.py).
+"""
+import numpy as np
+import torch
+from torch import nn
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out += identity
+        return self.relu(out)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out += identity
+        return self.relu(out)
+
+
+class ResNet(nn.Module):
+    """nets/resnet.py:132-191."""
+
+    def __init__(self, block, layers, classes=100):
+        self.inplanes = 64
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)   # :136
+        self.bn1 = nn.BatchNorm2d(64)                                                     # :138
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)                   # :140
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.avgpool = nn.AvgPool2d(7, stride=1)                                          # :145
+        self.class_classifier = nn.Linear(512 * block.expansion, classes)                 # :146
+        for m in self.modules():                                                          # :149-154
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, block, planes, blocks, stride=1):                               # :156-171
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def forward(self, x, **kwargs):                                                       # :178-191
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x = self.avgpool(x)
+        x = x.view(x.size(0), -1)
+        return self.class_classifier(x)
+
+
+def resnet18(classes):
+    return ResNet(BasicBlock, [2, 2, 2, 2], classes=classes)     # nets/resnet.py:335
+
+
+def resnet50(classes):
+    return ResNet(Bottleneck, [3, 4, 6, 3], classes=classes)     # nets/resnet.py:359
+
+
+def seeded_state_dict(model, seed):
+    """Deterministic (numpy RandomState) re-initialisation with the reference's
+    init law (kaiming-normal fan_out for convs, BN gamma=1 beta=0, Linear
+    U(-1/sqrt(fan_in), 1/sqrt(fan_in))) so fixtures need not store weights.
+    BN gammas are perturbed around 1 and betas around 0 so that parity tests
+    are sensitive to the affine path."""
+    rs = np.random.RandomState(seed)
+    sd = {}
+    for k, v in model.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros_like(v)
+        elif v.dim() == 4:
+            fan_out = v.shape[0] * v.shape[2] * v.shape[3]
+            sd[k] = torch.from_numpy(rs.normal(0, np.sqrt(2.0 / fan_out), tuple(v.shape)).astype(np.float32))
+        elif v.dim() == 2:
+            b = 1.0 / np.sqrt(v.shape[1])
+            sd[k] = torch.from_numpy(rs.uniform(-b, b, tuple(v.shape)).astype(np.float32))
+        elif k.endswith("running_var"):
+            sd[k] = torch.ones_like(v)
+        elif k.endswith("running_mean"):
+            sd[k] = torch.zeros_like(v)
+        elif "bn" in k.split(".")[-2] or "downsample.1" in k:
+            if k.endswith("weight"):
+                sd[k] = torch.from_numpy(rs.uniform(0.8, 1.2, tuple(v.shape)).astype(np.float32))
+            else:
+                sd[k] = torch.from_numpy(rs.normal(0, 0.05, tuple(v.shape)).astype(np.float32))
+        else:   # linear bias
+            b = 1.0 / np.sqrt(model.class_classifier.in_features)
+            sd[k] = torch.from_numpy(rs.uniform(-b, b, tuple(v.shape)).astype(np.float32))
+    return sd
+
+
+def synth_batch(n, size, classes, seed=1):
+    """SURVEY.md 8d "Synthetic inputs 2": x ~ N(0,1), labels uniform."""
+    rs = np.random.RandomState(seed)
+    x = torch.from_numpy(rs.normal(0, 1, (n, 3, size, size)).astype(np.float32))
+    y = torch.from_numpy(rs.randint(0, classes, (n,)).astype(np.int64))
+    return x, y
+
+
+def train_step(model, x, y, lr):
+    """Body of fed_run.py:49-80: zero_grad, forward, CE (mean), backward,
+    SGD step p -= lr*g (fed_run.py:657: optim.SGD(params, lr), nothing else)."""
+    model.train()
+    for p in model.parameters():
+        p.grad = None
+    logit = model(x)
+    loss = nn.functional.cross_entropy(logit, y)
+    loss.backward()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(p.grad, alpha=-lr)   # torch.optim.SGD._single_tensor_sgd form
+    return loss.detach(), logit.detach()

@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running THE REFERENCE ITSELF on seeded inputs.
+
+Runs only where /root/reference exists (the build container).  It
+  * imports the reference's style_transfer/AdaIN/{net,function}.py as they lie,
+  * AST-extracts (and exec's, unmodified) the script-level functions
+    ``style_transfer`` (CCST_OverallStyleTransfer.py:32), ``calc_sum``
+    (mean_std_computation_effcientMem.py:103 and CCST_SingleStyleTransfer.py:55)
+    and ``train`` / ``test`` / ``communication`` (federated/fed_run.py:31,214,385)
+    because the scripts themselves execute argparse/model loading on import and
+    need torchvision,
+  * imports nets/resnet.py behind a stub ``torchvision.models.resnet`` that
+    supplies the oracle's restated BasicBlock/Bottleneck (torchvision is not
+    installed and not part of /root/reference),
+and stores inputs' seeds + the reference's outputs.  Only data is written:
+no reference source text is copied anywhere.
+
+Usage:  python tools/make_golden.py            (rewrites tests/golden/)
+"""
+import ast
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+from torch import nn
+
+from oracle import adain_ref as A
+from oracle import resnet_ref as R
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def extract_functions(path, names, namespace):
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            mod = ast.Module(body=[node], type_ignores=[])
+            exec(compile(mod, path, "exec"), namespace)
+    return namespace
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, {k: v.shape for k, v in out.items()})
+
+
+# --------------------------------------------------------------------------
+# AdaIN path
+# --------------------------------------------------------------------------
+sys.path.insert(0, os.path.join(REF, "style_transfer", "AdaIN"))
+import function as ref_function      # noqa: E402  (reference module)
+import net as ref_net                # noqa: E402  (reference module)
+
+VGG_W = A.he_weights(A.VGG_TABLE, seed=1234)
+DEC_W = A.he_weights(A.DECODER_TABLE, seed=4321)
+ref_vgg = ref_net.vgg
+ref_dec = ref_net.decoder
+ref_vgg.eval()
+ref_dec.eval()
+ref_vgg.load_state_dict(VGG_W)       # all 17 convs of the 53-layer net
+ref_dec.load_state_dict(DEC_W)
+ref_vgg31 = nn.Sequential(*list(ref_vgg.children())[:31])   # CCST_OverallStyleTransfer.py:124
+
+ns = {"torch": torch, "device": torch.device("cpu"),
+      "adaIN_StyleStat_ContentFeat": ref_function.adaIN_StyleStat_ContentFeat}
+extract_functions(os.path.join(REF, "style_transfer/AdaIN/CCST_OverallStyleTransfer.py"),
+                  {"style_transfer"}, ns)
+ref_style_transfer = ns["style_transfer"]
+ns1 = {"torch": torch}
+extract_functions(os.path.join(REF, "style_transfer/AdaIN/mean_std_computation_effcientMem.py"),
+                  {"calc_sum"}, ns1)
+ns2 = {"torch": torch}
+extract_functions(os.path.join(REF, "style_transfer/AdaIN/CCST_SingleStyleTransfer.py"),
+                  {"calc_sum"}, ns2)
+
+with torch.no_grad():
+    # 1. calc_mean_std on [2,8,5,7]
+    rs = np.random.RandomState(11)
+    feat = torch.from_numpy(rs.normal(0.3, 1.2, (2, 8, 5, 7)).astype(np.float32))
+    m, s = ref_function.calc_mean_std(feat)
+    save("calc_mean_std", seed=11, mean=m, std=s)
+
+    # 2. adaIN_StyleStat_ContentFeat / adaptive_instance_normalization on [2,512,8,8]
+    rs = np.random.RandomState(12)
+    cf = torch.from_numpy(np.abs(rs.normal(0.0, 0.6, (2, 512, 8, 8))).astype(np.float32))
+    sf = torch.from_numpy(np.abs(rs.normal(0.2, 0.9, (2, 512, 6, 10))).astype(np.float32))
+    stat = A.synth_style_stat(512, seed=7)
+    save("adain_feat", seed=12,
+         out_stat=ref_function.adaIN_StyleStat_ContentFeat(cf, stat),
+         out_feat=ref_function.adaptive_instance_normalization(cf, sf))
+
+    # 3. calc_sum over 3 batches + finalise (mean_std...py:117-137)
+    tot_s, tot_q, tot_n = 0, 0, 0
+    per = []
+    for b in range(3):
+        data = A.synth_content(2, 32, 48, seed=100 + b)
+        f = ref_vgg31(data)
+        s1, q1, n1 = ns1["calc_sum"](f)
+        s2, q2, n2 = ns2["calc_sum"](f)
+        assert torch.equal(s1, s2) and torch.equal(q1, q2) and n1 == n2
+        per.append((s1, q1, n1))
+        tot_s = tot_s + s1
+        tot_q = tot_q + q1
+        tot_n += n1
+    mean = tot_s / float(tot_n)
+    var = tot_q / float(tot_n) - mean ** 2
+    std = torch.sqrt(var + 1e-5)
+    save("overall_stats", seeds=[100, 101, 102], sum0=per[0][0], sq0=per[0][1], n0=per[0][2],
+         tot_sum=tot_s, tot_sq=tot_q, tot_n=tot_n, mean=mean, std=std)
+
+    # 4. encoder relu4_1 and style_transfer on [2,3,64,64]
+    content = A.synth_content(2, 64, 64, seed=1)
+    stat = A.synth_style_stat(512, seed=7)
+    enc = ref_vgg31(content)
+    out = ref_style_transfer(ref_vgg31, ref_dec, content, stat, 1.0)
+    out_a = ref_style_transfer(ref_vgg31, ref_dec, content, stat, 0.5)
+    save("style_transfer_64", seed=1, relu4_1=enc, out=out, out_alpha05=out_a)
+
+    # 5. odd size [1,3,222,222] -> [1,3,224,224]; non-square [1,3,50,84]
+    content = A.synth_content(1, 222, 222, seed=2)
+    out = ref_style_transfer(ref_vgg31, ref_dec, content, stat, 1.0)
+    assert tuple(out.shape) == (1, 3, 224, 224)
+    content2 = A.synth_content(1, 50, 84, seed=3)
+    out2 = ref_style_transfer(ref_vgg31, ref_dec, content2, stat, 1.0)
+    save("style_transfer_odd", seed=2, out_sub4=out[:, :, ::4, ::4].contiguous(),
+         out_shape=list(out.shape), chan_sum=out.sum(dim=(0, 2, 3)), chan_abs=out.abs().sum(dim=(0, 2, 3)),
+         seed2=3, out2=out2, out2_shape=list(out2.shape))
+
+# --------------------------------------------------------------------------
+# ResNet / FedAvg path
+# --------------------------------------------------------------------------
+tv = types.ModuleType("torchvision")
+tvm = types.ModuleType("torchvision.models")
+tvr = types.ModuleType("torchvision.models.resnet")
+tvr.BasicBlock, tvr.Bottleneck, tvr.model_urls = R.BasicBlock, R.Bottleneck, {}
+tv.models, tvm.resnet = tvm, tvr
+sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.models.resnet": tvr})
+sys.path.insert(0, REF)
+from nets import resnet as ref_resnet   # noqa: E402  (reference module: ResNet class, _make_layer, forward)
+
+
+def resnet_case(name, block, layers, classes, nb, seed):
+    model = ref_resnet.ResNet(block, layers, classes=classes)
+    ours = R.ResNet(block, layers, classes=classes)
+    sd = R.seeded_state_dict(ours, seed)
+    model.load_state_dict(sd)
+    x, y = R.synth_batch(nb, 222, classes, seed=seed + 1)
+    model.eval()
+    with torch.no_grad():
+        logit_eval = model(x)
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=0.01)       # fed_run.py:657 form
+    opt.zero_grad()
+    logit_train = model(x)
+    loss = nn.CrossEntropyLoss()(logit_train, y)               # fed_run.py:554
+    loss.backward()
+    g = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    opt.step()
+    model.eval()
+    with torch.no_grad():
+        logit_after = model(x)
+    sd_after = model.state_dict()
+    probe = {}
+    for k in ["conv1.weight", "bn1.weight", "bn1.bias", "class_classifier.weight", "class_classifier.bias",
+              "layer1.0.conv1.weight", "layer2.0.downsample.0.weight", "layer4.%d.conv2.weight" % (layers[3] - 1),
+              "layer3.0.bn2.weight"]:
+        probe["grad_sum/" + k] = g[k].sum()
+        probe["grad_abs/" + k] = g[k].abs().sum()
+        probe["grad_head/" + k] = g[k].flatten()[:16]
+    for k in ["bn1.running_mean", "bn1.running_var", "layer4.0.bn1.running_mean", "layer2.0.downsample.1.running_var",
+              "bn1.num_batches_tracked"]:
+        probe["state/" + k] = sd_after[k]
+    save(name, seed=seed, classes=classes, nb=nb, lr=0.01, logit_eval=logit_eval, logit_train=logit_train,
+         loss=loss, logit_after=logit_after, **probe)
+
+
+resnet_case("resnet18_step", R.BasicBlock, [2, 2, 2, 2], 2, 2, seed=50)
+resnet_case("resnet50_step", R.Bottleneck, [3, 4, 6, 3], 7, 2, seed=60)
+
+# communication() on 3 perturbed clients (fed_run.py:385-455, fedavg branch)
+nsf = {"torch": torch, "nn": nn}
+extract_functions(os.path.join(REF, "federated/fed_run.py"), {"communication"}, nsf)
+args = types.SimpleNamespace(mode="fedavg")
+server = ref_resnet.ResNet(R.BasicBlock, [1, 1, 1, 1], classes=3)
+server.load_state_dict(R.seeded_state_dict(R.ResNet(R.BasicBlock, [1, 1, 1, 1], classes=3), 70))
+import copy  # noqa: E402
+clients = [copy.deepcopy(server) for _ in range(3)]
+for ci, c in enumerate(clients):
+    rs = np.random.RandomState(71 + ci)
+    with torch.no_grad():
+        for k, v in c.state_dict().items():
+            if "num_batches_tracked" in k:
+                v.fill_(5 + ci)
+            else:
+                v += torch.from_numpy(rs.normal(0, 0.02, tuple(v.shape)).astype(np.float32))
+weights = [0.5, 0.3, 0.2]
+server, clients = nsf["communication"](args, server, clients, weights)
+keys = list(server.state_dict().keys())
+ksum = np.array([float(server.state_dict()[k].double().sum()) for k in keys])
+kabs = np.array([float(server.state_dict()[k].double().abs().sum()) for k in keys])
+nbt_server = [int(server.state_dict()[k]) for k in keys if "num_batches_tracked" in k]
+nbt_clients = [[int(c.state_dict()[k]) for k in keys if "num_batches_tracked" in k] for c in clients]
+same = all(torch.equal(server.state_dict()[k], c.state_dict()[k]) for c in clients for k in keys
+           if "num_batches_tracked" not in k)
+save("communication", seed=70, weights=weights, keys=np.array(keys), key_sum=ksum, key_abs=kabs,
+     conv1_head=server.state_dict()["conv1.weight"].flatten()[:32],
+     fc_bias=server.state_dict()["class_classifier.bias"],
+     nbt_server=nbt_server, nbt_clients=nbt_clients, clients_equal_server=same)
+print("done")
