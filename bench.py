@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Benchmark of the CCST hot path on MI355X.
+
+Metric (BASELINE.json): AdaIN stylised images/sec @512x512, B=6 -- one "step" is one
+style_transfer() pass (VGG encoder -> AdaIN -> decoder, CCST_OverallStyleTransfer.py:32-46) over one
+synthetic batch already resident in HBM.  With --gpus N (launched by torch.distributed.run, one
+rank per GPU) every rank stylises its own batch (content images are independent: no data-path
+collective), timing is barrier-bracketed and the max over ranks.
+
+Prints ONE JSON line on rank 0 (see the bench contract) including
+  roofline     : the dominant kernel (the 128x128-tile implicit-GEMM conv instance), algorithmic
+                 FLOPs of its launches / their HIP-event durations inside the timed region
+  cpu_baseline : the CPU oracle (a port of the reference path) timed on the host cores, rank 0, N=1
+  secondary    : ResNet50 train-step images/sec @222x222 B=64 (second half of the metric), if built
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=6)
+    ap.add_argument("--image_size", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from ccst_amd import net, ops, style
+    from oracle import adain_ref as A          # synthetic inputs + the cpu_baseline leg only
+
+    B, S = args.batch, args.image_size
+    vgg_w = A.he_weights(A.VGG_TABLE, seed=1234)
+    dec_w = A.he_weights(A.DECODER_TABLE, seed=4321)
+    net.vgg.load_state_dict(vgg_w)
+    net.decoder.load_state_dict(dec_w)
+    vgg31 = net.vgg[:31].to(dev).eval()
+    dec = net.decoder.to(dev).eval()
+    content = A.synth_content(B, S, S, seed=1 + rank).to(dev)
+    stat = [t.to(dev) for t in A.synth_style_stat(512, seed=7)]
+
+    def step():
+        with torch.no_grad():
+            return style.style_transfer(vgg31, dec, content, stat, 1.0)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    ops.TIMING = []                       # per-launch HIP events for the conv kernels
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timing, ops.TIMING = ops.TIMING, None
+    if distributed:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert bool(torch.isfinite(out).all())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel ------------------------------------------------
+    per_kernel = {}
+    for name, flops, e0, e1 in timing:
+        k = per_kernel.setdefault(name, [0, 0.0, 0.0])
+        k[0] += 1
+        k[1] += flops
+        k[2] += e0.elapsed_time(e1) * 1e-3
+    roofline = None
+    kernels = {}
+    for name, (cnt, fl, sec) in per_kernel.items():
+        kernels[name] = {"launches_per_step": cnt / args.steps, "avg_us": sec / cnt * 1e6,
+                         "gflop_per_launch": fl / cnt / 1e9, "tflops": fl / sec / 1e12}
+    if per_kernel:
+        dom = max(per_kernel, key=lambda n: per_kernel[n][2])
+        cnt, fl, sec = per_kernel[dom]
+        ach = fl / sec / 1e12
+        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "kernel": dom,
+                    "launches_per_step": cnt / args.steps, "avg_launch_us": round(sec / cnt * 1e6, 2),
+                    "gflop_per_launch": round(fl / cnt / 1e9, 3)}
+
+    result = {
+        "metric": "AdaIN stylised images/sec @512x512 B=6", "value": round(value, 3), "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "CCST_OverallStyleTransfer PACS %dx%d batch=%d (encoder->AdaIN->decoder)" % (S, S, B),
+                   "batch_per_gpu": B, "image_size": S, "sharding": "content batches per rank, no collective"},
+        "roofline": roofline,
+        "whole_path_tflops": round(253.07e9 * (S * S / 512.0 / 512.0) * B * world * args.steps / elapsed / 1e12, 2),
+        "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in kernels.items()},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        torch.set_num_threads(os.cpu_count() or 1)
+        cpu_content = A.synth_content(B, S, S, seed=1)
+        cpu_stat = A.synth_style_stat(512, seed=7)
+        with torch.no_grad():
+            A.style_transfer(vgg_w, dec_w, cpu_content[:1], cpu_stat, 1.0)        # warm-up, 1 image
+            c0 = time.perf_counter()
+            ref = A.style_transfer(vgg_w, dec_w, cpu_content, cpu_stat, 1.0)
+            c1 = time.perf_counter()
+        result["cpu_baseline"] = {"value": round(B / (c1 - c0), 4), "unit": "images/sec", "cores": torch.get_num_threads(),
+                                  "kind": "port", "sample": "1 batch of %d images %dx%d (oracle/adain_ref.py, torch CPU fp32)" % (B, S, S)}
+        result["max_abs_diff_vs_cpu"] = float((out.cpu() - ref).abs().max())
+
+    if rank == 0 and not args.no_secondary:
+        try:
+            from ccst_amd import bench_resnet
+            result["secondary"] = bench_resnet.run(dev, world)
+        except ImportError:
+            pass
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,95 @@
+"""ctypes binding of libccst_hip.so (the C ABI declared in include/ccst_hip.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the library is
+missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_void_p
+
+import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's copy
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libccst_hip.so")
+
+CONV_RELU, CONV_POOL2, CONV_UPS2, CONV_REFLECT = 1, 2, 4, 8
+
+
+class CcstConvDesc(Structure):
+    _fields_ = [("n", c_int32), ("ho", c_int32), ("wo", c_int32), ("hi", c_int32), ("wi", c_int32),
+                ("cin", c_int32), ("cout", c_int32), ("cout_pad", c_int32), ("nky", c_int32), ("nkx", c_int32),
+                ("ay", c_int32), ("by", c_int32), ("cy", c_int32), ("ax", c_int32), ("bx", c_int32), ("cx", c_int32),
+                ("tap_base", c_int32), ("tap_sy", c_int32), ("tap_sx", c_int32),
+                ("xsN", c_int64), ("xsH", c_int32), ("xsW", c_int32),
+                ("y_off", c_int64), ("ysN", c_int64), ("ysH", c_int32), ("ysW", c_int32), ("ysC", c_int32),
+                ("flags", c_uint32)]
+
+
+_P = c_void_p
+# name -> argtypes (restype is int unless listed in _RESTYPES).  Every symbol of include/ccst_hip.h.
+_SIGNATURES = {
+    "ccst_abi_version": [],
+    "ccst_last_error": [],
+    "ccst_conv2d_igemm_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P],
+    "ccst_pack_conv_weight_f32": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
+    "ccst_nchw_to_nhwc4_pad_f32": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
+    "ccst_nhwc_layer_f32": [c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    "ccst_nchw_to_nhwc_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
+    "ccst_nhwc_to_nchw_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
+    "ccst_conv2d_bwd_weight_f32": [POINTER(CcstConvDesc), _P, _P, _P, c_int, _P, c_int64, _P],
+    "ccst_calc_mean_std_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, c_int64, _P],
+    "ccst_adain_f32": [_P, _P, _P, c_int, c_float, _P, c_int, c_int, c_int, c_int, c_float, _P, c_int64, _P],
+    "ccst_chan_sums_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _P],
+    "ccst_stats_workspace_bytes": [c_int, c_int, c_int],
+    "ccst_bn_train_fwd_f32": [_P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P, _P, _P, c_int64, c_int, _P, c_int64, _P],
+    "ccst_bn_eval_fwd_f32": [_P, _P, _P, _P, _P, c_float, _P, c_int, _P, c_int64, c_int, _P],
+    "ccst_bn_train_bwd_f32": [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int64, c_int, _P, c_int64, _P],
+    "ccst_bn_workspace_bytes": [c_int64, c_int],
+    "ccst_maxpool3s2_fwd_f32": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
+    "ccst_maxpool3s2_bwd_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
+    "ccst_avgpool_fwd_f32": [_P, _P, c_int, c_int, c_int, _P],
+    "ccst_avgpool_bwd_f32": [_P, _P, c_int, c_int, c_int, _P],
+    "ccst_linear_fwd_f32": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
+    "ccst_linear_bwd_f32": [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
+    "ccst_softmax_ce_f32": [_P, _P, _P, _P, _P, c_int, c_int, _P],
+    "ccst_sgd_f32": [_P, _P, c_float, c_int64, _P],
+    "ccst_scale_f32": [_P, c_float, c_int64, _P],
+}
+_RESTYPES = {"ccst_last_error": c_char_p, "ccst_stats_workspace_bytes": c_int64, "ccst_bn_workspace_bytes": c_int64}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load the library once; raise loudly if it is absent (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "ccst_amd: %s not found. The HIP extension is required (there is no CPU/PyTorch fallback); "
+            "build it with `python -m ccst_amd.build`." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    if lib.ccst_abi_version() != 1:
+        raise RuntimeError("ccst_amd: ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().ccst_last_error()
+        raise RuntimeError("ccst_amd: %s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)

@@ -1,0 +1,272 @@
+// AdaIN feature statistics and normalisation (HBM-bound; gfx950).
+//
+//   partials : per-(n, split, c) fp32 sum and sum of squares over a slice of the H*W plane
+//              (each thread adds <= a few dozen values in fp32; wide 16-B loads)
+//   finalize : combines the split partials in fp64 -> mean, sqrt(var_unbiased+eps)   (calc_mean_std,
+//              function.py:4-13) or per-channel totals over N too (calc_sum, mean_std...py:103-115)
+//   apply    : y = ((x-mu_c)/sigma_c)*sigma_s+mu_s, then y*alpha + x*(1-alpha)      (function.py:26-33,
+//              CCST_OverallStyleTransfer.py:45), one read + one write of the tensor.
+// layout 0 = NCHW planes (API tensors), 1 = NHWC (the pipeline's internal layout).
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+// ---- NHWC: x[n][p][c]; thread = one float4 channel group, PL pixel lanes per block -----------
+__global__ __launch_bounds__(TPB) void partials_nhwc_kernel(const float* __restrict__ x, float* __restrict__ part, int HW, int C,
+                                                            int S, int cgb, int PL) {
+    __shared__ f32x4 red[2][TPB];
+    const int n = blockIdx.z, split = blockIdx.x;
+    const int t = threadIdx.x;
+    const int cgl = t % cgb, pl = t / cgb;
+    const int cg = blockIdx.y * cgb + cgl;
+    const int per = (HW + S - 1) / S;
+    const int p0 = split * per, p1 = min(HW, p0 + per);
+    f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
+    if (pl < PL && cg * 4 < C) {
+        const float* base = x + ((long long)n * HW) * C + cg * 4;
+        for (int p = p0 + pl; p < p1; p += PL) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)p * C);
+            s += v;
+            q += v * v;
+        }
+    }
+    red[0][t] = s;
+    red[1][t] = q;
+    __syncthreads();
+    if (pl == 0 && cg * 4 < C) {
+        for (int k = 1; k < PL; ++k) {
+            s += red[0][t + k * cgb];
+            q += red[1][t + k * cgb];
+        }
+        float* o = part + (((long long)n * S + split) * C + cg * 4) * 2;
+        // layout [n][split][c][2] interleaved (sum, sq) per channel
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[2 * j] = s[j];
+            o[2 * j + 1] = q[j];
+        }
+    }
+}
+
+// ---- NCHW: plane (n,c) contiguous; block = (plane, split) -----------------------------------
+__global__ __launch_bounds__(TPB) void partials_nchw_kernel(const float* __restrict__ x, float* __restrict__ part, int HW, int C,
+                                                            int S) {
+    __shared__ float red[2][TPB / 64];
+    const int plane = blockIdx.y, split = blockIdx.x;
+    const int n = plane / C, c = plane - n * C;
+    const int per = (HW + S - 1) / S;
+    const int p0 = split * per, p1 = min(HW, p0 + per);
+    const float* base = x + (long long)plane * HW;
+    float s = 0.f, q = 0.f;
+    for (int p = p0 + threadIdx.x; p < p1; p += TPB) {
+        const float v = base[p];
+        s += v;
+        q += v * v;
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s;
+        red[1][threadIdx.x >> 6] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float ts = 0.f, tq = 0.f;
+        for (int k = 0; k < TPB / 64; ++k) {
+            ts += red[0][k];
+            tq += red[1][k];
+        }
+        float* o = part + (((long long)n * S + split) * C + c) * 2;
+        o[0] = ts;
+        o[1] = tq;
+    }
+}
+
+// mean/std per (n,c) from the split partials, combined in fp64.
+__global__ void finalize_mean_std_kernel(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ stdv,
+                                         int N, int C, int S, int HW, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < S; ++k) {
+        const float* o = part + (((long long)n * S + k) * C + c) * 2;
+        s += (double)o[0];
+        q += (double)o[1];
+    }
+    const double cnt = (double)HW;
+    const double mu = s / cnt;
+    double var = (q - s * mu) / (cnt - 1.0);   // unbiased, function.py:9 (HW==1 -> NaN like the reference)
+    if (var < 0.0) var = 0.0;
+    mean[i] = (float)mu;
+    stdv[i] = sqrtf((float)var + eps);
+}
+
+// per-channel totals over n and splits (calc_sum)
+__global__ void finalize_chan_sums_kernel(const float* __restrict__ part, float* __restrict__ sum, float* __restrict__ sq, int N,
+                                          int C, int S) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < N * S; ++k) {
+        const float* o = part + ((long long)k * C + c) * 2;
+        s += (double)o[0];
+        q += (double)o[1];
+    }
+    sum[c] = (float)s;
+    sq[c] = (float)q;
+}
+
+__device__ __forceinline__ float adain_one(float x, float mu, float sd, float sm, float ss, float alpha, bool blend) {
+    float t = ((x - mu) / sd) * ss + sm;          // evaluation order of function.py:31-33
+    if (blend) t = t * alpha + x * (1.f - alpha); // CCST_OverallStyleTransfer.py:45
+    return t;
+}
+
+__global__ __launch_bounds__(TPB) void adain_apply_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                               const float* __restrict__ smean, const float* __restrict__ sstd,
+                                                               int style_per_n, float alpha, long long total4, int HW, int C) {
+    const int cg = C / 4;
+    const bool blend = (alpha != 1.f);
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total4; i += (long long)gridDim.x * TPB) {
+        const int c = (int)(i % cg) * 4;
+        const int n = (int)(i / ((long long)HW * cg));
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + n * C + c);
+        const f32x4 sd = *reinterpret_cast<const f32x4*>(stdv + n * C + c);
+        const int so = (style_per_n ? n * C : 0) + c;
+        const f32x4 sm = *reinterpret_cast<const f32x4*>(smean + so);
+        const f32x4 ss = *reinterpret_cast<const f32x4*>(sstd + so);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = adain_one(v[j], mu[j], sd[j], sm[j], ss[j], alpha, blend);
+        *reinterpret_cast<f32x4*>(y + i * 4) = o;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void adain_apply_nchw_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                               const float* __restrict__ smean, const float* __restrict__ sstd,
+                                                               int style_per_n, float alpha, int HW, int C) {
+    const int plane = blockIdx.y;
+    const int c = plane % C;
+    const float mu = mean[plane], sd = stdv[plane];
+    const int so = style_per_n ? plane : c;
+    const float sm = smean[so], ss = sstd[so];
+    const bool blend = (alpha != 1.f);
+    const float* xb = x + (long long)plane * HW;
+    float* yb = y + (long long)plane * HW;
+    for (int p = blockIdx.x * TPB + threadIdx.x; p < HW; p += gridDim.x * TPB) yb[p] = adain_one(xb[p], mu, sd, sm, ss, alpha, blend);
+}
+
+int pick_splits(int N, int C, int HW, int layout) {
+    // aim for ~1024 workgroups, at least ~8 pixels (NHWC) / 1024 elements (NCHW) per split
+    long long units = (layout == 1) ? (long long)N * ((C / 4 + 255) / 256) : (long long)N * C;
+    long long s = 1024 / (units > 0 ? units : 1);
+    const int minper = (layout == 1) ? 8 : 1024;
+    const long long smax = (HW + minper - 1) / minper;
+    if (s > smax) s = smax;
+    if (s < 1) s = 1;
+    if (s > 256) s = 256;
+    return (int)s;
+}
+
+int run_partials(const float* x, float* part, int N, int C, int HW, int layout, int S, hipStream_t st) {
+    if (layout == 1) {
+        const int cg = C / 4;
+        const int cgb = cg < TPB ? cg : TPB;
+        const int PL = TPB / cgb;
+        dim3 grid(S, (cg + cgb - 1) / cgb, N);
+        hipLaunchKernelGGL(partials_nhwc_kernel, grid, dim3(TPB), 0, st, x, part, HW, C, S, cgb, PL);
+    } else {
+        dim3 grid(S, N * C);
+        hipLaunchKernelGGL(partials_nchw_kernel, grid, dim3(TPB), 0, st, x, part, HW, C, S);
+    }
+    return ccst_launch_status("stats partials");
+}
+
+int check_common(const void* x, int N, int C, int HW, int layout) {
+    CCST_REQUIRE(x != nullptr, "stats: null tensor");
+    CCST_REQUIRE(N > 0 && C > 0 && HW > 0, "stats: bad extents N=%d C=%d HW=%d", N, C, HW);
+    CCST_REQUIRE(layout == 0 || layout == 1, "stats: layout must be 0 (NCHW) or 1 (NHWC)");
+    if (layout == 1) CCST_REQUIRE(C % 4 == 0, "stats: NHWC path needs C %% 4 == 0 (C=%d)", C);
+    CCST_REQUIRE(layout == 1 || (long long)N * C <= 65535, "stats: NCHW path supports at most 65535 planes");
+    CCST_REQUIRE(N <= 65535, "stats: N too large");
+    return CCST_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t ccst_stats_workspace_bytes(int N, int C, int HW) {
+    (void)HW;
+    // partials [N][S<=256][C][2] + mean[N*C] + std[N*C]
+    return ((int64_t)N * 256 * C * 2 + 2LL * N * C) * 4;
+}
+
+extern "C" int ccst_calc_mean_std_f32(const float* x, float* mean, float* stdv, int N, int C, int HW, int layout, float eps,
+                                      void* ws, int64_t ws_bytes, void* stream) {
+    int rc = check_common(x, N, C, HW, layout);
+    if (rc) return rc;
+    CCST_REQUIRE(mean && stdv && ws, "calc_mean_std: null pointer");
+    if (ws_bytes < ccst_stats_workspace_bytes(N, C, HW)) {
+        ccst_set_error("calc_mean_std: workspace %lld < %lld", (long long)ws_bytes, (long long)ccst_stats_workspace_bytes(N, C, HW));
+        return CCST_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int S = pick_splits(N, C, HW, layout);
+    float* part = (float*)ws;
+    rc = run_partials(x, part, N, C, HW, layout, S, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(finalize_mean_std_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, part, mean, stdv, N, C, S, HW, eps);
+    return ccst_launch_status("finalize_mean_std");
+}
+
+extern "C" int ccst_adain_f32(const float* x, const float* style_mean, const float* style_std, int style_per_n, float alpha,
+                              float* y, int N, int C, int HW, int layout, float eps, void* ws, int64_t ws_bytes, void* stream) {
+    int rc = check_common(x, N, C, HW, layout);
+    if (rc) return rc;
+    CCST_REQUIRE(style_mean && style_std && y && ws, "adain: null pointer");
+    CCST_REQUIRE(alpha >= 0.f && alpha <= 1.f, "adain: alpha=%f outside [0,1]", (double)alpha);
+    if (ws_bytes < ccst_stats_workspace_bytes(N, C, HW)) {
+        ccst_set_error("adain: workspace too small");
+        return CCST_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)ws;
+    float* mean = part + (int64_t)N * 256 * C * 2;
+    float* stdv = mean + (int64_t)N * C;
+    rc = ccst_calc_mean_std_f32(x, mean, stdv, N, C, HW, layout, eps, ws, ws_bytes, stream);
+    if (rc) return rc;
+    if (layout == 1) {
+        const long long total4 = (long long)N * HW * (C / 4);
+        const int grid = (int)((total4 + TPB - 1) / TPB < 4096 ? (total4 + TPB - 1) / TPB : 4096);
+        hipLaunchKernelGGL(adain_apply_nhwc_kernel, dim3(grid), dim3(TPB), 0, st, x, y, mean, stdv, style_mean, style_std,
+                           style_per_n, alpha, total4, HW, C);
+    } else {
+        const int gx = (HW + TPB - 1) / TPB < 64 ? (HW + TPB - 1) / TPB : 64;
+        hipLaunchKernelGGL(adain_apply_nchw_kernel, dim3(gx, N * C), dim3(TPB), 0, st, x, y, mean, stdv, style_mean, style_std,
+                           style_per_n, alpha, HW, C);
+    }
+    return ccst_launch_status("adain_apply");
+}
+
+extern "C" int ccst_chan_sums_f32(const float* x, float* sum, float* sqsum, int N, int C, int HW, int layout, void* ws,
+                                  int64_t ws_bytes, void* stream) {
+    int rc = check_common(x, N, C, HW, layout);
+    if (rc) return rc;
+    CCST_REQUIRE(sum && sqsum && ws, "chan_sums: null pointer");
+    if (ws_bytes < ccst_stats_workspace_bytes(N, C, HW)) {
+        ccst_set_error("chan_sums: workspace too small");
+        return CCST_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int S = pick_splits(N, C, HW, layout);
+    float* part = (float*)ws;
+    rc = run_partials(x, part, N, C, HW, layout, S, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(finalize_chan_sums_kernel, dim3((C + 63) / 64), dim3(64), 0, st, part, sum, sqsum, N, C, S);
+    return ccst_launch_status("finalize_chan_sums");
+}

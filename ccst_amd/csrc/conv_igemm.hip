@@ -1,0 +1,407 @@
+// Implicit-GEMM convolution for gfx950 on the fp32-input MFMA (v_mfma_f32_32x32x2_f32).
+//
+//   GEMM view:  D[m][co] = sum_{tap,ci} A[m][(tap,ci)] * W[(tap,ci)][co]
+//     m  = output pixel (n,oy,ox)            -> BM = 64*WM rows per workgroup
+//     co = output channel                    -> BN = 32*NT*WN columns per workgroup
+//     k  = (tap, ci), stepped CK=16 input channels of one tap at a time
+//   A is gathered on the fly from the NHWC activation (affine index map + zero / reflection
+//   padding + optional nearest-x2 upsample on read): no im2col or padded tensor is materialised.
+//
+//   Workgroup = 4 waves (256 threads), wave tile = 64 x (32*NT): 2 x NT MFMA 32x32 tiles,
+//   16 accumulator VGPRs each.  Per k-step the A tile [BM][16] and W tile [16][BN] are staged
+//   global -> VGPR -> LDS (double buffered, one barrier per step); fragments are read with
+//   ds_read_b128: lane (i=l&31, h=l>>5) takes channels 8q+4h .. 8q+4h+3 of row i, which feed four
+//   consecutive MFMAs (k = h  <->  ci = 8q+4h+s); the packed weight layout [tap][ci/4][co][4]
+//   gives the B fragment the same shape.  A rows are padded to 20 floats (80 B) so the 16-lane
+//   groups of ds_read_b128 hit 16 distinct 16-B slots.
+//
+//   Epilogue: bias is the initial accumulator; ReLU; either a strided store (NHWC / NCHW via the
+//   y strides) or the fused MaxPool2d(2,2,ceil) where the M index is laid out so that the four
+//   pixels of a pooling window sit in the four registers (reg&3) of one lane.
+#include "common.h"
+
+namespace {
+
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    float* y;
+    int N, Ho, Wo, Hi, Wi, Cin, Cout, CoutPad;
+    int nky, nkx, ay, by, cy, ax, bx, cx;
+    int tap_base, tap_sy, tap_sx;
+    long long xsN;
+    int xsH, xsW;
+    long long y_off, ysN;
+    int ysH, ysW, ysC;
+    unsigned flags;
+    int M;          // N*Ho*Wo
+    int tilesN;     // column tiles
+    int tilesY, tilesX;  // spatial tiles per image (pool mode)
+};
+
+constexpr int CK = 16;            // input channels per k-step
+constexpr int A_LD = CK + 4;      // floats per LDS A row (80 B)
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    // ReflectionPad2d: -1 -> 1, n -> n-2 (edge not repeated); clamp keeps overhanging
+    // tile rows (results discarded) inside the tensor.
+    i = (i < 0) ? -i : i;
+    i = (i >= n) ? 2 * n - 2 - i : i;
+    return min(max(i, 0), n - 1);
+}
+
+template <int WM, int WN, int NT, bool POOL>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+    constexpr int BM = 64 * WM;
+    constexpr int BN = 32 * NT * WN;
+    constexpr int AR = BM / 64;                    // A float4 units per thread per step
+    constexpr int BUNITS = (CK / 4) * BN;          // W float4 units per step
+    constexpr int BR = (BUNITS + 255) / 256;
+
+    __shared__ __attribute__((aligned(16))) float As[2][BM * A_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][CK * BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int bid = ccst_xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % p.tilesN;
+    const int tm = bid / p.tilesN;
+    const int co0 = tn * BN;
+
+    // ---- per-thread A rows: r = (tid>>2) + 64*a, float4 part = tid&3 ------------------
+    const int part = tid & 3;
+    int rowIy[AR], rowIx[AR];
+    long long rowBase[AR];
+    int pn = 0, pty = 0, ptx = 0;   // pool-mode tile coordinates
+    if (POOL) {
+        ptx = tm % p.tilesX;
+        pty = (tm / p.tilesX) % p.tilesY;
+        pn = tm / (p.tilesX * p.tilesY);
+    }
+#pragma unroll
+    for (int a = 0; a < AR; ++a) {
+        const int r = (tid >> 2) + 64 * a;
+        int n, oy, ox;
+        if (POOL) {
+            // row r -> M-tile T=r>>5, window w=(r&31)>>2, pos=r&3: py=2T+(pos>>1), px=2w+(pos&1)
+            const int T = r >> 5, i = r & 31;
+            n = pn;
+            oy = pty * (BM / 16) + 2 * T + ((i & 3) >> 1);
+            ox = ptx * 16 + 2 * (i >> 2) + (i & 1);
+            oy = min(oy, p.Ho - 1);
+            ox = min(ox, p.Wo - 1);
+        } else {
+            int m = tm * BM + r;
+            m = min(m, p.M - 1);
+            n = m / (p.Ho * p.Wo);
+            const int rem = m - n * (p.Ho * p.Wo);
+            oy = rem / p.Wo;
+            ox = rem - oy * p.Wo;
+        }
+        rowIy[a] = oy * p.ay + p.cy;
+        rowIx[a] = ox * p.ax + p.cx;
+        rowBase[a] = (long long)n * p.xsN + part * 4;
+    }
+    const bool reflect = (p.flags & CCST_CONV_REFLECT) != 0;
+    const int ups = (p.flags & CCST_CONV_UPS2) ? 1 : 0;
+
+    const int nchunks = p.Cin / CK;
+    const int T = p.nky * p.nkx * nchunks;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = co0 + wn * (32 * NT) + nt * 32 + li;
+        const float b = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = b;
+    }
+
+    // ---- staging registers + step state --------------------------------------------------
+    f32x4 ra[AR], rb[BR];
+    long long aoff[AR];   // element offset of the row's pixel for the current tap; <0: zero fill
+    int ky = 0, kx = 0, c = 0;
+
+    auto tap_offsets = [&](int ky_, int kx_) {
+#pragma unroll
+        for (int a = 0; a < AR; ++a) {
+            int iy = rowIy[a] + ky_ * p.by, ix = rowIx[a] + kx_ * p.bx;
+            bool ok = true;
+            if (reflect) {
+                iy = reflect_idx(iy, p.Hi);
+                ix = reflect_idx(ix, p.Wi);
+            } else {
+                ok = (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
+            }
+            iy >>= ups;
+            ix >>= ups;
+            aoff[a] = ok ? rowBase[a] + (long long)iy * p.xsH + (long long)ix * p.xsW : -1;
+        }
+    };
+    auto load_step = [&](int ky_, int kx_, int c_) {
+#pragma unroll
+        for (int a = 0; a < AR; ++a) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (aoff[a] >= 0) v = *reinterpret_cast<const f32x4*>(p.x + aoff[a] + c_ * CK);
+            ra[a] = v;
+        }
+        const int tap = p.tap_base + ky_ * p.tap_sy + kx_ * p.tap_sx;
+        const long long wrow = ((long long)tap * (p.Cin / 4) + c_ * (CK / 4)) * p.CoutPad;
+#pragma unroll
+        for (int b = 0; b < BR; ++b) {
+            const int u = tid + 256 * b;
+            if (BUNITS % 256 == 0 || u < BUNITS) {
+                const int g = u / BN, col = u - g * BN;
+                rb[b] = *reinterpret_cast<const f32x4*>(p.w + ((wrow + (long long)g * p.CoutPad) + co0 + col) * 4);
+            }
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int a = 0; a < AR; ++a) {
+            const int r = (tid >> 2) + 64 * a;
+            *reinterpret_cast<f32x4*>(&As[buf][r * A_LD + part * 4]) = ra[a];
+        }
+#pragma unroll
+        for (int b = 0; b < BR; ++b) {
+            const int u = tid + 256 * b;
+            if (BUNITS % 256 == 0 || u < BUNITS) *reinterpret_cast<f32x4*>(&Bs[buf][u * 4]) = rb[b];
+        }
+    };
+    auto advance = [&]() {
+        if (++c == nchunks) {
+            c = 0;
+            if (++kx == p.nkx) {
+                kx = 0;
+                ++ky;
+            }
+            tap_offsets(ky, kx);
+        }
+    };
+
+    tap_offsets(0, 0);
+    load_step(0, 0, 0);
+    store_step(0);
+    __syncthreads();
+
+    const float* aRd0 = &As[0][(wm * 64 + li) * A_LD + lh * 4];
+    const float* bRd0 = &Bs[0][(lh * BN + wn * (32 * NT) + li) * 4];
+
+    for (int t = 0; t < T; ++t) {
+        const int buf = t & 1;
+        const bool more = (t + 1 < T);
+        if (more) {
+            advance();
+            load_step(ky, kx, c);
+        }
+        const float* aRd = aRd0 + buf * (BM * A_LD);
+        const float* bRd = bRd0 + buf * (CK * BN);
+#pragma unroll
+        for (int q = 0; q < CK / 8; ++q) {
+            f32x4 af[2], bf[NT];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                af[mt] = *reinterpret_cast<const f32x4*>(aRd + mt * 32 * A_LD + q * 8);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                bf[nt] = *reinterpret_cast<const f32x4*>(bRd + (2 * q * BN + nt * 32) * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][s], bf[nt][s], acc[mt][nt], 0, 0, 0);
+        }
+        if (more) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------
+    const bool relu = (p.flags & CCST_CONV_RELU) != 0;
+    float* yb = p.y + p.y_off;
+    if (!POOL) {
+        const int HW = p.Ho * p.Wo;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = tm * BM + row;
+                if (m < p.M) {
+                    const int n = m / HW;
+                    const int rem = m - n * HW;
+                    const int oy = rem / p.Wo;
+                    const int ox = rem - oy * p.Wo;
+                    float* yrow = yb + (long long)n * p.ysN + (long long)oy * p.ysH + (long long)ox * p.ysW;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int co = co0 + wn * (32 * NT) + nt * 32 + li;
+                        float v = acc[mt][nt][r];
+                        if (relu) v = fmaxf(v, 0.f);
+                        if (co < p.Cout) yrow[(long long)co * p.ysC] = v;
+                    }
+                }
+            }
+        }
+    } else {
+        const int Hp = (p.Ho + 1) >> 1, Wp = (p.Wo + 1) >> 1;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int Tt = wm * 2 + mt;
+            const int pyp = pty * (BM / 32) + Tt;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int pxp = ptx * 8 + 2 * g + lh;
+                if (pyp < Hp && pxp < Wp) {
+                    const bool okx = (2 * pxp + 1 < p.Wo), oky = (2 * pyp + 1 < p.Ho);
+                    float* yrow = yb + (long long)pn * p.ysN + (long long)pyp * p.ysH + (long long)pxp * p.ysW;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int co = co0 + wn * (32 * NT) + nt * 32 + li;
+                        float v = acc[mt][nt][4 * g];
+                        if (okx) v = fmaxf(v, acc[mt][nt][4 * g + 1]);
+                        if (oky) v = fmaxf(v, acc[mt][nt][4 * g + 2]);
+                        if (okx && oky) v = fmaxf(v, acc[mt][nt][4 * g + 3]);
+                        if (relu) v = fmaxf(v, 0.f);
+                        if (co < p.Cout) yrow[(long long)co * p.ysC] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// OIHW -> packed [tap][K/4][n_pad][4]
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int ntap,
+                                   int transpose, int k_pad, int n_pad) {
+    const long long total = (long long)ntap * k_pad * n_pad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k4 = (int)(i & 3);
+        long long j = i >> 2;
+        const int ncol = (int)(j % n_pad);
+        j /= n_pad;
+        const int kg = (int)(j % (k_pad / 4));
+        const int tap = (int)(j / (k_pad / 4));
+        const int k = kg * 4 + k4;
+        const int ci = transpose ? ncol : k;
+        const int co = transpose ? k : ncol;
+        float v = 0.f;
+        if (ci < cin && co < cout) v = w[((long long)co * cin + ci) * ntap + tap];
+        out[i] = v;
+    }
+}
+
+// NCHW (C<=4) -> padded NHWC4
+__global__ void nchw_to_nhwc4_pad_kernel(const float* __restrict__ x, f32x4* __restrict__ y, int N, int C, int H, int W,
+                                         int pad, int Wp, int reflect) {
+    const int Hp = H + 2 * pad;
+    const long long total = (long long)N * Hp * Wp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int px = (int)(i % Wp);
+        const long long j = i / Wp;
+        const int py = (int)(j % Hp);
+        const int n = (int)(j / Hp);
+        int iy = py - pad, ix = px - pad;
+        bool ok = px < W + 2 * pad;
+        if (reflect) {
+            iy = reflect_idx(iy, H);
+            ix = reflect_idx(ix, W);
+        } else {
+            ok = ok && iy >= 0 && iy < H && ix >= 0 && ix < W;
+        }
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            const float* src = x + ((long long)n * C * H + iy) * W + ix;
+            v[0] = src[0];
+            if (C > 1) v[1] = src[(long long)H * W];
+            if (C > 2) v[2] = src[2LL * H * W];
+            if (C > 3) v[3] = src[3LL * H * W];
+        }
+        y[i] = v;
+    }
+}
+
+template <int WM, int WN, int NT, bool POOL>
+int launch_conv(ConvArgs& a, hipStream_t s) {
+    constexpr int BM = 64 * WM, BN = 32 * NT * WN;
+    a.tilesN = (a.Cout + BN - 1) / BN;
+    int tilesM;
+    if (POOL) {
+        a.tilesY = (a.Ho + BM / 16 - 1) / (BM / 16);
+        a.tilesX = (a.Wo + 15) / 16;
+        tilesM = a.N * a.tilesY * a.tilesX;
+    } else {
+        a.tilesY = a.tilesX = 0;
+        tilesM = (a.M + BM - 1) / BM;
+    }
+    const long long grid = (long long)tilesM * a.tilesN;
+    if (grid <= 0 || grid > 0x7fffffffLL) {
+        ccst_set_error("conv: bad grid %lld", grid);
+        return CCST_EINVAL;
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, NT, POOL>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    return ccst_launch_status("conv_igemm");
+}
+
+}  // namespace
+
+extern "C" int ccst_conv2d_igemm_f32(const CcstConvDesc* d, const float* x, const float* w_packed, const float* bias,
+                                     float* y, void* stream) {
+    CCST_REQUIRE(d && x && w_packed && y, "conv: null pointer");
+    CCST_REQUIRE(d->cin > 0 && d->cin % CK == 0, "conv: cin=%d must be a positive multiple of 16", d->cin);
+    CCST_REQUIRE(d->cout > 0 && d->cout_pad >= d->cout && d->cout_pad % 128 == 0, "conv: cout=%d cout_pad=%d (need multiple of 128)",
+                 d->cout, d->cout_pad);
+    CCST_REQUIRE(d->n > 0 && d->ho > 0 && d->wo > 0 && d->hi > 0 && d->wi > 0 && d->nky > 0 && d->nkx > 0, "conv: bad extents");
+    CCST_REQUIRE((long long)d->n * d->ho * d->wo < 0x7fffffffLL, "conv: M too large");
+    const bool pool = (d->flags & CCST_CONV_POOL2) != 0;
+    if (d->flags & CCST_CONV_REFLECT) CCST_REQUIRE(d->hi >= 2 && d->wi >= 2, "conv: reflection needs extent >= 2");
+    ConvArgs a;
+    a.x = x; a.w = w_packed; a.bias = bias; a.y = y;
+    a.N = d->n; a.Ho = d->ho; a.Wo = d->wo; a.Hi = d->hi; a.Wi = d->wi; a.Cin = d->cin; a.Cout = d->cout; a.CoutPad = d->cout_pad;
+    a.nky = d->nky; a.nkx = d->nkx; a.ay = d->ay; a.by = d->by; a.cy = d->cy; a.ax = d->ax; a.bx = d->bx; a.cx = d->cx;
+    a.tap_base = d->tap_base; a.tap_sy = d->tap_sy; a.tap_sx = d->tap_sx;
+    a.xsN = d->xsN; a.xsH = d->xsH; a.xsW = d->xsW;
+    a.y_off = d->y_off; a.ysN = d->ysN; a.ysH = d->ysH; a.ysW = d->ysW; a.ysC = d->ysC;
+    a.flags = d->flags;
+    a.M = d->n * d->ho * d->wo;
+    hipStream_t s = (hipStream_t)stream;
+    if (pool) {
+        if (d->cout <= 64) return launch_conv<4, 1, 2, true>(a, s);
+        return launch_conv<2, 2, 2, true>(a, s);
+    }
+    if (d->cout <= 32) return launch_conv<4, 1, 1, false>(a, s);
+    if (d->cout <= 64) return launch_conv<4, 1, 2, false>(a, s);
+    return launch_conv<2, 2, 2, false>(a, s);
+}
+
+extern "C" int ccst_pack_conv_weight_f32(const float* w_oihw, float* packed, int cout, int cin, int kh, int kw, int transpose,
+                                         int k_pad, int n_pad, void* stream) {
+    CCST_REQUIRE(w_oihw && packed, "pack: null pointer");
+    const int kdim = transpose ? cout : cin, ndim = transpose ? cin : cout;
+    CCST_REQUIRE(k_pad >= kdim && k_pad % 16 == 0, "pack: k_pad=%d must be a multiple of 16 >= %d", k_pad, kdim);
+    CCST_REQUIRE(n_pad >= ndim && n_pad % 128 == 0, "pack: n_pad=%d must be a multiple of 128 >= %d", n_pad, ndim);
+    const long long total = (long long)kh * kw * k_pad * n_pad;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, cout, cin, kh * kw,
+                       transpose, k_pad, n_pad);
+    return ccst_launch_status("pack_weight");
+}
+
+extern "C" int ccst_nchw_to_nhwc4_pad_f32(const float* x, float* y, int N, int C, int H, int W, int pad, int Wp, int reflect,
+                                          void* stream) {
+    CCST_REQUIRE(x && y && N > 0 && C >= 1 && C <= 4 && H > 0 && W > 0 && pad >= 0 && Wp >= W + 2 * pad, "nchw_to_nhwc4: bad args");
+    if (reflect) CCST_REQUIRE(H > pad && W > pad, "nchw_to_nhwc4: reflection pad %d needs extent > pad", pad);
+    const long long total = (long long)N * (H + 2 * pad) * Wp;
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(nchw_to_nhwc4_pad_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (f32x4*)y, N, C, H, W, pad, Wp,
+                       reflect);
+    return ccst_launch_status("nchw_to_nhwc4_pad");
+}

@@ -1,0 +1,138 @@
+// Stand-alone NHWC layer ops for the AdaIN networks (net.py:6-69) when a layer is NOT fused into a
+// convolution (arbitrary slices of the nn.Sequential), plus NCHW<->NHWC transposes for API tensors.
+// All HBM-bound; 16-B accesses along C.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int reflect1(int i, int n) {
+    i = (i < 0) ? -i : i;
+    return (i >= n) ? 2 * n - 2 - i : i;
+}
+
+// x[N,C,HW] -> y[N,HW,Cp] (Cp >= C, zero filled) through a 32x32 LDS tile.
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int HW, int Cp) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 8 rows per pass
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        tile[r][tx] = (c < C && p < HW) ? x[((long long)n * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        if (p < HW && c < Cp) y[((long long)n * HW + p) * Cp + c] = tile[tx][r];
+    }
+}
+
+// x[N,HW,Cs] (first C channels used) -> y[N,C,HW]
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int HW, int Cs) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z;
+    const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        tile[r][tx] = (c < C && p < HW) ? x[((long long)n * HW + p) * Cs + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        if (c < C && p < HW) y[((long long)n * C + c) * HW + p] = tile[tx][r];
+    }
+}
+
+// mode 0: ReLU (same shape)            mode 1: ReflectionPad2d(pad)   [H,W] -> [H+2p, W+2p]
+// mode 2: Upsample nearest x2          mode 3: MaxPool2d(2,2,ceil_mode=True)
+template <int MODE>
+__global__ void nhwc_map_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int N, int H, int W, int Ho, int Wo, int C4,
+                                int pad) {
+    const long long total = (long long)N * Ho * Wo * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4);
+        long long j = i / C4;
+        const int ox = (int)(j % Wo);
+        j /= Wo;
+        const int oy = (int)(j % Ho);
+        const int n = (int)(j / Ho);
+        const f32x4* xb = x + (long long)n * H * W * C4 + c;
+        f32x4 v;
+        if (MODE == 0) {
+            v = xb[((long long)oy * W + ox) * C4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        } else if (MODE == 1) {
+            v = xb[((long long)reflect1(oy - pad, H) * W + reflect1(ox - pad, W)) * C4];
+        } else if (MODE == 2) {
+            v = xb[((long long)(oy >> 1) * W + (ox >> 1)) * C4];
+        } else {
+            const int y0 = 2 * oy, x0 = 2 * ox;
+            v = xb[((long long)y0 * W + x0) * C4];
+            if (x0 + 1 < W) {
+                const f32x4 u = xb[((long long)y0 * W + x0 + 1) * C4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], u[k]);
+            }
+            if (y0 + 1 < H) {
+                f32x4 u = xb[((long long)(y0 + 1) * W + x0) * C4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], u[k]);
+                if (x0 + 1 < W) {
+                    u = xb[((long long)(y0 + 1) * W + x0 + 1) * C4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], u[k]);
+                }
+            }
+        }
+        y[i] = v;
+    }
+}
+
+int grid_for(long long total) {
+    long long g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" int ccst_nchw_to_nhwc_f32(const float* x, float* y, int N, int C, int HW, int Cp, void* stream) {
+    CCST_REQUIRE(x && y && N > 0 && C > 0 && HW > 0 && Cp >= C && N <= 65535, "nchw_to_nhwc: bad args");
+    dim3 grid((HW + 31) / 32, (Cp + 31) / 32, N);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, C, HW, Cp);
+    return ccst_launch_status("nchw_to_nhwc");
+}
+
+extern "C" int ccst_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int HW, int Cs, void* stream) {
+    CCST_REQUIRE(x && y && N > 0 && C > 0 && HW > 0 && Cs >= C && N <= 65535, "nhwc_to_nchw: bad args");
+    dim3 grid((HW + 31) / 32, (C + 31) / 32, N);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, C, HW, Cs);
+    return ccst_launch_status("nhwc_to_nchw");
+}
+
+extern "C" int ccst_nhwc_layer_f32(int mode, const float* x, float* y, int N, int H, int W, int C, int pad, void* stream) {
+    CCST_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "nhwc_layer: bad args (C %% 4 must be 0)");
+    const int C4 = C / 4;
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0) {
+        const long long t = (long long)N * H * W * C4;
+        hipLaunchKernelGGL(nhwc_map_kernel<0>, dim3(grid_for(t)), dim3(256), 0, s, (const f32x4*)x, (f32x4*)y, N, H, W, H, W, C4, 0);
+    } else if (mode == 1) {
+        CCST_REQUIRE(pad >= 0 && pad < H && pad < W, "reflection pad %d needs extent > pad", pad);
+        const int Ho = H + 2 * pad, Wo = W + 2 * pad;
+        const long long t = (long long)N * Ho * Wo * C4;
+        hipLaunchKernelGGL(nhwc_map_kernel<1>, dim3(grid_for(t)), dim3(256), 0, s, (const f32x4*)x, (f32x4*)y, N, H, W, Ho, Wo, C4, pad);
+    } else if (mode == 2) {
+        const long long t = (long long)N * 4 * H * W * C4;
+        hipLaunchKernelGGL(nhwc_map_kernel<2>, dim3(grid_for(t)), dim3(256), 0, s, (const f32x4*)x, (f32x4*)y, N, H, W, 2 * H, 2 * W, C4, 0);
+    } else if (mode == 3) {
+        const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+        const long long t = (long long)N * Ho * Wo * C4;
+        hipLaunchKernelGGL(nhwc_map_kernel<3>, dim3(grid_for(t)), dim3(256), 0, s, (const f32x4*)x, (f32x4*)y, N, H, W, Ho, Wo, C4, 0);
+    } else {
+        ccst_set_error("nhwc_layer: unknown mode %d", mode);
+        return CCST_EINVAL;
+    }
+    return ccst_launch_status("nhwc_layer");
+}

@@ -1,0 +1,317 @@
+"""Drop-in for style_transfer/AdaIN/net.py: module-level ``vgg`` and ``decoder``
+nn.Sequential objects with the reference's layer indices and state-dict keys
+(net.py:6-36, :38-92), executed by hand-written HIP kernels.
+
+* ``vgg`` / ``decoder`` are :class:`Sequential` instances.  Calling one (or any
+  slice ``vgg[:31]``, or ``Sequential(*list(vgg.children())[:31])``) compiles a
+  fused plan: ReflectionPad2d+Conv2d+ReLU(+MaxPool2d) and Upsample+Pad+Conv
+  become single implicit-GEMM launches; the 1x1 colour conv (net.py:39) is
+  folded into conv1_1's weights.
+* The children are subclasses of the torch.nn layers whose ``forward`` also
+  runs HIP kernels, so the reference idiom
+  ``nn.Sequential(*list(vgg.children())[:31])`` (CCST_OverallStyleTransfer.py:124)
+  still executes on this library -- un-fused and slower, same results.
+* Tensors at the boundary are logical NCHW fp32 CUDA tensors; feature maps are
+  returned as channels_last views of the internal NHWC buffers.
+
+There is no CPU execution path: CPU tensors raise.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+# ---------------------------------------------------------------------------
+# plan compiler
+# ---------------------------------------------------------------------------
+def _is_pad1(m):
+    return isinstance(m, nn.ReflectionPad2d) and tuple(m.padding) == (1, 1, 1, 1)
+
+
+def _is_conv(m, k=None):
+    if not isinstance(m, nn.Conv2d):
+        return False
+    if m.groups != 1 or tuple(m.dilation) != (1, 1) or m.padding_mode != "zeros" or isinstance(m.padding, str):
+        raise NotImplementedError("ccst_amd: unsupported Conv2d configuration %r" % (m,))
+    return k is None or tuple(m.kernel_size) == (k, k)
+
+
+def _is_valid3(m):
+    return _is_conv(m, 3) and tuple(m.stride) == (1, 1) and tuple(m.padding) == (0, 0)
+
+
+def _is_pool2(m):
+    def pair(v):
+        return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+    return isinstance(m, nn.MaxPool2d) and pair(m.kernel_size) == (2, 2) and pair(m.stride) == (2, 2) and \
+        pair(m.padding) == (0, 0) and m.ceil_mode and pair(m.dilation) == (1, 1)
+
+
+def _is_up2(m):
+    return isinstance(m, nn.Upsample) and m.mode == "nearest" and m.scale_factor is not None and \
+        float(m.scale_factor if not isinstance(m.scale_factor, (tuple, list)) else m.scale_factor[0]) == 2.0 and m.size is None
+
+
+class _Step(object):
+    """One launch (or launch pair) of the plan."""
+    __slots__ = ("kind", "pc", "kw", "kwp", "stride", "pad", "reflect", "relu", "pool", "ups", "out_nchw", "in_nchw")
+
+    def __init__(self, kind, **kw):
+        self.kind = kind
+        self.pc = self.kw = self.kwp = None
+        self.stride, self.pad = 1, 0
+        self.reflect = self.relu = self.pool = self.ups = self.out_nchw = self.in_nchw = False
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+
+def _compile(mods):
+    steps = []
+    n = len(mods)
+    i = 0
+    pending_up = False
+
+    def at(j):
+        return mods[j] if j < n else None
+
+    while i < n:
+        m = mods[i]
+        if _is_up2(m):
+            nxt, nxt2 = at(i + 1), at(i + 2)
+            if nxt is not None and _is_pad1(nxt) and nxt2 is not None and _is_valid3(nxt2) and nxt2.in_channels % 16 == 0:
+                pending_up = True
+            else:
+                steps.append(_Step("up"))
+            i += 1
+            continue
+        # folded colour conv: Conv2d(3,3,1x1) -> pad -> Conv2d(3,Cout,3x3)   (net.py:39-41)
+        if _is_conv(m, 1) and m.in_channels <= 4 and m.out_channels <= 4 and tuple(m.stride) == (1, 1) and \
+                tuple(m.padding) == (0, 0) and at(i + 1) is not None and _is_pad1(at(i + 1)) and at(i + 2) is not None and \
+                _is_valid3(at(i + 2)) and at(i + 2).in_channels == m.out_channels:
+            c0, c1 = m, at(i + 2)
+            w0 = c0.weight.detach()[:, :, 0, 0]                       # [mid, in]
+            w1 = c1.weight.detach()                                   # [out, mid, 3, 3]
+            wf = torch.einsum("omyx,mi->oiyx", w1, w0).contiguous()   # W' = W o W0
+            b0 = c0.bias.detach() if c0.bias is not None else torch.zeros(c0.out_channels, device=w1.device)
+            bf = torch.einsum("omyx,m->o", w1, b0)
+            if c1.bias is not None:
+                bf = bf + c1.bias.detach()
+            j = i + 3
+            relu = isinstance(at(j), nn.ReLU)
+            j += int(relu)
+            wv, kwp = ops.stem_virtual_weight(wf)
+            steps.append(_Step("stem", pc=ops.pack_conv_weight(wv, bf.contiguous()), kw=3, kwp=kwp, pad=1, reflect=True, relu=relu))
+            i = j
+            continue
+        if _is_pad1(m) and at(i + 1) is not None and _is_valid3(at(i + 1)):
+            conv = at(i + 1)
+            j = i + 2
+            relu = isinstance(at(j), nn.ReLU)
+            j += int(relu)
+            if conv.in_channels <= 4:
+                wv, kwp = ops.stem_virtual_weight(conv.weight.detach())
+                steps.append(_Step("stem", pc=ops.pack_conv_weight(wv, conv.bias), kw=3, kwp=kwp, pad=1, reflect=True, relu=relu))
+            else:
+                pool = at(j) is not None and _is_pool2(at(j)) and conv.out_channels % 16 == 0
+                j += int(pool)
+                steps.append(_Step("conv", pc=ops.pack_conv_weight(conv.weight.detach(), conv.bias), pad=1, reflect=True,
+                                   relu=relu, pool=pool, ups=pending_up))
+                pending_up = False
+            i = j
+            continue
+        if _is_conv(m):
+            if m.kernel_size[0] != m.kernel_size[1] or m.stride[0] != m.stride[1] or m.padding[0] != m.padding[1]:
+                raise NotImplementedError("ccst_amd: non-square Conv2d %r" % (m,))
+            j = i + 1
+            relu = isinstance(at(j), nn.ReLU)
+            j += int(relu)
+            if m.in_channels <= 4:
+                wv, kwp = ops.stem_virtual_weight(m.weight.detach())
+                steps.append(_Step("stem", pc=ops.pack_conv_weight(wv, m.bias), kw=m.kernel_size[1], kwp=kwp,
+                                   stride=m.stride[0], pad=m.padding[0], relu=relu))
+            else:
+                steps.append(_Step("conv", pc=ops.pack_conv_weight(m.weight.detach(), m.bias), stride=m.stride[0],
+                                   pad=m.padding[0], relu=relu))
+            i = j
+            continue
+        if isinstance(m, nn.ReLU):
+            steps.append(_Step("relu"))
+        elif isinstance(m, nn.ReflectionPad2d):
+            p = tuple(m.padding)
+            if len(set(p)) != 1:
+                raise NotImplementedError("ccst_amd: asymmetric ReflectionPad2d %r" % (p,))
+            steps.append(_Step("pad", pad=p[0]))
+        elif _is_pool2(m):
+            steps.append(_Step("pool"))
+        else:
+            raise NotImplementedError("ccst_amd: layer %r has no HIP implementation in this path" % (m,))
+        i += 1
+    # image edges: a conv producing <= 4 channels at the end writes NCHW directly
+    if steps and steps[-1].kind == "conv" and steps[-1].pc.cout <= 4:
+        steps[-1].out_nchw = True
+    for s in steps:
+        if s.kind == "conv" and s.pc.cout % 16 != 0 and not s.out_nchw:
+            raise NotImplementedError("ccst_amd: intermediate Conv2d with %d output channels (need a multiple of 16)" % s.pc.cout)
+    return steps
+
+
+def _run(steps, x):
+    """x: logical NCHW CUDA tensor.  Returns a logical NCHW tensor."""
+    if not (isinstance(x, torch.Tensor) and x.is_cuda):
+        raise RuntimeError("ccst_amd.net: input must be a CUDA (ROCm) tensor; the HIP path has no CPU fallback")
+    if x.dim() != 4:
+        raise RuntimeError("ccst_amd.net: expected a 4-D NCHW tensor")
+    C = x.shape[1]
+    cur = None          # NHWC buffer
+    api = x             # logical NCHW tensor not yet converted
+    for s in steps:
+        if s.kind == "stem":
+            if cur is not None:
+                api = ops.to_api(cur[..., :C]) if cur.shape[-1] != C else ops.to_api(cur)
+            img = ops.as_nchw_contiguous(api)
+            cur = ops.conv2d_stem_nchw(img, s.pc, s.kwp, s.kw, stride=s.stride, pad=s.pad, reflect=s.reflect, relu=s.relu)
+            C = s.pc.cout
+            api = None
+            continue
+        if cur is None:
+            cur = ops.from_api(api, cpad=16 if s.kind == "conv" else 4)
+            api = None
+        if s.kind == "conv":
+            if cur.shape[-1] != s.pc.k_pad:
+                cur = ops.from_api(ops.to_api(cur[..., :C]), cpad=16)
+            out = ops.conv2d_nhwc(cur, s.pc, stride=s.stride, pad=s.pad, reflect=s.reflect, relu=s.relu, pool=s.pool,
+                                  ups=s.ups, out_nchw=s.out_nchw)
+            C = s.pc.cout
+            if s.out_nchw:
+                return out
+            cur = out
+        elif s.kind == "relu":
+            cur = ops.relu_nhwc(cur)
+        elif s.kind == "pad":
+            cur = ops.reflection_pad_nhwc(cur, s.pad)
+        elif s.kind == "up":
+            cur = ops.upsample2_nhwc(cur)
+        elif s.kind == "pool":
+            cur = ops.maxpool2_ceil_nhwc(cur)
+    if cur is None:
+        return api
+    y = ops.to_api(cur)
+    return y if cur.shape[-1] == C else y[:, :C]
+
+
+def _signature(mods):
+    sig = []
+    for m in mods:
+        for p in m.parameters(recurse=False):
+            sig.append((id(p), p._version, p.data_ptr()))
+    return (tuple(id(m) for m in mods), tuple(sig))
+
+
+class _PlanCache(object):
+    def __init__(self):
+        self.sig = None
+        self.steps = None
+
+    def get(self, mods):
+        sig = _signature(mods)
+        if sig != self.sig:
+            for m in mods:
+                for p in m.parameters(recurse=False):
+                    if not p.is_cuda:
+                        raise RuntimeError("ccst_amd.net: move the network to the GPU first (.to('cuda')); no CPU fallback")
+            with torch.no_grad():
+                self.steps = _compile(mods)
+            self.sig = sig
+        return self.steps
+
+
+# ---------------------------------------------------------------------------
+# modules
+# ---------------------------------------------------------------------------
+class Sequential(nn.Sequential):
+    """nn.Sequential whose forward is the fused HIP plan.  Inference only (the CCST scripts run
+    these networks frozen, under no_grad: CCST_OverallStyleTransfer.py:151)."""
+
+    def forward(self, input):
+        cache = self.__dict__.get("_ccst_plan")
+        if cache is None:
+            cache = _PlanCache()
+            self.__dict__["_ccst_plan"] = cache
+        return _run(cache.get(list(self.children())), input)
+
+
+class _SingleMixin(object):
+    def _ccst_forward(self, input):
+        cache = self.__dict__.get("_ccst_plan")
+        if cache is None:
+            cache = _PlanCache()
+            self.__dict__["_ccst_plan"] = cache
+        return _run(cache.get([self]), input)
+
+
+class Conv2d(_SingleMixin, nn.Conv2d):
+    def forward(self, input):
+        return self._ccst_forward(input)
+
+
+class ReflectionPad2d(_SingleMixin, nn.ReflectionPad2d):
+    def forward(self, input):
+        return self._ccst_forward(input)
+
+
+class ReLU(_SingleMixin, nn.ReLU):
+    def forward(self, input):
+        return self._ccst_forward(input)
+
+
+class MaxPool2d(_SingleMixin, nn.MaxPool2d):
+    def forward(self, input):
+        return self._ccst_forward(input)
+
+
+class Upsample(_SingleMixin, nn.Upsample):
+    def forward(self, input):
+        return self._ccst_forward(input)
+
+
+def _pad():
+    return ReflectionPad2d((1, 1, 1, 1))
+
+
+def _block(cin, cout, relu=True):
+    layers = [_pad(), Conv2d(cin, cout, (3, 3))]
+    if relu:
+        layers.append(ReLU())
+    return layers
+
+
+def _pool():
+    return MaxPool2d((2, 2), (2, 2), (0, 0), ceil_mode=True)
+
+
+def _build_decoder():      # net.py:6-36
+    L = _block(512, 256) + [Upsample(scale_factor=2, mode='nearest')]
+    L += _block(256, 256) + _block(256, 256) + _block(256, 256) + _block(256, 128) + [Upsample(scale_factor=2, mode='nearest')]
+    L += _block(128, 128) + _block(128, 64) + [Upsample(scale_factor=2, mode='nearest')]
+    L += _block(64, 64) + _block(64, 3, relu=False)
+    return Sequential(*L)
+
+
+def _build_vgg():          # net.py:38-92
+    L = [Conv2d(3, 3, (1, 1))]
+    L += _block(3, 64) + _block(64, 64) + [_pool()]
+    L += _block(64, 128) + _block(128, 128) + [_pool()]
+    L += _block(128, 256) + _block(256, 256) + _block(256, 256) + _block(256, 256) + [_pool()]
+    L += _block(256, 512) + _block(512, 512) + _block(512, 512) + _block(512, 512) + [_pool()]
+    L += _block(512, 512) + _block(512, 512) + _block(512, 512) + _block(512, 512)
+    return Sequential(*L)
+
+
+decoder = _build_decoder()
+vgg = _build_vgg()
+
+
+def fuse(seq):
+    """Wrap any nn.Sequential of the supported layers into the fused HIP executor."""
+    return seq if isinstance(seq, Sequential) else Sequential(*list(seq.children()))

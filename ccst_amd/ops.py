@@ -1,0 +1,321 @@
+"""Thin Python wrappers over the C ABI: torch tensors in, raw device pointers
+out.  Activations are NHWC-contiguous fp32 tensors of shape [N,H,W,C];
+`to_api` / `from_api` convert to/from the logical-NCHW (channels_last) tensors
+the reference's Python surface exchanges -- zero-copy whenever possible.
+
+PyTorch here is plumbing (allocator, streams); every op is a HIP kernel from
+libccst_hip.so.  Nothing in this file falls back to torch compute on failure.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import CONV_POOL2, CONV_REFLECT, CONV_RELU, CONV_UPS2, CcstConvDesc, check, ptr, stream_ptr
+
+NCHW, NHWC = 0, 1
+
+# bench.py sets TIMING = [] to collect (kernel name, algorithmic flops, start event, end event) per conv launch.
+TIMING = None
+
+
+def _conv_kernel_name(cout, pool):
+    """Mirror of the tile dispatch in csrc/conv_igemm.hip (ccst_conv2d_igemm_f32)."""
+    if pool:
+        return "conv_igemm_kernel<4,1,2,pool>" if cout <= 64 else "conv_igemm_kernel<2,2,2,pool>"
+    if cout <= 32:
+        return "conv_igemm_kernel<4,1,1>"
+    return "conv_igemm_kernel<4,1,2>" if cout <= 64 else "conv_igemm_kernel<2,2,2>"
+
+
+def _launch_conv(d, x, pc, out, flops, pool, what):
+    lib = _lib.load()
+    if TIMING is None:
+        check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(x), ptr(pc.w), ptr(pc.bias), ptr(out), stream_ptr()), what)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(x), ptr(pc.w), ptr(pc.bias), ptr(out), stream_ptr()), what)
+    e1.record()
+    TIMING.append((_conv_kernel_name(pc.cout, pool), flops, e0, e1))
+
+
+def _require_cuda(t, name="tensor"):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise RuntimeError("ccst_amd: %s must be a CUDA (ROCm) tensor -- the HIP path has no CPU fallback" % name)
+    if t.dtype != torch.float32:
+        raise RuntimeError("ccst_amd: %s must be float32, got %s" % (name, t.dtype))
+
+
+def round_up(a, b):
+    return (a + b - 1) // b * b
+
+
+# ---------------------------------------------------------------------------
+# layout plumbing
+# ---------------------------------------------------------------------------
+def to_api(y_nhwc):
+    """[N,H,W,C] NHWC buffer -> logical NCHW view (channels_last strides), no copy."""
+    return y_nhwc.permute(0, 3, 1, 2)
+
+
+def from_api(x, cpad=1):
+    """Logical NCHW tensor -> NHWC-contiguous [N,H,W,Cp] (Cp = C rounded up to cpad, zero filled).
+    Zero-copy if x is already channels_last with C % cpad == 0."""
+    _require_cuda(x, "input")
+    assert x.dim() == 4
+    N, C, H, W = x.shape
+    Cp = round_up(C, cpad)
+    v = x.permute(0, 2, 3, 1)
+    if Cp == C and v.is_contiguous():
+        return v
+    x = as_nchw_contiguous(x)
+    y = torch.empty((N, H, W, Cp), device=x.device, dtype=torch.float32)
+    check(_lib.load().ccst_nchw_to_nhwc_f32(ptr(x), ptr(y), N, C, H * W, Cp, stream_ptr()), "nchw_to_nhwc")
+    return y
+
+
+def to_nchw_contiguous(y_nhwc, C=None):
+    N, H, W, Cs = y_nhwc.shape
+    C = Cs if C is None else C
+    out = torch.empty((N, C, H, W), device=y_nhwc.device, dtype=torch.float32)
+    check(_lib.load().ccst_nhwc_to_nchw_f32(ptr(y_nhwc), ptr(out), N, C, H * W, Cs, stream_ptr()), "nhwc_to_nchw")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# convolution
+# ---------------------------------------------------------------------------
+class PackedConv(object):
+    """Device-resident packed weight [kh*kw][K/4][n_pad][4] (+ optional bias)."""
+    __slots__ = ("w", "bias", "cin", "cout", "kh", "kw", "k_pad", "n_pad", "transpose")
+
+    def __init__(self, w, bias, cin, cout, kh, kw, k_pad, n_pad, transpose):
+        self.w, self.bias, self.cin, self.cout, self.kh, self.kw = w, bias, cin, cout, kh, kw
+        self.k_pad, self.n_pad, self.transpose = k_pad, n_pad, transpose
+
+
+def pack_conv_weight(w_oihw, bias=None, transpose=False, out=None):
+    """OIHW checkpoint tensor -> PackedConv.  transpose=True builds the backward-data operand."""
+    _require_cuda(w_oihw, "weight")
+    w = w_oihw.contiguous()
+    cout, cin, kh, kw = w.shape
+    kdim, ndim = (cout, cin) if transpose else (cin, cout)
+    k_pad, n_pad = round_up(kdim, 16), round_up(ndim, 128)
+    if out is None:
+        out = torch.empty(kh * kw * k_pad * n_pad, device=w.device, dtype=torch.float32)
+    check(_lib.load().ccst_pack_conv_weight_f32(ptr(w), ptr(out), cout, cin, kh, kw, int(transpose), k_pad, n_pad,
+                                                stream_ptr()), "pack_conv_weight")
+    b = None
+    if bias is not None:
+        _require_cuda(bias, "bias")
+        b = bias.detach().contiguous()
+    return PackedConv(out, b, cin, cout, kh, kw, k_pad, n_pad, transpose)
+
+
+def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, ups=False, out_nchw=False, out=None):
+    """Forward convolution of an NHWC tensor x [N,Hs,Ws,Cin_pad] with PackedConv pc.
+
+    ups:  x is read through a nearest x2 upsample (logical input is [2Hs,2Ws]).
+    pool: fused MaxPool2d(2,2,ceil_mode=True) epilogue.
+    out_nchw: write a contiguous NCHW tensor (the image edge of the decoder).
+    """
+    _require_cuda(x, "activation")
+    assert x.is_contiguous() and x.dim() == 4 and not pc.transpose
+    N, Hs, Ws, Cx = x.shape
+    assert Cx == pc.k_pad, "activation has %d channels, packed weight expects %d" % (Cx, pc.k_pad)
+    Hi, Wi = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
+    ho = (Hi + 2 * pad - pc.kh) // stride + 1
+    wo = (Wi + 2 * pad - pc.kw) // stride + 1
+    assert ho > 0 and wo > 0
+    d = CcstConvDesc()
+    d.n, d.ho, d.wo, d.hi, d.wi = N, ho, wo, Hi, Wi
+    d.cin, d.cout, d.cout_pad = pc.k_pad, pc.cout, pc.n_pad
+    d.nky, d.nkx = pc.kh, pc.kw
+    d.ay, d.by, d.cy = stride, 1, -pad
+    d.ax, d.bx, d.cx = stride, 1, -pad
+    d.tap_base, d.tap_sy, d.tap_sx = 0, pc.kw, 1
+    d.xsN, d.xsH, d.xsW = Hs * Ws * Cx, Ws * Cx, Cx
+    flags = (CONV_RELU if relu else 0) | (CONV_POOL2 if pool else 0) | (CONV_UPS2 if ups else 0) | \
+        (CONV_REFLECT if reflect else 0)
+    d.flags = flags
+    oh, ow = ((ho + 1) // 2, (wo + 1) // 2) if pool else (ho, wo)
+    if out_nchw:
+        assert not pool
+        if out is None:
+            out = torch.empty((N, pc.cout, oh, ow), device=x.device, dtype=torch.float32)
+        d.y_off, d.ysN, d.ysH, d.ysW, d.ysC = 0, pc.cout * oh * ow, ow, 1, oh * ow
+    else:
+        if out is None:
+            out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
+        d.y_off, d.ysN, d.ysH, d.ysW, d.ysC = 0, oh * ow * pc.cout, ow * pc.cout, pc.cout, 1
+    _launch_conv(d, x, pc, out, 2.0 * N * ho * wo * pc.cout * pc.cin * pc.kh * pc.kw, pool, "conv2d_igemm")
+    return out
+
+
+def stem_virtual_weight(w_oihw):
+    """[Cout,C<=4,kh,kw] -> [Cout, KWP*4, kh, 1]: the kx taps of a row become channels of a
+    'virtual pixel' of the NHWC4 image (K per row = KWP*4, a multiple of 16)."""
+    cout, c, kh, kw = w_oihw.shape
+    assert c <= 4
+    kwp = round_up(kw * 4, 16) // 4
+    wv = torch.zeros((cout, kwp, 4, kh), device=w_oihw.device, dtype=torch.float32)
+    wv[:, :kw, :c, :] = w_oihw.permute(0, 3, 1, 2)
+    return wv.reshape(cout, kwp * 4, kh, 1), kwp
+
+
+def conv2d_stem_nchw(x_nchw, pc_virtual, kwp, kw, stride=1, pad=0, reflect=False, relu=False):
+    """Small-Cin (<=4) stem on a contiguous NCHW image: pad+transpose to NHWC4 once, then an
+    implicit GEMM whose K runs over (ky, kx*4+ci).  Returns NHWC [N,ho,wo,Cout]."""
+    _require_cuda(x_nchw, "image")
+    x = as_nchw_contiguous(x_nchw)
+    N, C, H, W = x.shape
+    kh = pc_virtual.kh
+    ho = (H + 2 * pad - kh) // stride + 1
+    wo = (W + 2 * pad - kw) // stride + 1
+    Hp = H + 2 * pad
+    Wp = max(W + 2 * pad, (wo - 1) * stride + kwp)
+    xp = torch.empty((N, Hp, Wp, 4), device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    check(lib.ccst_nchw_to_nhwc4_pad_f32(ptr(x), ptr(xp), N, C, H, W, pad, Wp, int(reflect), stream_ptr()), "nchw_to_nhwc4_pad")
+    d = CcstConvDesc()
+    d.n, d.ho, d.wo, d.hi, d.wi = N, ho, wo, Hp, Wp
+    d.cin, d.cout, d.cout_pad = pc_virtual.k_pad, pc_virtual.cout, pc_virtual.n_pad
+    d.nky, d.nkx = kh, 1
+    d.ay, d.by, d.cy = stride, 1, 0
+    d.ax, d.bx, d.cx = stride, 0, 0
+    d.tap_base, d.tap_sy, d.tap_sx = 0, 1, 0
+    d.xsN, d.xsH, d.xsW = Hp * Wp * 4, Wp * 4, 4
+    d.flags = CONV_RELU if relu else 0
+    out = torch.empty((N, ho, wo, pc_virtual.cout), device=x.device, dtype=torch.float32)
+    d.y_off, d.ysN, d.ysH, d.ysW, d.ysC = 0, ho * wo * pc_virtual.cout, wo * pc_virtual.cout, pc_virtual.cout, 1
+    _launch_conv(d, xp, pc_virtual, out, 2.0 * N * ho * wo * pc_virtual.cout * C * kh * kw, False, "conv2d_igemm(stem)")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# stand-alone NHWC layers (un-fused use)
+# ---------------------------------------------------------------------------
+def _nhwc_layer(mode, x, pad=0):
+    _require_cuda(x, "activation")
+    assert x.is_contiguous() and x.dim() == 4
+    N, H, W, C = x.shape
+    if mode == 0:
+        shape = (N, H, W, C)
+    elif mode == 1:
+        shape = (N, H + 2 * pad, W + 2 * pad, C)
+    elif mode == 2:
+        shape = (N, 2 * H, 2 * W, C)
+    else:
+        shape = (N, (H + 1) // 2, (W + 1) // 2, C)
+    y = torch.empty(shape, device=x.device, dtype=torch.float32)
+    check(_lib.load().ccst_nhwc_layer_f32(mode, ptr(x), ptr(y), N, H, W, C, pad, stream_ptr()), "nhwc_layer")
+    return y
+
+
+def relu_nhwc(x):
+    return _nhwc_layer(0, x)
+
+
+def reflection_pad_nhwc(x, pad):
+    return _nhwc_layer(1, x, pad)
+
+
+def upsample2_nhwc(x):
+    return _nhwc_layer(2, x)
+
+
+def maxpool2_ceil_nhwc(x):
+    return _nhwc_layer(3, x)
+
+
+# ---------------------------------------------------------------------------
+# AdaIN statistics
+# ---------------------------------------------------------------------------
+def _stats_ws(N, C, HW, device):
+    nbytes = int(_lib.load().ccst_stats_workspace_bytes(N, C, HW))
+    return torch.empty(nbytes, device=device, dtype=torch.uint8), nbytes
+
+
+def nhwc_channel_stride(x):
+    """If logical-NCHW x is a (possibly channel-sliced) view of an NHWC buffer, return its channel
+    pitch Cs (>= C); else None."""
+    N, C, H, W = x.shape
+    sn, sc, sh, sw = x.stride()
+    if sc != 1 and C > 1:
+        return None
+    Cs = sw if W > 1 else (sh if H > 1 else C)
+    if Cs < C:
+        return None
+    if (W > 1 and sw != Cs) or (H > 1 and sh != W * Cs) or (N > 1 and sn != H * W * Cs):
+        return None
+    return Cs
+
+
+def as_nchw_contiguous(x):
+    """Logical-NCHW CUDA tensor -> NCHW-contiguous, using the HIP transpose when x is NHWC-strided."""
+    _require_cuda(x, "input")
+    if x.is_contiguous():
+        return x
+    Cs = nhwc_channel_stride(x)
+    if Cs is None:
+        raise RuntimeError("ccst_amd: tensor must be NCHW-contiguous or an NHWC (channels_last) view")
+    N, C, H, W = x.shape
+    out = torch.empty((N, C, H, W), device=x.device, dtype=torch.float32)
+    check(_lib.load().ccst_nhwc_to_nchw_f32(ptr(x), ptr(out), N, C, H * W, Cs, stream_ptr()), "nhwc_to_nchw")
+    return out
+
+
+def _layout_of(feat):
+    """feat: logical NCHW tensor.  Returns (buffer tensor, layout flag)."""
+    _require_cuda(feat, "feature map")
+    assert feat.dim() == 4
+    if feat.is_contiguous():
+        return feat, NCHW
+    v = feat.permute(0, 2, 3, 1)
+    if v.is_contiguous() and feat.shape[1] % 4 == 0:
+        return v, NHWC
+    return as_nchw_contiguous(feat), NCHW
+
+
+def calc_mean_std(feat, eps=1e-5):
+    """function.py:4-13 on a logical-NCHW CUDA tensor (either memory format)."""
+    N, C, H, W = feat.shape
+    buf, layout = _layout_of(feat)
+    mean = torch.empty((N, C, 1, 1), device=feat.device, dtype=torch.float32)
+    std = torch.empty((N, C, 1, 1), device=feat.device, dtype=torch.float32)
+    ws, nb = _stats_ws(N, C, H * W, feat.device)
+    check(_lib.load().ccst_calc_mean_std_f32(ptr(buf), ptr(mean), ptr(std), N, C, H * W, layout, eps, ptr(ws), nb,
+                                             stream_ptr()), "calc_mean_std")
+    return mean, std
+
+
+def adain(feat, style_mean, style_std, alpha=1.0, eps=1e-5):
+    """function.py:26-33 fused with the alpha blend (CCST_OverallStyleTransfer.py:45).
+    style_mean/std: [1,C,1,1] (broadcast over N) or [N,C,1,1].  Output has feat's memory format."""
+    N, C, H, W = feat.shape
+    buf, layout = _layout_of(feat)
+    sm = style_mean.to(device=feat.device, dtype=torch.float32).reshape(-1).contiguous()
+    ss = style_std.to(device=feat.device, dtype=torch.float32).reshape(-1).contiguous()
+    if sm.numel() == C and ss.numel() == C:
+        per_n = 0
+    elif sm.numel() == N * C and ss.numel() == N * C:
+        per_n = 1
+    else:
+        raise RuntimeError("ccst_amd: style statistics must have C or N*C elements")
+    out = torch.empty_like(buf)
+    ws, nb = _stats_ws(N, C, H * W, feat.device)
+    check(_lib.load().ccst_adain_f32(ptr(buf), ptr(sm), ptr(ss), per_n, float(alpha), ptr(out), N, C, H * W, layout, eps,
+                                     ptr(ws), nb, stream_ptr()), "adain")
+    return out if layout == NCHW else to_api(out)
+
+
+def chan_sums(feat):
+    """calc_sum (mean_std_computation_effcientMem.py:103-115): ([1,C,1,1] sum, [1,C,1,1] sqsum, count)."""
+    N, C, H, W = feat.shape
+    buf, layout = _layout_of(feat)
+    s = torch.empty((1, C, 1, 1), device=feat.device, dtype=torch.float32)
+    q = torch.empty((1, C, 1, 1), device=feat.device, dtype=torch.float32)
+    ws, nb = _stats_ws(N, C, H * W, feat.device)
+    check(_lib.load().ccst_chan_sums_f32(ptr(buf), ptr(s), ptr(q), N, C, H * W, layout, ptr(ws), nb, stream_ptr()), "chan_sums")
+    return s, q, N * H * W

@@ -1,0 +1,172 @@
+/*
+ * ccst_hip.h -- C ABI of libccst_hip.so, the MI355X (gfx950) kernels behind the
+ * CCST hot path.  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * The reference (JeremyCJM/CCST) is pure Python and has no FFI of its own
+ * (SURVEY.md 2.1): every entry point below replaces one of the *implicit ATen
+ * ops* the reference's hot path dispatches, cited per function as
+ * <file>:<line> relative to the reference root.  The Python host code in
+ * ccst_amd/ binds these with ctypes (see INTEGRATION.md for the stub).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's caching
+ *     allocator in practice); the library allocates nothing and keeps no
+ *     mutable global state; workspaces are passed explicitly;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL =
+ *     the default stream); no call synchronises;
+ *   - return 0 on success, a negative CCST_E* code for bad arguments, or a
+ *     positive hipError_t if the launch failed; nothing throws;
+ *   - activations are fp32 NHWC ("channels last") unless a flag says NCHW;
+ *     conv weights are fp32 in the packed layout produced by
+ *     ccst_pack_conv_weight_f32 from the checkpoint's OIHW tensor.
+ */
+#ifndef CCST_HIP_H
+#define CCST_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCST_OK 0
+#define CCST_EINVAL (-1)   /* bad argument / unsupported shape */
+#define CCST_EWORKSPACE (-2) /* workspace too small */
+
+#define CCST_ABI_VERSION 1
+int ccst_abi_version(void);
+/* Human-readable text for the last non-zero return on this thread. */
+const char* ccst_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Implicit-GEMM convolution on the fp32-input MFMA (v_mfma_f32_32x32x2_f32).
+ *
+ * One descriptor drives forward convs (any kernel size / stride / zero or
+ * reflection padding), the stride-1 and per-parity stride-2 backward-data
+ * convs, and the "virtual pixel" small-Cin stems, through affine index maps:
+ *     iy = oy*ay + ky*by + cy        ix = ox*ax + kx*bx + cx
+ *     weight tap = tap_base + ky*tap_sy + kx*tap_sx
+ *     &y[n,oy,ox,co] = y + y_off + n*ysN + oy*ysH + ox*ysW + co*ysC
+ *     &x[n,iy,ix,ci] = x + n*xsN + iy*xsH + ix*xsW + ci
+ * Replaces: nn.ReflectionPad2d+nn.Conv2d(3x3)+nn.ReLU (+MaxPool2d ceil /
+ * +Upsample nearest) of style_transfer/AdaIN/net.py:6-36,38-69, and the
+ * bias-free Conv2d's of nets/resnet.py:136,160-161 + torchvision blocks
+ * (forward and backward-data).
+ * ------------------------------------------------------------------------ */
+#define CCST_CONV_RELU      1u   /* ReLU epilogue                                   */
+#define CCST_CONV_POOL2     2u   /* fused MaxPool2d(2,2,ceil_mode=True) epilogue:
+                                    y is the POOLED tensor (ysH/ysW are its strides) */
+#define CCST_CONV_UPS2      4u   /* input is read through a nearest x2 upsample:
+                                    x is the SOURCE [N,Hi/2,Wi/2,Cin] tensor         */
+#define CCST_CONV_REFLECT   8u   /* reflection padding (else zero padding)           */
+
+typedef struct CcstConvDesc {
+    int32_t n, ho, wo;          /* output pixel grid; GEMM M = n*ho*wo                */
+    int32_t hi, wi;             /* logical input extent used for bounds / reflection  */
+    int32_t cin, cout;          /* cin % 16 == 0; cout arbitrary                      */
+    int32_t cout_pad;           /* packed-weight column count (multiple of 128)       */
+    int32_t nky, nkx;           /* taps iterated                                      */
+    int32_t ay, by, cy, ax, bx, cx;
+    int32_t tap_base, tap_sy, tap_sx;
+    int64_t xsN; int32_t xsH, xsW;
+    int64_t y_off, ysN; int32_t ysH, ysW, ysC;
+    uint32_t flags;
+} CcstConvDesc;
+
+int ccst_conv2d_igemm_f32(const CcstConvDesc* d, const float* x, const float* w_packed,
+                          const float* bias /* may be NULL */, float* y, void* stream);
+
+/* OIHW [cout][cin][kh][kw] -> packed [kh*kw][cin/4][cout_pad][4] (transpose=0), or the
+ * backward-data operand [kh*kw][cout/4][cin_pad][4] (transpose=1: GEMM-K runs over cout).
+ * The K-side extent (cin, or cout when transposed) must be a multiple of 4; it is padded
+ * with zeros up to k_pad (a multiple of 16).  n_pad: multiple of 128. */
+int ccst_pack_conv_weight_f32(const float* w_oihw, float* packed, int cout, int cin, int kh, int kw,
+                              int transpose, int k_pad, int n_pad, void* stream);
+
+/* NCHW [N,C<=4,H,W] -> zero/reflect padded NHWC4 [N, H+2*pad, Wp, 4] (Wp >= W+2*pad, extra
+ * columns and channels C..3 zero).  Feeds the small-Cin stems (net.py:39-41; nets/resnet.py:136)
+ * as "virtual pixel" convs. */
+int ccst_nchw_to_nhwc4_pad_f32(const float* x, float* y, int N, int C, int H, int W, int pad, int Wp,
+                               int reflect, void* stream);
+
+/* Stand-alone layers of net.py:6-69 for un-fused use (arbitrary slices of the nn.Sequential), NHWC,
+ * C % 4 == 0.  mode 0: nn.ReLU; 1: nn.ReflectionPad2d(pad) -> [H+2p,W+2p]; 2: nn.Upsample(x2 nearest)
+ * -> [2H,2W]; 3: nn.MaxPool2d((2,2),(2,2),(0,0),ceil_mode=True) -> [ceil(H/2),ceil(W/2)]. */
+int ccst_nhwc_layer_f32(int mode, const float* x, float* y, int N, int H, int W, int C, int pad, void* stream);
+/* API-edge layout changes: x[N,C,HW] -> y[N,HW,Cp] (channels C..Cp-1 zero) and back (first C of Cs). */
+int ccst_nchw_to_nhwc_f32(const float* x, float* y, int N, int C, int HW, int Cp, void* stream);
+int ccst_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int HW, int Cs, void* stream);
+
+/* Backward-weight: dW[tap][ci][co] = sum_m X[n, oy*ay+ky*by+cy, ox*ax+kx*bx+cx, ci] * dY[m, co]
+ * (zero padding), split over `splits` pixel ranges into ws[splits][ntap][cin][cout] partials, then
+ * reduced in fixed order (bitwise reproducible) into OIHW dw[cout][cin][kh][kw] (accumulate=0
+ * overwrites).  ws_bytes >= splits*ntap*cin*cout*4.  Replaces Conv2d's weight gradient in
+ * loss.backward(), federated/fed_run.py:79. */
+int ccst_conv2d_bwd_weight_f32(const CcstConvDesc* d, const float* x, const float* dy, float* dw_oihw,
+                               int splits, void* ws, int64_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * AdaIN feature statistics / normalisation.  layout: 0 = NCHW planes, 1 = NHWC.
+ * ------------------------------------------------------------------------ */
+/* function.py:4-13 calc_mean_std: per-(n,c) mean and sqrt(var_unbiased + eps).  mean/std: [N*C]. */
+int ccst_calc_mean_std_f32(const float* x, float* mean, float* std, int N, int C, int HW, int layout,
+                           float eps, void* ws, int64_t ws_bytes, void* stream);
+/* function.py:26-33 adaIN_StyleStat_ContentFeat fused with the alpha blend of
+ * CCST_OverallStyleTransfer.py:45:  t = ((x-mu_c)/sigma_c)*sigma_s + mu_s ; y = t*alpha + x*(1-alpha).
+ * style_mean/std: [C] if style_per_n==0 (broadcast over N) else [N*C] (function.py:16-24). */
+int ccst_adain_f32(const float* x, const float* style_mean, const float* style_std, int style_per_n,
+                   float alpha, float* y, int N, int C, int HW, int layout, float eps,
+                   void* ws, int64_t ws_bytes, void* stream);
+/* mean_std_computation_effcientMem.py:103-115 calc_sum: per-channel sum and sum of squares over
+ * N*H*W.  sum/sqsum: [C]. */
+int ccst_chan_sums_f32(const float* x, float* sum, float* sqsum, int N, int C, int HW, int layout,
+                       void* ws, int64_t ws_bytes, void* stream);
+/* Workspace bytes the three calls above need. */
+int64_t ccst_stats_workspace_bytes(int N, int C, int HW);
+
+/* ------------------------------------------------------------------------
+ * ResNet training ops (nets/resnet.py:132-191 + torchvision blocks; fed_run.py:49-80).  NHWC.
+ * ------------------------------------------------------------------------ */
+/* BatchNorm2d training forward: batch mean / biased var over N*H*W, running-stat update
+ * (momentum, unbiased var), y = (x-mean)*invstd*gamma+beta [+ residual] [ReLU].
+ * save_mean/save_invstd: [C] for backward.  residual may be NULL. */
+int ccst_bn_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
+                          float* running_var, float momentum, float eps, const float* residual, int relu,
+                          float* y, float* save_mean, float* save_invstd, int64_t M, int C,
+                          void* ws, int64_t ws_bytes, void* stream);
+/* BatchNorm2d eval forward with running stats (fed_run.py:216). */
+int ccst_bn_eval_fwd_f32(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, const float* residual, int relu, float* y,
+                         int64_t M, int C, void* stream);
+/* BatchNorm2d backward (with the ReLU mask taken from the saved output y when relu=1):
+ * dx, dgamma, dbeta; if d_residual != NULL it receives the masked incoming gradient. */
+int ccst_bn_train_bwd_f32(const float* dy, const float* x, const float* y, const float* gamma,
+                          const float* save_mean, const float* save_invstd, int relu, float* dx,
+                          float* d_residual, float* dgamma, float* dbeta, int64_t M, int C,
+                          void* ws, int64_t ws_bytes, void* stream);
+int64_t ccst_bn_workspace_bytes(int64_t M, int C);
+
+/* MaxPool2d(kernel 3, stride 2, padding 1) nets/resnet.py:140, NHWC. */
+int ccst_maxpool3s2_fwd_f32(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+int ccst_maxpool3s2_bwd_f32(const float* x, const float* dy, float* dx, int N, int H, int W, int C,
+                            int Ho, int Wo, void* stream);
+/* AvgPool2d(7) on a 7x7 map + flatten (nets/resnet.py:145,189-190): [N,HW,C] -> [N,C]. */
+int ccst_avgpool_fwd_f32(const float* x, float* y, int N, int HW, int C, void* stream);
+int ccst_avgpool_bwd_f32(const float* dy, float* dx, int N, int HW, int C, void* stream);
+/* Linear (nets/resnet.py:146): y[N,O] = x[N,K] w[O,K]^T + b. */
+int ccst_linear_fwd_f32(const float* x, const float* w, const float* b, float* y, int N, int K, int O, void* stream);
+int ccst_linear_bwd_f32(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
+                        int N, int K, int O, void* stream);
+/* CrossEntropyLoss (mean) forward+backward (fed_run.py:554,65): loss[1], dlogits[N,O] (already
+ * scaled by 1/N), correct[1] = #argmax==label (fed_run.py:67,71). */
+int ccst_softmax_ce_f32(const float* logits, const int64_t* labels, float* loss, float* dlogits,
+                        int32_t* correct, int N, int O, void* stream);
+/* SGD p -= lr*g over a flat arena (fed_run.py:657,80), and the FedAvg pre-scale p *= s. */
+int ccst_sgd_f32(float* p, const float* g, float lr, int64_t n, void* stream);
+int ccst_scale_f32(float* p, float s, int64_t n, void* stream);
+/* elementwise helpers: y = relu(a + b) and its backward mask are folded into the BN calls above. */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCST_HIP_H */
