@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--image_size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--layers", action="store_true", help="print a per-launch conv table (last step) to stderr")
     return ap.parse_args()
 
 
@@ -98,7 +99,12 @@ def main():
 
     # ---- roofline of the dominant kernel ------------------------------------------------
     per_kernel = {}
-    for name, flops, e0, e1 in timing:
+    if args.layers and rank == 0:
+        per_step = len(timing) // args.steps
+        for name, flops, e0, e1, info in timing[-per_step:]:
+            us = e0.elapsed_time(e1) * 1e3
+            print("%-32s %-48s %9.1f us %7.1f TF" % (name, info, us, flops / us / 1e6), file=sys.stderr)
+    for name, flops, e0, e1, _info in timing:
         k = per_kernel.setdefault(name, [0, 0.0, 0.0])
         k[0] += 1
         k[1] += flops

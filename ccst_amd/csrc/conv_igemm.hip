@@ -40,6 +40,7 @@ struct ConvArgs {
     int tilesY, tilesX;  // spatial tiles per image (pool mode)
 };
 
+constexpr unsigned CONV_DENSE_OUT = 0x80000000u;   // internal flag: output rows are m*ysW apart
 constexpr int CK = 16;            // input channels per k-step
 constexpr int A_LD = CK + 4;      // floats per LDS A row (80 B)
 
@@ -52,7 +53,7 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 }
 
 template <int WM, int WN, int NT, bool POOL>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(256, 3) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int BM = 64 * WM;
     constexpr int BN = 32 * NT * WN;
     constexpr int AR = BM / 64;                    // A float4 units per thread per step
@@ -74,9 +75,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
     const int co0 = tn * BN;
 
     // ---- per-thread A rows: r = (tid>>2) + 64*a, float4 part = tid&3 ------------------
+    // All offsets are 32-bit element offsets (host checks numel < 2^31).
     const int part = tid & 3;
     int rowIy[AR], rowIx[AR];
-    long long rowBase[AR];
+    unsigned rowBase[AR];
     int pn = 0, pty = 0, ptx = 0;   // pool-mode tile coordinates
     if (POOL) {
         ptx = tm % p.tilesX;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         }
         rowIy[a] = oy * p.ay + p.cy;
         rowIx[a] = ox * p.ax + p.cx;
-        rowBase[a] = (long long)n * p.xsN + part * 4;
+        rowBase[a] = (unsigned)(n * (int)p.xsN + part * 4);
     }
     const bool reflect = (p.flags & CCST_CONV_REFLECT) != 0;
     const int ups = (p.flags & CCST_CONV_UPS2) ? 1 : 0;
@@ -126,7 +128,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
 
     // ---- staging registers + step state --------------------------------------------------
     f32x4 ra[AR], rb[BR];
-    long long aoff[AR];   // element offset of the row's pixel for the current tap; <0: zero fill
+    unsigned aoff[AR];    // element offset of the row's pixel for the current tap (always in-bounds)
+    bool aok[AR];         // false: zero padding (the loaded value is discarded at the LDS write)
+    unsigned boff[BR];    // per-thread part of the packed-weight offset
+#pragma unroll
+    for (int b = 0; b < BR; ++b) {
+        const int u = min(tid + 256 * b, BUNITS - 1);
+        const int g = u / BN, col = u - g * BN;
+        boff[b] = (unsigned)((g * p.CoutPad + co0 + col) * 4);
+    }
     int ky = 0, kx = 0, c = 0;
 
     auto tap_offsets = [&](int ky_, int kx_) {
@@ -139,35 +149,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
                 ix = reflect_idx(ix, p.Wi);
             } else {
                 ok = (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi);
+                iy = min(max(iy, 0), p.Hi - 1);
+                ix = min(max(ix, 0), p.Wi - 1);
             }
             iy >>= ups;
             ix >>= ups;
-            aoff[a] = ok ? rowBase[a] + (long long)iy * p.xsH + (long long)ix * p.xsW : -1;
+            aok[a] = ok;
+            aoff[a] = rowBase[a] + (unsigned)(iy * p.xsH + ix * p.xsW);
         }
     };
     auto load_step = [&](int ky_, int kx_, int c_) {
+        const float* xc = p.x + c_ * CK;                                   // uniform
 #pragma unroll
-        for (int a = 0; a < AR; ++a) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (aoff[a] >= 0) v = *reinterpret_cast<const f32x4*>(p.x + aoff[a] + c_ * CK);
-            ra[a] = v;
-        }
+        for (int a = 0; a < AR; ++a) ra[a] = *reinterpret_cast<const f32x4*>(xc + aoff[a]);
         const int tap = p.tap_base + ky_ * p.tap_sy + kx_ * p.tap_sx;
-        const long long wrow = ((long long)tap * (p.Cin / 4) + c_ * (CK / 4)) * p.CoutPad;
+        const float* wc = p.w + ((long long)tap * (p.Cin / 4) + c_ * (CK / 4)) * p.CoutPad * 4;   // uniform
 #pragma unroll
-        for (int b = 0; b < BR; ++b) {
-            const int u = tid + 256 * b;
-            if (BUNITS % 256 == 0 || u < BUNITS) {
-                const int g = u / BN, col = u - g * BN;
-                rb[b] = *reinterpret_cast<const f32x4*>(p.w + ((wrow + (long long)g * p.CoutPad) + co0 + col) * 4);
-            }
-        }
+        for (int b = 0; b < BR; ++b) rb[b] = *reinterpret_cast<const f32x4*>(wc + boff[b]);
     };
     auto store_step = [&](int buf) {
 #pragma unroll
         for (int a = 0; a < AR; ++a) {
             const int r = (tid >> 2) + 64 * a;
-            *reinterpret_cast<f32x4*>(&As[buf][r * A_LD + part * 4]) = ra[a];
+            f32x4 v = ra[a];
+            if (!aok[a]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&As[buf][r * A_LD + part * 4]) = v;
         }
 #pragma unroll
         for (int b = 0; b < BR; ++b) {
@@ -186,21 +192,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
         }
     };
 
-    tap_offsets(0, 0);
-    load_step(0, 0, 0);
-    store_step(0);
-    __syncthreads();
-
     const float* aRd0 = &As[0][(wm * 64 + li) * A_LD + lh * 4];
     const float* bRd0 = &Bs[0][(lh * BN + wn * (32 * NT) + li) * 4];
-
-    for (int t = 0; t < T; ++t) {
-        const int buf = t & 1;
-        const bool more = (t + 1 < T);
-        if (more) {
-            advance();
-            load_step(ky, kx, c);
-        }
+    auto compute = [&](int buf) {
         const float* aRd = aRd0 + buf * (BM * A_LD);
         const float* bRd = bRd0 + buf * (CK * BN);
 #pragma unroll
@@ -220,15 +214,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
                     for (int nt = 0; nt < NT; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][s], bf[nt][s], acc[mt][nt], 0, 0, 0);
         }
-        if (more) store_step(buf ^ 1);
+    };
+
+    tap_offsets(0, 0);
+    load_step(0, 0, 0);
+    store_step(0);
+    __syncthreads();
+
+    // Steady state: the loads of step t+1 are in flight while step t's MFMAs run.  The body is
+    // unconditional (last step peeled) so hipcc keeps its vmcnt wait at the LDS write instead of
+    // hoisting it above the MFMAs.  aok[] is recomputed by advance() for exactly the tap whose
+    // data load_step() then fetches and store_step() writes.
+    for (int t = 0; t < T - 1; ++t) {
+        advance();
+        load_step(ky, kx, c);
+        __builtin_amdgcn_sched_barrier(0);     // keep the global loads ahead of the MFMA block
+        compute(t & 1);
+        __builtin_amdgcn_sched_barrier(0);     // ... and the vmcnt wait + LDS writes behind it
+        store_step((t + 1) & 1);
         __syncthreads();
     }
+    compute((T - 1) & 1);
 
     // ---- epilogue ------------------------------------------------------------------------
     const bool relu = (p.flags & CCST_CONV_RELU) != 0;
     float* yb = p.y + p.y_off;
     if (!POOL) {
         const int HW = p.Ho * p.Wo;
+        const bool dense = (p.flags & CONV_DENSE_OUT) != 0;   // &y[m] = y + m*ysW: no (n,oy,ox) decode
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -236,11 +249,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs p) {
                 const int row = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int m = tm * BM + row;
                 if (m < p.M) {
-                    const int n = m / HW;
-                    const int rem = m - n * HW;
-                    const int oy = rem / p.Wo;
-                    const int ox = rem - oy * p.Wo;
-                    float* yrow = yb + (long long)n * p.ysN + (long long)oy * p.ysH + (long long)ox * p.ysW;
+                    float* yrow;
+                    if (dense) {
+                        yrow = yb + (long long)m * p.ysW;
+                    } else {
+                        const int n = m / HW;
+                        const int rem = m - n * HW;
+                        const int oy = rem / p.Wo;
+                        const int ox = rem - oy * p.Wo;
+                        yrow = yb + (long long)n * p.ysN + (long long)oy * p.ysH + (long long)ox * p.ysW;
+                    }
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         const int co = co0 + wn * (32 * NT) + nt * 32 + li;
@@ -361,6 +379,7 @@ extern "C" int ccst_conv2d_igemm_f32(const CcstConvDesc* d, const float* x, cons
                  d->cout, d->cout_pad);
     CCST_REQUIRE(d->n > 0 && d->ho > 0 && d->wo > 0 && d->hi > 0 && d->wi > 0 && d->nky > 0 && d->nkx > 0, "conv: bad extents");
     CCST_REQUIRE((long long)d->n * d->ho * d->wo < 0x7fffffffLL, "conv: M too large");
+    CCST_REQUIRE((long long)d->n * d->xsN < 0x7fffffffLL, "conv: input tensor must have < 2^31 elements (32-bit offsets)");
     const bool pool = (d->flags & CCST_CONV_POOL2) != 0;
     if (d->flags & CCST_CONV_REFLECT) CCST_REQUIRE(d->hi >= 2 && d->wi >= 2, "conv: reflection needs extent >= 2");
     ConvArgs a;
@@ -370,7 +389,8 @@ extern "C" int ccst_conv2d_igemm_f32(const CcstConvDesc* d, const float* x, cons
     a.tap_base = d->tap_base; a.tap_sy = d->tap_sy; a.tap_sx = d->tap_sx;
     a.xsN = d->xsN; a.xsH = d->xsH; a.xsW = d->xsW;
     a.y_off = d->y_off; a.ysN = d->ysN; a.ysH = d->ysH; a.ysW = d->ysW; a.ysC = d->ysC;
-    a.flags = d->flags;
+    a.flags = d->flags & 0xffu;
+    if (!pool && d->ysH == (long long)d->wo * d->ysW && d->ysN == (long long)d->ho * d->wo * d->ysW) a.flags |= CONV_DENSE_OUT;
     a.M = d->n * d->ho * d->wo;
     hipStream_t s = (hipStream_t)stream;
     if (pool) {

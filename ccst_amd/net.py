@@ -55,11 +55,12 @@ def _is_up2(m):
 
 class _Step(object):
     """One launch (or launch pair) of the plan."""
-    __slots__ = ("kind", "pc", "kw", "kwp", "stride", "pad", "reflect", "relu", "pool", "ups", "out_nchw", "in_nchw")
+    __slots__ = ("kind", "pc", "kw", "kwp", "stride", "pad", "reflect", "relu", "pool", "ups", "out_nchw", "in_nchw",
+                 "w_small", "b_small", "cout")
 
     def __init__(self, kind, **kw):
         self.kind = kind
-        self.pc = self.kw = self.kwp = None
+        self.pc = self.kw = self.kwp = self.w_small = self.b_small = self.cout = None
         self.stride, self.pad = 1, 0
         self.reflect = self.relu = self.pool = self.ups = self.out_nchw = self.in_nchw = False
         for k, v in kw.items():
@@ -112,6 +113,11 @@ def _compile(mods):
             if conv.in_channels <= 4:
                 wv, kwp = ops.stem_virtual_weight(conv.weight.detach())
                 steps.append(_Step("stem", pc=ops.pack_conv_weight(wv, conv.bias), kw=3, kwp=kwp, pad=1, reflect=True, relu=relu))
+            elif conv.out_channels <= 4 and conv.in_channels % 16 == 0 and not pending_up:
+                # image edge of the decoder (net.py:35): direct VALU kernel writing NCHW
+                steps.append(_Step("smallco", w_small=conv.weight.detach().permute(2, 3, 1, 0).contiguous(),
+                                   b_small=None if conv.bias is None else conv.bias.detach().contiguous(),
+                                   cout=conv.out_channels, reflect=True, relu=relu))
             else:
                 pool = at(j) is not None and _is_pool2(at(j)) and conv.out_channels % 16 == 0
                 j += int(pool)
@@ -175,8 +181,14 @@ def _run(steps, x):
             api = None
             continue
         if cur is None:
-            cur = ops.from_api(api, cpad=16 if s.kind == "conv" else 4)
+            cur = ops.from_api(api, cpad=16 if s.kind in ("conv", "smallco") else 4)
             api = None
+        if s.kind == "smallco":
+            if cur.shape[-1] % 16 != 0:
+                cur = ops.from_api(ops.to_api(cur[..., :C]), cpad=16)
+            out = ops.conv3x3_smallco_nchw(cur, s.w_small, s.b_small, s.cout, reflect=s.reflect, relu=s.relu)
+            cur, api, C = None, out, s.cout
+            continue
         if s.kind == "conv":
             if cur.shape[-1] != s.pc.k_pad:
                 cur = ops.from_api(ops.to_api(cur[..., :C]), cpad=16)

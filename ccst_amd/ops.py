@@ -37,7 +37,8 @@ def _launch_conv(d, x, pc, out, flops, pool, what):
     e0.record()
     check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(x), ptr(pc.w), ptr(pc.bias), ptr(out), stream_ptr()), what)
     e1.record()
-    TIMING.append((_conv_kernel_name(pc.cout, pool), flops, e0, e1))
+    TIMING.append((_conv_kernel_name(pc.cout, pool), flops, e0, e1,
+                   "n%d %dx%d cin%d cout%d taps%dx%d flags%d" % (d.n, d.ho, d.wo, d.cin, d.cout, d.nky, d.nkx, d.flags)))
 
 
 def _require_cuda(t, name="tensor"):
@@ -150,6 +151,26 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
             out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
         d.y_off, d.ysN, d.ysH, d.ysW, d.ysC = 0, oh * ow * pc.cout, ow * pc.cout, pc.cout, 1
     _launch_conv(d, x, pc, out, 2.0 * N * ho * wo * pc.cout * pc.cin * pc.kh * pc.kw, pool, "conv2d_igemm")
+    return out
+
+
+def conv3x3_smallco_nchw(x, w_tap_ci_co, bias, cout, reflect=True, relu=False):
+    """Direct 3x3 conv with <= 4 output channels: NHWC in, contiguous NCHW out (decoder's last layer)."""
+    _require_cuda(x, "activation")
+    assert x.is_contiguous() and x.dim() == 4
+    N, H, W, Cin = x.shape
+    out = torch.empty((N, cout, H, W), device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    args = (ptr(x), ptr(w_tap_ci_co), ptr(bias), ptr(out), N, H, W, Cin, cout, int(reflect), int(relu), stream_ptr())
+    if TIMING is None:
+        check(lib.ccst_conv3x3_smallco_f32(*args), "conv3x3_smallco")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.ccst_conv3x3_smallco_f32(*args), "conv3x3_smallco")
+        e1.record()
+        TIMING.append(("conv3x3_smallco_kernel<%d>" % cout, 2.0 * N * H * W * cout * Cin * 9, e0, e1,
+                       "n%d %dx%d cin%d cout%d taps3x3" % (N, H, W, Cin, cout)))
     return out
 
 

@@ -76,6 +76,12 @@ typedef struct CcstConvDesc {
 int ccst_conv2d_igemm_f32(const CcstConvDesc* d, const float* x, const float* w_packed,
                           const float* bias /* may be NULL */, float* y, void* stream);
 
+/* Direct 3x3 stride-1 conv with 1..4 output channels writing NCHW (the decoder's last layer,
+ * net.py:35): x NHWC [N,H,W,Cin] (Cin % 16 == 0), w [3][3][Cin][Cout], y NCHW [N,Cout,H,W].
+ * HBM-bound (13 FLOP/B), so it runs on the VALU rather than padding Cout to an MFMA tile. */
+int ccst_conv3x3_smallco_f32(const float* x, const float* w_tap_ci_co, const float* bias, float* y,
+                             int N, int H, int W, int Cin, int Cout, int reflect, int relu, void* stream);
+
 /* OIHW [cout][cin][kh][kw] -> packed [kh*kw][cin/4][cout_pad][4] (transpose=0), or the
  * backward-data operand [kh*kw][cout/4][cin_pad][4] (transpose=1: GEMM-K runs over cout).
  * The K-side extent (cin, or cout when transposed) must be a multiple of 4; it is padded

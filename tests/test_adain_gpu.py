@@ -114,6 +114,24 @@ def test_conv_out_nchw(dev):
     assert maxdiff(y, ref) < 1e-4
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 12, 10, 3), (1, 32, 40, 70, 3), (1, 16, 9, 33, 4), (1, 64, 8, 32, 1)])
+@pytest.mark.parametrize("reflect", [True, False])
+def test_conv3x3_smallco(dev, shape, reflect):
+    from ccst_amd import ops
+    N, Cin, H, W, Cout = shape
+    x = rnd((N, Cin, H, W), 18)
+    w = rnd((Cout, Cin, 3, 3), 19, 0.05)
+    b = rnd((Cout,), 20, 0.1)
+    if reflect:
+        ref = F.conv2d(F.pad(x, (1,) * 4, mode="reflect"), w, b)
+    else:
+        ref = F.conv2d(x, w, b, padding=1)
+    y = ops.conv3x3_smallco_nchw(ops.from_api(x.to(dev), 16), w.to(dev).permute(2, 3, 1, 0).contiguous(), b.to(dev), Cout,
+                                 reflect=reflect)
+    assert y.is_contiguous() and tuple(y.shape) == tuple(ref.shape)
+    assert maxdiff(y, ref) < 1e-4
+
+
 # ------------------------------------------------------------------ statistics / AdaIN
 @pytest.mark.parametrize("channels_last", [False, True])
 def test_calc_mean_std_golden(dev, golden, channels_last):
