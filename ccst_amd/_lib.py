@@ -37,21 +37,22 @@ _SIGNATURES = {
     "ccst_nhwc_layer_f32": [c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "ccst_nchw_to_nhwc_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "ccst_nhwc_to_nchw_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
-    "ccst_conv2d_bwd_weight_f32": [POINTER(CcstConvDesc), _P, _P, _P, c_int, _P, c_int64, _P],
+    "ccst_conv2d_bwd_weight_f32": [POINTER(CcstConvDesc), _P, _P, _P, c_int, c_int, _P, c_int64, _P],
+    "ccst_conv2d_bwd_weight_splits": [c_int, c_int, c_int, c_int],
     "ccst_calc_mean_std_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, c_int64, _P],
     "ccst_adain_f32": [_P, _P, _P, c_int, c_float, _P, c_int, c_int, c_int, c_int, c_float, _P, c_int64, _P],
     "ccst_chan_sums_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _P],
     "ccst_stats_workspace_bytes": [c_int, c_int, c_int],
     "ccst_bn_train_fwd_f32": [_P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P, _P, _P, c_int64, c_int, _P, c_int64, _P],
     "ccst_bn_eval_fwd_f32": [_P, _P, _P, _P, _P, c_float, _P, c_int, _P, c_int64, c_int, _P],
-    "ccst_bn_train_bwd_f32": [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int64, c_int, _P, c_int64, _P],
+    "ccst_bn_train_bwd_f32": [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int64, c_int, _P, c_int64, _P],
     "ccst_bn_workspace_bytes": [c_int64, c_int],
-    "ccst_maxpool3s2_fwd_f32": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
+    "ccst_maxpool3s2_fwd_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "ccst_maxpool3s2_bwd_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "ccst_avgpool_fwd_f32": [_P, _P, c_int, c_int, c_int, _P],
     "ccst_avgpool_bwd_f32": [_P, _P, c_int, c_int, c_int, _P],
     "ccst_linear_fwd_f32": [_P, _P, _P, _P, c_int, c_int, c_int, _P],
-    "ccst_linear_bwd_f32": [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P],
+    "ccst_linear_bwd_f32": [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "ccst_softmax_ce_f32": [_P, _P, _P, _P, _P, c_int, c_int, _P],
     "ccst_sgd_f32": [_P, _P, c_float, c_int64, _P],
     "ccst_scale_f32": [_P, c_float, c_int64, _P],

@@ -1,0 +1,245 @@
+// Convolution backward-weight on the fp32-input MFMA (gfx950).
+//
+//   dW[tap][ci][co] = sum_m X[pixel(m,tap)][ci] * dY[m][co]          (zero padding)
+//   GEMM per tap: rows = ci, cols = co, reduction over the N*Ho*Wo output pixels m.
+//   Workgroup = 4 waves (2x2), tile BI x BJ = (64*MI) x (64*NJ); the pixel range is split over
+//   `splits` workgroups per tile; each writes an fp32 partial slab ws[split][tap][ci][co]; a second
+//   kernel sums the slabs in fixed order (bitwise reproducible, no float atomics) and transposes into
+//   the parameter's OIHW layout (optionally accumulating into the existing gradient).
+//   Per step PK pixels are staged: X rows gathered with the forward conv's affine index map, dY rows
+//   dense; LDS images are [pixel][channel] so the MFMA operands (lane = channel, k = pixel) are
+//   conflict-free ds_read_b32.
+#include "common.h"
+
+namespace {
+
+struct BwdWArgs {
+    const float* x;
+    const float* dy;
+    float* ws;
+    int N, Ho, Wo, Hi, Wi, Cin, Cout;
+    int nky, nkx, ay, by, cy, ax, bx, cx;
+    long long xsN;
+    int xsH, xsW;
+    int M, splits, tilesI, tilesJ;
+};
+
+template <int MI, int NJ, int PK>
+__global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs p) {
+    constexpr int BI = 64 * MI, BJ = 64 * NJ;
+    constexpr int LDI = BI + 4, LDJ = BJ + 4;            // +4 floats: rows land on different banks
+    constexpr int XU = PK * BI / 4, DU = PK * BJ / 4;    // float4 units per step
+    constexpr int XR = XU / 256, DR = DU / 256;
+    static_assert(XU % 256 == 0 && DU % 256 == 0, "tile/thread mismatch");
+
+    __shared__ __attribute__((aligned(16))) float Xs[2][PK * LDI];
+    __shared__ __attribute__((aligned(16))) float Ds[2][PK * LDJ];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    int b = blockIdx.x;
+    const int split = b % p.splits;
+    b /= p.splits;
+    const int tj = b % p.tilesJ;
+    b /= p.tilesJ;
+    const int ti = b % p.tilesI;
+    const int tap = b / p.tilesI;
+    const int ky = tap / p.nkx, kx = tap - ky * p.nkx;
+    const int ci0 = ti * BI, co0 = tj * BJ;
+
+    // pixel range of this split, in steps of PK
+    const int steps_total = (p.M + PK - 1) / PK;
+    const int sps = (steps_total + p.splits - 1) / p.splits;
+    const int s0 = split * sps;
+    const int s1 = min(steps_total, s0 + sps);
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int c = 0; c < NJ; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+    f32x4 rx[XR], rd[DR];
+    const int HW = p.Ho * p.Wo;
+
+    auto load_step = [&](int st) {
+        const int m0 = st * PK;
+#pragma unroll
+        for (int u = 0; u < XR; ++u) {
+            const int unit = tid + 256 * u;
+            const int px = unit / (BI / 4), cp = unit - px * (BI / 4);
+            const int m = m0 + px;
+            const int mc = min(m, p.M - 1);
+            const int n = mc / HW;
+            const int rem = mc - n * HW;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            int iy = oy * p.ay + ky * p.by + p.cy, ix = ox * p.ax + kx * p.bx + p.cx;
+            const int ci = ci0 + cp * 4;
+            const bool ok = (m < p.M) & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi) & (ci < p.Cin);
+            iy = min(max(iy, 0), p.Hi - 1);
+            ix = min(max(ix, 0), p.Wi - 1);
+            const int cic = min(ci, p.Cin - 4);
+            f32x4 v = *reinterpret_cast<const f32x4*>(p.x + (long long)n * p.xsN + (long long)iy * p.xsH + (long long)ix * p.xsW + cic);
+            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            rx[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < DR; ++u) {
+            const int unit = tid + 256 * u;
+            const int px = unit / (BJ / 4), cp = unit - px * (BJ / 4);
+            const int mc = min(m0 + px, p.M - 1);
+            const int co = min(co0 + cp * 4, p.Cout - 4);
+            rd[u] = *reinterpret_cast<const f32x4*>(p.dy + (long long)mc * p.Cout + co);
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < XR; ++u) {
+            const int unit = tid + 256 * u;
+            const int px = unit / (BI / 4), cp = unit - px * (BI / 4);
+            *reinterpret_cast<f32x4*>(&Xs[buf][px * LDI + cp * 4]) = rx[u];
+        }
+#pragma unroll
+        for (int u = 0; u < DR; ++u) {
+            const int unit = tid + 256 * u;
+            const int px = unit / (BJ / 4), cp = unit - px * (BJ / 4);
+            *reinterpret_cast<f32x4*>(&Ds[buf][px * LDJ + cp * 4]) = rd[u];
+        }
+    };
+    auto compute = [&](int buf) {
+        const float* xr = &Xs[buf][lh * LDI + wi * (32 * MI) + li];
+        const float* dr = &Ds[buf][lh * LDJ + wj * (32 * NJ) + li];
+#pragma unroll
+        for (int k2 = 0; k2 < PK / 2; ++k2) {
+            float av[MI], bv[NJ];
+#pragma unroll
+            for (int a = 0; a < MI; ++a) av[a] = xr[2 * k2 * LDI + a * 32];
+#pragma unroll
+            for (int c = 0; c < NJ; ++c) bv[c] = dr[2 * k2 * LDJ + c * 32];
+#pragma unroll
+            for (int a = 0; a < MI; ++a)
+#pragma unroll
+                for (int c = 0; c < NJ; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[c], acc[a][c], 0, 0, 0);
+        }
+    };
+
+    if (s0 < s1) {
+        load_step(s0);
+        store_step(0);
+        __syncthreads();
+        for (int st = s0; st < s1 - 1; ++st) {
+            load_step(st + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute((st - s0) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            store_step((st - s0 + 1) & 1);
+            __syncthreads();
+        }
+        compute((s1 - 1 - s0) & 1);
+    }
+
+    // partial slab store: ws[((split*ntap + tap)*Cin + ci)*Cout + co]
+    float* wsb = p.ws + ((long long)split * (p.nky * p.nkx) + tap) * p.Cin * p.Cout;
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wi * (32 * MI) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (ci < p.Cin) {
+#pragma unroll
+                for (int c = 0; c < NJ; ++c) {
+                    const int co = co0 + wj * (32 * NJ) + c * 32 + li;
+                    if (co < p.Cout) wsb[(long long)ci * p.Cout + co] = acc[a][c][r];
+                }
+            }
+        }
+}
+
+// dw[co][ci][tap] (+)= sum_s ws[s][tap][ci][co]   (32x32 transposing tiles over (ci, co))
+__global__ __launch_bounds__(256) void bwd_weight_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int ntap, int Cin,
+                                                                int Cout, int splits, int accumulate) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        float s = 0.f;
+        if (ci < Cin && co < Cout) {
+            for (int k = 0; k < splits; ++k) s += ws[(((long long)k * ntap + tap) * Cin + ci) * Cout + co];
+        }
+        tile[r][tx] = s;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        if (ci < Cin && co < Cout) {
+            const long long o = ((long long)co * Cin + ci) * ntap + tap;
+            dw[o] = accumulate ? dw[o] + tile[tx][r] : tile[tx][r];
+        }
+    }
+}
+
+template <int MI, int NJ, int PK>
+int launch(BwdWArgs& a, hipStream_t s) {
+    a.tilesI = (a.Cin + 64 * MI - 1) / (64 * MI);
+    a.tilesJ = (a.Cout + 64 * NJ - 1) / (64 * NJ);
+    const long long grid = (long long)a.nky * a.nkx * a.tilesI * a.tilesJ * a.splits;
+    if (grid <= 0 || grid > 0x7fffffffLL) {
+        ccst_set_error("bwd_weight: bad grid");
+        return CCST_EINVAL;
+    }
+    hipLaunchKernelGGL((conv_bwd_weight_kernel<MI, NJ, PK>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    return ccst_launch_status("conv_bwd_weight");
+}
+
+}  // namespace
+
+// Suggested split count (also the number of slabs the workspace must hold).
+extern "C" int ccst_conv2d_bwd_weight_splits(int M, int cin, int cout, int ntap) {
+    const bool big = (cin >= 128 && cout >= 128);
+    const int bi = big ? 128 : 64;
+    const long long tiles = (long long)ntap * ((cin + bi - 1) / bi) * ((cout + bi - 1) / bi);
+    long long s = (1024 + tiles - 1) / tiles;
+    const int pk = big ? 16 : 32;
+    const long long smax = (M / pk) / 8 > 0 ? (M / pk) / 8 : 1;     // >= 8 steps per workgroup
+    if (s > smax) s = smax;
+    if (s > 512) s = 512;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+extern "C" int ccst_conv2d_bwd_weight_f32(const CcstConvDesc* d, const float* x, const float* dy, float* dw_oihw, int splits,
+                                          int accumulate, void* ws, int64_t ws_bytes, void* stream) {
+    CCST_REQUIRE(d && x && dy && dw_oihw && ws, "bwd_weight: null pointer");
+    CCST_REQUIRE(d->cin > 0 && d->cin % 4 == 0 && d->cout > 0 && d->cout % 4 == 0, "bwd_weight: cin/cout must be multiples of 4");
+    CCST_REQUIRE(d->n > 0 && d->ho > 0 && d->wo > 0 && d->nky > 0 && d->nkx > 0 && splits >= 1, "bwd_weight: bad extents");
+    CCST_REQUIRE((long long)d->n * d->ho * d->wo < 0x7fffffffLL, "bwd_weight: M too large");
+    const int ntap = d->nky * d->nkx;
+    const long long need = (long long)splits * ntap * d->cin * d->cout * 4;
+    if (ws_bytes < need) {
+        ccst_set_error("bwd_weight: workspace %lld < %lld", (long long)ws_bytes, need);
+        return CCST_EWORKSPACE;
+    }
+    BwdWArgs a;
+    a.x = x; a.dy = dy; a.ws = (float*)ws;
+    a.N = d->n; a.Ho = d->ho; a.Wo = d->wo; a.Hi = d->hi; a.Wi = d->wi; a.Cin = d->cin; a.Cout = d->cout;
+    a.nky = d->nky; a.nkx = d->nkx; a.ay = d->ay; a.by = d->by; a.cy = d->cy; a.ax = d->ax; a.bx = d->bx; a.cx = d->cx;
+    a.xsN = d->xsN; a.xsH = d->xsH; a.xsW = d->xsW;
+    a.M = d->n * d->ho * d->wo;
+    a.splits = splits;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (d->cin >= 128 && d->cout >= 128) rc = launch<2, 2, 16>(a, s);
+    else rc = launch<1, 1, 32>(a, s);
+    if (rc) return rc;
+    dim3 grid((d->cout + 31) / 32, (d->cin + 31) / 32, ntap);
+    hipLaunchKernelGGL(bwd_weight_reduce_kernel, grid, dim3(256), 0, s, (const float*)ws, dw_oihw, ntap, d->cin, d->cout, splits,
+                       accumulate);
+    return ccst_launch_status("bwd_weight_reduce");
+}

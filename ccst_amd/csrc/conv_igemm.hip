@@ -19,6 +19,7 @@
 //   y strides) or the fused MaxPool2d(2,2,ceil) where the M index is laid out so that the four
 //   pixels of a pooling window sit in the four registers (reg&3) of one lane.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -393,12 +394,28 @@ extern "C" int ccst_conv2d_igemm_f32(const CcstConvDesc* d, const float* x, cons
     if (!pool && d->ysH == (long long)d->wo * d->ysW && d->ysN == (long long)d->ho * d->wo * d->ysW) a.flags |= CONV_DENSE_OUT;
     a.M = d->n * d->ho * d->wo;
     hipStream_t s = (hipStream_t)stream;
+    // Tile choice: 128x128 (2,2,2) by default; Cout <= 64 -> BN = 64; Cout <= 32 -> BN = 32.  When the
+    // 128x128 grid would not give every CU ~3 workgroups, halve BN (2,2,1) to fill the chip.
+    // CCST_CONV_TILE=222|221|412|411 overrides (tuning experiments only).
+    int tile = 222;
+    if (d->cout <= 32 && !pool) tile = 411;
+    else if (d->cout <= 64) tile = 412;
+    else {
+        const long long tiles128 = (((long long)a.M + 127) / 128) * ((d->cout + 127) / 128);
+        if (tiles128 < 640) tile = 221;
+    }
+    if (const char* e = getenv("CCST_CONV_TILE")) {
+        const int t = atoi(e);
+        if (t == 222 || t == 221 || t == 412 || (t == 411 && !pool)) tile = t;
+    }
     if (pool) {
-        if (d->cout <= 64) return launch_conv<4, 1, 2, true>(a, s);
+        if (tile == 412) return launch_conv<4, 1, 2, true>(a, s);
+        if (tile == 221) return launch_conv<2, 2, 1, true>(a, s);
         return launch_conv<2, 2, 2, true>(a, s);
     }
-    if (d->cout <= 32) return launch_conv<4, 1, 1, false>(a, s);
-    if (d->cout <= 64) return launch_conv<4, 1, 2, false>(a, s);
+    if (tile == 411) return launch_conv<4, 1, 1, false>(a, s);
+    if (tile == 412) return launch_conv<4, 1, 2, false>(a, s);
+    if (tile == 221) return launch_conv<2, 2, 1, false>(a, s);
     return launch_conv<2, 2, 2, false>(a, s);
 }
 

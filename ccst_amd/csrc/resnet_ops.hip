@@ -1,0 +1,525 @@
+// ResNet training ops other than convolution (nets/resnet.py:132-191 + torchvision blocks;
+// federated/fed_run.py:49-80).  All NHWC fp32, all HBM-bound: 16-B accesses along C, per-channel
+// reductions as (split partials in fp32) -> (fixed-order fp64 combine), so results are bitwise
+// reproducible run to run (no float atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int MAXS = 512;   // max row-splits of a per-channel reduction
+
+// ------------------------------------------------------------------------------------------
+// per-channel partial reductions over rows of x[M][C].
+// MODE 0: (sum x, sum x^2)                                   -> BN forward statistics
+// MODE 1: (sum dy', sum dy' * xhat), dy' = relu ? dy*(y>0) : dy  -> BN backward
+// thread = one float4 channel group; PL row lanes per block; grid (S, ceil(C/4/cgb)).
+// ------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(TPB) void chan_partials_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ y, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, int relu, float* __restrict__ part,
+                                                            long long M, int C, int S, int cgb, int PL) {
+    __shared__ f32x4 red[2][TPB];
+    const int split = blockIdx.x, t = threadIdx.x;
+    const int cgl = t % cgb, pl = t / cgb;
+    const int cg = blockIdx.y * cgb + cgl;
+    const long long per = (M + S - 1) / S;
+    const long long r0 = split * per;
+    const long long r1 = (r0 + per < M) ? r0 + per : M;
+    f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+    if (pl < PL && cg * 4 < C) {
+        f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
+        if (MODE == 1) {
+            mu = *reinterpret_cast<const f32x4*>(mean + cg * 4);
+            is = *reinterpret_cast<const f32x4*>(invstd + cg * 4);
+        }
+        for (long long r = r0 + pl; r < r1; r += PL) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + cg * 4);
+            if (MODE == 0) {
+                a += v;
+                b += v * v;
+            } else {
+                f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * C + cg * 4);
+                if (relu) {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(y + r * C + cg * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
+                }
+                a += g;
+                b += g * ((v - mu) * is);
+            }
+        }
+    }
+    red[0][t] = a;
+    red[1][t] = b;
+    __syncthreads();
+    if (pl == 0 && cg * 4 < C) {
+        for (int k = 1; k < PL; ++k) {
+            a += red[0][t + k * cgb];
+            b += red[1][t + k * cgb];
+        }
+        float* o = part + ((long long)split * C + cg * 4) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[2 * j] = a[j];
+            o[2 * j + 1] = b[j];
+        }
+    }
+}
+
+// BN forward finalize: batch mean / biased var, running-stat update (unbiased var), scale/shift.
+__global__ void bn_fwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                       float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
+                                       float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ scale,
+                                       float* __restrict__ shift, long long M, int C, int S) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int k = 0; k < S; ++k) {
+        s += (double)part[((long long)k * C + c) * 2];
+        q += (double)part[((long long)k * C + c) * 2 + 1];
+    }
+    const double mu = s / (double)M;
+    double var = q / (double)M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    save_mean[c] = (float)mu;
+    save_invstd[c] = invstd;
+    if (running_mean) {
+        const double unb = (M > 1) ? var * (double)M / (double)(M - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mu * sc;
+}
+
+// y = x*scale + shift (+ residual) (ReLU).  scale/shift either precomputed (train) or derived from
+// running stats on the fly (eval: scale==nullptr).
+__global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ rmean,
+                                                       const float* __restrict__ rvar, float eps, const float* __restrict__ residual,
+                                                       int relu, float* __restrict__ y, long long total4, int C) {
+    const int cg = C / 4;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total4; i += (long long)gridDim.x * TPB) {
+        const int c = (int)(i % cg) * 4;
+        f32x4 sc, sh;
+        if (scale) {
+            sc = *reinterpret_cast<const f32x4*>(scale + c);
+            sh = *reinterpret_cast<const f32x4*>(shift + c);
+        } else {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
+            const f32x4 m = *reinterpret_cast<const f32x4*>(rmean + c), v = *reinterpret_cast<const f32x4*>(rvar + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sc[j] = g[j] / sqrtf(v[j] + eps);
+                sh[j] = b[j] - m[j] * sc[j];
+            }
+        }
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        v = v * sc + sh;
+        if (residual) v += *reinterpret_cast<const f32x4*>(residual + i * 4);
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(y + i * 4) = v;
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ sums, int C, int S, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < S; ++k) {
+        a += (double)part[((long long)k * C + c) * 2];
+        b += (double)part[((long long)k * C + c) * 2 + 1];
+    }
+    sums[c] = (float)a;          // sum dy'
+    sums[C + c] = (float)b;      // sum dy' * xhat
+    if (accumulate) {
+        dbeta[c] += (float)a;
+        dgamma[c] += (float)b;
+    } else {
+        dbeta[c] = (float)a;
+        dgamma[c] = (float)b;
+    }
+}
+
+// dx = gamma*invstd*(dy' - mean(dy') - xhat*mean(dy'*xhat));  d_residual = dy'
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ y, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ sums, int relu, float* __restrict__ dx,
+                                                           float* __restrict__ dres, long long total4, int C, float invM) {
+    const int cg = C / 4;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total4; i += (long long)gridDim.x * TPB) {
+        const int c = (int)(i % cg) * 4;
+        f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4);
+        if (relu) {
+            const f32x4 o = *reinterpret_cast<const f32x4*>(y + i * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
+        }
+        if (dres) *reinterpret_cast<f32x4*>(dres + i * 4) = g;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + c), s2 = *reinterpret_cast<const f32x4*>(sums + C + c);
+        const f32x4 xh = (v - mu) * is;
+        *reinterpret_cast<f32x4*>(dx + i * 4) = ga * is * (g - s1 * invM - xh * (s2 * invM));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// MaxPool2d(3, stride 2, padding 1), NHWC.  idx = position (0..8) of the first maximum in the window.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void maxpool3s2_fwd_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y,
+                                                             unsigned* __restrict__ idx, int N, int H, int W, int C4, int Ho, int Wo) {
+    const long long total = (long long)N * Ho * Wo * C4;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        const int c = (int)(i % C4);
+        long long j = i / C4;
+        const int ox = (int)(j % Wo);
+        j /= Wo;
+        const int oy = (int)(j % Ho);
+        const int n = (int)(j / Ho);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        unsigned bi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy - 1 + ky;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox - 1 + kx;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                    const f32x4 v = x[(((long long)n * H + iy) * W + ix) * C4 + c];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (v[k] > best[k] || (v[k] != v[k])) {   // first maximum wins; NaN propagates like torch
+                            best[k] = v[k];
+                            bi[k] = ky * 3 + kx;
+                        }
+                }
+            }
+        }
+        y[i] = best;
+        idx[i] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+    }
+}
+
+__global__ __launch_bounds__(TPB) void maxpool3s2_bwd_kernel(const f32x4* __restrict__ dy, const unsigned* __restrict__ idx,
+                                                             f32x4* __restrict__ dx, int N, int H, int W, int C4, int Ho, int Wo) {
+    const long long total = (long long)N * H * W * C4;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        const int c = (int)(i % C4);
+        long long j = i / C4;
+        const int ix = (int)(j % W);
+        j /= W;
+        const int iy = (int)(j % H);
+        const int n = (int)(j / H);
+        f32x4 g = {0, 0, 0, 0};
+        // windows (oy,ox) with 2*oy-1+ky == iy  =>  oy = (iy+1-ky)/2 for ky of matching parity
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = iy + 1 - ky;
+            if (ty < 0 || (ty & 1)) continue;
+            const int oy = ty >> 1;
+            if (oy >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = ix + 1 - kx;
+                if (tx < 0 || (tx & 1)) continue;
+                const int ox = tx >> 1;
+                if (ox >= Wo) continue;
+                const long long o = (((long long)n * Ho + oy) * Wo + ox) * C4 + c;
+                const unsigned id = idx[o];
+                const f32x4 d = dy[o];
+                const unsigned me = ky * 3 + kx;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (((id >> (8 * k)) & 0xffu) == me) g[k] += d[k];
+            }
+        }
+        dx[i] = g;
+    }
+}
+
+// AvgPool2d over the whole HW map + flatten: [N,HW,C] -> [N,C]
+__global__ void avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int HW, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += x[((long long)n * HW + p) * C + c];
+    y[i] = s / (float)HW;
+}
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int HW, int C) {
+    const long long total = (long long)N * HW * C;
+    const float inv = 1.f / (float)HW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int n = (int)(i / ((long long)HW * C));
+        dx[i] = dy[n * C + c] * inv;
+    }
+}
+
+// Linear: one wave per output element (n,o); K-strided dot product + wave reduction.
+__global__ __launch_bounds__(TPB) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ b, float* __restrict__ y, int N, int K, int O) {
+    const int wave = (blockIdx.x * TPB + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= N * O) return;
+    const int n = wave / O, o = wave - n * O;
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) s = fmaf(x[(long long)n * K + k], w[(long long)o * K + k], s);
+    s = wave_sum(s);
+    if (lane == 0) y[wave] = s + (b ? b[o] : 0.f);
+}
+// dx[n,k] = sum_o dy[n,o] w[o,k]
+__global__ void linear_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int N, int K,
+                                     int O) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)N * K) return;
+    const int n = (int)(i / K), k = (int)(i - (long long)n * K);
+    float s = 0.f;
+    for (int o = 0; o < O; ++o) s = fmaf(dy[n * O + o], w[(long long)o * K + k], s);
+    dx[i] = s;
+}
+// dw[o,k] (+)= sum_n dy[n,o] x[n,k] ;  db[o] (+)= sum_n dy[n,o]
+__global__ void linear_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
+                                     float* __restrict__ db, int N, int K, int O, int accumulate) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long long)O * K) {
+        const int o = (int)(i / K), k = (int)(i - (long long)o * K);
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s = fmaf(dy[n * O + o], x[(long long)n * K + k], s);
+        dw[i] = accumulate ? dw[i] + s : s;
+    }
+    if (db && i < O) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += dy[n * O + (int)i];
+        db[i] = accumulate ? db[i] + s : s;
+    }
+}
+
+// CrossEntropyLoss(mean): one thread per row, then a single-block fixed-order reduction.
+__global__ __launch_bounds__(TPB) void softmax_ce_kernel(const float* __restrict__ logits, const long long* __restrict__ labels,
+                                                         float* __restrict__ loss, float* __restrict__ dlogits,
+                                                         int* __restrict__ correct, int N, int O) {
+    __shared__ float sl[TPB];
+    __shared__ int sc[TPB];
+    float lsum = 0.f;
+    int csum = 0;
+    for (int n = threadIdx.x; n < N; n += TPB) {
+        const float* z = logits + (long long)n * O;
+        float m = z[0];
+        int am = 0;
+        for (int o = 1; o < O; ++o)
+            if (z[o] > m) {
+                m = z[o];
+                am = o;
+            }
+        float se = 0.f;
+        for (int o = 0; o < O; ++o) se += expf(z[o] - m);
+        const float lse = m + logf(se);
+        const int lab = (int)labels[n];
+        lsum += lse - z[lab];
+        csum += (am == lab);
+        if (dlogits) {
+            const float invN = 1.f / (float)N;
+            for (int o = 0; o < O; ++o) dlogits[(long long)n * O + o] = (expf(z[o] - lse) - (o == lab ? 1.f : 0.f)) * invN;
+        }
+    }
+    sl[threadIdx.x] = lsum;
+    sc[threadIdx.x] = csum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        int c = 0;
+        for (int k = 0; k < TPB; ++k) {
+            t += sl[k];
+            c += sc[k];
+        }
+        loss[0] = t / (float)N;
+        if (correct) correct[0] = c;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float lr, long long n) {
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long long)gridDim.x * TPB) {
+        f32x4 a = reinterpret_cast<f32x4*>(p)[i];
+        const f32x4 b = reinterpret_cast<const f32x4*>(g)[i];
+        a = a - b * lr;     // p.add_(g, alpha=-lr), fed_run.py:80
+        reinterpret_cast<f32x4*>(p)[i] = a;
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) p[i] -= lr * g[i];
+}
+__global__ __launch_bounds__(TPB) void scale_kernel(float* __restrict__ p, float s, long long n) {
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long long)gridDim.x * TPB) {
+        reinterpret_cast<f32x4*>(p)[i] = reinterpret_cast<f32x4*>(p)[i] * s;
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) p[i] *= s;
+}
+
+int grid_for(long long total) {
+    long long g = (total + TPB - 1) / TPB;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+struct Split {
+    int S, cgb, PL, gy;
+};
+Split pick_split(long long M, int C) {
+    Split sp;
+    const int cg = C / 4;
+    sp.cgb = cg < TPB ? cg : TPB;
+    sp.PL = TPB / sp.cgb;
+    sp.gy = (cg + sp.cgb - 1) / sp.cgb;
+    long long s = 2048 / sp.gy;                        // ~2048 workgroups
+    const long long smax = (M + 8LL * sp.PL - 1) / (8LL * sp.PL);   // >= 8 rows per row lane
+    if (s > smax) s = smax;
+    if (s > MAXS) s = MAXS;
+    if (s < 1) s = 1;
+    sp.S = (int)s;
+    return sp;
+}
+
+}  // namespace
+
+extern "C" int64_t ccst_bn_workspace_bytes(int64_t M, int C) {
+    (void)M;
+    return ((int64_t)MAXS * C * 2 + 4LL * C) * 4;     // partials + scale/shift (fwd) or sums (bwd)
+}
+
+extern "C" int ccst_bn_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                     float momentum, float eps, const float* residual, int relu, float* y, float* save_mean,
+                                     float* save_invstd, int64_t M, int C, void* ws, int64_t ws_bytes, void* stream) {
+    CCST_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && ws, "bn_train_fwd: null pointer");
+    CCST_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_train_fwd: need M>0 and C %% 4 == 0 (C=%d)", C);
+    CCST_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_fwd: running stats must come together");
+    if (ws_bytes < ccst_bn_workspace_bytes(M, C)) {
+        ccst_set_error("bn_train_fwd: workspace too small");
+        return CCST_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const Split sp = pick_split(M, C);
+    float* part = (float*)ws;
+    float* scale = part + (int64_t)MAXS * C * 2;
+    float* shift = scale + C;
+    hipLaunchKernelGGL(chan_partials_kernel<0>, dim3(sp.S, sp.gy), dim3(TPB), 0, st, x, nullptr, nullptr, nullptr, nullptr, 0, part,
+                       (long long)M, C, sp.S, sp.cgb, sp.PL);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, part, gamma, beta, running_mean, running_var,
+                       momentum, eps, save_mean, save_invstd, scale, shift, (long long)M, C, sp.S);
+    const long long total4 = (long long)M * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(TPB), 0, st, x, scale, shift, nullptr, nullptr, nullptr, nullptr,
+                       eps, residual, relu, y, total4, C);
+    return ccst_launch_status("bn_train_fwd");
+}
+
+extern "C" int ccst_bn_eval_fwd_f32(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                                    const float* running_var, float eps, const float* residual, int relu, float* y, int64_t M, int C,
+                                    void* stream) {
+    CCST_REQUIRE(x && gamma && beta && running_mean && running_var && y, "bn_eval_fwd: null pointer");
+    CCST_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_eval_fwd: need M>0 and C %% 4 == 0");
+    const long long total4 = (long long)M * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(TPB), 0, (hipStream_t)stream, x, nullptr, nullptr, gamma, beta,
+                       running_mean, running_var, eps, residual, relu, y, total4, C);
+    return ccst_launch_status("bn_eval_fwd");
+}
+
+extern "C" int ccst_bn_train_bwd_f32(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean,
+                                     const float* save_invstd, int relu, float* dx, float* d_residual, float* dgamma, float* dbeta,
+                                     int accumulate, int64_t M, int C, void* ws, int64_t ws_bytes, void* stream) {
+    CCST_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws, "bn_train_bwd: null pointer");
+    CCST_REQUIRE(!relu || y, "bn_train_bwd: relu=1 needs the saved output y");
+    CCST_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_train_bwd: need M>0 and C %% 4 == 0");
+    if (ws_bytes < ccst_bn_workspace_bytes(M, C)) {
+        ccst_set_error("bn_train_bwd: workspace too small");
+        return CCST_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const Split sp = pick_split(M, C);
+    float* part = (float*)ws;
+    float* sums = part + (int64_t)MAXS * C * 2;
+    hipLaunchKernelGGL(chan_partials_kernel<1>, dim3(sp.S, sp.gy), dim3(TPB), 0, st, x, dy, y, save_mean, save_invstd, relu, part,
+                       (long long)M, C, sp.S, sp.cgb, sp.PL);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, part, dgamma, dbeta, sums, C, sp.S, accumulate);
+    const long long total4 = (long long)M * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(TPB), 0, st, dy, x, y, gamma, save_mean, save_invstd, sums,
+                       relu, dx, d_residual, total4, C, 1.f / (float)M);
+    return ccst_launch_status("bn_train_bwd");
+}
+
+extern "C" int ccst_maxpool3s2_fwd_f32(const float* x, float* y, uint32_t* idx, int N, int H, int W, int C, int Ho, int Wo,
+                                       void* stream) {
+    CCST_REQUIRE(x && y && idx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool_fwd: bad args");
+    CCST_REQUIRE(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, "maxpool_fwd: Ho/Wo must be floor((H+2-3)/2)+1");
+    const long long total = (long long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, (const f32x4*)x, (f32x4*)y, idx,
+                       N, H, W, C / 4, Ho, Wo);
+    return ccst_launch_status("maxpool_fwd");
+}
+
+extern "C" int ccst_maxpool3s2_bwd_f32(const float* dy, const uint32_t* idx, float* dx, int N, int H, int W, int C, int Ho, int Wo,
+                                       void* stream) {
+    CCST_REQUIRE(dy && idx && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool_bwd: bad args");
+    const long long total = (long long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, (hipStream_t)stream, (const f32x4*)dy, idx,
+                       (f32x4*)dx, N, H, W, C / 4, Ho, Wo);
+    return ccst_launch_status("maxpool_bwd");
+}
+
+extern "C" int ccst_avgpool_fwd_f32(const float* x, float* y, int N, int HW, int C, void* stream) {
+    CCST_REQUIRE(x && y && N > 0 && HW > 0 && C > 0, "avgpool_fwd: bad args");
+    hipLaunchKernelGGL(avgpool_fwd_kernel, dim3((N * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, y, N, HW, C);
+    return ccst_launch_status("avgpool_fwd");
+}
+extern "C" int ccst_avgpool_bwd_f32(const float* dy, float* dx, int N, int HW, int C, void* stream) {
+    CCST_REQUIRE(dy && dx && N > 0 && HW > 0 && C > 0, "avgpool_bwd: bad args");
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid_for((long long)N * HW * C)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, HW, C);
+    return ccst_launch_status("avgpool_bwd");
+}
+
+extern "C" int ccst_linear_fwd_f32(const float* x, const float* w, const float* b, float* y, int N, int K, int O, void* stream) {
+    CCST_REQUIRE(x && w && y && N > 0 && K > 0 && O > 0, "linear_fwd: bad args");
+    const long long waves = (long long)N * O;
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)((waves * 64 + TPB - 1) / TPB)), dim3(TPB), 0, (hipStream_t)stream, x, w, b, y,
+                       N, K, O);
+    return ccst_launch_status("linear_fwd");
+}
+extern "C" int ccst_linear_bwd_f32(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int accumulate,
+                                   int N, int K, int O, void* stream) {
+    CCST_REQUIRE(x && w && dy && N > 0 && K > 0 && O > 0, "linear_bwd: bad args");
+    hipStream_t st = (hipStream_t)stream;
+    if (dx) hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((unsigned)(((long long)N * K + 255) / 256)), dim3(256), 0, st, dy, w, dx, N, K, O);
+    if (dw) hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((unsigned)(((long long)O * K + 255) / 256)), dim3(256), 0, st, dy, x, dw, db, N,
+                               K, O, accumulate);
+    return ccst_launch_status("linear_bwd");
+}
+
+extern "C" int ccst_softmax_ce_f32(const float* logits, const int64_t* labels, float* loss, float* dlogits, int32_t* correct, int N,
+                                   int O, void* stream) {
+    CCST_REQUIRE(logits && labels && loss && N > 0 && O > 0, "softmax_ce: bad args");
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(TPB), 0, (hipStream_t)stream, logits, (const long long*)labels, loss, dlogits,
+                       correct, N, O);
+    return ccst_launch_status("softmax_ce");
+}
+
+extern "C" int ccst_sgd_f32(float* p, const float* g, float lr, int64_t n, void* stream) {
+    CCST_REQUIRE(p && g && n > 0, "sgd: bad args");
+    CCST_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0), "sgd: arenas must be 16-byte aligned");
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4 + 1)), dim3(TPB), 0, (hipStream_t)stream, p, g, lr, (long long)n);
+    return ccst_launch_status("sgd");
+}
+extern "C" int ccst_scale_f32(float* p, float s, int64_t n, void* stream) {
+    CCST_REQUIRE(p && n > 0, "scale: bad args");
+    CCST_REQUIRE((uintptr_t)p % 16 == 0, "scale: arena must be 16-byte aligned");
+    hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n / 4 + 1)), dim3(TPB), 0, (hipStream_t)stream, p, s, (long long)n);
+    return ccst_launch_status("scale");
+}

@@ -1,0 +1,243 @@
+"""Drop-in for the federated hot path of federated/fed_run.py on HIP kernels + RCCL:
+
+    train(model, train_loader, optimizer, loss_fun, client_num, device, args, iter_idx, logger)   fed_run.py:31-88
+    test(model, test_loader, loss_fun, device, args)                                               fed_run.py:214-259
+    communication(args, server_model, models, client_weights)                                       fed_run.py:385-455
+
+plus the pieces the reference takes from torch: ``CrossEntropyLoss`` (fed_run.py:554) and ``SGD``
+(fed_run.py:657), here as single HIP launches over a flat parameter arena (``FlatParams``), and
+``communication_distributed`` -- the MI355X form of FedAvg: one process per GPU/client, the weighted
+average is ONE all-reduce(SUM) over xGMI of the flat fp32 state.
+"""
+import torch
+from torch import nn
+
+from . import _lib, nn_ops, ops
+from ._lib import check, ptr, stream_ptr
+
+
+# ---------------------------------------------------------------------------
+# flat parameter arena
+# ---------------------------------------------------------------------------
+class FlatParams(object):
+    """Re-homes a model's float parameters and float buffers (BN running stats) into one contiguous
+    fp32 arena [params | buffers], and the gradients into a second one.  SGD is then one launch, and
+    FedAvg one all-reduce with no packing copies.  ``num_batches_tracked`` (int64) stays outside."""
+
+    def __init__(self, model):
+        params = [p for p in model.parameters()]
+        bufs = [b for b in model.buffers() if b.dtype == torch.float32]
+        if not params:
+            raise ValueError("model has no parameters")
+        dev = params[0].device      # arena = memory re-homing only; the kernels that use it need the GPU
+
+        def al(n):
+            return (n + 3) // 4 * 4          # keep every tensor 16-byte aligned inside the arena
+
+        self.n_param = sum(al(p.numel()) for p in params)
+        self.n_total = self.n_param + sum(al(b.numel()) for b in bufs)
+        self.flat = torch.zeros(self.n_total, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(self.n_param, device=dev, dtype=torch.float32)
+        off = 0
+        with torch.no_grad():
+            for p in params:
+                n = p.numel()
+                self.flat[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat[off:off + n].view(p.shape)
+                p.grad = self.grad[off:off + n].view(p.shape)
+                off += al(n)
+            assert off == self.n_param
+            for b in bufs:
+                n = b.numel()
+                self.flat[off:off + n].copy_(b.reshape(-1))
+                b.data = self.flat[off:off + n].view(b.shape)
+                off += al(n)
+        self.params = params
+        self.model = model
+        model.__dict__["_ccst_arena"] = self
+
+    @staticmethod
+    def of(model):
+        a = model.__dict__.get("_ccst_arena")
+        if a is None:
+            a = FlatParams(model)
+        return a
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, off in self._slots():
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
+                p.grad = self.grad[off:off + p.numel()].view(p.shape)
+
+    def _slots(self):
+        off = 0
+        for p in self.params:
+            yield p, off
+            off += (p.numel() + 3) // 4 * 4
+
+
+class SGD(object):
+    """optim.SGD(params, lr) with no momentum / weight decay (fed_run.py:657): p -= lr * g, one launch."""
+
+    def __init__(self, model_or_params, lr):
+        if isinstance(model_or_params, nn.Module):
+            self.arena = FlatParams.of(model_or_params)
+        elif isinstance(model_or_params, FlatParams):
+            self.arena = model_or_params
+        else:
+            raise TypeError("ccst_amd.fed.SGD takes the model (or its FlatParams), e.g. SGD(model, lr=args.lr)")
+        self.lr = float(lr)
+        self.param_groups = [{"lr": self.lr, "params": self.arena.params}]
+
+    def zero_grad(self, set_to_none=False):
+        self.arena.zero_grad()
+
+    def step(self):
+        a = self.arena
+        check(_lib.load().ccst_sgd_f32(ptr(a.flat), ptr(a.grad), float(self.param_groups[0]["lr"]), a.n_param, stream_ptr()), "sgd")
+        ops.bump_weights_epoch()
+
+
+class CrossEntropyLoss(nn.Module):
+    """nn.CrossEntropyLoss() (mean).  The last call's argmax==label count is kept in ``correct``
+    (a device int32), so train()/test() need no second pass over the logits."""
+
+    def __init__(self):
+        super().__init__()
+        self.correct = None
+
+    def forward(self, logits, labels):
+        if self.correct is None or self.correct.device != logits.device:
+            self.correct = torch.zeros(1, device=logits.device, dtype=torch.int32)
+        return nn_ops.CrossEntropyFn.apply(logits, labels, self.correct)
+
+
+# ---------------------------------------------------------------------------
+# train / test  (fed_run.py:31-88, :214-259)
+# ---------------------------------------------------------------------------
+def _dg(args):
+    return (getattr(args, "dg_method", "") or "").lower()
+
+
+def train(model, train_loader, optimizer, loss_fun, client_num, device, args, iter_idx, logger):
+    if _dg(args) in ("rsc", "jigsaw", "mixstyle"):
+        raise NotImplementedError("ccst_amd.fed: --dg_method %s is outside the hot path" % args.dg_method)
+    model.to(device)
+    model.train()
+    num_data = 0
+    loss_all = torch.zeros((), device=device)
+    correct_all = torch.zeros((), device=device, dtype=torch.int64)
+    it = -1
+    fused_acc = isinstance(loss_fun, CrossEntropyLoss)
+    for it, data in enumerate(train_loader):
+        img, class_l = data
+        img, class_l = img.to(device, non_blocking=True), class_l.to(device, non_blocking=True)
+        optimizer.zero_grad()
+        class_logit = model(img)
+        loss = loss_fun(class_logit, class_l)
+        if fused_acc:
+            batch_correct = loss_fun.correct[0]
+        else:
+            batch_correct = torch.sum(class_logit.max(dim=1)[1] == class_l.data)
+        # the reference syncs twice per iteration on .item() (fed_run.py:69,76); accumulate on device instead
+        loss_all += loss.detach()
+        correct_all += batch_correct
+        num_data += img.size(0)
+        if logger is not None:
+            logger.log(it, len(train_loader), {"train_loss": loss.item()}, {"class_acc": int(batch_correct)}, img.shape[0])
+        loss.backward()
+        optimizer.step()
+        del img, class_l
+    train_loss = float(loss_all) / (it + 1)
+    train_acc = float(correct_all) / num_data
+    # fed_run.py:85 moves the model back to the CPU after every client epoch; on MI355X the client
+    # model stays resident in HBM (288 GB): pass args.offload_models=True to reproduce the move.
+    if getattr(args, "offload_models", False):
+        model.to('cpu')
+    return train_loss, train_acc
+
+
+def test(model, test_loader, loss_fun, device, args):
+    if getattr(args, "IN_test", False):
+        raise NotImplementedError("ccst_amd.fed: --IN_test is outside the hot path")
+    model.to(device)
+    model.eval()
+    num_data = 0
+    loss_all = torch.zeros((), device=device)
+    correct_all = torch.zeros((), device=device, dtype=torch.int64)
+    it = -1
+    fused_acc = isinstance(loss_fun, CrossEntropyLoss)
+    with torch.no_grad():
+        for it, (data, class_l) in enumerate(test_loader):
+            data, class_l = data.to(device, non_blocking=True), class_l.to(device, non_blocking=True)
+            class_logit = model(data)
+            loss = loss_fun(class_logit, class_l)
+            loss_all += loss
+            correct_all += loss_fun.correct[0] if fused_acc else torch.sum(class_logit.max(dim=1)[1] == class_l.data)
+            num_data += data.size(0)
+    class_acc = float(correct_all) / num_data
+    test_loss = float(loss_all) / (it + 1)
+    if getattr(args, "offload_models", False):
+        model.to('cpu')
+    return test_loss, class_acc
+
+
+# ---------------------------------------------------------------------------
+# FedAvg
+# ---------------------------------------------------------------------------
+def _axpy(dst, src, w):
+    """dst += w * src on flat fp32 tensors (16-byte aligned), HIP."""
+    check(_lib.load().ccst_sgd_f32(ptr(dst), ptr(src), -float(w), dst.numel(), stream_ptr()), "axpy")
+
+
+def communication(args, server_model, models, client_weights):
+    """fed_run.py:385-455, the branch every non-'fedbn' mode takes (:400-414): for each state key,
+    'num_batches_tracked' -> server takes client 0's value (clients keep theirs); otherwise
+    server = sum_i w_i * client_i and every client is overwritten with it.  In-process form (all
+    models on one GPU) for API parity; see communication_distributed for the one-client-per-GPU form."""
+    mode = (getattr(args, "mode", "fedavg") or "fedavg").lower()
+    if mode == "fedbn":
+        raise NotImplementedError("ccst_amd.fed: --mode fedbn is outside the hot path (SURVEY.md 8f-4)")
+    with torch.no_grad():
+        arenas = [FlatParams.of(m) for m in [server_model] + list(models)]
+        srv, clients = arenas[0], arenas[1:]
+        if any(c.n_total != srv.n_total for c in clients):
+            raise ValueError("communication: client and server models differ in size")
+        srv.flat.zero_()
+        for ci in range(len(client_weights)):
+            _axpy(srv.flat, clients[ci].flat, client_weights[ci])
+        for ci in range(len(client_weights)):
+            clients[ci].flat.copy_(srv.flat)                      # device-to-device memcpy
+        ops.bump_weights_epoch()
+        ssd, c0 = server_model.state_dict(), models[0].state_dict()
+        for key in ssd.keys():
+            if 'num_batches_tracked' in key:
+                ssd[key].data.copy_(c0[key])
+    return server_model, models
+
+
+def _hip_scale(flat, w, n):
+    if not flat.is_cuda:
+        raise RuntimeError("ccst_amd.fed: the FedAvg pre-scale runs on the GPU; no CPU fallback")
+    check(_lib.load().ccst_scale_f32(ptr(flat), float(w), n, stream_ptr()), "scale")
+
+
+def communication_distributed(args, model, client_weight, group=None, server_counters=None, scale_fn=_hip_scale):
+    """FedAvg with one client per rank/GPU: theta <- sum_i w_i * theta_i as ONE all-reduce(SUM) of the
+    flat arena (parameters + BN running stats) over RCCL/xGMI; each rank pre-scales by its own w_i.
+    After the call every rank holds the server model (what fed_run.py:411-414 copies to all clients).
+    num_batches_tracked: each client keeps its own; the server's copy is client 0's (fed_run.py:404-405),
+    returned in `server_counters` (broadcast from rank 0) when given."""
+    import torch.distributed as dist
+    mode = (getattr(args, "mode", "fedavg") or "fedavg").lower()
+    if mode == "fedbn":
+        raise NotImplementedError("ccst_amd.fed: --mode fedbn is outside the hot path")
+    arena = FlatParams.of(model)
+    with torch.no_grad():
+        scale_fn(arena.flat, client_weight, arena.n_total)      # tests of the gloo protocol inject a host scale
+        dist.all_reduce(arena.flat, op=dist.ReduceOp.SUM, group=group)
+        ops.bump_weights_epoch()
+        if server_counters is not None:
+            for t in server_counters:
+                dist.broadcast(t, src=0, group=group)
+    return model

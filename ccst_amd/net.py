@@ -217,7 +217,7 @@ def _signature(mods):
     for m in mods:
         for p in m.parameters(recurse=False):
             sig.append((id(p), p._version, p.data_ptr()))
-    return (tuple(id(m) for m in mods), tuple(sig))
+    return (tuple(id(m) for m in mods), tuple(sig), ops.WEIGHTS_EPOCH)
 
 
 class _PlanCache(object):

@@ -1,0 +1,262 @@
+"""Drop-in for nets/resnet.py (ResNet :132-191, resnet18 :326-345, resnet50 :350-370) on HIP kernels.
+
+Same attribute names (conv1, bn1, relu, maxpool, layer1..4, avgpool, class_classifier) and
+state-dict keys as the reference + torchvision's BasicBlock/Bottleneck, so checkpoints interchange.
+The blocks are restated here because the reference imports them from torchvision
+(nets/resnet.py:3), which is not part of the reference tree: v1.5 layout, stride on the 3x3 conv.
+
+Layers are subclasses of the torch.nn layers (isinstance checks and nn.init loops of the reference
+keep working) whose forward runs HIP kernels; tensors between layers are logical NCHW views of NHWC
+buffers.  BatchNorm is fused with the following ReLU and the residual add.  No CPU path.
+"""
+import os
+
+import torch
+from torch import nn
+
+from .. import nn_ops, ops
+
+
+def _to_nhwc(x):
+    return ops.from_api(x, cpad=1)
+
+
+class Conv2d(nn.Conv2d):
+    """Bias-free zero-padded convolution (the only kind in the ResNet trunk)."""
+
+    def _check(self):
+        if self.bias is not None or self.groups != 1 or self.dilation != (1, 1) or self.padding_mode != "zeros" or \
+                self.kernel_size[0] != self.kernel_size[1] or self.stride[0] != self.stride[1] or self.padding[0] != self.padding[1]:
+            raise NotImplementedError("ccst_amd.nets: unsupported Conv2d %r" % (self,))
+
+    def _cached(self, name, fn):
+        w = self.weight
+        key = (w._version, w.data_ptr(), ops.WEIGHTS_EPOCH)
+        slot = self.__dict__.get("_ccst_" + name)
+        if slot is None or slot[0] != key:
+            with torch.no_grad():
+                slot = (key, fn(w.detach()))
+            self.__dict__["_ccst_" + name] = slot
+        return slot[1]
+
+    def packed(self):
+        return self._cached("pk", lambda w: ops.pack_conv_weight(w))
+
+    def packed_t(self):
+        return self._cached("pkt", lambda w: ops.pack_conv_weight(w, transpose=True))
+
+    def packed_stem(self):
+        def build(w):
+            wv, kwp = ops.stem_virtual_weight(w)
+            return ops.pack_conv_weight(wv), kwp
+        return self._cached("pks", build)
+
+    def forward(self, x):
+        self._check()
+        if not x.is_cuda:
+            raise RuntimeError("ccst_amd.nets: CUDA (ROCm) tensors only; no CPU fallback")
+        if self.in_channels <= 4:
+            return ops.to_api(nn_ops.StemConvFn.apply(x, self.weight, self))
+        return ops.to_api(nn_ops.ConvFn.apply(_to_nhwc(x), self.weight, self))
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """BatchNorm2d fused with an optional residual add and ReLU: y = relu(bn(x) + residual)."""
+
+    def forward(self, x, residual=None, relu=False):
+        if not (self.affine and x.is_cuda):
+            raise NotImplementedError("ccst_amd.nets: affine CUDA BatchNorm2d only")
+        if not self.training and not self.track_running_stats:
+            raise NotImplementedError("ccst_amd.nets: eval-mode BatchNorm2d needs running statistics")
+        res = _to_nhwc(residual) if residual is not None else None
+        y = nn_ops.BNFn.apply(_to_nhwc(x), self.weight, self.bias, res, self, bool(relu))
+        return ops.to_api(y)
+
+
+class ReLU(nn.ReLU):
+    """Kept for attribute/state parity (``model.relu``); in the forward pass ReLU is fused into BatchNorm2d."""
+
+    def forward(self, x):
+        if x.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("ccst_amd.nets: stand-alone differentiable ReLU is not used by the ResNet path "
+                                      "(it is fused: bn(x, relu=True))")
+        return ops.to_api(ops.relu_nhwc(ops.from_api(x, cpad=4)))
+
+
+class MaxPool2d(nn.MaxPool2d):
+    def forward(self, x):
+        if (self.kernel_size, self.stride, self.padding, self.ceil_mode) != (3, 2, 1, False):
+            raise NotImplementedError("ccst_amd.nets: only MaxPool2d(3, 2, 1) (nets/resnet.py:140)")
+        return ops.to_api(nn_ops.MaxPool3s2Fn.apply(_to_nhwc(x)))
+
+
+class AvgPool2d(nn.AvgPool2d):
+    def forward(self, x):
+        k = self.kernel_size if isinstance(self.kernel_size, int) else self.kernel_size[0]
+        H, W = x.shape[2], x.shape[3]
+        if H < k or W < k:
+            raise RuntimeError("Given input size: (%dx%dx%d). Calculated output size: (%dx%dx%d). Output size is too small"
+                               % (x.shape[1], H, W, x.shape[1], H - k + 1, W - k + 1))
+        if (H, W) != (k, k):
+            raise NotImplementedError("ccst_amd.nets: AvgPool2d(%d) is implemented for a %dx%d map (image_size 193..224)" % (k, k, k))
+        y = nn_ops.AvgPoolFlattenFn.apply(_to_nhwc(x))
+        return y.view(y.shape[0], y.shape[1], 1, 1)
+
+
+class Linear(nn.Linear):
+    def forward(self, x):
+        return nn_ops.LinearFn.apply(x, self.weight, self.bias)
+
+
+def conv3x3(in_planes, out_planes, stride=1):
+    return Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+def conv1x1(in_planes, out_planes, stride=1):
+    return Conv2d(in_planes, out_planes, kernel_size=1, stride=stride, bias=False)
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.bn1 = BatchNorm2d(planes)
+        self.relu = ReLU(inplace=True)
+        self.conv2 = conv3x3(planes, planes)
+        self.bn2 = BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.conv2(out)
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        return self.bn2(out, residual=identity, relu=True)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = conv1x1(inplanes, planes)
+        self.bn1 = BatchNorm2d(planes)
+        self.conv2 = conv3x3(planes, planes, stride)
+        self.bn2 = BatchNorm2d(planes)
+        self.conv3 = conv1x1(planes, planes * self.expansion)
+        self.bn3 = BatchNorm2d(planes * self.expansion)
+        self.relu = ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        identity = x
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
+        out = self.conv3(out)
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        return self.bn3(out, residual=identity, relu=True)
+
+
+class ResNet(nn.Module):
+    """nets/resnet.py:132-191."""
+
+    def __init__(self, block, layers, classes=100):
+        self.inplanes = 64
+        super(ResNet, self).__init__()
+        self.conv1 = Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = BatchNorm2d(64)
+        self.relu = ReLU(inplace=True)
+        self.maxpool = MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.avgpool = AvgPool2d(7, stride=1)
+        self.class_classifier = Linear(512 * block.expansion, classes)
+
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                BatchNorm2d(planes * block.expansion),
+            )
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def is_patch_based(self):
+        return False
+
+    def _bump_counters(self):
+        # BatchNorm2d.num_batches_tracked += 1 for every BN, as one fused launch
+        cs = self.__dict__.get("_ccst_nbt")
+        if cs is None:
+            cs = [m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
+            self.__dict__["_ccst_nbt"] = cs
+        if cs:
+            torch._foreach_add_(cs, 1)
+
+    def forward(self, x, **kwargs):
+        if self.training:
+            self._bump_counters()
+        x = self.conv1(x)
+        x = self.bn1(x, relu=True)
+        x = self.maxpool(x)
+        x = self.layer1(x)
+        x = self.layer2(x)
+        x = self.layer3(x)
+        x = self.layer4(x)
+        x = self.avgpool(x)
+        x = x.view(x.size(0), -1)
+        return self.class_classifier(x)
+
+    def _apply(self, fn, *a, **k):
+        self.__dict__.pop("_ccst_nbt", None)
+        return super()._apply(fn, *a, **k)
+
+
+def _maybe_pretrained(model, name, pretrained):
+    """nets/resnet.py:340-344,364-369 load ImageNet weights through model_zoo (network access).  Here:
+    load from $CCST_PRETRAINED_DIR/<name>.pth if present, else keep the reference's kaiming init."""
+    if not pretrained:
+        return model
+    d = os.environ.get("CCST_PRETRAINED_DIR", "")
+    path = os.path.join(d, name + ".pth")
+    if d and os.path.exists(path):
+        model.load_state_dict(torch.load(path, map_location="cpu"), strict=False)
+        print("Use pretrained %s" % name)
+    return model
+
+
+def _unsupported(args):
+    dg = getattr(args, "dg_method", "") or ""
+    if dg.lower() in ("jigsaw", "mixstyle"):
+        raise NotImplementedError("ccst_amd.nets: --dg_method %s is outside the hot path (SURVEY.md section 2)" % dg)
+
+
+def resnet18(args, pretrained=True, **kwargs):
+    """Constructs a ResNet-18 model (nets/resnet.py:326-345)."""
+    _unsupported(args)
+    return _maybe_pretrained(ResNet(BasicBlock, [2, 2, 2, 2], **kwargs), "resnet18", pretrained)
+
+
+def resnet50(args, pretrained=True, **kwargs):
+    """Constructs a ResNet-50 model (nets/resnet.py:350-370)."""
+    _unsupported(args)
+    return _maybe_pretrained(ResNet(Bottleneck, [3, 4, 6, 3], **kwargs), "resnet50", pretrained)

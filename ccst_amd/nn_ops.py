@@ -1,0 +1,310 @@
+"""torch.autograd.Function wrappers of the ResNet training kernels (C ABI in include/ccst_hip.h).
+
+Autograd is plumbing here: every forward/backward body is one or a few HIP launches.  Activations
+are NHWC-contiguous [N,H,W,C] fp32 tensors.  Parameter gradients are accumulated by the kernels
+directly into ``param.grad`` (allocated on first use, or a view of a flat arena set up by
+``fed.FlatParams``) and the Functions return None for them, so autograd never runs its own
+accumulation kernels.
+"""
+import ctypes
+
+import torch
+
+from . import _lib, ops
+from ._lib import CcstConvDesc, check, ptr, stream_ptr
+
+_WS = {}
+
+
+def _workspace(nbytes, device):
+    """Grow-only per-device scratch buffer (split-K slabs, BN partials).  Kernels on one stream run
+    in order, so a single buffer is safe; it is allocated outside any graph capture at first use."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), device=device, dtype=torch.uint8)
+        _WS[key] = buf
+    return buf
+
+
+def _grad_slot(p):
+    """Return (tensor to write, accumulate flag) for parameter p."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+    return p.grad
+
+
+# ---------------------------------------------------------------------------
+# convolution
+# ---------------------------------------------------------------------------
+def _fwd_desc(N, Hs, Ws, Cx, kh, kw, stride, pad, cin_k, cout, n_pad):
+    ho = (Hs + 2 * pad - kh) // stride + 1
+    wo = (Ws + 2 * pad - kw) // stride + 1
+    d = CcstConvDesc()
+    d.n, d.ho, d.wo, d.hi, d.wi = N, ho, wo, Hs, Ws
+    d.cin, d.cout, d.cout_pad = cin_k, cout, n_pad
+    d.nky, d.nkx = kh, kw
+    d.ay, d.by, d.cy = stride, 1, -pad
+    d.ax, d.bx, d.cx = stride, 1, -pad
+    d.tap_base, d.tap_sy, d.tap_sx = 0, kw, 1
+    d.xsN, d.xsH, d.xsW = Hs * Ws * Cx, Ws * Cx, Cx
+    return d, ho, wo
+
+
+def conv_bwd_data(dy, pc_t, x_shape, stride, pad):
+    """dX of a zero-padded conv: an implicit GEMM over dY with the transposed packed weight.
+    Stride 1: one launch (iy = oy + pad - ky).  Stride s: one launch per output parity class."""
+    N, H, W, Cin = x_shape
+    _, Ho, Wo, Cout = dy.shape
+    kh, kw = pc_t.kh, pc_t.kw
+    lib = _lib.load()
+    if stride == 1:
+        dx = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
+        classes = [(0, 0)]
+    else:
+        dx = torch.zeros(x_shape, device=dy.device, dtype=torch.float32)
+        classes = [(py, px) for py in range(stride) for px in range(stride)]
+    for py, px in classes:
+        ky0, kx0 = (py + pad) % stride, (px + pad) % stride
+        nky, nkx = len(range(ky0, kh, stride)), len(range(kx0, kw, stride))
+        Hc, Wc = len(range(py, H, stride)), len(range(px, W, stride))
+        if nky == 0 or nkx == 0 or Hc == 0 or Wc == 0:
+            continue
+        d = CcstConvDesc()
+        d.n, d.ho, d.wo, d.hi, d.wi = N, Hc, Wc, Ho, Wo
+        d.cin, d.cout, d.cout_pad = pc_t.k_pad, Cin, pc_t.n_pad
+        d.nky, d.nkx = nky, nkx
+        d.ay, d.by, d.cy = 1, -1, (py + pad - ky0) // stride
+        d.ax, d.bx, d.cx = 1, -1, (px + pad - kx0) // stride
+        d.tap_base, d.tap_sy, d.tap_sx = ky0 * kw + kx0, stride * kw, stride
+        d.xsN, d.xsH, d.xsW = Ho * Wo * Cout, Wo * Cout, Cout
+        d.y_off, d.ysN, d.ysH, d.ysW, d.ysC = (py * W + px) * Cin, H * W * Cin, stride * W * Cin, stride * Cin, 1
+        d.flags = 0
+        check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(dy), ptr(pc_t.w), None, ptr(dx), stream_ptr()), "conv bwd-data")
+    return dx
+
+
+def conv_bwd_weight(d, x, dy, weight_grad_oihw, accumulate=True):
+    lib = _lib.load()
+    M = d.n * d.ho * d.wo
+    ntap = d.nky * d.nkx
+    splits = lib.ccst_conv2d_bwd_weight_splits(M, d.cin, d.cout, ntap)
+    need = splits * ntap * d.cin * d.cout * 4
+    ws = _workspace(need, x.device)
+    check(lib.ccst_conv2d_bwd_weight_f32(ctypes.byref(d), ptr(x), ptr(dy), ptr(weight_grad_oihw), splits, int(accumulate),
+                                         ptr(ws), ws.numel(), stream_ptr()), "conv bwd-weight")
+
+
+class ConvFn(torch.autograd.Function):
+    """Bias-free zero-padded Conv2d on NHWC (nets/resnet.py:160-161 + torchvision blocks)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, mod):
+        pc = mod.packed()
+        y = ops.conv2d_nhwc(x, pc, stride=mod.stride[0], pad=mod.padding[0])
+        ctx.save_for_backward(x, weight)
+        ctx.mod = mod
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        mod = ctx.mod
+        dy = dy.contiguous()
+        stride, pad = mod.stride[0], mod.padding[0]
+        N, H, W, Cin = x.shape
+        if weight.requires_grad:
+            d, _, _ = _fwd_desc(N, H, W, Cin, weight.shape[2], weight.shape[3], stride, pad, Cin, weight.shape[0], 0)
+            conv_bwd_weight(d, x, dy, _grad_slot(weight))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = conv_bwd_data(dy, mod.packed_t(), tuple(x.shape), stride, pad)
+        return dx, None, None
+
+
+class StemConvFn(torch.autograd.Function):
+    """Conv2d with <= 4 input channels on the NCHW image (nets/resnet.py:136): no input gradient."""
+
+    @staticmethod
+    def forward(ctx, x_nchw, weight, mod):
+        pc, kwp = mod.packed_stem()
+        stride, pad, kw = mod.stride[0], mod.padding[0], weight.shape[3]
+        x = ops.as_nchw_contiguous(x_nchw)
+        N, C, H, W = x.shape
+        kh = weight.shape[2]
+        ho = (H + 2 * pad - kh) // stride + 1
+        wo = (W + 2 * pad - kw) // stride + 1
+        Hp, Wp = H + 2 * pad, max(W + 2 * pad, (wo - 1) * stride + kwp)
+        xp = torch.empty((N, Hp, Wp, 4), device=x.device, dtype=torch.float32)
+        lib = _lib.load()
+        check(lib.ccst_nchw_to_nhwc4_pad_f32(ptr(x), ptr(xp), N, C, H, W, pad, Wp, 0, stream_ptr()), "nchw_to_nhwc4_pad")
+        d = CcstConvDesc()
+        d.n, d.ho, d.wo, d.hi, d.wi = N, ho, wo, Hp, Wp
+        d.cin, d.cout, d.cout_pad = pc.k_pad, pc.cout, pc.n_pad
+        d.nky, d.nkx = kh, 1
+        d.ay, d.by, d.cy = stride, 1, 0
+        d.ax, d.bx, d.cx = stride, 0, 0
+        d.tap_base, d.tap_sy, d.tap_sx = 0, 1, 0
+        d.xsN, d.xsH, d.xsW = Hp * Wp * 4, Wp * 4, 4
+        d.flags = 0
+        y = torch.empty((N, ho, wo, pc.cout), device=x.device, dtype=torch.float32)
+        d.y_off, d.ysN, d.ysH, d.ysW, d.ysC = 0, ho * wo * pc.cout, wo * pc.cout, pc.cout, 1
+        check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(xp), ptr(pc.w), None, ptr(y), stream_ptr()), "stem conv")
+        ctx.save_for_backward(xp, weight)
+        ctx.geom = (N, ho, wo, Hp, Wp, kh, kw, kwp, stride, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, weight = ctx.saved_tensors
+        N, ho, wo, Hp, Wp, kh, kw, kwp, stride, C = ctx.geom
+        if weight.requires_grad:
+            cout = weight.shape[0]
+            d = CcstConvDesc()
+            d.n, d.ho, d.wo, d.hi, d.wi = N, ho, wo, Hp, Wp
+            d.cin, d.cout = kwp * 4, cout
+            d.nky, d.nkx = kh, 1
+            d.ay, d.by, d.cy = stride, 1, 0
+            d.ax, d.bx, d.cx = stride, 0, 0
+            d.xsN, d.xsH, d.xsW = Hp * Wp * 4, Wp * 4, 4
+            gv = torch.empty((cout, kwp * 4, kh, 1), device=dy.device, dtype=torch.float32)    # virtual-pixel gradient
+            conv_bwd_weight(d, xp, dy.contiguous(), gv, accumulate=False)
+            # un-fold (kx, ci) <- virtual channel kx*4+ci : 9.4k floats of glue
+            g = gv.reshape(cout, kwp, 4, kh)[:, :kw, :C, :].permute(0, 2, 3, 1)
+            _grad_slot(weight).add_(g)
+        return None, None, None
+
+
+# ---------------------------------------------------------------------------
+# batch norm (+ residual + ReLU)
+# ---------------------------------------------------------------------------
+class BNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, residual, mod, relu):
+        lib = _lib.load()
+        N, H, W, C = x.shape
+        M = N * H * W
+        y = torch.empty_like(x)
+        if mod.training:
+            save = torch.empty((2, C), device=x.device, dtype=torch.float32)
+            nb = int(lib.ccst_bn_workspace_bytes(M, C))
+            ws = _workspace(nb, x.device)
+            track = mod.track_running_stats and mod.running_mean is not None
+            check(lib.ccst_bn_train_fwd_f32(ptr(x), ptr(gamma), ptr(beta), ptr(mod.running_mean if track else None),
+                                            ptr(mod.running_var if track else None), float(mod.momentum), float(mod.eps),
+                                            ptr(residual), int(relu), ptr(y), ptr(save[0]), ptr(save[1]), M, C, ptr(ws),
+                                            ws.numel(), stream_ptr()), "bn_train_fwd")
+            ctx.save_for_backward(x, y, gamma, beta, save)
+            ctx.relu, ctx.has_res = bool(relu), residual is not None
+        else:
+            check(lib.ccst_bn_eval_fwd_f32(ptr(x), ptr(gamma), ptr(beta), ptr(mod.running_mean), ptr(mod.running_var),
+                                           float(mod.eps), ptr(residual), int(relu), ptr(y), M, C, stream_ptr()), "bn_eval_fwd")
+            ctx.save_for_backward()
+            ctx.eval_mode = True
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if getattr(ctx, "eval_mode", False):
+            raise RuntimeError("ccst_amd: backward through eval-mode BatchNorm is not on the reference path")
+        x, y, gamma, beta, save = ctx.saved_tensors
+        lib = _lib.load()
+        N, H, W, C = x.shape
+        M = N * H * W
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dres = torch.empty_like(x) if ctx.has_res else None
+        ws = _workspace(int(lib.ccst_bn_workspace_bytes(M, C)), x.device)
+        check(lib.ccst_bn_train_bwd_f32(ptr(dy), ptr(x), ptr(y), ptr(gamma), ptr(save[0]), ptr(save[1]), int(ctx.relu), ptr(dx),
+                                        ptr(dres), ptr(_grad_slot(gamma)), ptr(_grad_slot(beta)), 1, M, C, ptr(ws), ws.numel(),
+                                        stream_ptr()), "bn_train_bwd")
+        return dx, None, None, dres, None, None
+
+
+# ---------------------------------------------------------------------------
+# pools, linear, loss
+# ---------------------------------------------------------------------------
+class MaxPool3s2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, H, W, C = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.float32)
+        idx = torch.empty((N, Ho, Wo, C // 4), device=x.device, dtype=torch.int32)
+        check(_lib.load().ccst_maxpool3s2_fwd_f32(ptr(x), ptr(y), ptr(idx), N, H, W, C, Ho, Wo, stream_ptr()), "maxpool_fwd")
+        ctx.save_for_backward(idx)
+        ctx.shape = (N, H, W, C, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        N, H, W, C, Ho, Wo = ctx.shape
+        dx = torch.empty((N, H, W, C), device=dy.device, dtype=torch.float32)
+        check(_lib.load().ccst_maxpool3s2_bwd_f32(ptr(dy.contiguous()), ptr(idx), ptr(dx), N, H, W, C, Ho, Wo, stream_ptr()),
+              "maxpool_bwd")
+        return dx
+
+
+class AvgPoolFlattenFn(torch.autograd.Function):
+    """AvgPool2d over the whole map + flatten: [N,H,W,C] -> [N,C]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        N, H, W, C = x.shape
+        y = torch.empty((N, C), device=x.device, dtype=torch.float32)
+        check(_lib.load().ccst_avgpool_fwd_f32(ptr(x), ptr(y), N, H * W, C, stream_ptr()), "avgpool_fwd")
+        ctx.shape = (N, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, H, W, C = ctx.shape
+        dx = torch.empty((N, H, W, C), device=dy.device, dtype=torch.float32)
+        check(_lib.load().ccst_avgpool_bwd_f32(ptr(dy.contiguous()), ptr(dx), N, H * W, C, stream_ptr()), "avgpool_bwd")
+        return dx
+
+
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        N, K = x.shape
+        O = weight.shape[0]
+        y = torch.empty((N, O), device=x.device, dtype=torch.float32)
+        check(_lib.load().ccst_linear_fwd_f32(ptr(x), ptr(weight), ptr(bias), ptr(y), N, K, O, stream_ptr()), "linear_fwd")
+        ctx.save_for_backward(x, weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias = ctx.saved_tensors
+        N, K = x.shape
+        O = weight.shape[0]
+        dy = dy.contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = _grad_slot(weight) if weight.requires_grad else None
+        db = _grad_slot(bias) if (bias is not None and bias.requires_grad) else None
+        check(_lib.load().ccst_linear_bwd_f32(ptr(x), ptr(weight), ptr(dy), ptr(dx), ptr(dw), ptr(db), 1, N, K, O, stream_ptr()),
+              "linear_bwd")
+        return dx, None, None
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """nn.CrossEntropyLoss() (mean) with the argmax==label count of fed_run.py:67,71 as a by-product."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, correct_out):
+        logits = logits.contiguous()
+        N, O = logits.shape
+        loss = torch.empty((1,), device=logits.device, dtype=torch.float32)
+        dlog = torch.empty_like(logits)
+        check(_lib.load().ccst_softmax_ce_f32(ptr(logits), ptr(labels.contiguous()), ptr(loss), ptr(dlog), ptr(correct_out), N, O,
+                                              stream_ptr()), "softmax_ce")
+        ctx.save_for_backward(dlog)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlog,) = ctx.saved_tensors
+        return dlog * g, None, None

@@ -15,17 +15,34 @@ from ._lib import CONV_POOL2, CONV_REFLECT, CONV_RELU, CONV_UPS2, CcstConvDesc, 
 
 NCHW, NHWC = 0, 1
 
+# Bumped whenever a kernel rewrites parameters through raw pointers (SGD step, FedAvg), which torch's
+# tensor version counters cannot see; packed-weight caches key on it.
+WEIGHTS_EPOCH = 0
+
+
+def bump_weights_epoch():
+    global WEIGHTS_EPOCH
+    WEIGHTS_EPOCH += 1
+
+
 # bench.py sets TIMING = [] to collect (kernel name, algorithmic flops, start event, end event) per conv launch.
 TIMING = None
 
 
-def _conv_kernel_name(cout, pool):
+def _conv_kernel_name(cout, pool, M):
     """Mirror of the tile dispatch in csrc/conv_igemm.hip (ccst_conv2d_igemm_f32)."""
-    if pool:
-        return "conv_igemm_kernel<4,1,2,pool>" if cout <= 64 else "conv_igemm_kernel<2,2,2,pool>"
-    if cout <= 32:
-        return "conv_igemm_kernel<4,1,1>"
-    return "conv_igemm_kernel<4,1,2>" if cout <= 64 else "conv_igemm_kernel<2,2,2>"
+    import os
+    tile = 222
+    if cout <= 32 and not pool:
+        tile = 411
+    elif cout <= 64:
+        tile = 412
+    elif ((M + 127) // 128) * ((cout + 127) // 128) < 640:
+        tile = 221
+    t = os.environ.get("CCST_CONV_TILE")
+    if t in ("222", "221", "412") or (t == "411" and not pool):
+        tile = int(t)
+    return "conv_igemm_kernel<%s,%s,%s%s>" % (str(tile)[0], str(tile)[1], str(tile)[2], ",pool" if pool else "")
 
 
 def _launch_conv(d, x, pc, out, flops, pool, what):
@@ -37,7 +54,7 @@ def _launch_conv(d, x, pc, out, flops, pool, what):
     e0.record()
     check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(x), ptr(pc.w), ptr(pc.bias), ptr(out), stream_ptr()), what)
     e1.record()
-    TIMING.append((_conv_kernel_name(pc.cout, pool), flops, e0, e1,
+    TIMING.append((_conv_kernel_name(pc.cout, pool, d.n * d.ho * d.wo), flops, e0, e1,
                    "n%d %dx%d cin%d cout%d taps%dx%d flags%d" % (d.n, d.ho, d.wo, d.cin, d.cout, d.nky, d.nkx, d.flags)))
 
 
@@ -70,6 +87,9 @@ def from_api(x, cpad=1):
     v = x.permute(0, 2, 3, 1)
     if Cp == C and v.is_contiguous():
         return v
+    if x.requires_grad and torch.is_grad_enabled():
+        raise RuntimeError("ccst_amd: a differentiable input must already be channels_last (NHWC in memory) with a "
+                           "channel count the kernel accepts; the layout conversion kernels are not differentiable")
     x = as_nchw_contiguous(x)
     y = torch.empty((N, H, W, Cp), device=x.device, dtype=torch.float32)
     check(_lib.load().ccst_nchw_to_nhwc_f32(ptr(x), ptr(y), N, C, H * W, Cp, stream_ptr()), "nchw_to_nhwc")

@@ -104,12 +104,15 @@ int ccst_nchw_to_nhwc_f32(const float* x, float* y, int N, int C, int HW, int Cp
 int ccst_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int HW, int Cs, void* stream);
 
 /* Backward-weight: dW[tap][ci][co] = sum_m X[n, oy*ay+ky*by+cy, ox*ax+kx*bx+cx, ci] * dY[m, co]
- * (zero padding), split over `splits` pixel ranges into ws[splits][ntap][cin][cout] partials, then
- * reduced in fixed order (bitwise reproducible) into OIHW dw[cout][cin][kh][kw] (accumulate=0
- * overwrites).  ws_bytes >= splits*ntap*cin*cout*4.  Replaces Conv2d's weight gradient in
- * loss.backward(), federated/fed_run.py:79. */
+ * (zero padding; x indexed with d's x strides, dY dense [M][cout]), split over `splits` pixel
+ * ranges into ws[splits][ntap][cin][cout] partial slabs, then summed in fixed order (bitwise
+ * reproducible, no float atomics) into OIHW dw[cout][cin][nky][nkx]; accumulate=1 adds to dw.
+ * ws_bytes >= splits*ntap*cin*cout*4.  cin, cout multiples of 4.  Replaces Conv2d's weight
+ * gradient inside loss.backward(), federated/fed_run.py:79. */
 int ccst_conv2d_bwd_weight_f32(const CcstConvDesc* d, const float* x, const float* dy, float* dw_oihw,
-                               int splits, void* ws, int64_t ws_bytes, void* stream);
+                               int splits, int accumulate, void* ws, int64_t ws_bytes, void* stream);
+/* Split count that fills the chip for this problem (M = n*ho*wo). */
+int ccst_conv2d_bwd_weight_splits(int M, int cin, int cout, int ntap);
 
 /* ------------------------------------------------------------------------
  * AdaIN feature statistics / normalisation.  layout: 0 = NCHW planes, 1 = NHWC.
@@ -145,16 +148,20 @@ int ccst_bn_eval_fwd_f32(const float* x, const float* gamma, const float* beta, 
                          const float* running_var, float eps, const float* residual, int relu, float* y,
                          int64_t M, int C, void* stream);
 /* BatchNorm2d backward (with the ReLU mask taken from the saved output y when relu=1):
- * dx, dgamma, dbeta; if d_residual != NULL it receives the masked incoming gradient. */
+ * dx, dgamma, dbeta (accumulate=1 adds into dgamma/dbeta); if d_residual != NULL it receives the
+ * masked incoming gradient (the skip connection's share). */
 int ccst_bn_train_bwd_f32(const float* dy, const float* x, const float* y, const float* gamma,
                           const float* save_mean, const float* save_invstd, int relu, float* dx,
-                          float* d_residual, float* dgamma, float* dbeta, int64_t M, int C,
+                          float* d_residual, float* dgamma, float* dbeta, int accumulate, int64_t M, int C,
                           void* ws, int64_t ws_bytes, void* stream);
 int64_t ccst_bn_workspace_bytes(int64_t M, int C);
 
-/* MaxPool2d(kernel 3, stride 2, padding 1) nets/resnet.py:140, NHWC. */
-int ccst_maxpool3s2_fwd_f32(const float* x, float* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
-int ccst_maxpool3s2_bwd_f32(const float* x, const float* dy, float* dx, int N, int H, int W, int C,
+/* MaxPool2d(kernel 3, stride 2, padding 1) nets/resnet.py:140, NHWC, C % 4 == 0.  idx[N,Ho,Wo,C/4]
+ * packs, per channel, the window position (0..8) of the first maximum (one byte each); backward
+ * gathers through it (deterministic, no atomics). */
+int ccst_maxpool3s2_fwd_f32(const float* x, float* y, uint32_t* idx, int N, int H, int W, int C, int Ho, int Wo,
+                            void* stream);
+int ccst_maxpool3s2_bwd_f32(const float* dy, const uint32_t* idx, float* dx, int N, int H, int W, int C,
                             int Ho, int Wo, void* stream);
 /* AvgPool2d(7) on a 7x7 map + flatten (nets/resnet.py:145,189-190): [N,HW,C] -> [N,C]. */
 int ccst_avgpool_fwd_f32(const float* x, float* y, int N, int HW, int C, void* stream);
@@ -162,7 +169,7 @@ int ccst_avgpool_bwd_f32(const float* dy, float* dx, int N, int HW, int C, void*
 /* Linear (nets/resnet.py:146): y[N,O] = x[N,K] w[O,K]^T + b. */
 int ccst_linear_fwd_f32(const float* x, const float* w, const float* b, float* y, int N, int K, int O, void* stream);
 int ccst_linear_bwd_f32(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
-                        int N, int K, int O, void* stream);
+                        int accumulate, int N, int K, int O, void* stream);
 /* CrossEntropyLoss (mean) forward+backward (fed_run.py:554,65): loss[1], dlogits[N,O] (already
  * scaled by 1/N), correct[1] = #argmax==label (fed_run.py:67,71). */
 int ccst_softmax_ce_f32(const float* logits, const int64_t* labels, float* loss, float* dlogits,

@@ -155,7 +155,25 @@ sys.path.insert(0, REF)
 from nets import resnet as ref_resnet   # noqa: E402  (reference module: ResNet class, _make_layer, forward)
 
 
-def resnet_case(name, block, layers, classes, nb, seed):
+def _run_case(model, x, y, lr):
+    model.eval()
+    with torch.no_grad():
+        logit_eval = model(x)
+    model.train()
+    opt = torch.optim.SGD(model.parameters(), lr=lr)
+    opt.zero_grad()
+    logit_train = model(x)
+    loss = nn.CrossEntropyLoss()(logit_train, y)
+    loss.backward()
+    g = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    opt.step()
+    model.eval()
+    with torch.no_grad():
+        logit_after = model(x)
+    return logit_eval, logit_train, loss, g, logit_after, model.state_dict()
+
+
+def resnet_case(name, block, layers, classes, nb, seed, lr=0.001):
     model = ref_resnet.ResNet(block, layers, classes=classes)
     ours = R.ResNet(block, layers, classes=classes)
     sd = R.seeded_state_dict(ours, seed)
@@ -165,7 +183,7 @@ def resnet_case(name, block, layers, classes, nb, seed):
     with torch.no_grad():
         logit_eval = model(x)
     model.train()
-    opt = torch.optim.SGD(model.parameters(), lr=0.01)       # fed_run.py:657 form
+    opt = torch.optim.SGD(model.parameters(), lr=lr)         # fed_run.py:657 form, README.md:99 lr
     opt.zero_grad()
     logit_train = model(x)
     loss = nn.CrossEntropyLoss()(logit_train, y)               # fed_run.py:554
@@ -186,12 +204,27 @@ def resnet_case(name, block, layers, classes, nb, seed):
     for k in ["bn1.running_mean", "bn1.running_var", "layer4.0.bn1.running_mean", "layer2.0.downsample.1.running_var",
               "bn1.num_batches_tracked"]:
         probe["state/" + k] = sd_after[k]
-    save(name, seed=seed, classes=classes, nb=nb, lr=0.01, logit_eval=logit_eval, logit_train=logit_train,
+    # conditioning of the problem: the SAME reference model in float64.  |fp32 - fp64| per probe is the
+    # noise floor any fp32 implementation sits on (tiny batch + train-mode BN + ReLU/max-pool masks).
+    m64 = ref_resnet.ResNet(block, layers, classes=classes)
+    m64.load_state_dict(sd)
+    m64 = m64.double()
+    le64, lt64, loss64, g64, la64, _ = _run_case(m64, x.double(), y, lr)
+    probe["noise/logit_eval"] = (logit_eval.double() - le64).abs().max()
+    probe["noise/logit_train"] = (logit_train.double() - lt64).abs().max()
+    probe["noise/logit_after"] = (logit_after.double() - la64).abs().max()
+    probe["noise/loss"] = (loss.double() - loss64).abs()
+    for k in list(probe):
+        if k.startswith("grad_head/"):
+            n_ = k[10:]
+            probe["noise/grad_head/" + n_] = (g[n_].flatten()[:16].double() - g64[n_].flatten()[:16]).abs().max()
+            probe["noise/grad_abs/" + n_] = (g[n_].abs().sum().double() - g64[n_].abs().sum()).abs()
+    save(name, seed=seed, classes=classes, nb=nb, lr=lr, logit_eval=logit_eval, logit_train=logit_train,
          loss=loss, logit_after=logit_after, **probe)
 
 
-resnet_case("resnet18_step", R.BasicBlock, [2, 2, 2, 2], 2, 2, seed=50)
-resnet_case("resnet50_step", R.Bottleneck, [3, 4, 6, 3], 7, 2, seed=60)
+resnet_case("resnet18_step", R.BasicBlock, [2, 2, 2, 2], 2, 4, seed=50)
+resnet_case("resnet50_step", R.Bottleneck, [3, 4, 6, 3], 7, 8, seed=60)
 
 # communication() on 3 perturbed clients (fed_run.py:385-455, fedavg branch)
 nsf = {"torch": torch, "nn": nn}
