@@ -37,6 +37,7 @@ _SIGNATURES = {
     "ccst_nhwc_layer_f32": [c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "ccst_nchw_to_nhwc_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "ccst_nhwc_to_nchw_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
+    "ccst_quantize_u8_hwc_f32": [_P, _P, c_int, c_int, c_int, _P],
     "ccst_conv2d_bwd_weight_f32": [POINTER(CcstConvDesc), _P, _P, _P, c_int, c_int, _P, c_int64, _P],
     "ccst_conv2d_bwd_weight_splits": [c_int, c_int, c_int, c_int],
     "ccst_calc_mean_std_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, c_int64, _P],

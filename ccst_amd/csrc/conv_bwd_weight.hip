@@ -160,27 +160,40 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs p) 
         }
 }
 
-// dw[co][ci][tap] (+)= sum_s ws[s][tap][ci][co]   (32x32 transposing tiles over (ci, co))
+// dw[co][ci][tap] (+)= sum_s ws[s][tap][ci][co].  One output element per thread (8 ci x 32 co tile per
+// workgroup => enough workgroups even for 64x64 weights), the split sum unrolled 8 deep so 8 loads are
+// in flight, fixed summation order; the tile is transposed through LDS so stores run along ci.
 __global__ __launch_bounds__(256) void bwd_weight_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int ntap, int Cin,
                                                                 int Cout, int splits, int accumulate) {
-    __shared__ float tile[32][33];
+    __shared__ float tile[8][33];
     const int tap = blockIdx.z;
-    const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+    const int ci0 = blockIdx.y * 8, co0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int r = ty; r < 32; r += 8) {
-        const int ci = ci0 + r, co = co0 + tx;
+    {
+        const int ci = ci0 + ty, co = co0 + tx;
         float s = 0.f;
         if (ci < Cin && co < Cout) {
-            for (int k = 0; k < splits; ++k) s += ws[(((long long)k * ntap + tap) * Cin + ci) * Cout + co];
+            const long long stride = (long long)ntap * Cin * Cout;
+            const float* p = ws + ((long long)tap * Cin + ci) * Cout + co;
+            int k = 0;
+            for (; k + 8 <= splits; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = p[(long long)(k + j) * stride];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += v[j];
+            }
+            for (; k < splits; ++k) s += p[(long long)k * stride];
         }
-        tile[r][tx] = s;
+        tile[ty][tx] = s;
     }
     __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        const int co = co0 + r, ci = ci0 + tx;
+    {
+        const int cil = threadIdx.x & 7, col = threadIdx.x >> 3;
+        const int ci = ci0 + cil, co = co0 + col;
         if (ci < Cin && co < Cout) {
             const long long o = ((long long)co * Cin + ci) * ntap + tap;
-            dw[o] = accumulate ? dw[o] + tile[tx][r] : tile[tx][r];
+            dw[o] = accumulate ? dw[o] + tile[cil][col] : tile[cil][col];
         }
     }
 }
@@ -238,7 +251,7 @@ extern "C" int ccst_conv2d_bwd_weight_f32(const CcstConvDesc* d, const float* x,
     if (d->cin >= 128 && d->cout >= 128) rc = launch<2, 2, 16>(a, s);
     else rc = launch<1, 1, 32>(a, s);
     if (rc) return rc;
-    dim3 grid((d->cout + 31) / 32, (d->cin + 31) / 32, ntap);
+    dim3 grid((d->cout + 31) / 32, (d->cin + 7) / 8, ntap);
     hipLaunchKernelGGL(bwd_weight_reduce_kernel, grid, dim3(256), 0, s, (const float*)ws, dw_oihw, ntap, d->cin, d->cout, splits,
                        accumulate);
     return ccst_launch_status("bwd_weight_reduce");

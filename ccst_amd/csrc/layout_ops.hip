@@ -90,6 +90,20 @@ __global__ void nhwc_map_kernel(const f32x4* __restrict__ x, f32x4* __restrict__
     }
 }
 
+// torchvision.utils.save_image's quantisation (x*255+0.5, clamp to [0,255], uint8, CHW->HWC) in one pass,
+// so only a quarter of the bytes cross PCIe (CCST_OverallStyleTransfer.py:156,167).
+__global__ void quantize_u8_hwc_kernel(const float* __restrict__ x, unsigned char* __restrict__ y, int C, int HW, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / HW;
+        const int p = (int)(i - n * HW);
+        for (int c = 0; c < C; ++c) {
+            float v = x[(n * C + c) * HW + p] * 255.f + 0.5f;
+            v = fminf(fmaxf(v, 0.f), 255.f);
+            y[i * C + c] = (unsigned char)v;
+        }
+    }
+}
+
 int grid_for(long long total) {
     long long g = (total + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -109,6 +123,13 @@ extern "C" int ccst_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int
     dim3 grid((HW + 31) / 32, (C + 31) / 32, N);
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, C, HW, Cs);
     return ccst_launch_status("nhwc_to_nchw");
+}
+
+extern "C" int ccst_quantize_u8_hwc_f32(const float* x_nchw, uint8_t* y_nhwc, int N, int C, int HW, void* stream) {
+    CCST_REQUIRE(x_nchw && y_nhwc && N > 0 && C > 0 && HW > 0, "quantize_u8: bad args");
+    const long long total = (long long)N * HW;
+    hipLaunchKernelGGL(quantize_u8_hwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x_nchw, y_nhwc, C, HW, total);
+    return ccst_launch_status("quantize_u8");
 }
 
 extern "C" int ccst_nhwc_layer_f32(int mode, const float* x, float* y, int N, int H, int W, int C, int pad, void* stream) {

@@ -7,7 +7,7 @@
 namespace {
 
 constexpr int TPB = 256;
-constexpr int MAXS = 512;   // max row-splits of a per-channel reduction
+constexpr int MAXS = 256;   // max row-splits of a per-channel reduction
 
 // ------------------------------------------------------------------------------------------
 // per-channel partial reductions over rows of x[M][C].
@@ -68,18 +68,42 @@ __global__ __launch_bounds__(TPB) void chan_partials_kernel(const float* __restr
     }
 }
 
-// BN forward finalize: batch mean / biased var, running-stat update (unbiased var), scale/shift.
-__global__ void bn_fwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                       float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
-                                       float* __restrict__ save_mean, float* __restrict__ save_invstd, float* __restrict__ scale,
-                                       float* __restrict__ shift, long long M, int C, int S) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int k = 0; k < S; ++k) {
-        s += (double)part[((long long)k * C + c) * 2];
-        q += (double)part[((long long)k * C + c) * 2 + 1];
+// Sum the S split partials of 16 channels with 16 split-lanes each (fp64), then combine the lanes in
+// fixed order through LDS.  Returns the two totals for channel c (valid on lanes with sl == 0).
+__device__ __forceinline__ void reduce_partials16(const float* __restrict__ part, int C, int S, int c, int sl, double& s, double& q) {
+    __shared__ double red[2][16][17];
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        for (int k = sl; k < S; k += 16) {
+            const float2 v = *reinterpret_cast<const float2*>(part + ((long long)k * C + c) * 2);
+            a += (double)v.x;
+            b += (double)v.y;
+        }
     }
+    red[0][sl][c & 15] = a;
+    red[1][sl][c & 15] = b;
+    __syncthreads();
+    s = 0.0;
+    q = 0.0;
+    if (sl == 0) {
+        for (int k = 0; k < 16; ++k) {
+            s += red[0][k][c & 15];
+            q += red[1][k][c & 15];
+        }
+    }
+}
+
+// BN forward finalize: batch mean / biased var, running-stat update (unbiased var), scale/shift.
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var, float momentum, float eps,
+                                                              float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                              float* __restrict__ scale, float* __restrict__ shift, long long M, int C,
+                                                              int S) {
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), sl = threadIdx.x >> 4;
+    double s, q;
+    reduce_partials16(part, C, S, c, sl, s, q);
+    if (sl != 0 || c >= C) return;
     const double mu = s / (double)M;
     double var = q / (double)M - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -130,15 +154,13 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       float* __restrict__ sums, int C, int S, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double a = 0.0, b = 0.0;
-    for (int k = 0; k < S; ++k) {
-        a += (double)part[((long long)k * C + c) * 2];
-        b += (double)part[((long long)k * C + c) * 2 + 1];
-    }
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ sums, int C, int S,
+                                                              int accumulate) {
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), sl = threadIdx.x >> 4;
+    double a, b;
+    reduce_partials16(part, C, S, c, sl, a, b);
+    if (sl != 0 || c >= C) return;
     sums[c] = (float)a;          // sum dy'
     sums[C + c] = (float)b;      // sum dy' * xhat
     if (accumulate) {
@@ -381,7 +403,7 @@ Split pick_split(long long M, int C) {
     sp.cgb = cg < TPB ? cg : TPB;
     sp.PL = TPB / sp.cgb;
     sp.gy = (cg + sp.cgb - 1) / sp.cgb;
-    long long s = 2048 / sp.gy;                        // ~2048 workgroups
+    long long s = 1024 / sp.gy;                        // ~1024 workgroups
     const long long smax = (M + 8LL * sp.PL - 1) / (8LL * sp.PL);   // >= 8 rows per row lane
     if (s > smax) s = smax;
     if (s > MAXS) s = MAXS;
@@ -414,7 +436,7 @@ extern "C" int ccst_bn_train_fwd_f32(const float* x, const float* gamma, const f
     float* shift = scale + C;
     hipLaunchKernelGGL(chan_partials_kernel<0>, dim3(sp.S, sp.gy), dim3(TPB), 0, st, x, nullptr, nullptr, nullptr, nullptr, 0, part,
                        (long long)M, C, sp.S, sp.cgb, sp.PL);
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, part, gamma, beta, running_mean, running_var,
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, gamma, beta, running_mean, running_var,
                        momentum, eps, save_mean, save_invstd, scale, shift, (long long)M, C, sp.S);
     const long long total4 = (long long)M * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(TPB), 0, st, x, scale, shift, nullptr, nullptr, nullptr, nullptr,
@@ -449,7 +471,7 @@ extern "C" int ccst_bn_train_bwd_f32(const float* dy, const float* x, const floa
     float* sums = part + (int64_t)MAXS * C * 2;
     hipLaunchKernelGGL(chan_partials_kernel<1>, dim3(sp.S, sp.gy), dim3(TPB), 0, st, x, dy, y, save_mean, save_invstd, relu, part,
                        (long long)M, C, sp.S, sp.cgb, sp.PL);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, part, dgamma, dbeta, sums, C, sp.S, accumulate);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, dgamma, dbeta, sums, C, sp.S, accumulate);
     const long long total4 = (long long)M * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(TPB), 0, st, dy, x, y, gamma, save_mean, save_invstd, sums,
                        relu, dx, d_residual, total4, C, 1.f / (float)M);

@@ -80,7 +80,15 @@ def conv_bwd_data(dy, pc_t, x_shape, stride, pad):
         d.xsN, d.xsH, d.xsW = Ho * Wo * Cout, Wo * Cout, Cout
         d.y_off, d.ysN, d.ysH, d.ysW, d.ysC = (py * W + px) * Cin, H * W * Cin, stride * W * Cin, stride * Cin, 1
         d.flags = 0
-        check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(dy), ptr(pc_t.w), None, ptr(dx), stream_ptr()), "conv bwd-data")
+        if ops.TIMING is None:
+            check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(dy), ptr(pc_t.w), None, ptr(dx), stream_ptr()), "conv bwd-data")
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(dy), ptr(pc_t.w), None, ptr(dx), stream_ptr()), "conv bwd-data")
+            e1.record()
+            ops.TIMING.append(("bwd_data:" + ops._conv_kernel_name(Cin, False, N * Hc * Wc), 2.0 * N * Hc * Wc * Cin * Cout * nky * nkx,
+                               e0, e1, "n%d %dx%d cin%d cout%d taps%dx%d s%d" % (N, Hc, Wc, Cout, Cin, nky, nkx, stride)))
     return dx
 
 
@@ -91,8 +99,15 @@ def conv_bwd_weight(d, x, dy, weight_grad_oihw, accumulate=True):
     splits = lib.ccst_conv2d_bwd_weight_splits(M, d.cin, d.cout, ntap)
     need = splits * ntap * d.cin * d.cout * 4
     ws = _workspace(need, x.device)
+    if ops.TIMING is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib.ccst_conv2d_bwd_weight_f32(ctypes.byref(d), ptr(x), ptr(dy), ptr(weight_grad_oihw), splits, int(accumulate),
                                          ptr(ws), ws.numel(), stream_ptr()), "conv bwd-weight")
+    if ops.TIMING is not None:
+        e1.record()
+        ops.TIMING.append(("bwd_weight", 2.0 * M * d.cin * d.cout * ntap, e0, e1,
+                           "n%d %dx%d cin%d cout%d taps%dx%d splits%d" % (d.n, d.ho, d.wo, d.cin, d.cout, d.nky, d.nkx, splits)))
 
 
 class ConvFn(torch.autograd.Function):

@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Drop-in for the reference's federated/fed_run.py (fedavg path): same flags (:458-503), console lines,
+checkpoint dicts ({'server_model', 'a_iter'}, best and '_latest', :733-766) and --resume / --test.
+
+Two launch forms
+  * python federated/fed_run.py ...                      one process, clients trained one after another on
+                                                         one GPU, in-process communication() (the reference's
+                                                         schedule, fed_run.py:663-684)
+  * torchrun --nproc-per-node K federated/fed_run.py ... one process per GPU = one client per GPU (K = number
+                                                         of --source domains); the FedAvg average is ONE RCCL
+                                                         all-reduce of the flat fp32 state per global round.
+Out of scope: fedbn / adafea / fedprox aggregation variants, RSC / Jigsaw / MixStyle /
+FedDG, Tent, tensorboard / Excel logging."""
+import argparse
+import copy
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from ccst_amd import data, fed  # noqa: E402
+from ccst_amd.nets.models import get_network, nets_map  # noqa: E402
+
+available_datasets = ["art_painting", "cartoon", "photo", "sketch", 'art', 'clipart', 'product', 'real_world',
+                      'MNIST', 'MNIST_M', 'SVHN', 'SynthDigits', 'USPS',
+                      'hospital1', 'hospital2', 'hospital3', 'hospital4', 'hospital5']
+
+
+def parse():
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--log', action='store_true', help='whether to make a log')
+    parser.add_argument('--test', action='store_true', help='test the pretrained model')
+    parser.add_argument('--IN_test', action='store_true', help='test the pretrained model using IN with affine')
+    parser.add_argument('--batch', type=int, default=32, help='batch size')
+    parser.add_argument('--iters', type=int, default=500, help='iterations for communication')
+    parser.add_argument('--wk_iters', type=int, default=1, help='optimization iters in local worker between communication')
+    parser.add_argument('--mode', type=str, default='fedavg', choices=['fedavg', 'fedbn', 'adafea', 'fedprox', 'deepall'])
+    parser.add_argument('--mu', type=float, default=1e-2)
+    parser.add_argument('--save_path', type=str, default='../checkpoint', help='path to save the checkpoint')
+    parser.add_argument('--resume', action='store_true', help='resume training from the save path checkpoint')
+    parser.add_argument('--percent', type=float, default=0.1)
+    parser.add_argument("--n_classes", "-c", type=int, default=10, help="Number of classes")
+    parser.add_argument("--dataset", choices=['pacs', 'officehome', 'digitsfive', 'camelyon17'], default='pacs')
+    parser.add_argument("--source", choices=available_datasets, help="Source", nargs='+')
+    parser.add_argument("--target", choices=available_datasets, help="Target")
+    parser.add_argument("--limit_source", default=None, type=int)
+    parser.add_argument("--limit_target", default=None, type=int)
+    parser.add_argument("--val_size", type=float, default="0.1")
+    parser.add_argument('--lr', type=float, default=1e-2, help='learning rate')
+    parser.add_argument("--fusion_mode", default='no_fusion',
+                        choices=['no_fusion'] + ['adain-%s-K%d' % (m, k) for m in ('single', 'overall') for k in (1, 2, 3, 4)])
+    parser.add_argument("--dg_method", choices=['no_DG', 'RSC', 'Jigsaw', 'MixStyle', 'feddg'], default='no_DG')
+    parser.add_argument("--network", choices=nets_map.keys(), default="resnet50")
+    parser.add_argument("--image_size", type=int, default=225, help="Image size")
+    parser.add_argument("--min_scale", default=0.8, type=float)
+    parser.add_argument("--max_scale", default=1.0, type=float)
+    parser.add_argument("--random_horiz_flip", default=0.0, type=float)
+    parser.add_argument("--tf_logger", type=bool, default=True)
+    parser.add_argument('--gpu', type=int, default=0, help='gpu device number')
+    parser.add_argument('--seed', type=int, default=1, help='random seed number')
+    parser.add_argument('--save_freq', type=int, default=1)
+    # additions
+    parser.add_argument('--synthetic', type=int, default=0, help='N seeded synthetic images per client instead of the list files')
+    parser.add_argument('--txt_root', type=str, default='data/txt_lists')
+    parser.add_argument('--pretrained', action='store_true', help='load $CCST_PRETRAINED_DIR/<network>.pth (no network access here)')
+    return parser.parse_args()
+
+
+def main():
+    args = parse()
+    if args.mode.lower() not in ('fedavg', 'deepall') or args.dg_method not in ('no_DG',):
+        raise NotImplementedError("only --mode fedavg/deepall with --dg_method no_DG is on the hot path")
+    if not torch.cuda.is_available():
+        raise SystemExit("ccst_amd: an MI355X (ROCm) device is required; there is no CPU path")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(args.gpu)))
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=device)
+    seed = args.seed
+    random.seed(a=seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed_all(seed)
+    print('Device:', device)
+    exp_folder = f'{args.dataset}/{args.mode}_{args.fusion_mode}_{args.dg_method}_{args.network}_locIter{args.wk_iters}/Target_{args.target}_seed_{seed}'
+    args.save_path = os.path.join(args.save_path, exp_folder)
+    SAVE_PATH = os.path.join(args.save_path, '{}'.format(args.mode))
+    if rank == 0:
+        os.makedirs(args.save_path, exist_ok=True)
+    logfile = open(os.path.join(args.save_path, '{}.log'.format(args.mode)), 'a') if (args.log and rank == 0) else None
+
+    print("Building server's model...")
+    server_model = get_network(args.network)(args, pretrained=args.pretrained, classes=args.n_classes)
+    loss_fun = fed.CrossEntropyLoss()
+    print("Preparing data...")
+    train_loaders, val_loaders, target_test_loader = data.get_fed_dataloaders(args, args.txt_root)
+    datasets = args.source
+    client_num = len(datasets) if args.mode != 'deepall' else 1
+    client_weights = [float(1. / client_num) for _ in range(client_num)]
+    if world > 1 and world != client_num:
+        raise SystemExit("torchrun --nproc-per-node must equal the number of --source clients (%d)" % client_num)
+    my_clients = [rank] if world > 1 else list(range(client_num))
+    server_model.to(device)
+    models = {ci: copy.deepcopy(server_model) for ci in my_clients}
+
+    if args.test:
+        print('Loading snapshots...')
+        server_model.load_state_dict(torch.load(SAVE_PATH)['server_model'])
+        _, test_acc = fed.test(server_model, target_test_loader, loss_fun, device, args)
+        print(' {:<11s}| Test  Acc: {:.4f}'.format(args.target, test_acc))
+        return
+    resume_iter = 0
+    if args.resume:
+        checkpoint = torch.load(SAVE_PATH + '_latest')
+        server_model.load_state_dict(checkpoint['server_model'])
+        for m in models.values():
+            m.load_state_dict(checkpoint['server_model'])
+        resume_iter = int(checkpoint['a_iter']) + 1
+        print('Resume training from epoch {}'.format(resume_iter))
+
+    def log(msg):
+        print(msg)
+        if logfile:
+            logfile.write(msg + "\n")
+            logfile.flush()
+
+    best_val_class_acc, best_test = 0., 0.
+    for a_iter in range(resume_iter, args.iters):
+        log("=============Global iter is {} ===============".format(a_iter))
+        log("----------------Training----------------")
+        optimizers = {ci: fed.SGD(models[ci], lr=args.lr) for ci in my_clients}      # fresh every round, :657
+        for wi in range(args.wk_iters):
+            iter_idx = wi + a_iter * args.wk_iters
+            log("== Train epoch {} ===".format(iter_idx))
+            for ci in my_clients:
+                train_loss, train_acc = fed.train(models[ci], train_loaders[ci], optimizers[ci], loss_fun, client_num, device,
+                                                  args, iter_idx, None)
+                log(' {:<11s}| Train Loss: {:.4f}'.format(datasets[ci], train_loss))
+                log(' {:<11s}| Train Class Acc: {:.4f}'.format(datasets[ci], train_acc))
+        with torch.no_grad():
+            if world > 1:
+                fed.communication_distributed(args, models[rank], client_weights[rank])
+                srv = models[rank]                    # after the all-reduce every rank holds the server model
+            else:
+                server_model, ms = fed.communication(args, server_model, [models[ci] for ci in my_clients], client_weights)
+                srv = server_model
+            print("----------------Validate global model on source domains----------------")
+            val_acc_sum = 0.0
+            for ci in my_clients:
+                val_loss, val_acc = fed.test(srv, val_loaders[ci], loss_fun, device, args)
+                log(' {:<11s}| Global Val Loss: {:.4f}'.format(datasets[ci], val_loss))
+                log(' {:<11s}| Global Val Class Acc: {:.4f}'.format(datasets[ci], val_acc))
+                val_acc_sum += val_acc
+            if world > 1:
+                t = torch.tensor([val_acc_sum], device=device, dtype=torch.float64)
+                dist.all_reduce(t)
+                val_acc_sum = float(t)
+            val_class_acc_average = val_acc_sum / client_num
+            if rank == 0:
+                print("-------------Test server model on target domain testset----------------")
+                test_loss, test_acc = fed.test(srv, target_test_loader, loss_fun, device, args)
+                log(' {:<11s}| Global Test Loss: {:.4f}'.format(args.target, test_loss))
+                log(' {:<11s}| Global Test Class Acc: {:.4f}'.format(args.target, test_acc))
+                sd = {k: v.detach().cpu() for k, v in srv.state_dict().items()}
+                if a_iter % args.save_freq == 0 and a_iter > 0:
+                    torch.save({'server_model': sd, 'a_iter': a_iter}, SAVE_PATH + '_latest')
+                if val_class_acc_average > best_val_class_acc:
+                    best_val_class_acc, best_test = val_class_acc_average, test_acc
+                    log(' Saving current best checkpoints to {}...'.format(SAVE_PATH))
+                    torch.save({'server_model': sd, 'a_iter': a_iter}, SAVE_PATH)
+    if logfile:
+        logfile.write(f'Test result using the global model with best val accuracy: {best_test} on {args.target}')
+        logfile.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -103,6 +103,10 @@ int ccst_nhwc_layer_f32(int mode, const float* x, float* y, int N, int H, int W,
 int ccst_nchw_to_nhwc_f32(const float* x, float* y, int N, int C, int HW, int Cp, void* stream);
 int ccst_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int HW, int Cs, void* stream);
 
+/* Image output edge (CCST_OverallStyleTransfer.py:156-167, torchvision save_image semantics):
+ * NCHW float -> NHWC uint8 with v*255+0.5 clamped to [0,255]. */
+int ccst_quantize_u8_hwc_f32(const float* x_nchw, uint8_t* y_nhwc, int N, int C, int HW, void* stream);
+
 /* Backward-weight: dW[tap][ci][co] = sum_m X[n, oy*ay+ky*by+cy, ox*ax+kx*bx+cx, ci] * dY[m, co]
  * (zero padding; x indexed with d's x strides, dY dense [M][cout]), split over `splits` pixel
  * ranges into ws[splits][ntap][cin][cout] partial slabs, then summed in fixed order (bitwise
