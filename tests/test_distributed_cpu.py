@@ -1,0 +1,76 @@
+"""CPU, world_size 2 over gloo: the multi-rank protocols (FedAvg all-reduce, sharded style statistics).
+The GPU pre-scale kernel is replaced by an injected host scale (test harness only)."""
+import copy
+import os
+import tempfile
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import fed_ref
+from oracle import resnet_ref as R
+
+
+def _client_state(ci):
+    m = R.ResNet(R.BasicBlock, [1, 1, 1, 1], classes=3)
+    m.load_state_dict(R.seeded_state_dict(m, 70))
+    rs = np.random.RandomState(71 + ci)
+    with torch.no_grad():
+        for k, v in m.state_dict().items():
+            if "num_batches_tracked" in k:
+                v.fill_(5 + ci)
+            else:
+                v += torch.from_numpy(rs.normal(0, 0.02, tuple(v.shape)).astype(np.float32))
+    return m
+
+
+def _worker(rank, world, initfile, outdir):
+    import types
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    from ccst_amd import fed, style
+    from ccst_amd.nets import resnet
+    weights = [0.6, 0.4]
+    ours = resnet.ResNet(resnet.BasicBlock, [1, 1, 1, 1], classes=3)
+    ours.load_state_dict(_client_state(rank).state_dict())
+    counters = [b.clone() for n, b in ours.named_buffers() if n.endswith("num_batches_tracked")]
+    fed.communication_distributed(types.SimpleNamespace(mode="fedavg"), ours, weights[rank], server_counters=counters,
+                                  scale_fn=lambda flat, w, n: flat.mul_(float(w)))
+    torch.save({"sd": ours.state_dict(), "server_counters": counters}, os.path.join(outdir, "fed_%d.pt" % rank))
+    # sharded style statistics: each rank accumulates its own batches, one all-reduce at the end
+    acc = style.StyleStatAccumulator()
+    rs = np.random.RandomState(5 + rank)
+    acc.sum = torch.from_numpy(rs.uniform(1, 2, (1, 8, 1, 1)).astype(np.float32))
+    acc.sqsum = torch.from_numpy(rs.uniform(3, 4, (1, 8, 1, 1)).astype(np.float32))
+    acc.count, acc.images = 100 * (rank + 1), rank + 1
+    acc.all_reduce()
+    torch.save({"sum": acc.sum, "sq": acc.sqsum, "count": acc.count, "images": acc.images}, os.path.join(outdir, "st_%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fedavg_and_style_stats_world2():
+    with tempfile.TemporaryDirectory() as d:
+        initfile = os.path.join(d, "init")
+        mp.spawn(_worker, args=(2, initfile, d), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(d, "fed_0.pt"), weights_only=False)
+        r1 = torch.load(os.path.join(d, "fed_1.pt"), weights_only=False)
+        server = _client_state(0)
+        clients = [_client_state(0), _client_state(1)]
+        server, clients = fed_ref.communication_fedavg(server, clients, [0.6, 0.4])
+        ssd = server.state_dict()
+        for k, v in ssd.items():
+            if "num_batches_tracked" in k:
+                assert int(r0["sd"][k]) == 5 and int(r1["sd"][k]) == 6          # clients keep their own
+            else:
+                assert torch.allclose(r0["sd"][k], v, rtol=1e-6, atol=1e-7), k
+                assert torch.equal(r0["sd"][k], r1["sd"][k]), k                  # every rank holds the server model
+        assert all(int(c) == 5 for c in r0["server_counters"]) and all(int(c) == 5 for c in r1["server_counters"])
+        s0 = torch.load(os.path.join(d, "st_0.pt"), weights_only=False)
+        s1 = torch.load(os.path.join(d, "st_1.pt"), weights_only=False)
+        assert s0["count"] == s1["count"] == 300 and s0["images"] == 3
+        e0 = np.random.RandomState(5).uniform(1, 2, (1, 8, 1, 1)).astype(np.float32)
+        e1 = np.random.RandomState(6).uniform(1, 2, (1, 8, 1, 1)).astype(np.float32)
+        assert np.allclose(s0["sum"].numpy(), e0 + e1, rtol=1e-6) and torch.equal(s0["sum"], s1["sum"])

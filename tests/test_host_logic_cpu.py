@@ -1,0 +1,102 @@
+"""CPU: host-side logic of the drop-in surface (no kernels run)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import adain_ref as A
+from oracle import resnet_ref as R
+
+
+def test_net_state_dict_keys_match_reference_layout():
+    from ccst_amd import net
+    assert len(net.vgg) == 53 and len(net.decoder) == 29
+    vk = ["%d.%s" % (i, s) for i, _, _, _ in A.conv_keys(A.VGG_TABLE) for s in ("weight", "bias")]
+    dk = ["%d.%s" % (i, s) for i, _, _, _ in A.conv_keys(A.DECODER_TABLE) for s in ("weight", "bias")]
+    assert list(net.vgg.state_dict().keys()) == vk and list(net.decoder.state_dict().keys()) == dk
+    net.vgg.load_state_dict(A.he_weights(A.VGG_TABLE, 1))
+    sliced = net.vgg[:31]
+    assert isinstance(sliced, net.Sequential) and len(sliced) == 31
+    assert isinstance(torch.nn.Sequential(*list(net.vgg.children())[:31])[2], torch.nn.Conv2d)
+
+
+def test_no_cpu_fallback():
+    from ccst_amd import function, net
+    with pytest.raises(RuntimeError):
+        net.vgg[:4](torch.zeros(1, 3, 8, 8))
+    with pytest.raises(RuntimeError):
+        function.calc_mean_std(torch.zeros(1, 4, 4, 4))
+    with pytest.raises(AssertionError):
+        function.calc_mean_std(torch.zeros(4, 4, 4))
+
+
+def test_registries():
+    from ccst_amd.nets import model_factory, models
+    args = types.SimpleNamespace(dg_method="no_DG")
+    assert set(models.nets_map) == {'resnet18', 'resnet18IN', 'resnet50', 'DigitModel', 'densenet'}
+    assert set(model_factory.nets_map) == {'caffenet', 'alexnet', 'resnet18', 'resnet50', 'lenet'}
+    with pytest.raises(ValueError, match="Name of network unknown foo"):
+        models.get_network("foo")
+    with pytest.raises(ValueError):
+        model_factory.get_network("foo")
+    m = models.get_network("resnet18")(args, pretrained=False, classes=2)
+    assert list(m.state_dict().keys()) == list(R.resnet18(2).state_dict().keys())
+    for name in ("conv1", "bn1", "relu", "maxpool", "layer1", "layer2", "layer3", "layer4", "avgpool", "class_classifier"):
+        assert hasattr(m, name)
+    m2 = model_factory.get_network("resnet50")(pretrained=False, classes=7)
+    assert m2.class_classifier.out_features == 7
+    with pytest.raises(NotImplementedError):
+        models.get_network("densenet")(args)
+    with pytest.raises(NotImplementedError):
+        models.get_network("resnet50")(types.SimpleNamespace(dg_method="Jigsaw"), classes=7)
+
+
+def test_style_stat_finalise_and_file_format(tmp_path):
+    from ccst_amd import style
+    rs = np.random.RandomState(0)
+    s = torch.from_numpy(rs.uniform(100, 200, (1, 512, 1, 1)).astype(np.float32))
+    q = s * s / 1000 + torch.from_numpy(rs.uniform(50, 60, (1, 512, 1, 1)).astype(np.float32))
+    m, sd = style.finalise_style_stats(s, q, 1000)
+    rm, rsd = A.finalise_stats(s, q, 1000)
+    assert torch.equal(m, rm) and torch.equal(sd, rsd)
+    p = str(tmp_path / "x_mean_std.npy")
+    style.save_style_stat(p, m, sd)
+    a = np.load(p)
+    assert a.shape == (2, 1, 512, 1, 1) and a.dtype == np.float32        # CCST_OverallStyleTransfer.py:140-144
+    lm, ls = style.load_style_stat(p, "cpu")
+    assert torch.equal(lm, m) and torch.equal(ls, sd)
+
+
+def test_output_naming_rule():
+    from ccst_amd import data
+    f = "/disk1/cjm/research/CCST/data/PACS/kfold/art_painting/dog/pic_001.jpg"
+    assert data.stylised_name(f, "art_painting", "cartoon", "all_style_transferred_Overall") == \
+        "/disk1/cjm/research/CCST/data/PACS/all_style_transferred_Overall/art_painting/cartoon/dog/pic_001_cartoon.jpg"
+
+
+def test_flat_params_arena_views():
+    from ccst_amd import fed
+    from ccst_amd.nets import resnet
+    m = resnet.ResNet(resnet.BasicBlock, [1, 1, 1, 1], classes=3)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    a = fed.FlatParams(m)
+    assert a.n_param >= sum(p.numel() for p in m.parameters()) and a.n_total > a.n_param
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k])
+    lo, hi = a.flat.data_ptr(), a.flat.data_ptr() + 4 * a.n_total
+    for p in m.parameters():
+        assert lo <= p.data_ptr() < hi and p.data_ptr() % 16 == 0
+        assert a.grad.data_ptr() <= p.grad.data_ptr() < a.grad.data_ptr() + 4 * a.n_param
+    nb = [b for n, b in m.named_buffers() if n.endswith("num_batches_tracked")]
+    assert all(not (lo <= b.data_ptr() < hi) for b in nb)
+    a.flat[:a.n_param].fill_(2.0)
+    assert float(m.conv1.weight[0, 0, 0, 0]) == 2.0
+    assert fed.FlatParams.of(m) is a
+
+
+def test_bench_conv_kernel_name_mirror():
+    from ccst_amd import ops
+    assert ops._conv_kernel_name(256, False, 98304) == "conv_igemm_kernel<2,2,2>"
+    assert ops._conv_kernel_name(64, True, 1572864) == "conv_igemm_kernel<4,1,2,pool>"
+    assert ops._conv_kernel_name(256, False, 24576) == "conv_igemm_kernel<2,2,1>"
