@@ -135,7 +135,8 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        torch.set_num_threads(os.cpu_count() or 1)
+        from ccst_amd.bench_resnet import host_cores
+        torch.set_num_threads(host_cores())
         cpu_content = A.synth_content(B, S, S, seed=1)
         cpu_stat = A.synth_style_stat(512, seed=7)
         with torch.no_grad():
@@ -147,12 +148,13 @@ def main():
                                   "kind": "port", "sample": "1 batch of %d images %dx%d (oracle/adain_ref.py, torch CPU fp32)" % (B, S, S)}
         result["max_abs_diff_vs_cpu"] = float((out.cpu() - ref).abs().max())
 
-    if rank == 0 and not args.no_secondary:
-        try:
-            from ccst_amd import bench_resnet
-            result["secondary"] = bench_resnet.run(dev, world)
-        except ImportError:
-            pass
+    if not args.no_secondary:           # second half of the BASELINE metric; every rank takes part
+        from ccst_amd import bench_resnet
+        del out, content
+        torch.cuda.empty_cache()
+        sec = bench_resnet.run(dev, world, steps=max(3, args.steps // 2), warmup=2,
+                               cpu_baseline=(world == 1 and not args.no_cpu_baseline))
+        result["secondary"] = sec
 
     if rank == 0:
         print(json.dumps(result), flush=True)

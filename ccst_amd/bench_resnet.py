@@ -16,6 +16,20 @@ GFLOP_PER_IMAGE = {"resnet50": 24.51, "resnet18": 10.87}      # SURVEY.md 8d (fw
 PEAK_F32_MFMA_TFLOPS = 157.3
 
 
+def host_cores():
+    """CPU cores this process may actually use: min(affinity, cgroup quota) -- the GPU boxes expose 256
+    logical CPUs but cap the container at a 16-core quota, and oversubscribed torch threads run 5x slower."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def build(dev, arch="resnet50", classes=7, batch=64, size=222, lr=0.001, seed=1):
     from . import fed
     from .nets import models
@@ -62,10 +76,20 @@ def layer_table(step):
 
 
 def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False, cpu_baseline=False, layers=False):
-    model, opt, loss_fun, x, y = build(dev, arch=arch, batch=batch)
+    """One client per rank (weak scaling).  With world > 1 (torch.distributed already initialised by the
+    caller) the timed region is K local train steps followed by ONE FedAvg all-reduce of the flat state
+    (fed_run.py's round: local epoch(s) then communication()), barrier-bracketed, max over ranks."""
+    import torch.distributed as dist
+    from . import fed
+    distributed = world > 1 and dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank() if distributed else 0
+    model, opt, loss_fun, x, y = build(dev, arch=arch, batch=batch, seed=1 + rank)
     step = make_step(model, opt, loss_fun, x, y)
+    args = types.SimpleNamespace(mode="fedavg")
     for _ in range(warmup):
         loss = step()
+    if distributed:
+        fed.communication_distributed(args, model, 1.0 / world)
     torch.cuda.synchronize()
     if layers:
         layer_table(step)
@@ -77,23 +101,39 @@ def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False
         run_step = g.replay
     else:
         run_step = step
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         run_step()
+    if distributed:
+        fed.communication_distributed(args, model, 1.0 / world)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    if distributed:
+        dist.barrier()
+        torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([total], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        total = float(tt.item())
+    dt = total / steps
     gflop = GFLOP_PER_IMAGE.get(arch, 0.0) * batch
-    out = {"metric": "%s train images/sec @222x222 B=%d" % (arch, batch), "value": round(batch / dt, 2), "unit": "images/sec",
-           "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup, "dtype": "f32", "hip_graph": bool(graph),
-           "tflops": round(gflop / dt / 1e3, 2), "frac_of_f32_mfma_peak": round(gflop / dt / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
-           "final_loss": round(float(loss), 5)}
-    if cpu_baseline:
+    out = {"metric": "%s train images/sec @222x222 B=%d" % (arch, batch), "value": round(world * batch / dt, 2), "unit": "images/sec",
+           "n_gpus": world, "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup, "dtype": "f32",
+           "hip_graph": bool(graph), "scaling": "weak",
+           "config": {"workload": "fed_run.py train() body, %s classes=7, SGD lr 0.001, one client per GPU%s"
+                      % (arch, ", + 1 FedAvg all-reduce (RCCL) per %d steps" % steps if distributed else "")},
+           "tflops_per_gpu": round(gflop / dt / 1e3, 2), "frac_of_f32_mfma_peak": round(gflop / dt / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+           "final_loss": round(float(loss.detach()), 5)}
+    if cpu_baseline and rank == 0 and world == 1:
         from oracle import resnet_ref as R
-        torch.set_num_threads(os.cpu_count() or 1)
+        torch.set_num_threads(host_cores())
         ref = R.resnet50(7) if arch == "resnet50" else R.resnet18(7)
         nb = 8
         xc, yc = R.synth_batch(nb, 222, 7, seed=2)
-        R.train_step(ref, xc[:2], yc[:2], 0.001)
+        R.train_step(ref, xc[:1], yc[:1], 0.001)
         c0 = time.perf_counter()
         R.train_step(ref, xc, yc, 0.001)
         c1 = time.perf_counter()

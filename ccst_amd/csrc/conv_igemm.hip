@@ -53,9 +53,9 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return min(max(i, 0), n - 1);
 }
 
-template <int WM, int WN, int NT, bool POOL>
-__global__ __launch_bounds__(256, 3) void conv_igemm_kernel(const ConvArgs p) {
-    constexpr int BM = 64 * WM;
+template <int WM, int WN, int NT, bool POOL, int MT = 2>
+__global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void conv_igemm_kernel(const ConvArgs p) {
+    constexpr int BM = 32 * MT * WM;
     constexpr int BN = 32 * NT * WN;
     constexpr int AR = BM / 64;                    // A float4 units per thread per step
     constexpr int BUNITS = (CK / 4) * BN;          // W float4 units per step
@@ -116,13 +116,13 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(const ConvArgs p) {
     const int nchunks = p.Cin / CK;
     const int T = p.nky * p.nkx * nchunks;
 
-    f32x16 acc[2][NT];
+    f32x16 acc[MT][NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = co0 + wn * (32 * NT) + nt * 32 + li;
         const float b = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = b;
     }
@@ -193,16 +193,16 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(const ConvArgs p) {
         }
     };
 
-    const float* aRd0 = &As[0][(wm * 64 + li) * A_LD + lh * 4];
+    const float* aRd0 = &As[0][(wm * (32 * MT) + li) * A_LD + lh * 4];
     const float* bRd0 = &Bs[0][(lh * BN + wn * (32 * NT) + li) * 4];
     auto compute = [&](int buf) {
         const float* aRd = aRd0 + buf * (BM * A_LD);
         const float* bRd = bRd0 + buf * (CK * BN);
 #pragma unroll
         for (int q = 0; q < CK / 8; ++q) {
-            f32x4 af[2], bf[NT];
+            f32x4 af[MT], bf[NT];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
                 af[mt] = *reinterpret_cast<const f32x4*>(aRd + mt * 32 * A_LD + q * 8);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][s], bf[nt][s], acc[mt][nt], 0, 0, 0);
@@ -244,10 +244,10 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(const ConvArgs p) {
         const int HW = p.Ho * p.Wo;
         const bool dense = (p.flags & CONV_DENSE_OUT) != 0;   // &y[m] = y + m*ysW: no (n,oy,ox) decode
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = wm * (32 * MT) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int m = tm * BM + row;
                 if (m < p.M) {
                     float* yrow;
@@ -273,8 +273,8 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_kernel(const ConvArgs p) {
     } else {
         const int Hp = (p.Ho + 1) >> 1, Wp = (p.Wo + 1) >> 1;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int Tt = wm * 2 + mt;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int Tt = wm * MT + mt;
             const int pyp = pty * (BM / 32) + Tt;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -348,9 +348,9 @@ __global__ void nchw_to_nhwc4_pad_kernel(const float* __restrict__ x, f32x4* __r
     }
 }
 
-template <int WM, int WN, int NT, bool POOL>
+template <int WM, int WN, int NT, bool POOL, int MT = 2>
 int launch_conv(ConvArgs& a, hipStream_t s) {
-    constexpr int BM = 64 * WM, BN = 32 * NT * WN;
+    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     a.tilesN = (a.Cout + BN - 1) / BN;
     int tilesM;
     if (POOL) {
@@ -366,7 +366,7 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
         ccst_set_error("conv: bad grid %lld", grid);
         return CCST_EINVAL;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, NT, POOL>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, NT, POOL, MT>), dim3((unsigned)grid), dim3(256), 0, s, a);
     return ccst_launch_status("conv_igemm");
 }
 
@@ -396,7 +396,9 @@ extern "C" int ccst_conv2d_igemm_f32(const CcstConvDesc* d, const float* x, cons
     hipStream_t s = (hipStream_t)stream;
     // Tile choice: 128x128 (2,2,2) by default; Cout <= 64 -> BN = 64; Cout <= 32 -> BN = 32.  When the
     // 128x128 grid would not give every CU ~3 workgroups, halve BN (2,2,1) to fill the chip.
-    // CCST_CONV_TILE=222|221|412|411 overrides (tuning experiments only).
+    // CCST_CONV_TILE=222|221|412|411 overrides (tuning experiments only).  A 256x128 tile (MT=4: per-wave
+    // 128x64, 128 accumulators, 2 waves/SIMD) was measured at 92-115 TF against 129 TF for 128x128 at 3
+    // waves/SIMD (it needs 247-256+ VGPRs and spills), so it is not dispatched.
     int tile = 222;
     if (d->cout <= 32 && !pool) tile = 411;
     else if (d->cout <= 64) tile = 412;
