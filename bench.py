@@ -118,8 +118,16 @@ def main():
         dom = max(per_kernel, key=lambda n: per_kernel[n][2])
         cnt, fl, sec = per_kernel[dom]
         ach = fl / sec / 1e12
+        traffic, tsrc = None, os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tsrc):      # HBM bytes/launch from the separate rocprofv3 --pmc passes (tools/profile_bench.sh)
+            with open(tsrc) as fh:
+                tj = json.load(fh)
+            key = "void conv_igemm_kernel<%s, %s, 2>" % (", ".join(dom[len("conv_igemm_kernel<"):-1].replace(",pool", "").split(",")),
+                                                          "true" if ",pool" in dom else "false")
+            if key in tj:
+                traffic = round(tj[key]["total_bytes_per_launch"])
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "kernel": dom,
+                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "kernel": dom,
                     "launches_per_step": cnt / args.steps, "avg_launch_us": round(sec / cnt * 1e6, 2),
                     "gflop_per_launch": round(fl / cnt / 1e9, 3)}
 

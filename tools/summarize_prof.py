@@ -50,3 +50,24 @@ for sub, ctr, mult in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SI
     print("== %s (KB per launch x%.0f correction => MB/launch)" % (ctr, mult))
     for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1]):
         print("%-72s %8d launches  %12.3f MB/launch" % (k, v[0], v[1] / v[0] * mult * 1024 / 1e6))
+
+# machine-readable HBM traffic per launch (bytes), FETCH_SIZE doubled per the gfx950 correction
+import json
+traffic = {}
+for sub, ctr, mult in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SIZE", 1.0)):
+    f = find(sub, "*counter_collection.csv")
+    if not f:
+        continue
+    acc = defaultdict(lambda: [0, 0.0])
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            if r.get("Counter_Name") != ctr:
+                continue
+            k = acc[short(r["Kernel_Name"])]
+            k[0] += 1
+            k[1] += float(r["Counter_Value"])
+    for k, v in acc.items():
+        traffic.setdefault(k, {})[ctr] = v[1] / v[0] * mult * 1024.0
+if traffic:
+    with open(os.path.join(out, "traffic.json"), "w") as fh:
+        json.dump({k: dict(v, total_bytes_per_launch=sum(v.values())) for k, v in traffic.items() if "conv" in k or "adain" in k or "partials" in k}, fh, indent=1)
