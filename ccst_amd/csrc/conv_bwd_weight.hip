@@ -22,7 +22,19 @@ struct BwdWArgs {
     long long xsN;
     int xsH, xsW;
     int M, splits, tilesI, tilesJ;
+    float invHW, invWo;     // reciprocals for the division-free pixel decode (valid while M < 2^22)
+    int fastdiv;
 };
+
+// floor(m / d) for 0 <= m < 2^22 via one float multiply + correction (an integer division costs ~40
+// VALU instructions and this runs 4x per thread per k-step).
+__device__ __forceinline__ int fdiv(int m, int d, float inv) {
+    int q = (int)((float)m * inv);
+    const int r = m - q * d;
+    q += (r >= d) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
 
 template <int MI, int NJ, int PK>
 __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs p) {
@@ -75,9 +87,16 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs p) 
             const int px = unit / (BI / 4), cp = unit - px * (BI / 4);
             const int m = m0 + px;
             const int mc = min(m, p.M - 1);
-            const int n = mc / HW;
+            int n, oy;
+            if (p.fastdiv) {
+                n = fdiv(mc, HW, p.invHW);
+                oy = fdiv(mc - n * HW, p.Wo, p.invWo);
+            } else {
+                n = mc / HW;
+                oy = (mc - n * HW) / p.Wo;
+            }
             const int rem = mc - n * HW;
-            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const int ox = rem - oy * p.Wo;
             int iy = oy * p.ay + ky * p.by + p.cy, ix = ox * p.ax + kx * p.bx + p.cx;
             const int ci = ci0 + cp * 4;
             const bool ok = (m < p.M) & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi) & (ci < p.Cin);
@@ -246,6 +265,9 @@ extern "C" int ccst_conv2d_bwd_weight_f32(const CcstConvDesc* d, const float* x,
     a.xsN = d->xsN; a.xsH = d->xsH; a.xsW = d->xsW;
     a.M = d->n * d->ho * d->wo;
     a.splits = splits;
+    a.invHW = 1.0f / (float)(d->ho * d->wo);
+    a.invWo = 1.0f / (float)d->wo;
+    a.fastdiv = a.M < (1 << 22);
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (d->cin >= 128 && d->cout >= 128) rc = launch<2, 2, 16>(a, s);

@@ -24,6 +24,7 @@
 //   y strides) or the fused MaxPool2d(2,2,ceil) where the M index is laid out so that the four
 //   pixels of a pooling window sit in the four registers (reg&3) of one lane.
 #include "common.h"
+#include <math.h>
 #include <stdlib.h>
 
 namespace {
@@ -47,8 +48,7 @@ struct ConvArgs {
 };
 
 constexpr unsigned CONV_DENSE_OUT = 0x80000000u;   // internal flag: output rows are m*ysW apart
-constexpr int CK = 16;            // input channels per k-step
-constexpr int A_LD = CK + 4;      // floats per LDS A row (80 B)
+constexpr int CK_MIN = 16;        // smallest k-step (input channels of one tap per step)
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {
     // ReflectionPad2d: -1 -> 1, n -> n-2 (edge not repeated); clamp keeps overhanging
@@ -58,11 +58,13 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return min(max(i, 0), n - 1);
 }
 
-template <int WM, int WN, int NT, bool POOL, int MT = 2>
-__global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void conv_igemm_kernel(const ConvArgs p) {
+template <int WM, int WN, int NT, bool POOL, int MT = 2, int CK = 16>
+__global__ __launch_bounds__(256, ((MT == 2 && CK == 16) ? 3 : 2)) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int BM = 32 * MT * WM;
     constexpr int BN = 32 * NT * WN;
-    constexpr int AR = BM / 64;                    // A float4 units per thread per step
+    constexpr int A_LD = CK + 4;                   // floats per LDS A row (+16 B: conflict-free ds_read_b128)
+    constexpr int PPR = CK / 4;                    // float4 parts per A row
+    constexpr int AR = BM * PPR / 256;             // A float4 units per thread per step
     constexpr int BUNITS = (CK / 4) * BN;          // W float4 units per step
     constexpr int BR = (BUNITS + 255) / 256;
 
@@ -80,9 +82,9 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void conv_igemm_kernel(cons
     const int tm = bid / p.tilesN;
     const int co0 = tn * BN;
 
-    // ---- per-thread A rows: r = (tid>>2) + 64*a, float4 part = tid&3 ------------------
+    // ---- per-thread A rows: unit u = tid + 256*a -> row u / PPR, float4 part u % PPR ------
     // All offsets are 32-bit element offsets (host checks numel < 2^31).
-    const int part = tid & 3;
+    const int part = tid % PPR;
     int rowIy[AR], rowIx[AR];
     unsigned rowBase[AR];
     int pn = 0, pty = 0, ptx = 0;   // pool-mode tile coordinates
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void conv_igemm_kernel(cons
     }
 #pragma unroll
     for (int a = 0; a < AR; ++a) {
-        const int r = (tid >> 2) + 64 * a;
+        const int r = tid / PPR + (256 / PPR) * a;
         int n, oy, ox;
         if (POOL) {
             // row r -> M-tile T=r>>5, window w=(r&31)>>2, pos=r&3: py=2T+(pos>>1), px=2w+(pos&1)
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256, (MT == 2 ? 3 : 2)) void conv_igemm_kernel(cons
     auto store_step = [&](int buf) {
 #pragma unroll
         for (int a = 0; a < AR; ++a) {
-            const int r = (tid >> 2) + 64 * a;
+            const int r = tid / PPR + (256 / PPR) * a;
             f32x4 v = ra[a];
             if (!aok[a]) v = f32x4{0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<f32x4*>(&As[buf][r * A_LD + part * 4]) = v;
@@ -353,7 +355,7 @@ __global__ void nchw_to_nhwc4_pad_kernel(const float* __restrict__ x, f32x4* __r
     }
 }
 
-template <int WM, int WN, int NT, bool POOL, int MT = 2>
+template <int WM, int WN, int NT, bool POOL, int MT = 2, int CK = 16>
 int launch_conv(ConvArgs& a, hipStream_t s) {
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     a.tilesN = (a.Cout + BN - 1) / BN;
@@ -371,16 +373,44 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
         ccst_set_error("conv: bad grid %lld", grid);
         return CCST_EINVAL;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, NT, POOL, MT>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, NT, POOL, MT, CK>), dim3((unsigned)grid), dim3(256), 0, s, a);
     return ccst_launch_status("conv_igemm");
 }
 
 }  // namespace
 
+// Tile choice.  128x128 (222) is the most efficient tile (measured 129 TF vs 116 for 256x64 and 114 for
+// 128x64) but a launch only runs at that rate while every CU holds ~3 workgroups: with 768 resident
+// slots a grid of 784 workgroups costs two rounds.  Cost model: rounds(grid / 768 slots) x tile area /
+// relative tile efficiency; the cheapest candidate wins.  CCST_CONV_TILE=222|221|412|411 overrides
+// (tuning experiments only).  A 256x128 tile (MT=4, 2 waves/SIMD) and a 32-channel k-step (CK=32, 2
+// workgroups/CU) were measured slower (92-115 / 112 TF) and are not dispatched.
+static int choose_tile(int M, int cout, bool pool) {
+    int tile;
+    if (cout <= 32 && !pool) tile = 411;
+    else if (cout <= 64) tile = 412;
+    else {
+        const double slots = 768.0;
+        const long long g222 = (((long long)M + 127) / 128) * ((cout + 127) / 128);
+        const long long g221 = (((long long)M + 127) / 128) * ((cout + 63) / 64);
+        const double c222 = ceil(g222 / slots) * (128.0 * 128.0) / 1.00;
+        const double c221 = ceil(g221 / slots) * (128.0 * 64.0) / 0.88;
+        tile = (c221 < c222) ? 221 : 222;
+    }
+    if (const char* e = getenv("CCST_CONV_TILE")) {
+        const int t = atoi(e);
+        if (t == 222 || t == 221 || t == 412 || (t == 411 && !pool)) tile = t;
+    }
+    return tile;
+}
+
+// Tile code (WM WN NT as decimal digits) the dispatcher picks for this problem; bench.py names kernels with it.
+extern "C" int ccst_conv2d_igemm_tile(int M, int cout, int pool) { return choose_tile(M, cout, pool != 0); }
+
 extern "C" int ccst_conv2d_igemm_f32(const CcstConvDesc* d, const float* x, const float* w_packed, const float* bias,
                                      float* y, void* stream) {
     CCST_REQUIRE(d && x && w_packed && y, "conv: null pointer");
-    CCST_REQUIRE(d->cin > 0 && d->cin % CK == 0, "conv: cin=%d must be a positive multiple of 16", d->cin);
+    CCST_REQUIRE(d->cin > 0 && d->cin % CK_MIN == 0, "conv: cin=%d must be a positive multiple of 16", d->cin);
     CCST_REQUIRE(d->cout > 0 && d->cout_pad >= d->cout && d->cout_pad % 128 == 0, "conv: cout=%d cout_pad=%d (need multiple of 128)",
                  d->cout, d->cout_pad);
     CCST_REQUIRE(d->n > 0 && d->ho > 0 && d->wo > 0 && d->hi > 0 && d->wi > 0 && d->nky > 0 && d->nkx > 0, "conv: bad extents");
@@ -399,22 +429,7 @@ extern "C" int ccst_conv2d_igemm_f32(const CcstConvDesc* d, const float* x, cons
     if (!pool && d->ysH == (long long)d->wo * d->ysW && d->ysN == (long long)d->ho * d->wo * d->ysW) a.flags |= CONV_DENSE_OUT;
     a.M = d->n * d->ho * d->wo;
     hipStream_t s = (hipStream_t)stream;
-    // Tile choice: 128x128 (2,2,2) by default; Cout <= 64 -> BN = 64; Cout <= 32 -> BN = 32.  When the
-    // 128x128 grid would not give every CU ~3 workgroups, halve BN (2,2,1) to fill the chip.
-    // CCST_CONV_TILE=222|221|412|411 overrides (tuning experiments only).  A 256x128 tile (MT=4: per-wave
-    // 128x64, 128 accumulators, 2 waves/SIMD) was measured at 92-115 TF against 129 TF for 128x128 at 3
-    // waves/SIMD (it needs 247-256+ VGPRs and spills), so it is not dispatched.
-    int tile = 222;
-    if (d->cout <= 32 && !pool) tile = 411;
-    else if (d->cout <= 64) tile = 412;
-    else {
-        const long long tiles128 = (((long long)a.M + 127) / 128) * ((d->cout + 127) / 128);
-        if (tiles128 < 640) tile = 221;
-    }
-    if (const char* e = getenv("CCST_CONV_TILE")) {
-        const int t = atoi(e);
-        if (t == 222 || t == 221 || t == 412 || (t == 411 && !pool)) tile = t;
-    }
+    const int tile = choose_tile(a.M, d->cout, pool);
     if (pool) {
         if (tile == 412) return launch_conv<4, 1, 2, true>(a, s);
         if (tile == 221) return launch_conv<2, 2, 1, true>(a, s);
@@ -423,6 +438,7 @@ extern "C" int ccst_conv2d_igemm_f32(const CcstConvDesc* d, const float* x, cons
     if (tile == 411) return launch_conv<4, 1, 1, false>(a, s);
     if (tile == 412) return launch_conv<4, 1, 2, false>(a, s);
     if (tile == 221) return launch_conv<2, 2, 1, false>(a, s);
+    if (getenv("CCST_CONV_CK32") && d->cin % 32 == 0) return launch_conv<2, 2, 2, false, 2, 32>(a, s);
     return launch_conv<2, 2, 2, false>(a, s);
 }
 

@@ -30,19 +30,9 @@ TIMING = None
 
 
 def _conv_kernel_name(cout, pool, M):
-    """Mirror of the tile dispatch in csrc/conv_igemm.hip (ccst_conv2d_igemm_f32)."""
-    import os
-    tile = 222
-    if cout <= 32 and not pool:
-        tile = 411
-    elif cout <= 64:
-        tile = 412
-    elif ((M + 127) // 128) * ((cout + 127) // 128) < 640:
-        tile = 221
-    t = os.environ.get("CCST_CONV_TILE")
-    if t in ("222", "221", "412") or (t == "411" and not pool):
-        tile = int(t)
-    return "conv_igemm_kernel<%s,%s,%s%s>" % (str(tile)[0], str(tile)[1], str(tile)[2], ",pool" if pool else "")
+    """Name of the kernel instance the C dispatcher picks (ccst_conv2d_igemm_tile)."""
+    t = str(_lib.load().ccst_conv2d_igemm_tile(int(M), int(cout), int(bool(pool))))
+    return "conv_igemm_kernel<%s,%s,%s%s>" % (t[0], t[1], t[2], ",pool" if pool else "")
 
 
 def _launch_conv(d, x, pc, out, flops, pool, what):

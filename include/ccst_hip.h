@@ -76,6 +76,10 @@ typedef struct CcstConvDesc {
 int ccst_conv2d_igemm_f32(const CcstConvDesc* d, const float* x, const float* w_packed,
                           const float* bias /* may be NULL */, float* y, void* stream);
 
+/* The tile code (WM WN NT as decimal digits: 222 = 128x128, 221 = 128x64, 412 = 256x64, 411 = 256x32)
+ * ccst_conv2d_igemm_f32 dispatches for M = n*ho*wo output pixels and cout channels. */
+int ccst_conv2d_igemm_tile(int M, int cout, int pool);
+
 /* Direct 3x3 stride-1 conv with 1..4 output channels writing NCHW (the decoder's last layer,
  * net.py:35): x NHWC [N,H,W,Cin] (Cin % 16 == 0), w [3][3][Cin][Cout], y NCHW [N,Cout,H,W].
  * HBM-bound (13 FLOP/B), so it runs on the VALU rather than padding Cout to an MFMA tile. */
