@@ -1,0 +1,303 @@
+// 3x3 stride-1 "same" convolution (reflection or zero padding) on the fp32-input MFMA with the input HALO
+// staged in LDS -- the AdaIN encoder/decoder layers (net.py:6-69).
+//
+// conv_igemm.hip gathers an [M x 16] A tile per (tap, 16-channel chunk): every input element is loaded from
+// L2 and written to LDS nine times.  Here a workgroup owns a spatial tile of TH x 16 output pixels of one
+// image; per 16-channel chunk the (TH+2) x 18 halo is loaded ONCE (reflection / zero padding and the
+// optional nearest-x2 upsample applied in that loader) and the nine taps read their A fragments from the
+// same LDS image at shifted addresses.  A-side global loads, address arithmetic and ds_writes drop 9x
+// (measured on the gather kernel: staging costs ~12 % of the time); the per-step work is the weight tile only.
+//
+//   GEMM roles, MFMA operand layout, packed weights [tap][ci/4][co][4], accumulators, bias/ReLU/fused
+//   2x2 ceil max-pool epilogue: as conv_igemm.hip.  Row r of the M tile maps to the pixel
+//   (py, px) = (2*(r>>5) + ((r&3)>>1), 2*((r&31)>>2) + (r&1)) so a pooling window sits in one lane's reg&3.
+//   LDS: halo [2][(TH+2)*18][16+4] floats (80-B pixel pitch: conflict-free ds_read_b128) + W [2][16][BN].
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+struct HaloArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    float* y;
+    int N, H, W, Hs, Ws, Cin, Cout, CoutPad;     // H,W: conv (= output) extent; Hs,Ws: source extent (H/2,W/2 if ups)
+    int reflect, ups, relu;
+    long long ysN;
+    int ysH, ysW;                                 // output strides (of the pooled tensor when POOL)
+    int tilesX, tilesY, tilesN;
+};
+
+constexpr int CKH = 16, PITCH = CKH + 4, HW_ = 18;
+
+__device__ __forceinline__ int reflect_h(int i, int n) {
+    i = (i < 0) ? -i : i;
+    i = (i >= n) ? 2 * n - 2 - i : i;
+    return min(max(i, 0), n - 1);
+}
+
+template <int WM, int WN, int NT, bool POOL>
+__global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) {
+    constexpr int MT = 2;
+    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+    constexpr int TH = BM / 16, HH = TH + 2;
+    constexpr int HPIX = HH * HW_;                         // halo pixels
+    constexpr int HUNITS = HPIX * (CKH / 4);               // float4 units per chunk
+    constexpr int HR = (HUNITS + 255) / 256;               // halo units per thread per chunk
+    constexpr int BUNITS = (CKH / 4) * BN;
+    constexpr int BR = (BUNITS + 255) / 256;
+    static_assert(HR <= 9, "halo load rounds must fit the 9 tap steps of a chunk");
+
+    __shared__ __attribute__((aligned(16))) float Hs_[2][HPIX * PITCH];
+    __shared__ __attribute__((aligned(16))) float Bs[2][CKH * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    int bid = ccst_xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % p.tilesN;
+    bid /= p.tilesN;
+    const int tx = bid % p.tilesX;
+    bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int n = bid / p.tilesY;
+    const int co0 = tn * BN;
+    const int oy0 = ty * TH, ox0 = tx * 16;
+
+    // ---- halo load units of this thread (pixel coordinates are chunk-invariant) -------------------
+    unsigned hoff[HR];
+    bool hok[HR];
+#pragma unroll
+    for (int i = 0; i < HR; ++i) {
+        const int u = min(tid + 256 * i, HUNITS - 1);
+        const int pix = u >> 2, part = u & 3;
+        const int hy = pix / HW_, hx = pix - hy * HW_;
+        int gy = oy0 + hy - 1, gx = ox0 + hx - 1;
+        bool ok = true;
+        if (p.reflect) {
+            gy = reflect_h(gy, p.H);
+            gx = reflect_h(gx, p.W);
+        } else {
+            ok = (gy >= 0) & (gy < p.H) & (gx >= 0) & (gx < p.W);
+            gy = min(max(gy, 0), p.H - 1);
+            gx = min(max(gx, 0), p.W - 1);
+        }
+        gy >>= p.ups;
+        gx >>= p.ups;
+        hok[i] = ok;
+        hoff[i] = (unsigned)(((n * p.Hs + gy) * p.Ws + gx) * p.Cin + part * 4);
+    }
+    unsigned boff[BR];
+#pragma unroll
+    for (int b = 0; b < BR; ++b) {
+        const int u = min(tid + 256 * b, BUNITS - 1);
+        const int g = u / BN, col = u - g * BN;
+        boff[b] = (unsigned)((g * p.CoutPad + co0 + col) * 4);
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = co0 + wn * (32 * NT) + nt * 32 + li;
+        const float b = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = b;
+    }
+
+    // A fragment base per M tile: pixel (py,px) of row li of tile Tt, channel slot lh
+    int aBase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int Tt = wm * MT + mt;
+        const int py = 2 * Tt + ((li & 3) >> 1), px = 2 * (li >> 2) + (li & 1);
+        aBase[mt] = (py * HW_ + px) * PITCH + lh * 4;
+    }
+    const float* bRd0 = &Bs[0][(lh * BN + wn * (32 * NT) + li) * 4];
+
+    const int nchunks = p.Cin / CKH;
+    f32x4 rh, rb[BR];
+
+    auto load_b = [&](int c_, int tap) {
+        const float* wc = p.w + ((long long)tap * (p.Cin / 4) + c_ * (CKH / 4)) * p.CoutPad * 4;   // uniform
+#pragma unroll
+        for (int b = 0; b < BR; ++b) rb[b] = *reinterpret_cast<const f32x4*>(wc + boff[b]);
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int b = 0; b < BR; ++b) {
+            const int u = tid + 256 * b;
+            if (BUNITS % 256 == 0 || u < BUNITS) *reinterpret_cast<f32x4*>(&Bs[buf][u * 4]) = rb[b];
+        }
+    };
+    // halo unit i of chunk c_: global -> register, register -> LDS
+    auto load_h = [&](int c_, int i, unsigned off) { rh = *reinterpret_cast<const f32x4*>(p.x + off + c_ * CKH); (void)i; };
+    auto store_h = [&](int buf, int i, bool ok) {
+        const int u = tid + 256 * i;
+        if (u < HUNITS) {
+            f32x4 v = rh;
+            if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&Hs_[buf][(u >> 2) * PITCH + (u & 3) * 4]) = v;
+        }
+    };
+    auto compute = [&](int hbuf, int bbuf, int tapoff) {
+        const float* hb = &Hs_[hbuf][tapoff];
+        const float* bRd = bRd0 + bbuf * (CKH * BN);
+#pragma unroll
+        for (int q = 0; q < CKH / 8; ++q) {
+            f32x4 af[MT], bf[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4*>(hb + aBase[mt] + q * 8);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const f32x4*>(bRd + (2 * q * BN + nt * 32) * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][s], bf[nt][s], acc[mt][nt], 0, 0, 0);
+        }
+    };
+
+    // ---- prologue: halo of chunk 0 and weights of step 0 -------------------------------------------
+#pragma unroll
+    for (int i = 0; i < HR; ++i) {
+        load_h(0, i, hoff[i]);
+        store_h(0, i, hok[i]);
+    }
+    load_b(0, 0);
+    store_b(0);
+    __syncthreads();
+
+    // ---- main loop: chunk c, taps fully unrolled so that every step's code is static (no conditional
+    // loads: hipcc hoists conservative vmcnt waits above the MFMAs otherwise).  During taps 0..HR-1 the next
+    // chunk's halo is fetched one unit per step into the other halo buffer; the very last steps prefetch a
+    // clamped (redundant, never read) chunk / weight tile instead of branching. --------------------------
+    for (int c = 0; c < nchunks; ++c) {
+        const int cn = min(c + 1, nchunks - 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int t = c * 9 + tap;
+            if (tap < 8) load_b(c, tap + 1);
+            else load_b(cn, 0);
+            if (tap < HR) load_h(cn, tap, hoff[tap]);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(c & 1, t & 1, ((tap / 3) * HW_ + (tap % 3)) * PITCH);
+            __builtin_amdgcn_sched_barrier(0);
+            store_b((t + 1) & 1);
+            if (tap < HR) store_h((c + 1) & 1, tap, hok[tap]);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------------------
+    const bool relu = p.relu != 0;
+    if (!POOL) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int Tt = wm * MT + mt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // row = (r&3) + 8*(r>>2) + 4*lh within the 32-row tile -> window w = 2*(r>>2)+lh, pos = r&3
+                const int oy = oy0 + 2 * Tt + ((r & 3) >> 1);
+                const int ox = ox0 + 2 * (2 * (r >> 2) + lh) + (r & 1);
+                if (oy < p.H && ox < p.W) {
+                    float* yrow = p.y + (long long)n * p.ysN + (long long)oy * p.ysH + (long long)ox * p.ysW;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int co = co0 + wn * (32 * NT) + nt * 32 + li;
+                        float v = acc[mt][nt][r];
+                        if (relu) v = fmaxf(v, 0.f);
+                        if (co < p.Cout) yrow[co] = v;
+                    }
+                }
+            }
+        }
+    } else {
+        const int Hp = (p.H + 1) >> 1, Wp = (p.W + 1) >> 1;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int pyp = (oy0 >> 1) + wm * MT + mt;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int pxp = (ox0 >> 1) + 2 * g + lh;
+                if (pyp < Hp && pxp < Wp) {
+                    const bool okx = (2 * pxp + 1 < p.W), oky = (2 * pyp + 1 < p.H);
+                    float* yrow = p.y + (long long)n * p.ysN + (long long)pyp * p.ysH + (long long)pxp * p.ysW;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int co = co0 + wn * (32 * NT) + nt * 32 + li;
+                        float v = acc[mt][nt][4 * g];
+                        if (okx) v = fmaxf(v, acc[mt][nt][4 * g + 1]);
+                        if (oky) v = fmaxf(v, acc[mt][nt][4 * g + 2]);
+                        if (okx && oky) v = fmaxf(v, acc[mt][nt][4 * g + 3]);
+                        if (relu) v = fmaxf(v, 0.f);
+                        if (co < p.Cout) yrow[co] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int NT, bool POOL>
+int launch_halo(HaloArgs& a, hipStream_t s) {
+    constexpr int BM = 64 * WM, BN = 32 * NT * WN, TH = BM / 16;
+    a.tilesN = (a.Cout + BN - 1) / BN;
+    a.tilesY = (a.H + TH - 1) / TH;
+    a.tilesX = (a.W + 15) / 16;
+    const long long grid = (long long)a.N * a.tilesY * a.tilesX * a.tilesN;
+    if (grid <= 0 || grid > 0x7fffffffLL) {
+        ccst_set_error("conv3x3_halo: bad grid %lld", grid);
+        return CCST_EINVAL;
+    }
+    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, WN, NT, POOL>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    return ccst_launch_status("conv3x3_halo");
+}
+
+}  // namespace
+
+// x: NHWC source [N,Hs,Ws,Cin] (Hs = H/2 if CCST_CONV_UPS2), w: packed [9][Cin/4][cout_pad][4], y: NHWC
+// [N,H,W,Cout] or its 2x2 ceil-pooled form.  flags: CCST_CONV_RELU | POOL2 | UPS2 | REFLECT.
+extern "C" int ccst_conv3x3_halo_f32(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W,
+                                     int Cin, int Cout, int cout_pad, uint32_t flags, void* stream) {
+    CCST_REQUIRE(x && w_packed && y, "conv3x3_halo: null pointer");
+    CCST_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0, "conv3x3_halo: bad shape");
+    CCST_REQUIRE(cout_pad >= Cout && cout_pad % 128 == 0, "conv3x3_halo: cout_pad must be a multiple of 128 >= cout");
+    const bool pool = (flags & CCST_CONV_POOL2) != 0, ups = (flags & CCST_CONV_UPS2) != 0;
+    if (ups) CCST_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv3x3_halo: upsampled extent must be even");
+    if (flags & CCST_CONV_REFLECT) CCST_REQUIRE(H >= 2 && W >= 2, "conv3x3_halo: reflection needs extent >= 2");
+    HaloArgs a;
+    a.x = x; a.w = w_packed; a.bias = bias; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.Hs = ups ? H / 2 : H; a.Ws = ups ? W / 2 : W; a.Cin = Cin; a.Cout = Cout; a.CoutPad = cout_pad;
+    a.reflect = (flags & CCST_CONV_REFLECT) ? 1 : 0; a.ups = ups ? 1 : 0; a.relu = (flags & CCST_CONV_RELU) ? 1 : 0;
+    CCST_REQUIRE((long long)N * a.Hs * a.Ws * Cin < 0x7fffffffLL, "conv3x3_halo: input must have < 2^31 elements");
+    const int oh = pool ? (H + 1) / 2 : H, ow = pool ? (W + 1) / 2 : W;
+    a.ysW = Cout; a.ysH = ow * Cout; a.ysN = (long long)oh * ow * Cout;
+    hipStream_t s = (hipStream_t)stream;
+    // 128x128 tiles unless Cout <= 64 or the grid would leave CUs short of ~3 workgroups (768 slots):
+    // same cost model as conv_igemm.hip's choose_tile (rounds x tile area / relative efficiency).
+    bool narrow = Cout <= 64;
+    if (!narrow) {
+        const long long sp = (long long)N * ((H + 7) / 8) * ((W + 15) / 16);
+        const double c222 = ceil(sp * ((Cout + 127) / 128) / 768.0) * 2.0 / 1.00;
+        const double c221 = ceil(sp * ((Cout + 63) / 64) / 768.0) * 1.0 / 0.93;
+        narrow = c221 < c222;
+    }
+    if (narrow) return pool ? launch_halo<2, 2, 1, true>(a, s) : launch_halo<2, 2, 1, false>(a, s);
+    return pool ? launch_halo<2, 2, 2, true>(a, s) : launch_halo<2, 2, 2, false>(a, s);
+}
+
+// 1 if the dispatcher above picks the 128x64 tile (bench.py names kernels with it).
+extern "C" int ccst_conv3x3_halo_narrow(int N, int H, int W, int Cout) {
+    if (Cout <= 64) return 1;
+    const long long sp = (long long)N * ((H + 7) / 8) * ((W + 15) / 16);
+    const double c222 = ceil(sp * ((Cout + 127) / 128) / 768.0) * 2.0 / 1.00;
+    const double c221 = ceil(sp * ((Cout + 63) / 64) / 768.0) * 1.0 / 0.93;
+    return c221 < c222 ? 1 : 0;
+}

@@ -7,6 +7,7 @@ PyTorch here is plumbing (allocator, streams); every op is a HIP kernel from
 libccst_hip.so.  Nothing in this file falls back to torch compute on failure.
 """
 import ctypes
+import os
 
 import torch
 
@@ -24,6 +25,12 @@ def bump_weights_epoch():
     global WEIGHTS_EPOCH
     WEIGHTS_EPOCH += 1
 
+
+# 3x3 reflect-pad convs go through the halo-in-LDS kernel (conv3x3_halo.hip); CCST_CONV_HALO=0 keeps the gather kernel.
+USE_HALO = os.environ.get("CCST_CONV_HALO", "1") != "0"
+# zero-padded 3x3 stride-1 convs (the ResNet trunk: 7x7..56x56 maps) measure the same on either kernel (2279 vs 2276 img/s);
+# they stay on the gather kernel unless CCST_CONV_HALO_ZERO=1
+HALO_ZERO_PAD = os.environ.get("CCST_CONV_HALO_ZERO", "0") != "0"
 
 # bench.py sets TIMING = [] to collect (kernel name, algorithmic flops, start event, end event) per conv launch.
 TIMING = None
@@ -151,6 +158,23 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
         (CONV_REFLECT if reflect else 0)
     d.flags = flags
     oh, ow = ((ho + 1) // 2, (wo + 1) // 2) if pool else (ho, wo)
+    if USE_HALO and (reflect or HALO_ZERO_PAD) and pc.kh == 3 and pc.kw == 3 and stride == 1 and pad == 1 and not out_nchw \
+            and out is None:
+        out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
+        lib = _lib.load()
+        args = (ptr(x), ptr(pc.w), ptr(pc.bias), ptr(out), N, Hi, Wi, Cx, pc.cout, pc.n_pad, flags, stream_ptr())
+        if TIMING is None:
+            check(lib.ccst_conv3x3_halo_f32(*args), "conv3x3_halo")
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib.ccst_conv3x3_halo_f32(*args), "conv3x3_halo")
+            e1.record()
+            TIMING.append(("conv3x3_halo_kernel<%s%s>" % ("2,2,1" if lib.ccst_conv3x3_halo_narrow(N, Hi, Wi, pc.cout) else "2,2,2",
+                                                           ",pool" if pool else ""),
+                           2.0 * N * ho * wo * pc.cout * pc.cin * 9, e0, e1,
+                           "n%d %dx%d cin%d cout%d taps3x3 flags%d" % (N, ho, wo, pc.cin, pc.cout, flags)))
+        return out
     if out_nchw:
         assert not pool
         if out is None:

@@ -76,6 +76,15 @@ typedef struct CcstConvDesc {
 int ccst_conv2d_igemm_f32(const CcstConvDesc* d, const float* x, const float* w_packed,
                           const float* bias /* may be NULL */, float* y, void* stream);
 
+/* 3x3 stride-1 "same" conv (reflection or zero padding) with the input halo staged once per 16-channel
+ * chunk in LDS (A-side loads / LDS writes 9x fewer than the gather form): the AdaIN encoder/decoder
+ * layers net.py:6-69.  x NHWC source [N,Hs,Ws,Cin] (Hs=H/2 with CCST_CONV_UPS2), w_packed as for
+ * ccst_conv2d_igemm_f32, y dense NHWC [N,H,W,Cout] or its pooled form (CCST_CONV_POOL2).  flags: CCST_CONV_*. */
+int ccst_conv3x3_halo_f32(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W,
+                          int Cin, int Cout, int cout_pad, uint32_t flags, void* stream);
+
+int ccst_conv3x3_halo_narrow(int N, int H, int W, int Cout);   /* 1: the 128x64 tile is dispatched, 0: 128x128 */
+
 /* The tile code (WM WN NT as decimal digits: 222 = 128x128, 221 = 128x64, 412 = 256x64, 411 = 256x32)
  * ccst_conv2d_igemm_f32 dispatches for M = n*ho*wo output pixels and cout channels. */
 int ccst_conv2d_igemm_tile(int M, int cout, int pool);

@@ -103,6 +103,41 @@ def test_stem_cases(dev, k, stride, pad, reflect, H, W):
     assert d < 1e-4, "stem k=%d: max abs diff %g" % (k, d)
 
 
+@pytest.mark.parametrize("case", [
+    # N, H, W, Cin, Cout, reflect, relu, pool, ups
+    (2, 16, 16, 64, 64, True, True, False, False),
+    (1, 13, 19, 64, 128, True, True, True, False),      # odd sizes, partial tiles, fused ceil pool
+    (2, 8, 12, 128, 64, True, True, False, True),       # upsample on read
+    (1, 9, 33, 32, 160, True, False, False, False),     # Cout not a multiple of 64/128
+    (1, 24, 40, 48, 256, False, True, False, False),    # zero padding
+    (3, 7, 5, 16, 32, True, True, True, True),          # tiny maps
+])
+@pytest.mark.parametrize("halo", [True, False])
+def test_conv3x3_halo_vs_gather(dev, case, halo):
+    """The halo-in-LDS 3x3 kernel and the gather implicit-GEMM kernel both match F.conv2d."""
+    from ccst_amd import ops
+    N, H, W, Cin, Cout, reflect, relu, pool, ups = case
+    x = rnd((N, Cin, H, W), 31)
+    w = rnd((Cout, Cin, 3, 3), 32, (2.0 / (Cin * 9)) ** 0.5)
+    b = rnd((Cout,), 33, 0.1)
+    ref = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+    ref = F.conv2d(F.pad(ref, (1,) * 4, mode="reflect"), w, b) if reflect else F.conv2d(ref, w, b, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2, 0, ceil_mode=True)
+    old = (ops.USE_HALO, ops.HALO_ZERO_PAD)
+    ops.USE_HALO, ops.HALO_ZERO_PAD = halo, halo
+    try:
+        y = ops.conv2d_nhwc(ops.from_api(x.to(dev), 16), ops.pack_conv_weight(w.to(dev), b.to(dev)), pad=1, reflect=reflect,
+                            relu=relu, pool=pool, ups=ups)
+    finally:
+        ops.USE_HALO, ops.HALO_ZERO_PAD = old
+    got = ops.to_api(y)
+    assert tuple(got.shape) == tuple(ref.shape)
+    assert maxdiff(got, ref) < 1e-4
+
+
 def test_conv_out_nchw(dev):
     from ccst_amd import ops
     x = rnd((2, 64, 12, 10), 8)
