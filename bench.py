@@ -122,8 +122,10 @@ def main():
         if os.path.exists(tsrc):      # HBM bytes/launch from the separate rocprofv3 --pmc passes (tools/profile_bench.sh)
             with open(tsrc) as fh:
                 tj = json.load(fh)
-            key = "void conv_igemm_kernel<%s, %s, 2>" % (", ".join(dom[len("conv_igemm_kernel<"):-1].replace(",pool", "").split(",")),
-                                                          "true" if ",pool" in dom else "false")
+            base, targs = dom[:-1].split("<")
+            targs = targs.split(",")
+            nums, pooled = ", ".join(a for a in targs if a != "pool"), ("true" if "pool" in targs else "false")
+            key = ("void conv_igemm_kernel<%s, %s, 2, 16>" if base == "conv_igemm_kernel" else "void " + base + "<%s, %s>") % (nums, pooled)
             if key in tj:
                 traffic = round(tj[key]["total_bytes_per_launch"])
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

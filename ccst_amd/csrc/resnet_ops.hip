@@ -15,10 +15,13 @@ constexpr int MAXS = 256;   // max row-splits of a per-channel reduction
 // MODE 1: (sum dy', sum dy' * xhat), dy' = relu ? dy*(y>0) : dy  -> BN backward
 // thread = one float4 channel group; PL row lanes per block; grid (S, ceil(C/4/cgb)).
 // ------------------------------------------------------------------------------------------
+// relu mask: from the saved output y (y > 0) or, when y == nullptr (no residual was added), recomputed from x:
+// z = (x-mean)*invstd*gamma + beta > 0 -- one tensor read less in both backward passes.
 template <int MODE>
 __global__ __launch_bounds__(TPB) void chan_partials_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ y, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, int relu, float* __restrict__ part,
+                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int relu, float* __restrict__ part,
                                                             long long M, int C, int S, int cgb, int PL) {
     __shared__ f32x4 red[2][TPB];
     const int split = blockIdx.x, t = threadIdx.x;
@@ -29,10 +32,14 @@ __global__ __launch_bounds__(TPB) void chan_partials_kernel(const float* __restr
     const long long r1 = (r0 + per < M) ? r0 + per : M;
     f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
     if (pl < PL && cg * 4 < C) {
-        f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
+        f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0}, ga = {0, 0, 0, 0}, be = {0, 0, 0, 0};
         if (MODE == 1) {
             mu = *reinterpret_cast<const f32x4*>(mean + cg * 4);
             is = *reinterpret_cast<const f32x4*>(invstd + cg * 4);
+            if (relu && !y) {
+                ga = *reinterpret_cast<const f32x4*>(gamma + cg * 4);
+                be = *reinterpret_cast<const f32x4*>(beta + cg * 4);
+            }
         }
         for (long long r = r0 + pl; r < r1; r += PL) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + cg * 4);
@@ -41,13 +48,14 @@ __global__ __launch_bounds__(TPB) void chan_partials_kernel(const float* __restr
                 b += v * v;
             } else {
                 f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * C + cg * 4);
+                const f32x4 xh = (v - mu) * is;
                 if (relu) {
-                    const f32x4 o = *reinterpret_cast<const f32x4*>(y + r * C + cg * 4);
+                    const f32x4 o = y ? *reinterpret_cast<const f32x4*>(y + r * C + cg * 4) : xh * ga + be;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
                 }
                 a += g;
-                b += g * ((v - mu) * is);
+                b += g * xh;
             }
         }
     }
@@ -175,24 +183,25 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 // dx = gamma*invstd*(dy' - mean(dy') - xhat*mean(dy'*xhat));  d_residual = dy'
 __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ y, const float* __restrict__ gamma,
-                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const float* __restrict__ sums, int relu, float* __restrict__ dx,
-                                                           float* __restrict__ dres, long long total4, int C, float invM) {
+                                                           const float* __restrict__ beta, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ sums, int relu,
+                                                           float* __restrict__ dx, float* __restrict__ dres, long long total4, int C,
+                                                           float invM) {
     const int cg = C / 4;
     for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total4; i += (long long)gridDim.x * TPB) {
         const int c = (int)(i % cg) * 4;
         f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 xh = (v - mu) * is;
         if (relu) {
-            const f32x4 o = *reinterpret_cast<const f32x4*>(y + i * 4);
+            const f32x4 o = y ? *reinterpret_cast<const f32x4*>(y + i * 4) : xh * ga + *reinterpret_cast<const f32x4*>(beta + c);
 #pragma unroll
             for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
         }
         if (dres) *reinterpret_cast<f32x4*>(dres + i * 4) = g;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
         const f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + c), s2 = *reinterpret_cast<const f32x4*>(sums + C + c);
-        const f32x4 xh = (v - mu) * is;
         *reinterpret_cast<f32x4*>(dx + i * 4) = ga * is * (g - s1 * invM - xh * (s2 * invM));
     }
 }
@@ -434,7 +443,7 @@ extern "C" int ccst_bn_train_fwd_f32(const float* x, const float* gamma, const f
     float* part = (float*)ws;
     float* scale = part + (int64_t)MAXS * C * 2;
     float* shift = scale + C;
-    hipLaunchKernelGGL(chan_partials_kernel<0>, dim3(sp.S, sp.gy), dim3(TPB), 0, st, x, nullptr, nullptr, nullptr, nullptr, 0, part,
+    hipLaunchKernelGGL(chan_partials_kernel<0>, dim3(sp.S, sp.gy), dim3(TPB), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, part,
                        (long long)M, C, sp.S, sp.cgb, sp.PL);
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, gamma, beta, running_mean, running_var,
                        momentum, eps, save_mean, save_invstd, scale, shift, (long long)M, C, sp.S);
@@ -455,11 +464,13 @@ extern "C" int ccst_bn_eval_fwd_f32(const float* x, const float* gamma, const fl
     return ccst_launch_status("bn_eval_fwd");
 }
 
-extern "C" int ccst_bn_train_bwd_f32(const float* dy, const float* x, const float* y, const float* gamma, const float* save_mean,
-                                     const float* save_invstd, int relu, float* dx, float* d_residual, float* dgamma, float* dbeta,
-                                     int accumulate, int64_t M, int C, void* ws, int64_t ws_bytes, void* stream) {
+extern "C" int ccst_bn_train_bwd_f32(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
+                                     const float* save_mean, const float* save_invstd, int relu, float* dx, float* d_residual,
+                                     float* dgamma, float* dbeta, int accumulate, int64_t M, int C, void* ws, int64_t ws_bytes,
+                                     void* stream) {
     CCST_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws, "bn_train_bwd: null pointer");
-    CCST_REQUIRE(!relu || y, "bn_train_bwd: relu=1 needs the saved output y");
+    CCST_REQUIRE(!relu || y || beta, "bn_train_bwd: relu=1 needs the saved output y, or beta to recompute the mask from x");
+    CCST_REQUIRE(!(relu && d_residual && !y), "bn_train_bwd: with a residual the ReLU mask must come from the saved output y");
     CCST_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_train_bwd: need M>0 and C %% 4 == 0");
     if (ws_bytes < ccst_bn_workspace_bytes(M, C)) {
         ccst_set_error("bn_train_bwd: workspace too small");
@@ -469,11 +480,11 @@ extern "C" int ccst_bn_train_bwd_f32(const float* dy, const float* x, const floa
     const Split sp = pick_split(M, C);
     float* part = (float*)ws;
     float* sums = part + (int64_t)MAXS * C * 2;
-    hipLaunchKernelGGL(chan_partials_kernel<1>, dim3(sp.S, sp.gy), dim3(TPB), 0, st, x, dy, y, save_mean, save_invstd, relu, part,
+    hipLaunchKernelGGL(chan_partials_kernel<1>, dim3(sp.S, sp.gy), dim3(TPB), 0, st, x, dy, y, save_mean, save_invstd, gamma, beta, relu, part,
                        (long long)M, C, sp.S, sp.cgb, sp.PL);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, dgamma, dbeta, sums, C, sp.S, accumulate);
     const long long total4 = (long long)M * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(TPB), 0, st, dy, x, y, gamma, save_mean, save_invstd, sums,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(TPB), 0, st, dy, x, y, gamma, beta, save_mean, save_invstd, sums,
                        relu, dx, d_residual, total4, C, 1.f / (float)M);
     return ccst_launch_status("bn_train_bwd");
 }

@@ -209,8 +209,11 @@ class BNFn(torch.autograd.Function):
                                             ptr(mod.running_var if track else None), float(mod.momentum), float(mod.eps),
                                             ptr(residual), int(relu), ptr(y), ptr(save[0]), ptr(save[1]), M, C, ptr(ws),
                                             ws.numel(), stream_ptr()), "bn_train_fwd")
-            ctx.save_for_backward(x, y, gamma, beta, save)
             ctx.relu, ctx.has_res = bool(relu), residual is not None
+            # the output is only needed for the ReLU mask, and only when a residual was added (else the mask is
+            # recomputed from x in the backward kernels)
+            need_y = ctx.relu and ctx.has_res
+            ctx.save_for_backward(x, y if need_y else None, gamma, beta, save)
         else:
             check(lib.ccst_bn_eval_fwd_f32(ptr(x), ptr(gamma), ptr(beta), ptr(mod.running_mean), ptr(mod.running_var),
                                            float(mod.eps), ptr(residual), int(relu), ptr(y), M, C, stream_ptr()), "bn_eval_fwd")
@@ -230,7 +233,7 @@ class BNFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
         ws = _workspace(int(lib.ccst_bn_workspace_bytes(M, C)), x.device)
-        check(lib.ccst_bn_train_bwd_f32(ptr(dy), ptr(x), ptr(y), ptr(gamma), ptr(save[0]), ptr(save[1]), int(ctx.relu), ptr(dx),
+        check(lib.ccst_bn_train_bwd_f32(ptr(dy), ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(save[0]), ptr(save[1]), int(ctx.relu), ptr(dx),
                                         ptr(dres), ptr(_grad_slot(gamma)), ptr(_grad_slot(beta)), 1, M, C, ptr(ws), ws.numel(),
                                         stream_ptr()), "bn_train_bwd")
         return dx, None, None, dres, None, None

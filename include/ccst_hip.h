@@ -164,10 +164,11 @@ int ccst_bn_train_fwd_f32(const float* x, const float* gamma, const float* beta,
 int ccst_bn_eval_fwd_f32(const float* x, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, const float* residual, int relu, float* y,
                          int64_t M, int C, void* stream);
-/* BatchNorm2d backward (with the ReLU mask taken from the saved output y when relu=1):
- * dx, dgamma, dbeta (accumulate=1 adds into dgamma/dbeta); if d_residual != NULL it receives the
- * masked incoming gradient (the skip connection's share). */
-int ccst_bn_train_bwd_f32(const float* dy, const float* x, const float* y, const float* gamma,
+/* BatchNorm2d backward: dx, dgamma, dbeta (accumulate=1 adds into dgamma/dbeta).  With relu=1 the ReLU mask
+ * comes from the saved output y (y > 0), or -- when y == NULL, allowed only if no residual was added in
+ * the forward -- is recomputed from x as (x-mean)*invstd*gamma+beta > 0 (one tensor read less per pass).
+ * If d_residual != NULL it receives the masked incoming gradient (the skip connection's share). */
+int ccst_bn_train_bwd_f32(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
                           const float* save_mean, const float* save_invstd, int relu, float* dx,
                           float* d_residual, float* dgamma, float* dbeta, int accumulate, int64_t M, int C,
                           void* ws, int64_t ws_bytes, void* stream);
