@@ -293,6 +293,89 @@ def test_full_size_vs_oracle_and_batch_independence(dev, nets, A):
     assert bool(torch.isfinite(out).all())
 
 
+def test_single_mode_config3_full_size(dev, nets, A):
+    """BASELINE config 3 (CCST_SingleStyleTransfer, B=32, 512x512): one style image per batch, its mu/sigma by the
+    sum / sum-of-squares formula (CCST_SingleStyleTransfer.py:195-212).  Checked on two images against the
+    oracle, and through batch independence for the rest."""
+    from ccst_amd import style
+    vgg31, dec, vgg_w, dec_w = nets
+    content = A.synth_content(32, 512, 512, seed=11)
+    style_img = A.synth_content(1, 512, 512, seed=12)
+    with torch.no_grad():
+        sf = vgg31(style_img.to(dev))
+        s, q, n = style.calc_sum(sf)
+        assert n == 64 * 64 and tuple(s.shape) == (1, 512, 1, 1)
+        stat = list(style.finalise_style_stats(s, q, n))
+        out = style.style_transfer(vgg31, dec, content.to(dev), stat, 1.0)
+    assert tuple(out.shape) == (32, 3, 512, 512) and bool(torch.isfinite(out).all())
+    rs_, rq, rn = A.calc_sum(A.encoder(style_img, vgg_w))
+    rstat = list(A.finalise_stats(rs_, rq, rn))
+    assert maxdiff(stat[0], rstat[0]) < 1e-4 and maxdiff(stat[1], rstat[1]) < 1e-3
+    for i in (0, 31):
+        ref = A.style_transfer(vgg_w, dec_w, content[i:i + 1], rstat, 1.0)
+        assert maxdiff(out[i:i + 1], ref) < TOL
+    with torch.no_grad():
+        one = style.style_transfer(vgg31, dec, content[17:18].to(dev), stat, 1.0)
+    assert maxdiff(one, out[17:18]) < 1e-4
+
+
+def test_stage1_config0_full_size(dev, nets, A):
+    """BASELINE config 0 shape (mean_std_computation_effcientMem, B=32, 512x512): streaming per-channel sums are
+    additive -- accumulating 4 sub-batches of 8 must give the statistics of the one batch of 32 -- and two of
+    the images are checked against the oracle's calc_sum."""
+    from ccst_amd import style
+    vgg31, _, vgg_w, _ = nets
+    content = A.synth_content(32, 512, 512, seed=21)
+    with torch.no_grad():
+        feat = vgg31(content.to(dev))
+        s32, q32, n32 = style.calc_sum(feat)
+        acc = style.StyleStatAccumulator()
+        for k in range(4):
+            acc.update(vgg31(content[8 * k:8 * k + 8].to(dev)))
+    assert n32 == 32 * 64 * 64 == acc.count and acc.images == 32
+    assert float(((acc.sum - s32).abs() / s32.abs().clamp_min(1.0)).max()) < 1e-5
+    assert float(((acc.sqsum - q32).abs() / q32.abs().clamp_min(1.0)).max()) < 1e-5
+    m, sd = acc.finalise()
+    assert bool(torch.isfinite(m).all()) and bool((sd > 0).all())
+    rs_, rq, rn = A.calc_sum(A.encoder(content[:2], vgg_w))
+    with torch.no_grad():
+        s2, q2, n2 = style.calc_sum(vgg31(content[:2].to(dev)))
+    assert n2 == rn
+    assert float(((s2.cpu() - rs_).abs() / rs_.abs().clamp_min(1.0)).max()) < 1e-4
+    assert float(((q2.cpu() - rq).abs() / rq.abs().clamp_min(1.0)).max()) < 1e-4
+
+
+def test_cli_scripts_run_end_to_end(dev, tmp_path):
+    """The three AdaIN CLI drop-ins, as subprocesses, on seeded synthetic content (datasets / checkpoints absent)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "style_transfer", "AdaIN")
+    env = dict(os.environ, PYTHONPATH=root)
+    common = ["--dataset", "pacs", "--synthetic", "6", "--random_weights", "--batch", "3", "--output", str(tmp_path / "out")]
+    for dom in ("cartoon", "photo", "sketch", "art_painting"):
+        subprocess.check_call([sys.executable, os.path.join(d, "mean_std_computation_effcientMem.py"), "--target", dom,
+                               "--image_size", "64"] + common, cwd=str(tmp_path), env=env, stdout=subprocess.DEVNULL)
+    stat = np.load(str(tmp_path / "style_stats" / "pacs" / "cartoon_mean_std.npy"))
+    assert stat.shape == (2, 1, 512, 1, 1) and stat.dtype == np.float32 and np.isfinite(stat).all()
+    assert (tmp_path / "style_stats" / "pacs" / "cartoon_style_comp_time.txt").read_text().startswith("Target cartoon: Finished in")
+    subprocess.check_call([sys.executable, os.path.join(d, "CCST_OverallStyleTransfer.py"), "--target", "art_painting",
+                           "--image_size", "64", "--output_size", "48"] + common, cwd=str(tmp_path), env=env, stdout=subprocess.DEVNULL)
+    subprocess.check_call([sys.executable, os.path.join(d, "CCST_SingleStyleTransfer.py"), "--target", "art_painting",
+                           "--image_size", "64", "--style_size", "64"] + common, cwd=str(tmp_path), env=env, stdout=subprocess.DEVNULL)
+    imgs = []
+    for r, _, fs in os.walk(str(tmp_path / "out")):
+        imgs += [os.path.join(r, f) for f in fs if f.endswith(".jpg")]
+    assert len(imgs) == 2 * 3 * 6                    # 2 scripts x 3 style domains x 6 content images
+    assert any("all_style_transferred_Overall/art_painting/cartoon/" in p and p.endswith("_cartoon.jpg") for p in imgs)
+    from PIL import Image
+    ov = [p for p in imgs if "all_style_transferred_Overall" in p][0]
+    assert Image.open(ov).size == (48, 48)
+    txt = (tmp_path / "pacs_art_painting_overall_stylize_time.txt").read_text()
+    assert "Images number: 6" in txt and "Batch_size: 3" in txt
+
+
 def test_no_cpu_fallback(nets):
     vgg31, _, _, _ = nets
     with pytest.raises(RuntimeError):

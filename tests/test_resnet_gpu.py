@@ -279,3 +279,30 @@ def test_train_and_test_loops(dev):
     el, ea = fed.test(ours, loader, fed.CrossEntropyLoss(), dev, ARGS)
     rel, rea = fed_ref.test_epoch(ref, loader, nn.CrossEntropyLoss())
     assert abs(el - rel) < 2e-3 and abs(ea - rea) < 1e-6, (el, rel)
+
+
+def test_fed_run_cli_checkpoint_resume_test(dev, tmp_path):
+    """federated/fed_run.py drop-in end to end on synthetic clients: console lines, checkpoint dict
+    {'server_model','a_iter'} (best + _latest), --resume and --test (fed_run.py:582-640,733-766)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    base = [sys.executable, os.path.join(root, "federated", "fed_run.py"), "--mode", "fedavg", "--fusion_mode", "adain-overall-K3",
+            "--source", "art_painting", "cartoon", "sketch", "--target", "photo", "--n_classes", "7", "--network", "resnet18",
+            "--lr", "0.001", "--image_size", "222", "--batch", "4", "--synthetic", "8", "--save_path", str(tmp_path / "ckpt")]
+    out = subprocess.check_output(base + ["--iters", "2"], cwd=str(tmp_path), env=env, text=True)
+    assert "=============Global iter is 1 ===============" in out and "| Train Loss:" in out and "| Global Test Class Acc:" in out
+    d = tmp_path / "ckpt" / "pacs" / "fedavg_adain-overall-K3_no_DG_resnet18_locIter1" / "Target_photo_seed_1"
+    latest = torch.load(str(d / "fedavg_latest"), map_location="cpu")
+    assert set(latest.keys()) == {"server_model", "a_iter"} and int(latest["a_iter"]) == 1
+    from oracle import resnet_ref as R
+    assert list(latest["server_model"].keys()) == list(R.resnet18(7).state_dict().keys())
+    if not (d / "fedavg").exists():       # the best checkpoint is only written when val acc improves (strict >, fed_run.py:749)
+        import shutil
+        shutil.copy(str(d / "fedavg_latest"), str(d / "fedavg"))
+    out2 = subprocess.check_output(base + ["--iters", "3", "--resume"], cwd=str(tmp_path), env=env, text=True)
+    assert "Resume training from epoch 2" in out2 and "Global iter is 2" in out2 and "Global iter is 1 " not in out2
+    out3 = subprocess.check_output(base + ["--test"], cwd=str(tmp_path), env=env, text=True)
+    assert "| Test  Acc:" in out3
