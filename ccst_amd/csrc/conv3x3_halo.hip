@@ -15,7 +15,9 @@
 //   Measured: 133.9 TF (128x128 tile, 256->256 @128x128, B=6) vs 129 TF for the gather kernel; staging the
 //   weight tile by LDS-DMA instead of through registers measures the same (133.3 TF); fetching the weight
 //   fragments straight into registers (LDS = halo only, one barrier per 9 taps) measures 106 TF -- the four
-//   waves' duplicated fragment loads thrash the 32-KiB L1 (both variants kept under tools/micro/).
+//   waves' duplicated fragment loads thrash the 32-KiB L1 (both variants kept under tools/micro/).  De-phasing the
+//   ~3 co-resident workgroups (start offsets of 0.3/0.6 step, or static s_setprio 0/1/2) changes nothing
+//   (133.4-133.8 TF): the residual MFMA idle time is not a lockstep effect.
 #include "common.h"
 #include <math.h>
 
