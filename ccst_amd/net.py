@@ -55,14 +55,14 @@ def _is_up2(m):
 
 class _Step(object):
     """One launch (or launch pair) of the plan."""
-    __slots__ = ("kind", "pc", "kw", "kwp", "stride", "pad", "reflect", "relu", "pool", "ups", "out_nchw", "in_nchw",
+    __slots__ = ("kind", "pc", "kw", "kwp", "stride", "pad", "reflect", "relu", "pool", "ups", "out_nchw",
                  "w_small", "b_small", "cout")
 
     def __init__(self, kind, **kw):
         self.kind = kind
         self.pc = self.kw = self.kwp = self.w_small = self.b_small = self.cout = None
         self.stride, self.pad = 1, 0
-        self.reflect = self.relu = self.pool = self.ups = self.out_nchw = self.in_nchw = False
+        self.reflect = self.relu = self.pool = self.ups = self.out_nchw = False
         for k, v in kw.items():
             setattr(self, k, v)
 

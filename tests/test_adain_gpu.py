@@ -376,6 +376,17 @@ def test_cli_scripts_run_end_to_end(dev, tmp_path):
     assert "Images number: 6" in txt and "Batch_size: 3" in txt
 
 
+def test_style_transfer_bitwise_reproducible(dev, nets, A):
+    from ccst_amd import style
+    vgg31, dec, _, _ = nets
+    content = A.synth_content(3, 96, 160, seed=41).to(dev)
+    stat = [t.to(dev) for t in A.synth_style_stat(512, seed=7)]
+    with torch.no_grad():
+        a = style.style_transfer(vgg31, dec, content, stat, 0.7)
+        b = style.style_transfer(vgg31, dec, content, stat, 0.7)
+    assert torch.equal(a, b)
+
+
 def test_no_cpu_fallback(nets):
     vgg31, _, _, _ = nets
     with pytest.raises(RuntimeError):

@@ -306,3 +306,34 @@ def test_fed_run_cli_checkpoint_resume_test(dev, tmp_path):
     assert "Resume training from epoch 2" in out2 and "Global iter is 2" in out2 and "Global iter is 1 " not in out2
     out3 = subprocess.check_output(base + ["--test"], cwd=str(tmp_path), env=env, text=True)
     assert "| Test  Acc:" in out3
+
+
+def test_train_step_bitwise_reproducible(dev):
+    """No float atomics anywhere on the path (split partials + fixed-order reduces): the same step from the same
+    state gives bit-identical logits, loss, gradients and updated weights."""
+    from ccst_amd import fed
+    from ccst_amd.nets import resnet
+    from oracle import resnet_ref as R
+
+    def run():
+        m = resnet.ResNet(resnet.Bottleneck, [1, 1, 1, 1], classes=5)
+        m.load_state_dict(R.seeded_state_dict(R.ResNet(R.Bottleneck, [1, 1, 1, 1], classes=5), 123))
+        m.to(dev).train()
+        opt = fed.SGD(m, lr=0.01)
+        ce = fed.CrossEntropyLoss()
+        x, y = R.synth_batch(6, 222, 5, seed=124)
+        outs = []
+        for _ in range(2):
+            opt.zero_grad()
+            logit = m(x.to(dev))
+            loss = ce(logit, y.to(dev))
+            loss.backward()
+            outs += [logit.detach().clone(), loss.detach().clone(), fed.FlatParams.of(m).grad.clone()]
+            opt.step()
+        outs.append(fed.FlatParams.of(m).flat.clone())
+        torch.cuda.synchronize()
+        return outs
+
+    a, b = run(), run()
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
