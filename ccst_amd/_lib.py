@@ -31,6 +31,8 @@ _SIGNATURES = {
     "ccst_abi_version": [],
     "ccst_last_error": [],
     "ccst_conv2d_igemm_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P],
+    "ccst_conv2d_igemm_stats_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P, _P],
+    "ccst_conv2d_igemm_stats_groups": [c_int, c_int],
     "ccst_conv3x3_halo_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_conv3x3_halo_narrow": [c_int, c_int, c_int, c_int],
     "ccst_conv2d_igemm_tile": [c_int, c_int, c_int],
@@ -47,7 +49,7 @@ _SIGNATURES = {
     "ccst_adain_f32": [_P, _P, _P, c_int, c_float, _P, c_int, c_int, c_int, c_int, c_float, _P, c_int64, _P],
     "ccst_chan_sums_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _P],
     "ccst_stats_workspace_bytes": [c_int, c_int, c_int],
-    "ccst_bn_train_fwd_f32": [_P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P, _P, _P, c_int64, c_int, _P, c_int64, _P],
+    "ccst_bn_train_fwd_f32": [_P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P, _P, _P, c_int64, c_int, _P, c_int, _P, c_int64, _P],
     "ccst_bn_eval_fwd_f32": [_P, _P, _P, _P, _P, c_float, _P, c_int, _P, c_int64, c_int, _P],
     "ccst_bn_train_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int64, c_int, _P, c_int64, _P],
     "ccst_bn_workspace_bytes": [c_int64, c_int],

@@ -47,6 +47,7 @@ struct ConvArgs {
     int tilesY, tilesX;  // spatial tiles per image (pool mode)
     float invHW, invWo;  // reciprocals for the division-free pixel decode (valid while M < 2^22)
     int fastdiv;
+    float* stats;        // optional [row groups][Cout][2]: per-64-row (sum, sum of squares) of the output (BN statistics)
 };
 
 // floor(m / d) for 0 <= m < 2^22 via one float multiply + correction (an integer division is ~40 VALU
@@ -260,6 +261,32 @@ __global__ __launch_bounds__(256, ((MT == 2 && CK == 16) ? 3 : 2)) void conv_ige
     // ---- epilogue ------------------------------------------------------------------------
     const bool relu = (p.flags & CCST_CONV_RELU) != 0;
     float* yb = p.y + p.y_off;
+    if (!POOL && p.stats != nullptr) {
+        // BatchNorm statistics for free: this wave's 64 rows x 32*NT columns -> per-column (sum, sum^2) partials,
+        // slab index = tile row * WM + wave row.  Rows beyond M are excluded; the fp64 combine happens in the BN
+        // finalize kernel, so the result does not depend on the tiling beyond fp32 partial-sum rounding.
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * (32 * MT) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float v = (tm * BM + row < p.M) ? acc[mt][nt][r] : 0.f;
+                    s1 += v;
+                    s2 += v * v;
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            const int co = co0 + wn * (32 * NT) + nt * 32 + li;
+            if (lh == 0 && co < p.Cout) {
+                float* o = p.stats + ((long long)(tm * WM + wm) * p.Cout + co) * 2;
+                o[0] = s1;
+                o[1] = s2;
+            }
+        }
+    }
     if (!POOL) {
         const int HW = p.Ho * p.Wo;
         const bool dense = (p.flags & CONV_DENSE_OUT) != 0;   // &y[m] = y + m*ysW: no (n,oy,ox) decode
@@ -420,8 +447,30 @@ static int choose_tile(int M, int cout, bool pool) {
 // Tile code (WM WN NT as decimal digits) the dispatcher picks for this problem; bench.py names kernels with it.
 extern "C" int ccst_conv2d_igemm_tile(int M, int cout, int pool) { return choose_tile(M, cout, pool != 0); }
 
+// Row groups of 64 output rows that ccst_conv2d_igemm_stats_f32 writes for a problem of M rows and cout columns.
+extern "C" int ccst_conv2d_igemm_stats_groups(int M, int cout) {
+    const int tile = choose_tile(M, cout, false);
+    const int BM = (tile / 100 == 4) ? 256 : 128;
+    return ((M + BM - 1) / BM) * (BM / 64);
+}
+
+static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w_packed, const float* bias, float* y,
+                           float* stats, void* stream);
+
 extern "C" int ccst_conv2d_igemm_f32(const CcstConvDesc* d, const float* x, const float* w_packed, const float* bias,
                                      float* y, void* stream) {
+    return conv_igemm_impl(d, x, w_packed, bias, y, nullptr, stream);
+}
+
+extern "C" int ccst_conv2d_igemm_stats_f32(const CcstConvDesc* d, const float* x, const float* w_packed, const float* bias,
+                                           float* y, float* stats, void* stream) {
+    CCST_REQUIRE(stats != nullptr, "conv_stats: null stats buffer");
+    CCST_REQUIRE(d && !(d->flags & (CCST_CONV_POOL2 | CCST_CONV_RELU)), "conv_stats: statistics are of the raw conv output (no ReLU / pool)");
+    return conv_igemm_impl(d, x, w_packed, bias, y, stats, stream);
+}
+
+static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w_packed, const float* bias, float* y,
+                           float* stats, void* stream) {
     CCST_REQUIRE(d && x && w_packed && y, "conv: null pointer");
     CCST_REQUIRE(d->cin > 0 && d->cin % CK_MIN == 0, "conv: cin=%d must be a positive multiple of 16", d->cin);
     CCST_REQUIRE(d->cout > 0 && d->cout_pad >= d->cout && d->cout_pad % 128 == 0, "conv: cout=%d cout_pad=%d (need multiple of 128)",
@@ -444,6 +493,7 @@ extern "C" int ccst_conv2d_igemm_f32(const CcstConvDesc* d, const float* x, cons
     a.invHW = 1.0f / (float)(d->ho * d->wo);
     a.invWo = 1.0f / (float)d->wo;
     a.fastdiv = a.M < (1 << 22);
+    a.stats = stats;
     hipStream_t s = (hipStream_t)stream;
     const int tile = choose_tile(a.M, d->cout, pool);
     if (pool) {

@@ -17,7 +17,7 @@ constexpr int MAXS = 256;   // max row-splits of a per-channel reduction
 // ------------------------------------------------------------------------------------------
 // relu mask: from the saved output y (y > 0) or, when y == nullptr (no residual was added), recomputed from x:
 // z = (x-mean)*invstd*gamma + beta > 0 -- one tensor read less in both backward passes.
-template <int MODE>
+template <int MODE, int MASK = 0>      // MASK: 0 no ReLU, 1 mask from the saved output y, 2 mask recomputed from x
 __global__ __launch_bounds__(TPB) void chan_partials_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(TPB) void chan_partials_kernel(const float* __restr
         if (MODE == 1) {
             mu = *reinterpret_cast<const f32x4*>(mean + cg * 4);
             is = *reinterpret_cast<const f32x4*>(invstd + cg * 4);
-            if (relu && !y) {
+            if (MASK == 2) {
                 ga = *reinterpret_cast<const f32x4*>(gamma + cg * 4);
                 be = *reinterpret_cast<const f32x4*>(beta + cg * 4);
             }
@@ -49,8 +49,10 @@ __global__ __launch_bounds__(TPB) void chan_partials_kernel(const float* __restr
             } else {
                 f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * C + cg * 4);
                 const f32x4 xh = (v - mu) * is;
-                if (relu) {
-                    const f32x4 o = y ? *reinterpret_cast<const f32x4*>(y + r * C + cg * 4) : xh * ga + be;
+                if (MASK != 0) {
+                    f32x4 o;
+                    if (MASK == 1) o = *reinterpret_cast<const f32x4*>(y + r * C + cg * 4);
+                    else o = xh * ga + be;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
                 }
@@ -76,41 +78,45 @@ __global__ __launch_bounds__(TPB) void chan_partials_kernel(const float* __restr
     }
 }
 
-// Sum the S split partials of 16 channels with 16 split-lanes each (fp64), then combine the lanes in
+// Sum the S split partials of NCH channels with 256/NCH split-lanes each (fp64), then combine the lanes in
 // fixed order through LDS.  Returns the two totals for channel c (valid on lanes with sl == 0).
-__device__ __forceinline__ void reduce_partials16(const float* __restrict__ part, int C, int S, int c, int sl, double& s, double& q) {
-    __shared__ double red[2][16][17];
+// NCH = 16 for the BN kernels' own <= 256 splits, 4 when the conv epilogue supplies thousands of row groups.
+template <int NCH>
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int C, int S, int c, int sl, double& s, double& q) {
+    constexpr int NL = 256 / NCH;
+    __shared__ double red[2][NL][NCH + 1];
     double a = 0.0, b = 0.0;
     if (c < C) {
-        for (int k = sl; k < S; k += 16) {
+        for (int k = sl; k < S; k += NL) {
             const float2 v = *reinterpret_cast<const float2*>(part + ((long long)k * C + c) * 2);
             a += (double)v.x;
             b += (double)v.y;
         }
     }
-    red[0][sl][c & 15] = a;
-    red[1][sl][c & 15] = b;
+    red[0][sl][c % NCH] = a;
+    red[1][sl][c % NCH] = b;
     __syncthreads();
     s = 0.0;
     q = 0.0;
     if (sl == 0) {
-        for (int k = 0; k < 16; ++k) {
-            s += red[0][k][c & 15];
-            q += red[1][k][c & 15];
+        for (int k = 0; k < NL; ++k) {
+            s += red[0][k][c % NCH];
+            q += red[1][k][c % NCH];
         }
     }
 }
 
 // BN forward finalize: batch mean / biased var, running-stat update (unbiased var), scale/shift.
+template <int NCH>
 __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float* __restrict__ running_mean,
                                                               float* __restrict__ running_var, float momentum, float eps,
                                                               float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                               float* __restrict__ scale, float* __restrict__ shift, long long M, int C,
                                                               int S) {
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * NCH + (threadIdx.x % NCH), sl = threadIdx.x / NCH;
     double s, q;
-    reduce_partials16(part, C, S, c, sl, s, q);
+    reduce_partials<NCH>(part, C, S, c, sl, s, q);
     if (sl != 0 || c >= C) return;
     const double mu = s / (double)M;
     double var = q / (double)M - mu * mu;
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               int accumulate) {
     const int c = blockIdx.x * 16 + (threadIdx.x & 15), sl = threadIdx.x >> 4;
     double a, b;
-    reduce_partials16(part, C, S, c, sl, a, b);
+    reduce_partials<16>(part, C, S, c, sl, a, b);
     if (sl != 0 || c >= C) return;
     sums[c] = (float)a;          // sum dy'
     sums[C + c] = (float)b;      // sum dy' * xhat
@@ -181,6 +187,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 }
 
 // dx = gamma*invstd*(dy' - mean(dy') - xhat*mean(dy'*xhat));  d_residual = dy'
+template <int MASK>
 __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ y, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, const float* __restrict__ mean,
@@ -195,8 +202,10 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
         const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
         const f32x4 xh = (v - mu) * is;
-        if (relu) {
-            const f32x4 o = y ? *reinterpret_cast<const f32x4*>(y + i * 4) : xh * ga + *reinterpret_cast<const f32x4*>(beta + c);
+        if (MASK != 0) {
+            f32x4 o;
+            if (MASK == 1) o = *reinterpret_cast<const f32x4*>(y + i * 4);
+            else o = xh * ga + *reinterpret_cast<const f32x4*>(beta + c);
 #pragma unroll
             for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
         }
@@ -430,7 +439,8 @@ extern "C" int64_t ccst_bn_workspace_bytes(int64_t M, int C) {
 
 extern "C" int ccst_bn_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                                      float momentum, float eps, const float* residual, int relu, float* y, float* save_mean,
-                                     float* save_invstd, int64_t M, int C, void* ws, int64_t ws_bytes, void* stream) {
+                                     float* save_invstd, int64_t M, int C, const float* stats_in, int stats_groups, void* ws,
+                                     int64_t ws_bytes, void* stream) {
     CCST_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && ws, "bn_train_fwd: null pointer");
     CCST_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_train_fwd: need M>0 and C %% 4 == 0 (C=%d)", C);
     CCST_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_fwd: running stats must come together");
@@ -443,10 +453,22 @@ extern "C" int ccst_bn_train_fwd_f32(const float* x, const float* gamma, const f
     float* part = (float*)ws;
     float* scale = part + (int64_t)MAXS * C * 2;
     float* shift = scale + C;
-    hipLaunchKernelGGL(chan_partials_kernel<0>, dim3(sp.S, sp.gy), dim3(TPB), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, part,
-                       (long long)M, C, sp.S, sp.cgb, sp.PL);
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, gamma, beta, running_mean, running_var,
-                       momentum, eps, save_mean, save_invstd, scale, shift, (long long)M, C, sp.S);
+    const float* fin = part;
+    int S = sp.S;
+    if (stats_in != nullptr) {          // per-channel (sum, sum^2) partials already produced by the conv epilogue
+        CCST_REQUIRE(stats_groups > 0, "bn_train_fwd: stats_groups must be positive");
+        fin = stats_in;
+        S = stats_groups;
+    } else {
+        hipLaunchKernelGGL(chan_partials_kernel<0>, dim3(sp.S, sp.gy), dim3(TPB), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, 0, part, (long long)M, C, sp.S, sp.cgb, sp.PL);
+    }
+    if (S > 512)
+        hipLaunchKernelGGL(bn_fwd_finalize_kernel<4>, dim3((C + 3) / 4), dim3(256), 0, st, fin, gamma, beta, running_mean, running_var,
+                           momentum, eps, save_mean, save_invstd, scale, shift, (long long)M, C, S);
+    else
+        hipLaunchKernelGGL(bn_fwd_finalize_kernel<16>, dim3((C + 15) / 16), dim3(256), 0, st, fin, gamma, beta, running_mean,
+                           running_var, momentum, eps, save_mean, save_invstd, scale, shift, (long long)M, C, S);
     const long long total4 = (long long)M * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(TPB), 0, st, x, scale, shift, nullptr, nullptr, nullptr, nullptr,
                        eps, residual, relu, y, total4, C);
@@ -480,12 +502,23 @@ extern "C" int ccst_bn_train_bwd_f32(const float* dy, const float* x, const floa
     const Split sp = pick_split(M, C);
     float* part = (float*)ws;
     float* sums = part + (int64_t)MAXS * C * 2;
-    hipLaunchKernelGGL(chan_partials_kernel<1>, dim3(sp.S, sp.gy), dim3(TPB), 0, st, x, dy, y, save_mean, save_invstd, gamma, beta, relu, part,
-                       (long long)M, C, sp.S, sp.cgb, sp.PL);
+    const int mask = !relu ? 0 : (y ? 1 : 2);
+#define CCST_PARTIALS1(MK)                                                                                                          \
+    hipLaunchKernelGGL((chan_partials_kernel<1, MK>), dim3(sp.S, sp.gy), dim3(TPB), 0, st, x, dy, y, save_mean, save_invstd, gamma, beta, \
+                       relu, part, (long long)M, C, sp.S, sp.cgb, sp.PL)
+    if (mask == 0) CCST_PARTIALS1(0);
+    else if (mask == 1) CCST_PARTIALS1(1);
+    else CCST_PARTIALS1(2);
+#undef CCST_PARTIALS1
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, dgamma, dbeta, sums, C, sp.S, accumulate);
     const long long total4 = (long long)M * (C / 4);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(TPB), 0, st, dy, x, y, gamma, beta, save_mean, save_invstd, sums,
-                       relu, dx, d_residual, total4, C, 1.f / (float)M);
+#define CCST_BWD_APPLY(MK)                                                                                                          \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<MK>), dim3(grid_for(total4)), dim3(TPB), 0, st, dy, x, y, gamma, beta, save_mean, save_invstd, \
+                       sums, relu, dx, d_residual, total4, C, 1.f / (float)M)
+    if (mask == 0) CCST_BWD_APPLY(0);
+    else if (mask == 1) CCST_BWD_APPLY(1);
+    else CCST_BWD_APPLY(2);
+#undef CCST_BWD_APPLY
     return ccst_launch_status("bn_train_bwd");
 }
 

@@ -51,26 +51,40 @@ class Conv2d(nn.Conv2d):
             return ops.pack_conv_weight(wv), kwp
         return self._cached("pks", build)
 
-    def forward(self, x):
+    def forward(self, x, want_stats=False):
+        """want_stats=True (training only): returns (y, stats) with the BatchNorm batch-statistic partials of y
+        produced in the conv epilogue; pass them to the following BatchNorm2d(..., stats=stats)."""
         self._check()
         if not x.is_cuda:
             raise RuntimeError("ccst_amd.nets: CUDA (ROCm) tensors only; no CPU fallback")
         if self.in_channels <= 4:
-            return ops.to_api(nn_ops.StemConvFn.apply(x, self.weight, self))
+            y = ops.to_api(nn_ops.StemConvFn.apply(x, self.weight, self))
+            return (y, None) if want_stats else y
+        if want_stats:
+            y, stats = nn_ops.ConvFn.apply(_to_nhwc(x), self.weight, self, True)
+            return ops.to_api(y), stats
         return ops.to_api(nn_ops.ConvFn.apply(_to_nhwc(x), self.weight, self))
 
 
 class BatchNorm2d(nn.BatchNorm2d):
     """BatchNorm2d fused with an optional residual add and ReLU: y = relu(bn(x) + residual)."""
 
-    def forward(self, x, residual=None, relu=False):
+    def forward(self, x, residual=None, relu=False, stats=None):
         if not (self.affine and x.is_cuda):
             raise NotImplementedError("ccst_amd.nets: affine CUDA BatchNorm2d only")
         if not self.training and not self.track_running_stats:
             raise NotImplementedError("ccst_amd.nets: eval-mode BatchNorm2d needs running statistics")
         res = _to_nhwc(residual) if residual is not None else None
-        y = nn_ops.BNFn.apply(_to_nhwc(x), self.weight, self.bias, res, self, bool(relu))
+        y = nn_ops.BNFn.apply(_to_nhwc(x), self.weight, self.bias, res, self, bool(relu), stats if self.training else None)
         return ops.to_api(y)
+
+
+def conv_bn(conv, bn, x, residual=None, relu=False):
+    """bn(conv(x)) [+ residual] [ReLU]; in training the batch statistics come out of the conv epilogue."""
+    if bn.training:
+        y, stats = conv(x, want_stats=True)
+        return bn(y, residual=residual, relu=relu, stats=stats)
+    return bn(conv(x), residual=residual, relu=relu)
 
 
 class ReLU(nn.ReLU):
@@ -131,11 +145,10 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         identity = x
-        out = self.bn1(self.conv1(x), relu=True)
-        out = self.conv2(out)
+        out = conv_bn(self.conv1, self.bn1, x, relu=True)
         if self.downsample is not None:
-            identity = self.downsample(x)
-        return self.bn2(out, residual=identity, relu=True)
+            identity = conv_bn(self.downsample[0], self.downsample[1], x)
+        return conv_bn(self.conv2, self.bn2, out, residual=identity, relu=True)
 
 
 class Bottleneck(nn.Module):
@@ -155,12 +168,11 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         identity = x
-        out = self.bn1(self.conv1(x), relu=True)
-        out = self.bn2(self.conv2(out), relu=True)
-        out = self.conv3(out)
+        out = conv_bn(self.conv1, self.bn1, x, relu=True)
+        out = conv_bn(self.conv2, self.bn2, out, relu=True)
         if self.downsample is not None:
-            identity = self.downsample(x)
-        return self.bn3(out, residual=identity, relu=True)
+            identity = conv_bn(self.downsample[0], self.downsample[1], x)
+        return conv_bn(self.conv3, self.bn3, out, residual=identity, relu=True)
 
 
 class ResNet(nn.Module):
@@ -215,8 +227,7 @@ class ResNet(nn.Module):
     def forward(self, x, **kwargs):
         if self.training:
             self._bump_counters()
-        x = self.conv1(x)
-        x = self.bn1(x, relu=True)
+        x = conv_bn(self.conv1, self.bn1, x, relu=True)
         x = self.maxpool(x)
         x = self.layer1(x)
         x = self.layer2(x)

@@ -42,14 +42,21 @@ def _conv_kernel_name(cout, pool, M):
     return "conv_igemm_kernel<%s,%s,%s%s>" % (t[0], t[1], t[2], ",pool" if pool else "")
 
 
-def _launch_conv(d, x, pc, out, flops, pool, what):
+def _launch_conv(d, x, pc, out, flops, pool, what, stats=None):
     lib = _lib.load()
+
+    def call():
+        if stats is None:
+            check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(x), ptr(pc.w), ptr(pc.bias), ptr(out), stream_ptr()), what)
+        else:
+            check(lib.ccst_conv2d_igemm_stats_f32(ctypes.byref(d), ptr(x), ptr(pc.w), ptr(pc.bias), ptr(out), ptr(stats),
+                                                  stream_ptr()), what)
     if TIMING is None:
-        check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(x), ptr(pc.w), ptr(pc.bias), ptr(out), stream_ptr()), what)
+        call()
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(x), ptr(pc.w), ptr(pc.bias), ptr(out), stream_ptr()), what)
+    call()
     e1.record()
     TIMING.append((_conv_kernel_name(pc.cout, pool, d.n * d.ho * d.wo), flops, e0, e1,
                    "n%d %dx%d cin%d cout%d taps%dx%d flags%d" % (d.n, d.ho, d.wo, d.cin, d.cout, d.nky, d.nkx, d.flags)))
@@ -131,12 +138,15 @@ def pack_conv_weight(w_oihw, bias=None, transpose=False, out=None):
     return PackedConv(out, b, cin, cout, kh, kw, k_pad, n_pad, transpose)
 
 
-def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, ups=False, out_nchw=False, out=None):
+def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, ups=False, out_nchw=False, out=None,
+                want_stats=False):
     """Forward convolution of an NHWC tensor x [N,Hs,Ws,Cin_pad] with PackedConv pc.
 
     ups:  x is read through a nearest x2 upsample (logical input is [2Hs,2Ws]).
     pool: fused MaxPool2d(2,2,ceil_mode=True) epilogue.
     out_nchw: write a contiguous NCHW tensor (the image edge of the decoder).
+    want_stats: also return the per-64-row (sum, sum^2) partials [groups, Cout, 2] of the output, produced in the
+                conv epilogue for the following BatchNorm2d (returns (out, stats)).
     """
     _require_cuda(x, "activation")
     assert x.is_contiguous() and x.dim() == 4 and not pc.transpose
@@ -159,7 +169,7 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
     d.flags = flags
     oh, ow = ((ho + 1) // 2, (wo + 1) // 2) if pool else (ho, wo)
     if USE_HALO and (reflect or HALO_ZERO_PAD) and pc.kh == 3 and pc.kw == 3 and stride == 1 and pad == 1 and not out_nchw \
-            and out is None:
+            and out is None and not want_stats:
         out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
         lib = _lib.load()
         args = (ptr(x), ptr(pc.w), ptr(pc.bias), ptr(out), N, Hi, Wi, Cx, pc.cout, pc.n_pad, flags, stream_ptr())
@@ -184,8 +194,13 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
         if out is None:
             out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
         d.y_off, d.ysN, d.ysH, d.ysW, d.ysC = 0, oh * ow * pc.cout, ow * pc.cout, pc.cout, 1
-    _launch_conv(d, x, pc, out, 2.0 * N * ho * wo * pc.cout * pc.cin * pc.kh * pc.kw, pool, "conv2d_igemm")
-    return out
+    stats = None
+    if want_stats:
+        assert not (relu or pool or out_nchw), "statistics are of the raw dense NHWC conv output"
+        groups = _lib.load().ccst_conv2d_igemm_stats_groups(N * ho * wo, pc.cout)
+        stats = torch.empty((groups, pc.cout, 2), device=x.device, dtype=torch.float32)
+    _launch_conv(d, x, pc, out, 2.0 * N * ho * wo * pc.cout * pc.cin * pc.kh * pc.kw, pool, "conv2d_igemm", stats)
+    return (out, stats) if want_stats else out
 
 
 def conv3x3_smallco_nchw(x, w_tap_ci_co, bias, cout, reflect=True, relu=False):

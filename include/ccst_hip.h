@@ -75,6 +75,12 @@ typedef struct CcstConvDesc {
 
 int ccst_conv2d_igemm_f32(const CcstConvDesc* d, const float* x, const float* w_packed,
                           const float* bias /* may be NULL */, float* y, void* stream);
+/* Same convolution (dense NHWC output, no ReLU / pool), additionally writing per-64-row (sum, sum of squares)
+ * partials of the output, stats[groups][cout][2] with groups = ccst_conv2d_igemm_stats_groups(M, cout): the
+ * batch statistics the following BatchNorm2d needs (nets/resnet.py:138,162), so BN skips its own read pass. */
+int ccst_conv2d_igemm_stats_f32(const CcstConvDesc* d, const float* x, const float* w_packed,
+                                const float* bias, float* y, float* stats, void* stream);
+int ccst_conv2d_igemm_stats_groups(int M, int cout);
 
 /* 3x3 stride-1 "same" conv (reflection or zero padding) with the input halo staged once per 16-channel
  * chunk in LDS (A-side loads / LDS writes 9x fewer than the gather form): the AdaIN encoder/decoder
@@ -153,13 +159,14 @@ int64_t ccst_stats_workspace_bytes(int N, int C, int HW);
 /* ------------------------------------------------------------------------
  * ResNet training ops (nets/resnet.py:132-191 + torchvision blocks; fed_run.py:49-80).  NHWC.
  * ------------------------------------------------------------------------ */
-/* BatchNorm2d training forward: batch mean / biased var over N*H*W, running-stat update
+/* BatchNorm2d training forward: batch mean / biased var over the M = N*H*W rows, running-stat update
  * (momentum, unbiased var), y = (x-mean)*invstd*gamma+beta [+ residual] [ReLU].
- * save_mean/save_invstd: [C] for backward.  residual may be NULL. */
+ * save_mean/save_invstd: [C] for backward.  residual may be NULL.  stats_in (may be NULL): per-channel
+ * (sum, sum^2) partials [stats_groups][C][2] from ccst_conv2d_igemm_stats_f32 -- then x is not re-read. */
 int ccst_bn_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
                           float* running_var, float momentum, float eps, const float* residual, int relu,
                           float* y, float* save_mean, float* save_invstd, int64_t M, int C,
-                          void* ws, int64_t ws_bytes, void* stream);
+                          const float* stats_in, int stats_groups, void* ws, int64_t ws_bytes, void* stream);
 /* BatchNorm2d eval forward with running stats (fed_run.py:216). */
 int ccst_bn_eval_fwd_f32(const float* x, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, const float* residual, int relu, float* y,
