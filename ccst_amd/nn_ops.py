@@ -30,6 +30,40 @@ def _workspace(nbytes, device):
     return buf
 
 
+# Weight gradients are off the critical path of the backward pass (nothing reads dW before the optimiser step), and
+# the ResNet GEMMs under-fill the chip individually, so they run on a second HIP stream, concurrently with the
+# backward-data / BatchNorm chain.  The main stream re-joins at the end of the autograd pass (engine callback).
+SIDE_STREAM = _os.environ.get("CCST_BWD_WEIGHT_STREAM", "1") != "0"
+_SIDE = {}
+_JOIN_PENDING = set()
+
+
+def _side_stream(device):
+    st = _SIDE.get(device.index)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _SIDE[device.index] = st
+    return st
+
+
+def _on_side_stream(device, tensors, fn):
+    """Run fn() on the side stream after everything enqueued so far on the current stream; keep `tensors` alive for it."""
+    main = torch.cuda.current_stream(device)
+    side = _side_stream(device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        fn()
+    for t in tensors:
+        t.record_stream(side)
+    if device.index not in _JOIN_PENDING:
+        _JOIN_PENDING.add(device.index)
+
+        def join():
+            _JOIN_PENDING.discard(device.index)
+            torch.cuda.current_stream(device).wait_stream(side)
+        torch.autograd.Variable._execution_engine.queue_callback(join)
+
+
 def _grad_slot(p):
     """Return (tensor to write, accumulate flag) for parameter p."""
     if p.grad is None:
@@ -140,7 +174,11 @@ class ConvFn(torch.autograd.Function):
         N, H, W, Cin = x.shape
         if weight.requires_grad:
             d, _, _ = _fwd_desc(N, H, W, Cin, weight.shape[2], weight.shape[3], stride, pad, Cin, weight.shape[0], 0)
-            conv_bwd_weight(d, x, dy, _grad_slot(weight))
+            g = _grad_slot(weight)
+            if SIDE_STREAM:
+                _on_side_stream(x.device, (x, dy), lambda: conv_bwd_weight(d, x, dy, g))
+            else:
+                conv_bwd_weight(d, x, dy, g)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = conv_bwd_data(dy, mod.packed_t(), tuple(x.shape), stride, pad)
