@@ -81,6 +81,9 @@ def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False
     (fed_run.py's round: local epoch(s) then communication()), barrier-bracketed, max over ranks."""
     import torch.distributed as dist
     from . import fed
+    if graph:       # the side stream forks work past the end of a step (weight pre-pack): not capturable as one graph
+        from . import nn_ops
+        nn_ops.SIDE_STREAM = False
     distributed = world > 1 and dist.is_available() and dist.is_initialized()
     rank = dist.get_rank() if distributed else 0
     model, opt, loss_fun, x, y = build(dev, arch=arch, batch=batch, seed=1 + rank)

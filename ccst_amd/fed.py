@@ -96,6 +96,7 @@ class SGD(object):
         a = self.arena
         check(_lib.load().ccst_sgd_f32(ptr(a.flat), ptr(a.grad), float(self.param_groups[0]["lr"]), a.n_param, stream_ptr()), "sgd")
         ops.bump_weights_epoch()
+        nn_ops.prepack_on_side(a.model)
 
 
 class CrossEntropyLoss(nn.Module):

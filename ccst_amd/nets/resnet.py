@@ -35,18 +35,31 @@ class Conv2d(nn.Conv2d):
         slot = self.__dict__.get("_ccst_" + name)
         if slot is None or slot[0] != key:
             with torch.no_grad():
-                slot = (key, fn(w.detach()))
+                slot = (key, fn(w.detach(), None if slot is None else slot[1]))
             self.__dict__["_ccst_" + name] = slot
+        else:
+            nn_ops.join_prepack(w.device)      # re-packs issued on the side stream by the optimiser step
         return slot[1]
 
+    @staticmethod
+    def _reuse(prev):
+        return None if prev is None or not isinstance(prev, ops.PackedConv) else prev.w
+
     def packed(self):
-        return self._cached("pk", lambda w: ops.pack_conv_weight(w))
+        return self._cached("pk", lambda w, prev: ops.pack_conv_weight(w, out=self._reuse(prev)))
 
     def packed_t(self):
-        return self._cached("pkt", lambda w: ops.pack_conv_weight(w, transpose=True))
+        return self._cached("pkt", lambda w, prev: ops.pack_conv_weight(w, transpose=True, out=self._reuse(prev)))
+
+    def prepack(self):
+        """Refresh the packed copies now (called on the side stream right after the optimiser step)."""
+        if self.in_channels > 4 and "_ccst_pk" in self.__dict__:
+            self.packed()
+            if "_ccst_pkt" in self.__dict__:
+                self.packed_t()
 
     def packed_stem(self):
-        def build(w):
+        def build(w, prev):
             wv, kwp = ops.stem_virtual_weight(w)
             return ops.pack_conv_weight(wv), kwp
         return self._cached("pks", build)

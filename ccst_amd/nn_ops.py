@@ -64,6 +64,32 @@ def _on_side_stream(device, tensors, fn):
         torch.autograd.Variable._execution_engine.queue_callback(join)
 
 
+_PREPACK_PENDING = set()
+
+
+def prepack_on_side(model):
+    """After an optimiser step: re-pack every conv weight on the side stream (into the existing packed buffers), so
+    the ~100 small pack launches overlap the next step's stem / first BN / max-pool instead of preceding them."""
+    if not SIDE_STREAM:
+        return
+    convs = [m for m in model.modules() if hasattr(m, "prepack")]
+    if not convs:
+        return
+    device = convs[0].weight.device
+    main, side = torch.cuda.current_stream(device), _side_stream(device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side), torch.no_grad():
+        for m in convs:
+            m.prepack()
+    _PREPACK_PENDING.add(device.index)
+
+
+def join_prepack(device):
+    if device.index in _PREPACK_PENDING:
+        _PREPACK_PENDING.discard(device.index)
+        torch.cuda.current_stream(device).wait_stream(_side_stream(device))
+
+
 def _grad_slot(p):
     """Return (tensor to write, accumulate flag) for parameter p."""
     if p.grad is None:
