@@ -201,6 +201,8 @@ def communication(args, server_model, models, client_weights):
         raise NotImplementedError("ccst_amd.fed: --mode fedbn is outside the hot path (SURVEY.md 8f-4)")
     with torch.no_grad():
         arenas = [FlatParams.of(m) for m in [server_model] + list(models)]
+        if arenas[0].flat.is_cuda:
+            nn_ops.join_prepack(arenas[0].flat.device)      # side-stream re-packs still read the client weights
         srv, clients = arenas[0], arenas[1:]
         if any(c.n_total != srv.n_total for c in clients):
             raise ValueError("communication: client and server models differ in size")
@@ -235,6 +237,8 @@ def communication_distributed(args, model, client_weight, group=None, server_cou
         raise NotImplementedError("ccst_amd.fed: --mode fedbn is outside the hot path")
     arena = FlatParams.of(model)
     with torch.no_grad():
+        if arena.flat.is_cuda:
+            nn_ops.join_prepack(arena.flat.device)           # side-stream re-packs still read these weights
         scale_fn(arena.flat, client_weight, arena.n_total)      # tests of the gloo protocol inject a host scale
         dist.all_reduce(arena.flat, op=dist.ReduceOp.SUM, group=group)
         ops.bump_weights_epoch()

@@ -33,12 +33,13 @@ class Conv2d(nn.Conv2d):
         w = self.weight
         key = (w._version, w.data_ptr(), ops.WEIGHTS_EPOCH)
         slot = self.__dict__.get("_ccst_" + name)
+        if w.is_cuda:
+            nn_ops.join_prepack(w.device)      # re-packs issued on the side stream by the optimiser step (reads AND
+                                               # the rebuild below must not overlap them: same destination buffers)
         if slot is None or slot[0] != key:
             with torch.no_grad():
                 slot = (key, fn(w.detach(), None if slot is None else slot[1]))
             self.__dict__["_ccst_" + name] = slot
-        else:
-            nn_ops.join_prepack(w.device)      # re-packs issued on the side stream by the optimiser step
         return slot[1]
 
     @staticmethod
