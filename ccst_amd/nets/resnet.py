@@ -33,7 +33,7 @@ class Conv2d(nn.Conv2d):
         w = self.weight
         key = (w._version, w.data_ptr(), ops.WEIGHTS_EPOCH)
         slot = self.__dict__.get("_ccst_" + name)
-        if w.is_cuda:
+        if w.is_cuda and name != "pks":        # (the stem's virtual-pixel pack is never re-packed on the side stream)
             nn_ops.join_prepack(w.device)      # re-packs issued on the side stream by the optimiser step (reads AND
                                                # the rebuild below must not overlap them: same destination buffers)
         if slot is None or slot[0] != key:
