@@ -10,7 +10,8 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 import torch  # noqa: F401  -- must be imported first so libamdhip64.so.7 resolves to torch's copy
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libccst_hip.so")
+# CCST_HIP_LIB points at an alternative build of the same ABI (kernel A/B experiments, tools/build_variant.sh)
+LIB_PATH = os.environ.get("CCST_HIP_LIB") or os.path.join(_HERE, "csrc", "libccst_hip.so")
 
 CONV_RELU, CONV_POOL2, CONV_UPS2, CONV_REFLECT = 1, 2, 4, 8
 

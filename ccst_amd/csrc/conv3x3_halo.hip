@@ -35,6 +35,16 @@ struct HaloArgs {
     int tilesX, tilesY, tilesN;
 };
 
+#ifndef LOAD_P
+#define LOAD_P 7
+#endif
+#ifndef STORE_P
+#define STORE_P 6
+#endif
+#ifndef READ1_P
+#define READ1_P 3
+#endif
+constexpr bool DEEP = STORE_P <= LOAD_P;
 constexpr int CKH = 16, PITCH = CKH + 4, HW_ = 18;
 
 __device__ __forceinline__ int reflect_h(int i, int n) {
@@ -150,27 +160,27 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
             *reinterpret_cast<f32x4*>(&Hs_[buf][(u >> 2) * PITCH + (u & 3) * 4]) = v;
         }
     };
-    auto compute = [&](int hbuf, int bbuf, int tapoff) {
+    f32x4 af[2][MT], bf[2][NT];
+    auto read_frags = [&](int hbuf, int bbuf, int tapoff, int q) {
         const float* hb = &Hs_[hbuf][tapoff];
         const float* bRd = bRd0 + bbuf * (CKH * BN);
 #pragma unroll
-        for (int q = 0; q < CKH / 8; ++q) {
-            f32x4 af[MT], bf[NT];
+        for (int mt = 0; mt < MT; ++mt) af[q][mt] = *reinterpret_cast<const f32x4*>(hb + aBase[mt] + q * 8);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4*>(hb + aBase[mt] + q * 8);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const f32x4*>(bRd + (2 * q * BN + nt * 32) * 4);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][s], bf[nt][s], acc[mt][nt], 0, 0, 0);
-        }
+        for (int nt = 0; nt < NT; ++nt) bf[q][nt] = *reinterpret_cast<const f32x4*>(bRd + (2 * q * BN + nt * 32) * 4);
     };
+    auto mfma_frags = [&](int q, int s0, int s1) {
+#pragma unroll
+        for (int s = s0; s < s1; ++s)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][mt][s], bf[q][nt][s], acc[mt][nt], 0, 0, 0);
+    };
+    static_assert(CKH == 16, "the step body below is written for two 8-channel halves");
 
-    // ---- prologue: halo of chunk 0 and weights of step 0 -------------------------------------------
+    // ---- prologue: halo of chunk 0 and weights of step 0 in LDS (deep pipeline: step 1's weights in flight) ----
 #pragma unroll
     for (int i = 0; i < HR; ++i) {
         load_h(0, i, hoff[i]);
@@ -178,25 +188,53 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
     }
     load_b(0, 0);
     store_b(0);
+    if (DEEP) load_b(0, 1);
     __syncthreads();
 
     // ---- main loop: chunk c, taps fully unrolled so that every step's code is static (no conditional
-    // loads: hipcc hoists conservative vmcnt waits above the MFMAs otherwise).  During taps 0..HR-1 the next
-    // chunk's halo is fetched one unit per step into the other halo buffer; the very last steps prefetch a
-    // clamped (redundant, never read) chunk / weight tile instead of branching. --------------------------
+    // loads: hipcc hoists conservative vmcnt waits above the MFMAs otherwise).  A step is 8 groups of 4 MFMAs;
+    // the staging is slotted between groups at compile-time positions (measured):
+    //   LOAD_P  - where the global loads of the following step's weights / next chunk's halo unit are issued.
+    //             Late is better: anything issued right behind the barrier delays the first MFMAs of the step.
+    //   STORE_P - where the fetched registers go to the idle LDS buffers.  STORE_P > LOAD_P: same step (plain
+    //             double buffer, the stores sit in front of the last MFMAs so their latency is covered);
+    //             STORE_P <= LOAD_P: the NEXT step (one stage deeper, a whole step for the loads to land).
+    // The very last steps prefetch a clamped (redundant, never read) chunk / weight tile instead of branching.
     for (int c = 0; c < nchunks; ++c) {
         const int cn = min(c + 1, nchunks - 1);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int t = c * 9 + tap;
-            if (tap < 8) load_b(c, tap + 1);
-            else load_b(cn, 0);
-            if (tap < HR) load_h(cn, tap, hoff[tap]);
+            const int tapoff = ((tap / 3) * HW_ + (tap % 3)) * PITCH;
+#pragma unroll
+            for (int pos = 0; pos <= 8; ++pos) {
+                if (pos == 0) read_frags(c & 1, t & 1, tapoff, 0);
+                if (pos == READ1_P) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_frags(c & 1, t & 1, tapoff, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (pos == STORE_P) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    store_b((t + 1) & 1);
+                    if (DEEP) {
+                        if (tap >= 1 && tap <= HR) store_h((c + 1) & 1, tap - 1, hok[tap - 1]);
+                    } else {
+                        if (tap < HR) store_h((c + 1) & 1, tap, hok[tap]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (pos == LOAD_P) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int tn_ = tap + (DEEP ? 2 : 1);
+                    if (tn_ < 9) load_b(c, tn_);
+                    else load_b(cn, tn_ - 9);
+                    if (tap < HR) load_h(cn, tap, hoff[tap]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (pos < 8) mfma_frags(pos >> 2, pos & 3, (pos & 3) + 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            compute(c & 1, t & 1, ((tap / 3) * HW_ + (tap % 3)) * PITCH);
-            __builtin_amdgcn_sched_barrier(0);
-            store_b((t + 1) & 1);
-            if (tap < HR) store_h((c + 1) & 1, tap, hok[tap]);
             __syncthreads();
         }
     }

@@ -1,0 +1,6 @@
+#!/bin/bash
+# A/B the AdaIN bench over every build/variants/lib_*.so given as arguments (default build first).
+cd "$(dirname "$0")/.."
+line() { python bench.py --steps 20 --warmup 3 --no-secondary --no-cpu-baseline 2>&1 | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], {k.replace('conv3x3_halo_kernel','halo').replace('conv_igemm_kernel','igemm'):v['tflops'] for k,v in d['kernels'].items()})"; }
+echo "default:"; line
+for v in "$@"; do echo "$v:"; CCST_HIP_LIB=$PWD/build/variants/lib_$v.so line; done
