@@ -24,6 +24,7 @@
 //   y strides) or the fused MaxPool2d(2,2,ceil) where the M index is laid out so that the four
 //   pixels of a pooling window sit in the four registers (reg&3) of one lane.
 #include "common.h"
+#include <type_traits>
 #include <math.h>
 #include <stdlib.h>
 
@@ -216,47 +217,77 @@ __global__ __launch_bounds__(256, ((MT == 2 && CK == 16) ? 3 : 2)) void conv_ige
 
     const float* aRd0 = &As[0][(wm * (32 * MT) + li) * A_LD + lh * 4];
     const float* bRd0 = &Bs[0][(lh * BN + wn * (32 * NT) + li) * 4];
-    auto compute = [&](int buf) {
+    constexpr int NQ = CK / 8;        // fragment reads per step (8 channels each)
+    constexpr int NG = 4 * NQ;        // MFMA groups per step: one k-pair of every (mt, nt) tile each
+    f32x4 af[NQ][MT], bf[NQ][NT];
+    auto read_frags = [&](int buf, int q) {
         const float* aRd = aRd0 + buf * (BM * A_LD);
         const float* bRd = bRd0 + buf * (CK * BN);
 #pragma unroll
-        for (int q = 0; q < CK / 8; ++q) {
-            f32x4 af[MT], bf[NT];
+        for (int mt = 0; mt < MT; ++mt) af[q][mt] = *reinterpret_cast<const f32x4*>(aRd + mt * 32 * A_LD + q * 8);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                af[mt] = *reinterpret_cast<const f32x4*>(aRd + mt * 32 * A_LD + q * 8);
+        for (int nt = 0; nt < NT; ++nt) bf[q][nt] = *reinterpret_cast<const f32x4*>(bRd + (2 * q * BN + nt * 32) * 4);
+    };
+    auto mfma_group = [&](int g) {
+        const int q = g >> 2, s_ = g & 3;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                bf[nt] = *reinterpret_cast<const f32x4*>(bRd + (2 * q * BN + nt * 32) * 4);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][s], bf[nt][s], acc[mt][nt], 0, 0, 0);
-        }
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][mt][s_], bf[q][nt][s_], acc[mt][nt], 0, 0, 0);
     };
+
+    // One k-step = NG MFMA groups with the staging slotted LATE between them (same structure and the same
+    // measurements as conv3x3_halo.hip): a step boundary is barrier -> ds_read -> MFMA only; the registers
+    // fetched during the previous step (data of step t+1) go to the idle LDS buffers in front of the last two
+    // groups, the fetch for step t+2 is issued in front of the last group, and each later 8-channel fragment
+    // pair is read one group ahead of its first use.  STORE/LOAD are compile-time so that the peeled last two
+    // steps stay branch-free (hipcc hoists conservative vmcnt waits above the MFMAs otherwise).
+    auto step = [&](int t, auto do_store, auto do_load) {
+        const int buf = t & 1;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g == 0) read_frags(buf, 0);
+            if (g == NG - 2 && decltype(do_store)::value) {
+                __builtin_amdgcn_sched_barrier(0);
+                store_step(buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g == NG - 1 && decltype(do_load)::value) {
+                __builtin_amdgcn_sched_barrier(0);
+                advance();
+                load_step(ky, kx, c);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if ((g & 3) == 3 && (g >> 2) + 1 < NQ) {
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(buf, (g >> 2) + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mfma_group(g);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
 
     tap_offsets(0, 0);
     load_step(0, 0, 0);
     store_step(0);
-    __syncthreads();
-
-    // Steady state: the loads of step t+1 are in flight while step t's MFMAs run.  The body is
-    // unconditional (last step peeled) so hipcc keeps its vmcnt wait at the LDS write instead of
-    // hoisting it above the MFMAs.  aok[] is recomputed by advance() for exactly the tap whose
-    // data load_step() then fetches and store_step() writes.
-    for (int t = 0; t < T - 1; ++t) {
+    if (T > 1) {
         advance();
-        load_step(ky, kx, c);
-        __builtin_amdgcn_sched_barrier(0);     // keep the global loads ahead of the MFMA block
-        compute(t & 1);
-        __builtin_amdgcn_sched_barrier(0);     // ... and the vmcnt wait + LDS writes behind it
-        store_step((t + 1) & 1);
+        load_step(ky, kx, c);      // step 1's data stays in registers until step 0 stores it
+    }
+    __syncthreads();
+    for (int t = 0; t < T - 2; ++t) {
+        step(t, Yes{}, Yes{});
         __syncthreads();
     }
-    compute((T - 1) & 1);
+    if (T > 1) {
+        step(T - 2, Yes{}, No{});
+        __syncthreads();
+    }
+    step(T - 1, No{}, No{});
 
     // ---- epilogue ------------------------------------------------------------------------
     const bool relu = (p.flags & CCST_CONV_RELU) != 0;
