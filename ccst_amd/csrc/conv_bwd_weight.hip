@@ -10,6 +10,7 @@
 //   dense; LDS images are [pixel][channel] so the MFMA operands (lane = channel, k = pixel) are
 //   conflict-free ds_read_b32.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -130,36 +131,72 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs p) 
             *reinterpret_cast<f32x4*>(&Ds[buf][px * LDJ + cp * 4]) = rd[u];
         }
     };
-    auto compute = [&](int buf) {
+    constexpr int NG = PK / 2;            // MFMA groups per step (one pixel pair each)
+    constexpr int NH = NG / 2;            // fragments are read in two halves
+    float av[2][NH][MI], bv[2][NH][NJ];
+    auto read_frags = [&](int buf, int h) {
         const float* xr = &Xs[buf][lh * LDI + wi * (32 * MI) + li];
         const float* dr = &Ds[buf][lh * LDJ + wj * (32 * NJ) + li];
 #pragma unroll
-        for (int k2 = 0; k2 < PK / 2; ++k2) {
-            float av[MI], bv[NJ];
+        for (int k = 0; k < NH; ++k) {
+            const int k2 = h * NH + k;
 #pragma unroll
-            for (int a = 0; a < MI; ++a) av[a] = xr[2 * k2 * LDI + a * 32];
+            for (int a = 0; a < MI; ++a) av[h][k][a] = xr[2 * k2 * LDI + a * 32];
 #pragma unroll
-            for (int c = 0; c < NJ; ++c) bv[c] = dr[2 * k2 * LDJ + c * 32];
-#pragma unroll
-            for (int a = 0; a < MI; ++a)
-#pragma unroll
-                for (int c = 0; c < NJ; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[c], acc[a][c], 0, 0, 0);
+            for (int c = 0; c < NJ; ++c) bv[h][k][c] = dr[2 * k2 * LDJ + c * 32];
         }
     };
+    auto mfma_group = [&](int g) {
+        const int h = g / NH, k = g % NH;
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int c = 0; c < NJ; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[h][k][a], bv[h][k][c], acc[a][c], 0, 0, 0);
+    };
+    // Same step structure as conv_igemm.hip: barrier -> ds_read -> MFMA at the step boundary; the registers
+    // fetched during the previous step go to the idle LDS buffers in front of the last two MFMA groups and the
+    // fetch for step st+2 (with its index arithmetic) is issued in front of the last group.
+    auto step = [&](int buf, int st_load, auto do_store, auto do_load) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g == 0) read_frags(buf, 0);
+            if (g == NG - 2 && decltype(do_store)::value) {
+                __builtin_amdgcn_sched_barrier(0);
+                store_step(buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g == NG - 1 && decltype(do_load)::value) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_step(st_load);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g == NH - 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(buf, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            mfma_group(g);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
 
     if (s0 < s1) {
+        const int T = s1 - s0;
         load_step(s0);
         store_step(0);
+        if (T > 1) load_step(s0 + 1);
         __syncthreads();
-        for (int st = s0; st < s1 - 1; ++st) {
-            load_step(st + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            compute((st - s0) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-            store_step((st - s0 + 1) & 1);
+        for (int t = 0; t < T - 2; ++t) {
+            step(t & 1, s0 + t + 2, Yes{}, Yes{});
             __syncthreads();
         }
-        compute((s1 - 1 - s0) & 1);
+        if (T > 1) {
+            step((T - 2) & 1, 0, Yes{}, No{});
+            __syncthreads();
+        }
+        step((T - 1) & 1, 0, No{}, No{});
     }
 
     // partial slab store: ws[((split*ntap + tap)*Cin + ci)*Cout + co]
