@@ -44,6 +44,12 @@ struct HaloArgs {
 #ifndef READ1_P
 #define READ1_P 3
 #endif
+#ifndef RING3
+#define RING3 1
+#endif
+#ifndef PRE_P
+#define PRE_P 5
+#endif
 constexpr bool DEEP = STORE_P <= LOAD_P;
 constexpr int CKH = 16, PITCH = CKH + 4, HW_ = 18;
 
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
     static_assert(HR <= 9, "halo load rounds must fit the 9 tap steps of a chunk");
 
     __shared__ __attribute__((aligned(16))) float Hs_[2][HPIX * PITCH];
-    __shared__ __attribute__((aligned(16))) float Bs[2][CKH * BN];
+    __shared__ __attribute__((aligned(16))) float Bs[RING3 ? 3 : 2][CKH * BN];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -186,6 +192,56 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
         load_h(0, i, hoff[i]);
         store_h(0, i, hok[i]);
     }
+#if RING3
+    // 3-deep weight ring: step t computes from Bs[t%3]; the registers fetched during step t-1 (weights of step
+    // t+2) are stored at group STORE_P, the fetch for step t+3 is issued at LOAD_P, and the first fragment pair of
+    // step t+1 -- already visible since the previous barrier -- is read before this step's barrier, so that a step
+    // boundary is barrier -> MFMA with no LDS latency behind it.
+    load_b(0, 0);
+    store_b(0);
+    load_b(0, 1);
+    store_b(1);
+    load_b(0, 2);
+    __syncthreads();
+    read_frags(0, 0, 0, 0);
+    for (int c = 0; c < nchunks; ++c) {
+        const int cn = min(c + 1, nchunks - 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int tapoff = ((tap / 3) * HW_ + (tap % 3)) * PITCH;
+#pragma unroll
+            for (int pos = 0; pos <= 8; ++pos) {
+                if (pos == READ1_P) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_frags(c & 1, tap % 3, tapoff, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (pos == STORE_P) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    store_b((tap + 2) % 3);
+                    if (tap >= 1 && tap <= HR) store_h((c + 1) & 1, tap - 1, hok[tap - 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (pos == LOAD_P) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tap + 3 < 9) load_b(c, tap + 3);
+                    else load_b(cn, tap + 3 - 9);
+                    if (tap < HR) load_h(cn, tap, hoff[tap]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (pos == PRE_P) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int tp = (tap + 1) % 9;
+                    read_frags(tap == 8 ? (c + 1) & 1 : c & 1, tp % 3, ((tp / 3) * HW_ + (tp % 3)) * PITCH, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (pos < 8) mfma_frags(pos >> 2, pos & 3, (pos & 3) + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+        }
+    }
+#else
     load_b(0, 0);
     store_b(0);
     if (DEEP) load_b(0, 1);
@@ -238,6 +294,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
             __syncthreads();
         }
     }
+#endif
 
     // ---- epilogue ----------------------------------------------------------------------------------------
     const bool relu = p.relu != 0;
