@@ -75,6 +75,23 @@ class FlatParams(object):
             yield p, off
             off += (p.numel() + 3) // 4 * 4
 
+    def key_ranges(self, pred):
+        """Merged [start, end) element ranges of the arena holding the state entries whose state_dict key
+        satisfies ``pred`` (layout: parameters in named_parameters() order, then the fp32 buffers)."""
+        named = [(k, v) for k, v in self.model.named_parameters()]
+        named += [(k, b) for k, b in self.model.named_buffers() if b.dtype == torch.float32]
+        out, off = [], 0
+        for k, v in named:
+            n = (v.numel() + 3) // 4 * 4
+            if pred(k):
+                if out and out[-1][1] == off:
+                    out[-1][1] = off + n
+                else:
+                    out.append([off, off + n])
+            off += n
+        assert off == self.n_total
+        return [(a, b) for a, b in out]
+
 
 class SGD(object):
     """optim.SGD(params, lr) with no momentum / weight decay (fed_run.py:657): p -= lr * g, one launch."""
@@ -197,8 +214,6 @@ def communication(args, server_model, models, client_weights):
     server = sum_i w_i * client_i and every client is overwritten with it.  In-process form (all
     models on one GPU) for API parity; see communication_distributed for the one-client-per-GPU form."""
     mode = (getattr(args, "mode", "fedavg") or "fedavg").lower()
-    if mode == "fedbn":
-        raise NotImplementedError("ccst_amd.fed: --mode fedbn is outside the hot path (SURVEY.md 8f-4)")
     with torch.no_grad():
         arenas = [FlatParams.of(m) for m in [server_model] + list(models)]
         if arenas[0].flat.is_cuda:
@@ -209,8 +224,15 @@ def communication(args, server_model, models, client_weights):
         srv.flat.zero_()
         for ci in range(len(client_weights)):
             _axpy(srv.flat, clients[ci].flat, client_weights[ci])
-        for ci in range(len(client_weights)):
-            clients[ci].flat.copy_(srv.flat)                      # device-to-device memcpy
+        if mode == "fedbn":
+            # fed_run.py:388-399: the server averages everything, clients keep every key whose name contains 'bn'
+            shared = srv.key_ranges(lambda k: 'bn' not in k)
+            for ci in range(len(client_weights)):
+                for a, b in shared:
+                    clients[ci].flat[a:b].copy_(srv.flat[a:b])
+        else:
+            for ci in range(len(client_weights)):
+                clients[ci].flat.copy_(srv.flat)                  # device-to-device memcpy
         ops.bump_weights_epoch()
         ssd, c0 = server_model.state_dict(), models[0].state_dict()
         for key in ssd.keys():
@@ -225,22 +247,38 @@ def _hip_scale(flat, w, n):
     check(_lib.load().ccst_scale_f32(ptr(flat), float(w), n, stream_ptr()), "scale")
 
 
-def communication_distributed(args, model, client_weight, group=None, server_counters=None, scale_fn=_hip_scale):
+def communication_distributed(args, model, client_weight, group=None, server_counters=None, scale_fn=_hip_scale,
+                              server_model=None):
     """FedAvg with one client per rank/GPU: theta <- sum_i w_i * theta_i as ONE all-reduce(SUM) of the
     flat arena (parameters + BN running stats) over RCCL/xGMI; each rank pre-scales by its own w_i.
     After the call every rank holds the server model (what fed_run.py:411-414 copies to all clients).
     num_batches_tracked: each client keeps its own; the server's copy is client 0's (fed_run.py:404-405),
-    returned in `server_counters` (broadcast from rank 0) when given."""
+    returned in `server_counters` (broadcast from rank 0) when given.
+    --mode fedbn (fed_run.py:388-399): the client keeps every entry whose key contains 'bn', so the averaged
+    model needs a home of its own: pass ``server_model`` (a replica on this rank); it receives the full
+    average and the client only the shared (non-'bn') entries."""
     import torch.distributed as dist
     mode = (getattr(args, "mode", "fedavg") or "fedavg").lower()
-    if mode == "fedbn":
-        raise NotImplementedError("ccst_amd.fed: --mode fedbn is outside the hot path")
     arena = FlatParams.of(model)
     with torch.no_grad():
         if arena.flat.is_cuda:
             nn_ops.join_prepack(arena.flat.device)           # side-stream re-packs still read these weights
-        scale_fn(arena.flat, client_weight, arena.n_total)      # tests of the gloo protocol inject a host scale
-        dist.all_reduce(arena.flat, op=dist.ReduceOp.SUM, group=group)
+        if mode == "fedbn":
+            if server_model is None:
+                raise ValueError("communication_distributed: --mode fedbn needs server_model (clients keep their BN entries)")
+            srv = FlatParams.of(server_model)
+            if srv.n_total != arena.n_total:
+                raise ValueError("communication: client and server models differ in size")
+            srv.flat.copy_(arena.flat)
+            scale_fn(srv.flat, client_weight, srv.n_total)
+            dist.all_reduce(srv.flat, op=dist.ReduceOp.SUM, group=group)
+            for a, b in arena.key_ranges(lambda k: 'bn' not in k):
+                arena.flat[a:b].copy_(srv.flat[a:b])
+        else:
+            scale_fn(arena.flat, client_weight, arena.n_total)      # tests of the gloo protocol inject a host scale
+            dist.all_reduce(arena.flat, op=dist.ReduceOp.SUM, group=group)
+            if server_model is not None and server_model is not model:
+                FlatParams.of(server_model).flat.copy_(arena.flat)
         ops.bump_weights_epoch()
         if server_counters is not None:
             for t in server_counters:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Drop-in for the reference's federated/fed_run.py (fedavg path): same flags (:458-503), console lines,
+"""Drop-in for the reference's federated/fed_run.py (fedavg / fedbn / deepall paths): same flags (:458-503), console lines,
 checkpoint dicts ({'server_model', 'a_iter'}, best and '_latest', :733-766) and --resume / --test.
 
 Two launch forms
@@ -9,7 +9,9 @@ Two launch forms
   * torchrun --nproc-per-node K federated/fed_run.py ... one process per GPU = one client per GPU (K = number
                                                          of --source domains); the FedAvg average is ONE RCCL
                                                          all-reduce of the flat fp32 state per global round.
-Out of scope: fedbn / adafea / fedprox aggregation variants, RSC / Jigsaw / MixStyle /
+--mode fedbn (fed_run.py:388-399, :693-698, :735-759): clients keep every state entry whose key contains 'bn',
+are validated with their local model, and checkpoints also carry 'model_{k}' state dicts.
+Out of scope: adafea / fedprox aggregation variants, RSC / Jigsaw / MixStyle /
 FedDG, Tent, tensorboard / Excel logging."""
 import argparse
 import copy
@@ -74,8 +76,8 @@ def parse():
 
 def main():
     args = parse()
-    if args.mode.lower() not in ('fedavg', 'deepall') or args.dg_method not in ('no_DG',):
-        raise NotImplementedError("only --mode fedavg/deepall with --dg_method no_DG is on the hot path")
+    if args.mode.lower() not in ('fedavg', 'fedbn', 'deepall') or args.dg_method not in ('no_DG',):
+        raise NotImplementedError("only --mode fedavg/fedbn/deepall with --dg_method no_DG is on the hot path")
     if not torch.cuda.is_available():
         raise SystemExit("ccst_amd: an MI355X (ROCm) device is required; there is no CPU path")
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,7 +150,11 @@ def main():
                 log(' {:<11s}| Train Loss: {:.4f}'.format(datasets[ci], train_loss))
                 log(' {:<11s}| Train Class Acc: {:.4f}'.format(datasets[ci], train_acc))
         with torch.no_grad():
-            if world > 1:
+            fedbn = args.mode.lower() == 'fedbn'
+            if world > 1 and fedbn:
+                fed.communication_distributed(args, models[rank], client_weights[rank], server_model=server_model)
+                srv = server_model                    # the average lives in this rank's server replica
+            elif world > 1:
                 fed.communication_distributed(args, models[rank], client_weights[rank])
                 srv = models[rank]                    # after the all-reduce every rank holds the server model
             else:
@@ -157,7 +163,8 @@ def main():
             print("----------------Validate global model on source domains----------------")
             val_acc_sum = 0.0
             for ci in my_clients:
-                val_loss, val_acc = fed.test(srv, val_loaders[ci], loss_fun, device, args)
+                # FedBN validates the local model on its source domain (fed_run.py:693-698)
+                val_loss, val_acc = fed.test(models[ci] if fedbn else srv, val_loaders[ci], loss_fun, device, args)
                 log(' {:<11s}| Global Val Loss: {:.4f}'.format(datasets[ci], val_loss))
                 log(' {:<11s}| Global Val Class Acc: {:.4f}'.format(datasets[ci], val_acc))
                 val_acc_sum += val_acc
@@ -171,13 +178,16 @@ def main():
                 test_loss, test_acc = fed.test(srv, target_test_loader, loss_fun, device, args)
                 log(' {:<11s}| Global Test Loss: {:.4f}'.format(args.target, test_loss))
                 log(' {:<11s}| Global Test Class Acc: {:.4f}'.format(args.target, test_acc))
-                sd = {k: v.detach().cpu() for k, v in srv.state_dict().items()}
+                ckpt = {'server_model': {k: v.detach().cpu() for k, v in srv.state_dict().items()}, 'a_iter': a_iter}
+                if fedbn:       # :735-739 -- one process holds every client only in the single-process form
+                    for ci in my_clients:
+                        ckpt['model_{}'.format(ci)] = {k: v.detach().cpu() for k, v in models[ci].state_dict().items()}
                 if a_iter % args.save_freq == 0 and a_iter > 0:
-                    torch.save({'server_model': sd, 'a_iter': a_iter}, SAVE_PATH + '_latest')
+                    torch.save(ckpt, SAVE_PATH + '_latest')
                 if val_class_acc_average > best_val_class_acc:
                     best_val_class_acc, best_test = val_class_acc_average, test_acc
                     log(' Saving current best checkpoints to {}...'.format(SAVE_PATH))
-                    torch.save({'server_model': sd, 'a_iter': a_iter}, SAVE_PATH)
+                    torch.save(ckpt, SAVE_PATH)
     if logfile:
         logfile.write(f'Test result using the global model with best val accuracy: {best_test} on {args.target}')
         logfile.close()

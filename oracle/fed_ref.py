@@ -23,6 +23,27 @@ def communication_fedavg(server_model, models, client_weights):
     return server_model, models
 
 
+def communication_fedbn(server_model, models, client_weights):
+    """federated/fed_run.py:388-399 (--mode fedbn): the server averages every key exactly as above,
+    but clients are only overwritten for keys whose NAME does not contain 'bn' -- so bn1/bnN weights,
+    biases and running stats stay local, while a downsample branch's BatchNorm ('downsample.1.*')
+    is still shared."""
+    with torch.no_grad():
+        ssd = server_model.state_dict()
+        for key in ssd.keys():
+            if 'num_batches_tracked' in key:
+                ssd[key].data.copy_(models[0].state_dict()[key])
+            else:
+                temp = torch.zeros_like(ssd[key])
+                for ci in range(len(client_weights)):
+                    temp += client_weights[ci] * models[ci].state_dict()[key]
+                ssd[key].data.copy_(temp)
+                if 'bn' not in key:
+                    for ci in range(len(client_weights)):
+                        models[ci].state_dict()[key].data.copy_(ssd[key])
+    return server_model, models
+
+
 def train_epoch(model, loader, lr, loss_fun):
     """federated/fed_run.py:31-88 without logging/device moves: returns
     (train_loss, train_acc) = (sum loss / n_batches, correct / num_data)."""

@@ -39,6 +39,13 @@ def _worker(rank, world, initfile, outdir):
     fed.communication_distributed(types.SimpleNamespace(mode="fedavg"), ours, weights[rank], server_counters=counters,
                                   scale_fn=lambda flat, w, n: flat.mul_(float(w)))
     torch.save({"sd": ours.state_dict(), "server_counters": counters}, os.path.join(outdir, "fed_%d.pt" % rank))
+    # --mode fedbn: the average goes to a server replica, the client keeps its 'bn' entries
+    mine = resnet.ResNet(resnet.BasicBlock, [1, 1, 1, 1], classes=3)
+    mine.load_state_dict(_client_state(rank).state_dict())
+    srv = resnet.ResNet(resnet.BasicBlock, [1, 1, 1, 1], classes=3)
+    fed.communication_distributed(types.SimpleNamespace(mode="fedbn"), mine, weights[rank], server_model=srv,
+                                  scale_fn=lambda flat, w, n: flat.mul_(float(w)))
+    torch.save({"client": mine.state_dict(), "server": srv.state_dict()}, os.path.join(outdir, "fedbn_%d.pt" % rank))
     # sharded style statistics: each rank accumulates its own batches, one all-reduce at the end
     acc = style.StyleStatAccumulator()
     rs = np.random.RandomState(5 + rank)
@@ -68,6 +75,20 @@ def test_fedavg_and_style_stats_world2():
                 assert torch.allclose(r0["sd"][k], v, rtol=1e-6, atol=1e-7), k
                 assert torch.equal(r0["sd"][k], r1["sd"][k]), k                  # every rank holds the server model
         assert all(int(c) == 5 for c in r0["server_counters"]) and all(int(c) == 5 for c in r1["server_counters"])
+        b = [torch.load(os.path.join(d, "fedbn_%d.pt" % r), weights_only=False) for r in range(2)]
+        server = _client_state(0)
+        clients = [_client_state(0), _client_state(1)]
+        server, clients = fed_ref.communication_fedbn(server, clients, [0.6, 0.4])
+        for k, v in server.state_dict().items():
+            if "num_batches_tracked" in k:
+                continue
+            for r in range(2):
+                assert torch.allclose(b[r]["server"][k], v, rtol=1e-6, atol=1e-7), k
+                if 'bn' in k:
+                    assert torch.equal(b[r]["client"][k], _client_state(r).state_dict()[k]), k      # untouched
+                else:
+                    assert torch.equal(b[r]["client"][k], b[r]["server"][k]), k
+                assert torch.allclose(b[r]["client"][k], clients[r].state_dict()[k], rtol=1e-6, atol=1e-7), k
         s0 = torch.load(os.path.join(d, "st_0.pt"), weights_only=False)
         s1 = torch.load(os.path.join(d, "st_1.pt"), weights_only=False)
         assert s0["count"] == s1["count"] == 300 and s0["images"] == 3

@@ -119,3 +119,29 @@ def test_communication(golden):
     assert [int(server.state_dict()[k]) for k in nbt] == list(g["nbt_server"]) == [5] * len(nbt)
     for ci, c in enumerate(clients):
         assert [int(c.state_dict()[k]) for k in nbt] == list(g["nbt_clients"][ci])
+
+
+def test_communication_fedbn(golden):
+    """--mode fedbn (fed_run.py:388-399): server averages everything, clients keep keys containing 'bn'."""
+    g = golden("communication_fedbn")
+    server = R.ResNet(R.BasicBlock, [1, 1, 1, 1], classes=3)
+    server.load_state_dict(R.seeded_state_dict(server, int(g["seed"])))
+    clients = [copy.deepcopy(server) for _ in range(3)]
+    for ci, c in enumerate(clients):
+        rs = np.random.RandomState(71 + ci)
+        with torch.no_grad():
+            for k, v in c.state_dict().items():
+                if "num_batches_tracked" in k:
+                    v.fill_(5 + ci)
+                else:
+                    v += torch.from_numpy(rs.normal(0, 0.02, tuple(v.shape)).astype(np.float32))
+    server, clients = Fd.communication_fedbn(server, clients, [float(w) for w in g["weights"]])
+    fkeys = [str(k) for k in g["keys"]]
+    assert fkeys == [k for k in server.state_dict().keys() if "num_batches_tracked" not in k]
+    assert np.array_equal(np.array([float(server.state_dict()[k].double().sum()) for k in fkeys]), g["server_sum"])
+    for ci, c in enumerate(clients):
+        assert np.array_equal(np.array([float(c.state_dict()[k].double().sum()) for k in fkeys]), g["client_sum"][ci])
+    shared = [all(torch.equal(server.state_dict()[k], c.state_dict()[k]) for c in clients) for k in fkeys]
+    assert shared == [bool(b) for b in g["shared"]] == ['bn' not in k for k in fkeys]
+    assert shared[fkeys.index("layer2.0.downsample.1.weight")] and not shared[fkeys.index("bn1.weight")]
+    assert torch.equal(clients[1].state_dict()["bn1.weight"].flatten()[:16], t(g["bn1_weight_client1"]))

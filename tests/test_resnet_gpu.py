@@ -259,6 +259,41 @@ def test_communication_golden(dev, golden):
                 assert torch.equal(c.state_dict()[k], server.state_dict()[k])
 
 
+def test_communication_fedbn_golden(dev, golden):
+    """--mode fedbn through the flat arenas: server = full average, clients keep keys containing 'bn'."""
+    import types
+    from ccst_amd import fed
+    from ccst_amd.nets import resnet
+    from oracle import resnet_ref as R
+    g = golden("communication_fedbn")
+    server = resnet.ResNet(resnet.BasicBlock, [1, 1, 1, 1], classes=3)
+    server.load_state_dict(R.seeded_state_dict(R.ResNet(R.BasicBlock, [1, 1, 1, 1], classes=3), int(g["seed"])))
+    clients = [copy.deepcopy(server) for _ in range(3)]
+    for ci, c in enumerate(clients):
+        rs = np.random.RandomState(71 + ci)
+        with torch.no_grad():
+            for k, v in c.state_dict().items():
+                if "num_batches_tracked" in k:
+                    v.fill_(5 + ci)
+                else:
+                    v += torch.from_numpy(rs.normal(0, 0.02, tuple(v.shape)).astype(np.float32))
+    server.to(dev)
+    clients = [c.to(dev) for c in clients]
+    server, clients = fed.communication(types.SimpleNamespace(mode="fedbn"), server, clients, [float(w) for w in g["weights"]])
+    fkeys = [str(k) for k in g["keys"]]
+    ssum = np.array([float(server.state_dict()[k].double().sum()) for k in fkeys])
+    sabs = np.array([float(server.state_dict()[k].double().abs().sum()) for k in fkeys])
+    assert np.allclose(sabs, g["server_abs"], rtol=1e-5) and np.allclose(ssum, g["server_sum"], rtol=1e-4, atol=1e-3)
+    for ci, c in enumerate(clients):
+        cabs = np.array([float(c.state_dict()[k].double().abs().sum()) for k in fkeys])
+        assert np.allclose(cabs, g["client_abs"][ci], rtol=1e-5)
+        for k, sh in zip(fkeys, g["shared"]):
+            assert torch.equal(c.state_dict()[k], server.state_dict()[k]) == bool(sh), k
+    assert float((clients[1].state_dict()["bn1.weight"].flatten()[:16].cpu() - torch.from_numpy(g["bn1_weight_client1"])).abs().max()) == 0.0
+    nbt = [k for k in server.state_dict().keys() if "num_batches_tracked" in k]
+    assert [int(server.state_dict()[k]) for k in nbt] == list(g["nbt_server"])
+
+
 def test_train_and_test_loops(dev):
     """train()/test() (fed_run.py:31-88,214-259) on a tiny synthetic loader vs the oracle loops."""
     from ccst_amd import fed
@@ -306,6 +341,28 @@ def test_fed_run_cli_checkpoint_resume_test(dev, tmp_path):
     assert "Resume training from epoch 2" in out2 and "Global iter is 2" in out2 and "Global iter is 1 " not in out2
     out3 = subprocess.check_output(base + ["--test"], cwd=str(tmp_path), env=env, text=True)
     assert "| Test  Acc:" in out3
+
+
+def test_fed_run_cli_fedbn(dev, tmp_path):
+    """--mode fedbn end to end: clients validated with their local model, checkpoint carries 'model_{k}' dicts whose
+    'bn' entries differ from the server's while the shared entries are identical (fed_run.py:388-399,735-759)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    cmd = [sys.executable, os.path.join(root, "federated", "fed_run.py"), "--mode", "fedbn", "--fusion_mode", "adain-overall-K3",
+           "--source", "art_painting", "cartoon", "sketch", "--target", "photo", "--n_classes", "7", "--network", "resnet18",
+           "--lr", "0.001", "--image_size", "222", "--batch", "4", "--synthetic", "8", "--save_path", str(tmp_path / "ckpt"),
+           "--iters", "2"]
+    out = subprocess.check_output(cmd, cwd=str(tmp_path), env=env, text=True)
+    assert "| Global Val Class Acc:" in out and "| Global Test Class Acc:" in out
+    d = tmp_path / "ckpt" / "pacs" / "fedbn_adain-overall-K3_no_DG_resnet18_locIter1" / "Target_photo_seed_1"
+    ck = torch.load(str(d / "fedbn_latest"), map_location="cpu")
+    assert set(ck.keys()) == {"server_model", "a_iter", "model_0", "model_1", "model_2"}
+    srv, m1 = ck["server_model"], ck["model_1"]
+    assert torch.equal(srv["conv1.weight"], m1["conv1.weight"]) and torch.equal(srv["layer2.0.downsample.1.weight"], m1["layer2.0.downsample.1.weight"])
+    assert not torch.equal(srv["bn1.running_mean"], m1["bn1.running_mean"])
 
 
 def test_train_step_bitwise_reproducible(dev):

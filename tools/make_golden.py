@@ -50,7 +50,13 @@ def extract_functions(path, names, namespace):
     return namespace
 
 
+ONLY = set(sys.argv[1:])      # e.g. `python tools/make_golden.py communication_fedbn` rewrites just that fixture
+
+
 def save(name, **arrs):
+    if ONLY and name not in ONLY:
+        print("skipped", name)
+        return
     out = {}
     for k, v in arrs.items():
         if isinstance(v, torch.Tensor):
@@ -255,4 +261,31 @@ save("communication", seed=70, weights=weights, keys=np.array(keys), key_sum=ksu
      conv1_head=server.state_dict()["conv1.weight"].flatten()[:32],
      fc_bias=server.state_dict()["class_classifier.bias"],
      nbt_server=nbt_server, nbt_clients=nbt_clients, clients_equal_server=same)
+
+# communication() --mode fedbn (fed_run.py:388-399): same 3 perturbed clients, BN keys stay local
+args = types.SimpleNamespace(mode="fedbn")
+server = ref_resnet.ResNet(R.BasicBlock, [1, 1, 1, 1], classes=3)
+server.load_state_dict(R.seeded_state_dict(R.ResNet(R.BasicBlock, [1, 1, 1, 1], classes=3), 70))
+clients = [copy.deepcopy(server) for _ in range(3)]
+for ci, c in enumerate(clients):
+    rs = np.random.RandomState(71 + ci)
+    with torch.no_grad():
+        for k, v in c.state_dict().items():
+            if "num_batches_tracked" in k:
+                v.fill_(5 + ci)
+            else:
+                v += torch.from_numpy(rs.normal(0, 0.02, tuple(v.shape)).astype(np.float32))
+server, clients = nsf["communication"](args, server, clients, weights)
+keys = list(server.state_dict().keys())
+fkeys = [k for k in keys if "num_batches_tracked" not in k]
+save("communication_fedbn", seed=70, weights=weights, keys=np.array(fkeys),
+     server_sum=np.array([float(server.state_dict()[k].double().sum()) for k in fkeys]),
+     server_abs=np.array([float(server.state_dict()[k].double().abs().sum()) for k in fkeys]),
+     client_sum=np.array([[float(c.state_dict()[k].double().sum()) for k in fkeys] for c in clients]),
+     client_abs=np.array([[float(c.state_dict()[k].double().abs().sum()) for k in fkeys] for c in clients]),
+     shared=np.array([all(torch.equal(server.state_dict()[k], c.state_dict()[k]) for c in clients) for k in fkeys]),
+     bn1_weight_client1=clients[1].state_dict()["bn1.weight"].flatten()[:16],
+     ds_bn_weight_client1=clients[1].state_dict()["layer2.0.downsample.1.weight"].flatten()[:16],
+     nbt_server=[int(server.state_dict()[k]) for k in keys if "num_batches_tracked" in k],
+     nbt_clients=[[int(c.state_dict()[k]) for k in keys if "num_batches_tracked" in k] for c in clients])
 print("done")
