@@ -80,7 +80,8 @@ def get_train_dataloader(args, txt_root='cjm_util/txt_lists'):
     if synthetic:
         out = getattr(args, 'output', 'output')
         names = [os.path.join(out, 'synthetic/kfold/%s/class0/img_%05d.jpg' % (args.target, i)) for i in range(synthetic)]
-        ds = SyntheticImages(names, [0] * synthetic, args.image_size)
+        import zlib
+        ds = SyntheticImages(names, [0] * synthetic, args.image_size, seed=1 + zlib.crc32(str(args.target).encode()) % 1000)
     else:
         names, labels = _dataset_info(lst)
         ds = ImageTestDataset(names, labels, args.image_size)

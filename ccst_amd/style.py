@@ -67,6 +67,27 @@ class StyleStatAccumulator(object):
         return finalise_style_stats(self.sum, self.sqsum, self.count)
 
 
+def domain_style_stat(vgg, loader, device, world=1, rank=0, progress=None):
+    """Stage 1 as a function (mean_std_computation_effcientMem.py:117-137): stream one domain's loader through
+    vgg[:31], accumulate the per-channel sums (this rank's share of the batches), all-reduce the additive triple,
+    finalise.  Returns ([mean, std] as stage 2 consumes them, accumulator).  Used by the stage-1 CLI and by stage
+    2's --fuse_stats, which skips the .npy round trip and keeps the file only as a cache."""
+    acc = StyleStatAccumulator()
+    with torch.no_grad():
+        for it, (batch, _) in enumerate(loader):
+            if it % world != rank:
+                continue
+            acc.update(vgg(batch.to(device)))
+            if progress is not None:
+                progress(it, len(loader))
+    if acc.images == 0:         # a rank without batches still takes part in the all-reduce
+        acc.sum = torch.zeros((1, 512, 1, 1), device=device)
+        acc.sqsum = torch.zeros((1, 512, 1, 1), device=device)
+    acc.all_reduce()
+    mean, std = acc.finalise()
+    return [mean, std], acc
+
+
 def save_style_stat(path, mean, std):
     """The stage-1 -> stage-2 hand-off: np.save of [mean, std] => float32 [2,1,C,1,1]
     (mean_std_computation_effcientMem.py:146, read at CCST_OverallStyleTransfer.py:140-144)."""

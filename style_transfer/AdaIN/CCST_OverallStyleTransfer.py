@@ -3,7 +3,13 @@
 mode): for every other domain's {style}_mean_std.npy, encoder -> AdaIN(stat) -> alpha blend -> decoder
 on every content batch, save the images under all_style_transferred_Overall (:138-175).  Same flags
 (:49-93).  Under torchrun, content batches are sharded over ranks (images are independent: no
-collective)."""
+collective).
+
+--fuse_stats (addition): stage 1 and stage 2 in one process -- a style domain whose
+{style}_mean_std.npy is absent (or every domain with --refresh_stats) has its statistics computed here by
+streaming that domain through the encoder (style.domain_style_stat, the stage-1 code), used straight from
+device memory, and written back as the [2,1,512,1,1] float32 .npy cache the other tools read."""
+import copy
 import os
 from datetime import datetime
 
@@ -16,6 +22,8 @@ from ccst_amd import data, style
 parser = base_parser(image_size_default=512)
 parser.add_argument('--output_size', type=int, default=-1, help='transform images into final size')
 parser.add_argument('--no_save', action='store_true', help='skip PIL encoding (throughput runs)')
+parser.add_argument('--fuse_stats', action='store_true', help='compute missing style statistics in-process (stage 1 + 2 fused)')
+parser.add_argument('--refresh_stats', action='store_true', help='with --fuse_stats: recompute even if the .npy cache exists')
 args = parser.parse_args()
 
 all_clients = ALL_CLIENTS[args.dataset.lower()]
@@ -25,12 +33,31 @@ os.makedirs(args.output, exist_ok=True)
 world = int(os.environ.get("WORLD_SIZE", "1"))
 rank = int(os.environ.get("RANK", "0"))
 
+if world > 1 and args.fuse_stats:
+    import torch.distributed as dist
+    dist.init_process_group(backend="nccl", device_id=device)       # only the fused statistics need a collective
+
 vgg, decoder = load_networks(args, device)
 data_loader = data.get_train_dataloader(args, args.txt_root)
 
+
+def style_stat_of(style_name):
+    path = f"style_stats/{args.dataset}/{style_name}_mean_std.npy"
+    if not args.fuse_stats or (os.path.exists(path) and not args.refresh_stats):
+        return style.load_style_stat(path, device)                    # :140-144
+    sargs = copy.copy(args)
+    sargs.target = style_name
+    stat, acc = style.domain_style_stat(vgg, data.get_train_dataloader(sargs, args.txt_root), device, world, rank)
+    print(f"    computed style statistics of {style_name} from {acc.images} images")
+    if rank == 0:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        style.save_style_stat(path, stat[0], stat[1])
+    return stat
+
+
 for style_name in style_domains:
     print(f"Content: {args.target} | Style: {style_name}")
-    style_stat = style.load_style_stat(f"style_stats/{args.dataset}/{style_name}_mean_std.npy", device)   # :140-144
+    style_stat = style_stat_of(style_name)
     start_time = datetime.now()
     img_count = 0
     for it, (batch, fpaths) in enumerate(data_loader):
@@ -52,3 +79,6 @@ for style_name in style_domains:
             f.write(f"Image resolution: {args.image_size}\n")
             f.write(f"Batch_size: {args.batch}\n")
 print(f"Target {args.target}: Finished in {(end_time - start_time).seconds} seconds")
+if world > 1 and args.fuse_stats:
+    dist.barrier()
+    dist.destroy_process_group()

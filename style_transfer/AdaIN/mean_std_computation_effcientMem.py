@@ -27,16 +27,9 @@ if world > 1:
 
 vgg, decoder = load_networks(args, device)
 data_loader = data.get_train_dataloader(args, args.txt_root)
-acc = style.StyleStatAccumulator()
 start_time = datetime.now()
-with torch.no_grad():
-    for it, (batch, _) in enumerate(data_loader):
-        if it % world != rank:
-            continue
-        acc.update(vgg(batch.to(device)))
-        print(f"{it}/{len(data_loader)}")
-acc.all_reduce()
-feat_mean, feat_std = acc.finalise()
+(feat_mean, feat_std), acc = style.domain_style_stat(vgg, data_loader, device, world, rank,
+                                                     progress=lambda it, n: print(f"{it}/{n}"))
 torch.cuda.synchronize()
 end_time = datetime.now()
 print(feat_mean.shape, feat_std.shape)

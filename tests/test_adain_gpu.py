@@ -374,6 +374,17 @@ def test_cli_scripts_run_end_to_end(dev, tmp_path):
     assert Image.open(ov).size == (48, 48)
     txt = (tmp_path / "pacs_art_painting_overall_stylize_time.txt").read_text()
     assert "Images number: 6" in txt and "Batch_size: 3" in txt
+    # stage 1 + 2 fused (--fuse_stats): same statistics without the .npy round trip, cache file rewritten identically
+    sdir = tmp_path / "style_stats" / "pacs"
+    before = {dom: np.load(str(sdir / f"{dom}_mean_std.npy")) for dom in ("cartoon", "photo", "sketch")}
+    assert np.abs(before["cartoon"] - before["photo"]).max() > 0          # synthetic domains differ
+    for dom in before:
+        os.remove(str(sdir / f"{dom}_mean_std.npy"))
+    subprocess.check_call([sys.executable, os.path.join(d, "CCST_OverallStyleTransfer.py"), "--target", "art_painting", "--image_size", "64",
+                           "--fuse_stats", "--no_save"] + common, cwd=str(tmp_path), env=env, stdout=subprocess.DEVNULL)
+    for dom, ref in before.items():
+        got = np.load(str(sdir / f"{dom}_mean_std.npy"))
+        assert got.shape == (2, 1, 512, 1, 1) and got.dtype == np.float32 and np.allclose(got, ref, rtol=1e-3, atol=1e-4)   # shuffled batches: summation order differs
 
 
 def test_style_transfer_bitwise_reproducible(dev, nets, A):
