@@ -11,13 +11,19 @@
 //   GEMM roles, MFMA operand layout, packed weights [tap][ci/4][co][4], accumulators, bias/ReLU/fused
 //   2x2 ceil max-pool epilogue: as conv_igemm.hip.  Row r of the M tile maps to the pixel
 //   (py, px) = (2*(r>>5) + ((r&3)>>1), 2*((r&31)>>2) + (r&1)) so a pooling window sits in one lane's reg&3.
-//   LDS: halo [2][(TH+2)*18][16+4] floats (80-B pixel pitch: conflict-free ds_read_b128) + W [2][16][BN].
+//   LDS: halo [2][(TH+2)*18][16+4] floats (80-B pixel pitch: conflict-free ds_read_b128) + W ring [3][16][BN].
 //   Measured: 133.9 TF (128x128 tile, 256->256 @128x128, B=6) vs 129 TF for the gather kernel; staging the
 //   weight tile by LDS-DMA instead of through registers measures the same (133.3 TF); fetching the weight
 //   fragments straight into registers (LDS = halo only, one barrier per 9 taps) measures 106 TF -- the four
 //   waves' duplicated fragment loads thrash the 32-KiB L1 (both variants kept under tools/micro/).  De-phasing the
 //   ~3 co-resident workgroups (start offsets of 0.3/0.6 step, or static s_setprio 0/1/2) changes nothing
 //   (133.4-133.8 TF): the residual MFMA idle time is not a lockstep effect.
+//   What did matter is WHERE in a k-step the staging sits (133.5 -> 143 TF, table in DESIGN.md 3.0): nothing but
+//   MFMAs right behind the barrier, loads / LDS writes in front of the last groups of the step.  A doubled main
+//   loop shows the loop itself at 150 TF; the rest is ~28 us per launch of tile prologue / epilogue / dispatch.  A
+//   persistent-workgroup version that requests the next tile's prologue ahead of the epilogue stores is slower
+//   (137 TF, tools/micro/conv3x3_halo_persistent_variant.hip.txt): 64 stores overflow the 6-bit vmcnt, so the
+//   prologue waits for the whole store drain, which the hardware dispatcher overlaps for free.
 #include "common.h"
 #include <math.h>
 
@@ -35,22 +41,19 @@ struct HaloArgs {
     int tilesX, tilesY, tilesN;
 };
 
+// Positions (in groups of 4 MFMAs, 8 groups per k-step) of the staging inside a step; measured sweep in DESIGN.md 3.0.
 #ifndef LOAD_P
-#define LOAD_P 7
+#define LOAD_P 7       // global loads of the weights of step t+3 / a halo unit of the next chunk
 #endif
 #ifndef STORE_P
-#define STORE_P 6
+#define STORE_P 6      // LDS writes of what was fetched during the previous step
 #endif
 #ifndef READ1_P
-#define READ1_P 3
-#endif
-#ifndef RING3
-#define RING3 1
+#define READ1_P 3      // second 8-channel fragment pair of this step
 #endif
 #ifndef PRE_P
-#define PRE_P 5
+#define PRE_P 5        // first fragment pair of the NEXT step (visible since the previous barrier: 3-deep weight ring)
 #endif
-constexpr bool DEEP = STORE_P <= LOAD_P;
 constexpr int CKH = 16, PITCH = CKH + 4, HW_ = 18;
 
 __device__ __forceinline__ int reflect_h(int i, int n) {
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
     static_assert(HR <= 9, "halo load rounds must fit the 9 tap steps of a chunk");
 
     __shared__ __attribute__((aligned(16))) float Hs_[2][HPIX * PITCH];
-    __shared__ __attribute__((aligned(16))) float Bs[RING3 ? 3 : 2][CKH * BN];
+    __shared__ __attribute__((aligned(16))) float Bs[3][CKH * BN];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -186,13 +189,12 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
     };
     static_assert(CKH == 16, "the step body below is written for two 8-channel halves");
 
-    // ---- prologue: halo of chunk 0 and weights of step 0 in LDS (deep pipeline: step 1's weights in flight) ----
+    // ---- prologue: halo of chunk 0, weights of steps 0 and 1 in LDS, weights of step 2 in flight -----------------
 #pragma unroll
     for (int i = 0; i < HR; ++i) {
         load_h(0, i, hoff[i]);
         store_h(0, i, hok[i]);
     }
-#if RING3
     // 3-deep weight ring: step t computes from Bs[t%3]; the registers fetched during step t-1 (weights of step
     // t+2) are stored at group STORE_P, the fetch for step t+3 is issued at LOAD_P, and the first fragment pair of
     // step t+1 -- already visible since the previous barrier -- is read before this step's barrier, so that a step
@@ -204,6 +206,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
     load_b(0, 2);
     __syncthreads();
     read_frags(0, 0, 0, 0);
+#ifdef ABLATE_LOOP_REPEAT
+    for (int rep_ = 0; rep_ < ABLATE_LOOP_REPEAT; ++rep_)
+#endif
     for (int c = 0; c < nchunks; ++c) {
         const int cn = min(c + 1, nchunks - 1);
 #pragma unroll
@@ -241,104 +246,83 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
             __syncthreads();
         }
     }
-#else
-    load_b(0, 0);
-    store_b(0);
-    if (DEEP) load_b(0, 1);
-    __syncthreads();
-
-    // ---- main loop: chunk c, taps fully unrolled so that every step's code is static (no conditional
-    // loads: hipcc hoists conservative vmcnt waits above the MFMAs otherwise).  A step is 8 groups of 4 MFMAs;
-    // the staging is slotted between groups at compile-time positions (measured):
-    //   LOAD_P  - where the global loads of the following step's weights / next chunk's halo unit are issued.
-    //             Late is better: anything issued right behind the barrier delays the first MFMAs of the step.
-    //   STORE_P - where the fetched registers go to the idle LDS buffers.  STORE_P > LOAD_P: same step (plain
-    //             double buffer, the stores sit in front of the last MFMAs so their latency is covered);
-    //             STORE_P <= LOAD_P: the NEXT step (one stage deeper, a whole step for the loads to land).
-    // The very last steps prefetch a clamped (redundant, never read) chunk / weight tile instead of branching.
-    for (int c = 0; c < nchunks; ++c) {
-        const int cn = min(c + 1, nchunks - 1);
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int t = c * 9 + tap;
-            const int tapoff = ((tap / 3) * HW_ + (tap % 3)) * PITCH;
-#pragma unroll
-            for (int pos = 0; pos <= 8; ++pos) {
-                if (pos == 0) read_frags(c & 1, t & 1, tapoff, 0);
-                if (pos == READ1_P) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    read_frags(c & 1, t & 1, tapoff, 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (pos == STORE_P) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    store_b((t + 1) & 1);
-                    if (DEEP) {
-                        if (tap >= 1 && tap <= HR) store_h((c + 1) & 1, tap - 1, hok[tap - 1]);
-                    } else {
-                        if (tap < HR) store_h((c + 1) & 1, tap, hok[tap]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (pos == LOAD_P) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    const int tn_ = tap + (DEEP ? 2 : 1);
-                    if (tn_ < 9) load_b(c, tn_);
-                    else load_b(cn, tn_ - 9);
-                    if (tap < HR) load_h(cn, tap, hoff[tap]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (pos < 8) mfma_frags(pos >> 2, pos & 3, (pos & 3) + 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-        }
-    }
-#endif
 
     // ---- epilogue ----------------------------------------------------------------------------------------
+#ifdef ABLATE_NO_STORE      // timing experiments only: keep one store so the accumulators stay live
+    if (acc[0][0][0] == 123.456f) p.y[0] = acc[1][NT - 1][15];
+    return;
+#endif
     const bool relu = p.relu != 0;
+    // Interior tiles (the common case) store through a buffer resource on the tile origin: the per-lane byte
+    // offset is ONE VGPR for the whole epilogue and the row's (dy, dx) -- which depend only on mt and the register
+    // index -- go into the scalar offset, so a store is `buffer_store v, v_off, s[rsrc], s_row offen offset:nt*128`
+    // with no vector address arithmetic and no predicate.  Edge tiles keep the predicated pointer path.
+    const int cw = wn * (32 * NT);                                            // uniform (wn is)
     if (!POOL) {
+        float* const tile = p.y + (long long)n * p.ysN + (long long)oy0 * p.ysH + (long long)ox0 * p.ysW + co0 + cw;
+        const unsigned lane_off = (unsigned)(2 * lh * p.ysW + li);
+        const bool interior = (oy0 + TH <= p.H) && (ox0 + 16 <= p.W) && (co0 + BN <= p.Cout);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int Tt = wm * MT + mt;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 // row = (r&3) + 8*(r>>2) + 4*lh within the 32-row tile -> window w = 2*(r>>2)+lh, pos = r&3
-                const int oy = oy0 + 2 * Tt + ((r & 3) >> 1);
-                const int ox = ox0 + 2 * (2 * (r >> 2) + lh) + (r & 1);
-                if (oy < p.H && ox < p.W) {
-                    float* yrow = p.y + (long long)n * p.ysN + (long long)oy * p.ysH + (long long)ox * p.ysW;
+                const int dy = 2 * Tt + ((r & 3) >> 1), dx = 4 * (r >> 2) + (r & 1);     // + 2*lh in x (lane_off)
+                float* const rowp = tile + (long long)dy * p.ysH + (long long)dx * p.ysW;
+                if (interior) {
+                    const int srow = (dy * p.ysH + dx * p.ysW) * 4;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        const int co = co0 + wn * (32 * NT) + nt * 32 + li;
                         float v = acc[mt][nt][r];
                         if (relu) v = fmaxf(v, 0.f);
-                        if (co < p.Cout) yrow[co] = v;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, lane_off * 4 + nt * 128, srow, 0);
+                    }
+                } else if (oy0 + dy < p.H && ox0 + dx + 2 * lh < p.W) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        float v = acc[mt][nt][r];
+                        if (relu) v = fmaxf(v, 0.f);
+                        if (co0 + cw + nt * 32 + li < p.Cout) rowp[lane_off + nt * 32] = v;
                     }
                 }
             }
         }
     } else {
         const int Hp = (p.H + 1) >> 1, Wp = (p.W + 1) >> 1;
+        const int py0 = oy0 >> 1, px0 = ox0 >> 1;
+        float* const tile = p.y + (long long)n * p.ysN + (long long)py0 * p.ysH + (long long)px0 * p.ysW + co0 + cw;
+        const unsigned lane_off = (unsigned)(lh * p.ysW + li);
+        const bool interior = (oy0 + TH <= p.H) && (ox0 + 16 <= p.W) && (co0 + BN <= p.Cout);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int pyp = (oy0 >> 1) + wm * MT + mt;
+            const int dyp = wm * MT + mt;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int pxp = (ox0 >> 1) + 2 * g + lh;
-                if (pyp < Hp && pxp < Wp) {
-                    const bool okx = (2 * pxp + 1 < p.W), oky = (2 * pyp + 1 < p.H);
-                    float* yrow = p.y + (long long)n * p.ysN + (long long)pyp * p.ysH + (long long)pxp * p.ysW;
+                float* const rowp = tile + (long long)dyp * p.ysH + (long long)(2 * g) * p.ysW;   // + lh in x (lane_off)
+                if (interior) {
+                    const int srow = (dyp * p.ysH + 2 * g * p.ysW) * 4;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        const int co = co0 + wn * (32 * NT) + nt * 32 + li;
-                        float v = acc[mt][nt][4 * g];
-                        if (okx) v = fmaxf(v, acc[mt][nt][4 * g + 1]);
-                        if (oky) v = fmaxf(v, acc[mt][nt][4 * g + 2]);
-                        if (okx && oky) v = fmaxf(v, acc[mt][nt][4 * g + 3]);
+                        float v = fmaxf(fmaxf(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1]), fmaxf(acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]));
                         if (relu) v = fmaxf(v, 0.f);
-                        if (co < p.Cout) yrow[co] = v;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, lane_off * 4 + nt * 128, srow, 0);
+                    }
+                } else {
+                    const int pyp = py0 + dyp, pxp = px0 + 2 * g + lh;
+                    if (pyp < Hp && pxp < Wp) {
+                        const bool okx = (2 * pxp + 1 < p.W), oky = (2 * pyp + 1 < p.H);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            float v = acc[mt][nt][4 * g];
+                            if (okx) v = fmaxf(v, acc[mt][nt][4 * g + 1]);
+                            if (oky) v = fmaxf(v, acc[mt][nt][4 * g + 2]);
+                            if (okx && oky) v = fmaxf(v, acc[mt][nt][4 * g + 3]);
+                            if (relu) v = fmaxf(v, 0.f);
+                            if (co0 + cw + nt * 32 + li < p.Cout) rowp[lane_off + nt * 32] = v;
+                        }
                     }
                 }
             }
