@@ -201,6 +201,22 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs p) 
 
     // partial slab store: ws[((split*ntap + tap)*Cin + ci)*Cout + co]
     float* wsb = p.ws + ((long long)split * (p.nky * p.nkx) + tap) * p.Cin * p.Cout;
+    if (ci0 + BI <= p.Cin && co0 + BJ <= p.Cout) {
+        // full tile: buffer stores with the row in the scalar offset (as conv_igemm.hip's dense epilogue)
+        float* const tile = wsb + (long long)(ci0 + wi * (32 * MI)) * p.Cout + co0 + wj * (32 * NJ);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile, 0, 0x7fffffff, 0x00020000);
+        const unsigned lane_off = (unsigned)(4 * lh * p.Cout + li) * 4u;
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int srow = (a * 32 + (r & 3) + 8 * (r >> 2)) * p.Cout * 4;
+#pragma unroll
+                for (int c = 0; c < NJ; ++c)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[a][c][r]), rsrc, lane_off + c * 128, srow, 0);
+            }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < MI; ++a)
 #pragma unroll

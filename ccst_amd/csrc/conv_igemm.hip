@@ -318,9 +318,28 @@ __global__ __launch_bounds__(256, ((MT == 2 && CK == 16) ? 3 : 2)) void conv_ige
             }
         }
     }
-    if (!POOL) {
+    const bool dense = (p.flags & CONV_DENSE_OUT) != 0;       // &y[m] = y + m*ysW: no (n,oy,ox) decode
+    if (!POOL && dense && p.ysC == 1 && tm * BM + BM <= p.M && co0 + BN <= p.Cout) {
+        // Full tile of a dense NHWC output (every ResNet layer, most of the time): store through a buffer resource
+        // on this wave's tile origin -- one per-lane byte offset for the whole epilogue, the row in the scalar
+        // offset, no predicates, no vector address arithmetic (as conv3x3_halo.hip).
+        float* const tile = yb + (long long)(tm * BM + wm * (32 * MT)) * p.ysW + co0 + wn * (32 * NT);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile, 0, 0x7fffffff, 0x00020000);
+        const unsigned lane_off = (unsigned)(4 * lh * p.ysW + li) * 4u;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int srow = (mt * 32 + (r & 3) + 8 * (r >> 2)) * p.ysW * 4;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    float v = acc[mt][nt][r];
+                    if (relu) v = fmaxf(v, 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, lane_off + nt * 128, srow, 0);
+                }
+            }
+    } else if (!POOL) {
         const int HW = p.Ho * p.Wo;
-        const bool dense = (p.flags & CONV_DENSE_OUT) != 0;   // &y[m] = y + m*ysW: no (n,oy,ox) decode
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
