@@ -74,7 +74,7 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 }
 
 template <int WM, int WN, int NT, bool POOL, int MT = 2, int CK = 16>
-__global__ __launch_bounds__(256, ((MT == 2 && CK == 16) ? 3 : 2)) void conv_igemm_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2)) void conv_igemm_kernel(const ConvArgs p) {
     constexpr int BM = 32 * MT * WM;
     constexpr int BN = 32 * NT * WN;
     constexpr int A_LD = CK + 4;                   // floats per LDS A row (+16 B: conflict-free ds_read_b128)
@@ -475,14 +475,19 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
 // relative tile efficiency; the cheapest candidate wins.  CCST_CONV_TILE=222|221|412|411 overrides
 // (tuning experiments only).  A 256x128 tile (MT=4, 2 waves/SIMD) and a 32-channel k-step (CK=32, 2
 // workgroups/CU) were measured slower (92-115 / 112 TF) and are not dispatched.
-static int choose_tile(int M, int cout, bool pool) {
+// Small problems (the 14x14 and 7x7 ResNet stages at B=64: M = 12544 / 3136) cannot fill 768 slots even with
+// 128x64 tiles; they run on 64x64 tiles (one MFMA tile per wave, code 1221) with a 32-channel k-step (1222) so a
+// step still carries 16 MFMAs per wave: 4x the workgroups, 4 per CU.  Measured on those layers, forward +
+// backward-data: 6.49 -> 6.09 ms per step (7x7 stages -10..14 %, 14x14 stages -1..3 %).
+static int choose_tile(int M, int cout, int cin, bool pool) {
     int tile;
+    const long long g221 = (((long long)M + 127) / 128) * ((cout + 63) / 64);
     if (cout <= 32 && !pool) tile = 411;
+    else if (!pool && g221 < 768) tile = (cin % 32 == 0) ? 1222 : 1221;   // under-filled grid: 64x64 tiles (see below)
     else if (cout <= 64) tile = 221;     // 128x64: 8-10 % faster than 256x64 on the ResNet Cout=64 layers (56x56, B=64)
     else {
         const double slots = 768.0;
         const long long g222 = (((long long)M + 127) / 128) * ((cout + 127) / 128);
-        const long long g221 = (((long long)M + 127) / 128) * ((cout + 63) / 64);
         const double c222 = ceil(g222 / slots) * (128.0 * 128.0) / 1.00;
         const double c221 = ceil(g221 / slots) * (128.0 * 64.0) / 0.88;
         tile = (c221 < c222) ? 221 : 222;
@@ -490,18 +495,19 @@ static int choose_tile(int M, int cout, bool pool) {
     if (const char* e = getenv("CCST_CONV_TILE")) {
         const int t = atoi(e);
         if (t == 222 || t == 221 || t == 412 || (t == 411 && !pool)) tile = t;
+        if ((t == 1221 || (t == 1222 && cin % 32 == 0)) && !pool) tile = t;
     }
     return tile;
 }
 
 // Tile code (WM WN NT as decimal digits) the dispatcher picks for this problem; bench.py names kernels with it.
-extern "C" int ccst_conv2d_igemm_tile(int M, int cout, int pool) { return choose_tile(M, cout, pool != 0); }
+extern "C" int ccst_conv2d_igemm_tile(int M, int cout, int cin, int pool) { return choose_tile(M, cout, cin, pool != 0); }
 
 // Row groups of 64 output rows that ccst_conv2d_igemm_stats_f32 writes for a problem of M rows and cout columns.
-extern "C" int ccst_conv2d_igemm_stats_groups(int M, int cout) {
-    const int tile = choose_tile(M, cout, false);
-    const int BM = (tile / 100 == 4) ? 256 : 128;
-    return ((M + BM - 1) / BM) * (BM / 64);
+extern "C" int ccst_conv2d_igemm_stats_groups(int M, int cout, int cin) {
+    const int tile = choose_tile(M, cout, cin, false);
+    const int WM = (tile / 100) % 10, BM = (tile >= 1000 ? 32 : 64) * WM;      // one slab per wave row
+    return ((M + BM - 1) / BM) * WM;
 }
 
 static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w_packed, const float* bias, float* y,
@@ -545,12 +551,14 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
     a.fastdiv = a.M < (1 << 22);
     a.stats = stats;
     hipStream_t s = (hipStream_t)stream;
-    const int tile = choose_tile(a.M, d->cout, pool);
+    const int tile = choose_tile(a.M, d->cout, d->cin, pool);
     if (pool) {
         if (tile == 412) return launch_conv<4, 1, 2, true>(a, s);
         if (tile == 221) return launch_conv<2, 2, 1, true>(a, s);
         return launch_conv<2, 2, 2, true>(a, s);
     }
+    if (tile == 1221) return launch_conv<2, 2, 1, false, 1, 16>(a, s);      // 64x64, experiments (CCST_CONV_TILE)
+    if (tile == 1222) return launch_conv<2, 2, 1, false, 1, 32>(a, s);      // 64x64, 32-channel k-step
     if (tile == 411) return launch_conv<4, 1, 1, false>(a, s);
     if (tile == 412) return launch_conv<4, 1, 2, false>(a, s);
     if (tile == 221) return launch_conv<2, 2, 1, false>(a, s);

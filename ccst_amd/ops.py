@@ -36,10 +36,13 @@ HALO_ZERO_PAD = os.environ.get("CCST_CONV_HALO_ZERO", "0") != "0"
 TIMING = None
 
 
-def _conv_kernel_name(cout, pool, M):
+def _conv_kernel_name(cout, pool, M, cin):
     """Name of the kernel instance the C dispatcher picks (ccst_conv2d_igemm_tile)."""
-    t = str(_lib.load().ccst_conv2d_igemm_tile(int(M), int(cout), int(bool(pool))))
-    return "conv_igemm_kernel<%s,%s,%s%s>" % (t[0], t[1], t[2], ",pool" if pool else "")
+    t = str(_lib.load().ccst_conv2d_igemm_tile(int(M), int(cout), int(cin), int(bool(pool))))
+    small = ""
+    if len(t) == 4:          # 1xyz: the 64x64 tile (one MFMA tile row per wave)
+        small, t = ",mt1" + ("" if t[3] == "1" else ",ck32"), t[1:3] + "1"
+    return "conv_igemm_kernel<%s,%s,%s%s%s>" % (t[0], t[1], t[2], small, ",pool" if pool else "")
 
 
 def _launch_conv(d, x, pc, out, flops, pool, what, stats=None):
@@ -58,7 +61,7 @@ def _launch_conv(d, x, pc, out, flops, pool, what, stats=None):
     e0.record()
     call()
     e1.record()
-    TIMING.append((_conv_kernel_name(pc.cout, pool, d.n * d.ho * d.wo), flops, e0, e1,
+    TIMING.append((_conv_kernel_name(pc.cout, pool, d.n * d.ho * d.wo, d.cin), flops, e0, e1,
                    "n%d %dx%d cin%d cout%d taps%dx%d flags%d" % (d.n, d.ho, d.wo, d.cin, d.cout, d.nky, d.nkx, d.flags)))
 
 
@@ -197,7 +200,7 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
     stats = None
     if want_stats:
         assert not (relu or pool or out_nchw), "statistics are of the raw dense NHWC conv output"
-        groups = _lib.load().ccst_conv2d_igemm_stats_groups(N * ho * wo, pc.cout)
+        groups = _lib.load().ccst_conv2d_igemm_stats_groups(N * ho * wo, pc.cout, pc.k_pad)
         stats = torch.empty((groups, pc.cout, 2), device=x.device, dtype=torch.float32)
     _launch_conv(d, x, pc, out, 2.0 * N * ho * wo * pc.cout * pc.cin * pc.kh * pc.kw, pool, "conv2d_igemm", stats)
     return (out, stats) if want_stats else out

@@ -200,7 +200,11 @@ def _model_case(dev, g, arch):
             got = named[name].grad.flatten()[:ref.numel()].cpu()
             scale = float(g["grad_abs/" + name]) / named[name].numel()
             d = float((got - ref).abs().max())
-            assert d < 1e-3 * max(scale, float(ref.abs().max())) + 8.0 * float(g["noise/" + k]) + 1e-6, (name, d)
+            # conditioning: 8x the reference's own fp32 error on these 16 elements, or 2x its worst fp32 error over the
+            # whole tensor (the 16-element sample under-estimates it up to 36x: layer2.0.downsample.0.weight of resnet18
+            # has 2.7e-5 on the head but 9.9e-4 over the tensor)
+            noise = max(8.0 * float(g["noise/" + k]), 2.0 * float(g["noise_full/grad/" + name]))
+            assert d < 1e-3 * max(scale, float(ref.abs().max())) + noise + 1e-6, (name, d)
     opt.step()
     sd = model.state_dict()
     for k in g.files:

@@ -225,6 +225,9 @@ def resnet_case(name, block, layers, classes, nb, seed, lr=0.001):
             n_ = k[10:]
             probe["noise/grad_head/" + n_] = (g[n_].flatten()[:16].double() - g64[n_].flatten()[:16]).abs().max()
             probe["noise/grad_abs/" + n_] = (g[n_].abs().sum().double() - g64[n_].abs().sum()).abs()
+            # the 16-element head is a small sample of the tensor's error distribution: also keep the reference's own
+            # worst fp32 error over the WHOLE gradient tensor (same conditioning, far steadier estimate)
+            probe["noise_full/grad/" + n_] = (g[n_].double() - g64[n_]).abs().max()
     save(name, seed=seed, classes=classes, nb=nb, lr=lr, logit_eval=logit_eval, logit_train=logit_train,
          loss=loss, logit_after=logit_after, **probe)
 
