@@ -37,7 +37,9 @@ __device__ __forceinline__ int fdiv(int m, int d, float inv) {
     return q;
 }
 
-template <int MI, int NJ, int PK>
+// PW: pointwise (1x1, stride 1, no padding, dense NHWC input) -- the input pixel of row m IS pixel m, so the
+// per-step (n, oy, ox) decode and bounds tests drop out (about half of the ResNet weight-gradient time).
+template <int MI, int NJ, int PK, bool PW>
 __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs p) {
     constexpr int BI = 64 * MI, BJ = 64 * NJ;
     constexpr int LDI = BI + 4, LDJ = BJ + 4;            // +4 floats: rows land on different banks
@@ -88,23 +90,30 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs p) 
             const int px = unit / (BI / 4), cp = unit - px * (BI / 4);
             const int m = m0 + px;
             const int mc = min(m, p.M - 1);
-            int n, oy;
-            if (p.fastdiv) {
-                n = fdiv(mc, HW, p.invHW);
-                oy = fdiv(mc - n * HW, p.Wo, p.invWo);
-            } else {
-                n = mc / HW;
-                oy = (mc - n * HW) / p.Wo;
-            }
-            const int rem = mc - n * HW;
-            const int ox = rem - oy * p.Wo;
-            int iy = oy * p.ay + ky * p.by + p.cy, ix = ox * p.ax + kx * p.bx + p.cx;
             const int ci = ci0 + cp * 4;
-            const bool ok = (m < p.M) & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi) & (ci < p.Cin);
-            iy = min(max(iy, 0), p.Hi - 1);
-            ix = min(max(ix, 0), p.Wi - 1);
             const int cic = min(ci, p.Cin - 4);
-            f32x4 v = *reinterpret_cast<const f32x4*>(p.x + (long long)n * p.xsN + (long long)iy * p.xsH + (long long)ix * p.xsW + cic);
+            bool ok;
+            f32x4 v;
+            if (PW) {
+                ok = (m < p.M) & (ci < p.Cin);
+                v = *reinterpret_cast<const f32x4*>(p.x + (long long)mc * p.xsW + cic);
+            } else {
+                int n, oy;
+                if (p.fastdiv) {
+                    n = fdiv(mc, HW, p.invHW);
+                    oy = fdiv(mc - n * HW, p.Wo, p.invWo);
+                } else {
+                    n = mc / HW;
+                    oy = (mc - n * HW) / p.Wo;
+                }
+                const int rem = mc - n * HW;
+                const int ox = rem - oy * p.Wo;
+                int iy = oy * p.ay + ky * p.by + p.cy, ix = ox * p.ax + kx * p.bx + p.cx;
+                ok = (m < p.M) & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi) & (ci < p.Cin);
+                iy = min(max(iy, 0), p.Hi - 1);
+                ix = min(max(ix, 0), p.Wi - 1);
+                v = *reinterpret_cast<const f32x4*>(p.x + (long long)n * p.xsN + (long long)iy * p.xsH + (long long)ix * p.xsW + cic);
+            }
             if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
             rx[u] = v;
         }
@@ -270,7 +279,7 @@ __global__ __launch_bounds__(256) void bwd_weight_reduce_kernel(const float* __r
     }
 }
 
-template <int MI, int NJ, int PK>
+template <int MI, int NJ, int PK, bool PW>
 int launch(BwdWArgs& a, hipStream_t s) {
     a.tilesI = (a.Cin + 64 * MI - 1) / (64 * MI);
     a.tilesJ = (a.Cout + 64 * NJ - 1) / (64 * NJ);
@@ -279,7 +288,7 @@ int launch(BwdWArgs& a, hipStream_t s) {
         ccst_set_error("bwd_weight: bad grid");
         return CCST_EINVAL;
     }
-    hipLaunchKernelGGL((conv_bwd_weight_kernel<MI, NJ, PK>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_bwd_weight_kernel<MI, NJ, PK, PW>), dim3((unsigned)grid), dim3(256), 0, s, a);
     return ccst_launch_status("conv_bwd_weight");
 }
 
@@ -323,8 +332,10 @@ extern "C" int ccst_conv2d_bwd_weight_f32(const CcstConvDesc* d, const float* x,
     a.fastdiv = a.M < (1 << 22);
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (d->cin >= 128 && d->cout >= 128) rc = launch<2, 2, 16>(a, s);
-    else rc = launch<1, 1, 32>(a, s);
+    const bool pw = ntap == 1 && d->ay == 1 && d->ax == 1 && d->cy == 0 && d->cx == 0 && d->hi == d->ho && d->wi == d->wo &&
+                    d->xsH == (long long)d->wi * d->xsW && d->xsN == (long long)d->hi * d->wi * d->xsW;
+    if (d->cin >= 128 && d->cout >= 128) rc = pw ? launch<2, 2, 16, true>(a, s) : launch<2, 2, 16, false>(a, s);
+    else rc = pw ? launch<1, 1, 32, true>(a, s) : launch<1, 1, 32, false>(a, s);
     if (rc) return rc;
     dim3 grid((d->cout + 31) / 32, (d->cin + 7) / 8, ntap);
     hipLaunchKernelGGL(bwd_weight_reduce_kernel, grid, dim3(256), 0, s, (const float*)ws, dw_oihw, ntap, d->cin, d->cout, splits,
