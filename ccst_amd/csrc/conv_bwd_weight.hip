@@ -39,8 +39,11 @@ __device__ __forceinline__ int fdiv(int m, int d, float inv) {
 
 // PW: pointwise (1x1, stride 1, no padding, dense NHWC input) -- the input pixel of row m IS pixel m, so the
 // per-step (n, oy, ox) decode and bounds tests drop out (about half of the ResNet weight-gradient time).
-template <int MI, int NJ, int PK, bool PW>
+// TP2: two taps share one 64-row ci tile (rows 0..31 = tap 2g, rows 32..63 = tap 2g+1) when Cin <= 32 -- the
+// ResNet stem's virtual-pixel form (7 taps x 32 channels), which otherwise leaves half of every MFMA tile empty.
+template <int MI, int NJ, int PK, bool PW, bool TP2 = false>
 __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs p) {
+    static_assert(!TP2 || (MI == 1 && !PW), "tap packing is for the 64x64 tile of a multi-tap problem");
     constexpr int BI = 64 * MI, BJ = 64 * NJ;
     constexpr int LDI = BI + 4, LDJ = BJ + 4;            // +4 floats: rows land on different banks
     constexpr int XU = PK * BI / 4, DU = PK * BJ / 4;    // float4 units per step
@@ -61,9 +64,11 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs p) 
     const int tj = b % p.tilesJ;
     b /= p.tilesJ;
     const int ti = b % p.tilesI;
-    const int tap = b / p.tilesI;
+    const int tapg = b / p.tilesI;
+    const int tap = TP2 ? 2 * tapg : tapg;
     const int ky = tap / p.nkx, kx = tap - ky * p.nkx;
     const int ci0 = ti * BI, co0 = tj * BJ;
+    const int ntap = p.nky * p.nkx;
 
     // pixel range of this split, in steps of PK
     const int steps_total = (p.M + PK - 1) / PK;
@@ -90,7 +95,15 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs p) 
             const int px = unit / (BI / 4), cp = unit - px * (BI / 4);
             const int m = m0 + px;
             const int mc = min(m, p.M - 1);
-            const int ci = ci0 + cp * 4;
+            int ci = ci0 + cp * 4, kyu = ky, kxu = kx;
+            bool tap_ok = true;
+            if (TP2) {          // step-invariant per thread (cp is): the compiler hoists it out of the k-loop
+                const int tapu = tap + (cp >> 3);
+                ci = (cp & 7) * 4;
+                kyu = tapu / p.nkx;
+                kxu = tapu - kyu * p.nkx;
+                tap_ok = tapu < ntap;
+            }
             const int cic = min(ci, p.Cin - 4);
             bool ok;
             f32x4 v;
@@ -108,8 +121,8 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs p) 
                 }
                 const int rem = mc - n * HW;
                 const int ox = rem - oy * p.Wo;
-                int iy = oy * p.ay + ky * p.by + p.cy, ix = ox * p.ax + kx * p.bx + p.cx;
-                ok = (m < p.M) & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi) & (ci < p.Cin);
+                int iy = oy * p.ay + kyu * p.by + p.cy, ix = ox * p.ax + kxu * p.bx + p.cx;
+                ok = (m < p.M) & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi) & (ci < p.Cin) & tap_ok;
                 iy = min(max(iy, 0), p.Hi - 1);
                 ix = min(max(ix, 0), p.Wi - 1);
                 v = *reinterpret_cast<const f32x4*>(p.x + (long long)n * p.xsN + (long long)iy * p.xsH + (long long)ix * p.xsW + cic);
@@ -209,7 +222,18 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs p) 
     }
 
     // partial slab store: ws[((split*ntap + tap)*Cin + ci)*Cout + co]
-    float* wsb = p.ws + ((long long)split * (p.nky * p.nkx) + tap) * p.Cin * p.Cout;
+    float* wsb = p.ws + ((long long)split * ntap + tap) * p.Cin * p.Cout;
+    if (TP2) {      // this wave's 32 rows are the ci of tap (2g + wi)
+        if (tap + wi >= ntap) return;
+        wsb += (long long)wi * p.Cin * p.Cout;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int co = co0 + wj * 32 + li;
+            if (ci < p.Cin && co < p.Cout) wsb[(long long)ci * p.Cout + co] = acc[0][0][r];
+        }
+        return;
+    }
     if (ci0 + BI <= p.Cin && co0 + BJ <= p.Cout) {
         // full tile: buffer stores with the row in the scalar offset (as conv_igemm.hip's dense epilogue)
         float* const tile = wsb + (long long)(ci0 + wi * (32 * MI)) * p.Cout + co0 + wj * (32 * NJ);
@@ -279,16 +303,17 @@ __global__ __launch_bounds__(256) void bwd_weight_reduce_kernel(const float* __r
     }
 }
 
-template <int MI, int NJ, int PK, bool PW>
+template <int MI, int NJ, int PK, bool PW, bool TP2 = false>
 int launch(BwdWArgs& a, hipStream_t s) {
     a.tilesI = (a.Cin + 64 * MI - 1) / (64 * MI);
     a.tilesJ = (a.Cout + 64 * NJ - 1) / (64 * NJ);
-    const long long grid = (long long)a.nky * a.nkx * a.tilesI * a.tilesJ * a.splits;
+    const int tapgroups = TP2 ? (a.nky * a.nkx + 1) / 2 : a.nky * a.nkx;
+    const long long grid = (long long)tapgroups * a.tilesI * a.tilesJ * a.splits;
     if (grid <= 0 || grid > 0x7fffffffLL) {
         ccst_set_error("bwd_weight: bad grid");
         return CCST_EINVAL;
     }
-    hipLaunchKernelGGL((conv_bwd_weight_kernel<MI, NJ, PK, PW>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_bwd_weight_kernel<MI, NJ, PK, PW, TP2>), dim3((unsigned)grid), dim3(256), 0, s, a);
     return ccst_launch_status("conv_bwd_weight");
 }
 
@@ -305,7 +330,8 @@ static void pick_tile(int cin, int cout, int* mi, int* nj) {
 extern "C" int ccst_conv2d_bwd_weight_splits(int M, int cin, int cout, int ntap) {
     int mi, nj;
     pick_tile(cin, cout, &mi, &nj);
-    const long long tiles = (long long)ntap * ((cin + 64 * mi - 1) / (64 * mi)) * ((cout + 64 * nj - 1) / (64 * nj));
+    const int tapgroups = (mi == 1 && ntap > 1 && cin <= 32) ? (ntap + 1) / 2 : ntap;      // tap packing, see the kernel
+    const long long tiles = (long long)tapgroups * ((cin + 64 * mi - 1) / (64 * mi)) * ((cout + 64 * nj - 1) / (64 * nj));
     long long s = (1024 + tiles - 1) / tiles;
     const int pk = (mi == 2 && nj == 2) ? 16 : 32;
     const long long smax = (M / pk) / 8 > 0 ? (M / pk) / 8 : 1;     // >= 8 steps per workgroup
@@ -344,6 +370,7 @@ extern "C" int ccst_conv2d_bwd_weight_f32(const CcstConvDesc* d, const float* x,
     int mi, nj;
     pick_tile(d->cin, d->cout, &mi, &nj);
     if (mi == 2 && nj == 2) rc = pw ? launch<2, 2, 16, true>(a, s) : launch<2, 2, 16, false>(a, s);
+    else if (!pw && ntap > 1 && d->cin <= 32) rc = launch<1, 1, 32, false, true>(a, s);      // two taps per ci tile
     else rc = pw ? launch<1, 1, 32, true>(a, s) : launch<1, 1, 32, false>(a, s);
     if (rc) return rc;
     dim3 grid((d->cout + 31) / 32, (d->cin + 7) / 8, ntap);
