@@ -183,8 +183,14 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
     };
     auto load_step = [&](int ky_, int kx_, int c_) {
         const float* xc = p.x + c_ * CK;                                   // uniform
+#ifndef ABLATE_NO_A_LOAD          // timing experiments only (tools/build_variant.sh): wrong results
 #pragma unroll
         for (int a = 0; a < AR; ++a) ra[a] = *reinterpret_cast<const f32x4*>(xc + aoff[a]);
+#else
+#pragma unroll
+        for (int a = 0; a < AR; ++a) ra[a] = f32x4{1.f, 2.f, 3.f, (float)c_};
+        (void)xc;
+#endif
         const int tap = p.tap_base + ky_ * p.tap_sy + kx_ * p.tap_sx;
         const float* wc = p.w + ((long long)tap * (p.Cin / 4) + c_ * (CK / 4)) * p.CoutPad * 4;   // uniform
 #pragma unroll
@@ -195,8 +201,14 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
         for (int a = 0; a < AR; ++a) {
             const int r = tid / PPR + (256 / PPR) * a;
             f32x4 v = ra[a];
+#ifndef ABLATE_NO_A_MASK
             if (!aok[a]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+#ifndef ABLATE_NO_A_STORE
             *reinterpret_cast<f32x4*>(&As[buf][r * A_LD + part * 4]) = v;
+#else
+            if (v[0] == 123.456f) As[buf][r * A_LD + part * 4] = v[1];
+#endif
         }
 #pragma unroll
         for (int b = 0; b < BR; ++b) {
