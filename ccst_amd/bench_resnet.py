@@ -45,12 +45,15 @@ def build(dev, arch="resnet50", classes=7, batch=64, size=222, lr=0.001, seed=1)
     return model, opt, loss_fun, x, y
 
 
-def make_step(model, opt, loss_fun, x, y):
+def make_step(model, opt, loss_fun, x, y, join_side=False):
     def step():
         opt.zero_grad()
         loss = loss_fun(model(x), y)
         loss.backward()
         opt.step()
+        if join_side:         # graph capture: every forked stream must re-join before the capture ends
+            from . import nn_ops
+            nn_ops.join_prepack(x.device)
         return loss
     return step
 
@@ -81,13 +84,13 @@ def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False
     (fed_run.py's round: local epoch(s) then communication()), barrier-bracketed, max over ranks."""
     import torch.distributed as dist
     from . import fed
-    if graph:       # the side stream forks work past the end of a step (weight pre-pack): not capturable as one graph
+    if graph and os.environ.get("CCST_GRAPH_SIDE", "1") == "0":       # single-stream capture
         from . import nn_ops
         nn_ops.SIDE_STREAM = False
     distributed = world > 1 and dist.is_available() and dist.is_initialized()
     rank = dist.get_rank() if distributed else 0
     model, opt, loss_fun, x, y = build(dev, arch=arch, batch=batch, seed=1 + rank)
-    step = make_step(model, opt, loss_fun, x, y)
+    step = make_step(model, opt, loss_fun, x, y, join_side=graph)
     args = types.SimpleNamespace(mode="fedavg")
     for _ in range(warmup):
         loss = step()

@@ -70,6 +70,8 @@ def parse():
     # additions
     parser.add_argument('--synthetic', type=int, default=0, help='N seeded synthetic images per client instead of the list files')
     parser.add_argument('--txt_root', type=str, default='data/txt_lists')
+    parser.add_argument('--hip_graph', action='store_true',
+                        help='capture the train iteration into a HIP graph and replay it per batch (launch-bound models: ResNet18, small batches)')
     parser.add_argument('--pretrained', action='store_true', help='load $CCST_PRETRAINED_DIR/<network>.pth (no network access here)')
     return parser.parse_args()
 

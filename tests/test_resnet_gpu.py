@@ -320,6 +320,37 @@ def test_train_and_test_loops(dev):
     assert abs(el - rel) < 2e-3 and abs(ea - rea) < 1e-6, (el, rel)
 
 
+def test_train_hip_graph_matches_eager(dev):
+    """fed.train(..., args.hip_graph=True): iterations 3.. are HIP-graph replays; same losses, accuracies and -- bit for
+    bit -- the same weights / BN statistics as the eager loop, across two calls with a FedAvg-style weight rewrite between."""
+    import types
+    from ccst_amd import fed, ops
+    from ccst_amd.nets import models
+    from oracle import resnet_ref as R
+    xs = [R.synth_batch(4, 222, 7, seed=300 + i) for i in range(5)] + [R.synth_batch(3, 222, 7, seed=400)]   # ragged last batch
+    loader = [(x, y) for x, y in xs]
+    out = {}
+    for mode in (False, True):
+        args = types.SimpleNamespace(mode="fedavg", dg_method="no_DG", hip_graph=mode)
+        model = models.get_network("resnet18")(args, pretrained=False, classes=7)
+        model.load_state_dict(R.seeded_state_dict(R.resnet18(7), 11))
+        model.to(dev)
+        ce = fed.CrossEntropyLoss()
+        r1 = fed.train(model, loader, fed.SGD(model, lr=0.01), ce, 1, dev, args, 0, None)
+        with torch.no_grad():                                  # weights rewritten outside the graph, as communication() does
+            fed.FlatParams.of(model).flat.mul_(0.999)
+            ops.bump_weights_epoch()
+        r2 = fed.train(model, loader, fed.SGD(model, lr=0.01), ce, 1, dev, args, 1, None)
+        r3 = fed.test(model, loader, ce, dev, args)
+        out[mode] = (r1, r2, r3, {k: v.detach().clone() for k, v in model.state_dict().items()})
+        if mode:
+            assert len(model.__dict__["_ccst_graph_steps"]) == 2        # full batch + the ragged last batch
+    for a, b in zip(out[False][:3], out[True][:3]):
+        assert abs(a[0] - b[0]) < 1e-6 * abs(a[0]) and a[1] == b[1], (a, b)      # the running loss is summed per graph, then added
+    for k, v in out[False][3].items():
+        assert torch.equal(v, out[True][3][k]), k
+
+
 def test_fed_run_cli_checkpoint_resume_test(dev, tmp_path):
     """federated/fed_run.py drop-in end to end on synthetic clients: console lines, checkpoint dict
     {'server_model','a_iter'} (best + _latest), --resume and --test (fed_run.py:582-640,733-766)."""
