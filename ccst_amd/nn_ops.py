@@ -22,7 +22,7 @@ BN_MASK_FROM_Y = _os.environ.get("CCST_BN_MASK_FROM_Y", "0") != "0"
 def _workspace(nbytes, device):
     """Grow-only per-device scratch buffer (split-K slabs, BN partials).  Kernels on one stream run
     in order, so a single buffer is safe; it is allocated outside any graph capture at first use."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _lib.raw_stream(device.index))
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), device=device, dtype=torch.uint8)
@@ -67,21 +67,52 @@ def _on_side_stream(device, tensors, fn):
 _PREPACK_PENDING = set()
 
 
+def _prepack_jobs(model, convs):
+    """Device table for ccst_pack_conv_weights_batch_f32 covering every packed copy the model's convs hold.  Rebuilt
+    only if a weight or a packed buffer moved (the key is the tuple of their addresses)."""
+    slots = []
+    for m in convs:
+        for name, transpose in (("_ccst_pk", 0), ("_ccst_pkt", 1)):
+            slot = m.__dict__.get(name)
+            if slot is not None and m.in_channels > 4:
+                slots.append((m, name, slot[1], transpose))
+    sig = tuple((m.weight.data_ptr(), pc.w.data_ptr()) for m, _n, pc, _t in slots)
+    cached = model.__dict__.get("_ccst_prepack_jobs")
+    if not slots:
+        return (sig, None, slots)
+    if cached is None or cached[0] != sig:
+        rows = [[m.weight.data_ptr(), pc.w.data_ptr(), m.out_channels, m.in_channels, pc.kh * pc.kw, t, pc.k_pad, pc.n_pad]
+                for m, _n, pc, t in slots]
+        dev = slots[0][0].weight.device
+        table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        cached = (sig, table, slots)
+        model.__dict__["_ccst_prepack_jobs"] = cached
+    return cached
+
+
 def prepack_on_side(model):
-    """After an optimiser step: re-pack every conv weight on the side stream (into the existing packed buffers), so
-    the ~100 small pack launches overlap the next step's stem / first BN / max-pool instead of preceding them."""
-    if not SIDE_STREAM:
-        return
-    convs = [m for m in model.modules() if hasattr(m, "prepack")]
+    """After an optimiser step: refresh every packed conv weight (into the existing buffers) with ONE batched launch on
+    the side stream, so it overlaps the next step's stem / first BN / max-pool instead of preceding them."""
+    convs = model.__dict__.get("_ccst_convs")
+    if convs is None:
+        convs = model.__dict__["_ccst_convs"] = [m for m in model.modules() if hasattr(m, "prepack")]
     if not convs:
         return
     device = convs[0].weight.device
-    main, side = torch.cuda.current_stream(device), _side_stream(device)
-    side.wait_stream(main)
-    with torch.cuda.stream(side), torch.no_grad():
-        for m in convs:
-            m.prepack()
-    _PREPACK_PENDING.add(device.index)
+    _sig, table, slots = _prepack_jobs(model, convs)
+    if table is None:
+        return
+    if SIDE_STREAM:
+        side = _side_stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            check(_lib.load().ccst_pack_conv_weights_batch_f32(ptr(table), len(slots), stream_ptr()), "pack_weights_batch")
+        _PREPACK_PENDING.add(device.index)
+    else:
+        check(_lib.load().ccst_pack_conv_weights_batch_f32(ptr(table), len(slots), stream_ptr()), "pack_weights_batch")
+    for m, name, pc, _t in slots:           # the packed copies now match the weights of this epoch
+        w = m.weight
+        m.__dict__[name] = ((w._version, w.data_ptr(), ops.WEIGHTS_EPOCH), pc)
 
 
 def join_prepack(device):

@@ -110,6 +110,11 @@ int ccst_conv3x3_smallco_f32(const float* x, const float* w_tap_ci_co, const flo
 int ccst_pack_conv_weight_f32(const float* w_oihw, float* packed, int cout, int cin, int kh, int kw,
                               int transpose, int k_pad, int n_pad, void* stream);
 
+/* ccst_pack_conv_weight_f32 for many tensors in one launch (the per-step refresh of a model's packed weights after
+ * ccst_sgd_f32, fed_run.py:80).  jobs_device: device array [njobs][8] of int64 {src OIHW pointer, dst packed pointer,
+ * cout, cin, kh*kw, transpose, k_pad, n_pad}. */
+int ccst_pack_conv_weights_batch_f32(const int64_t* jobs_device, int njobs, void* stream);
+
 /* NCHW [N,C<=4,H,W] -> zero/reflect padded NHWC4 [N, H+2*pad, Wp, 4] (Wp >= W+2*pad, extra
  * columns and channels C..3 zero).  Feeds the small-Cin stems (net.py:39-41; nets/resnet.py:136)
  * as "virtual pixel" convs. */
