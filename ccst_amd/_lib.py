@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CCST_HIP_LIB points at an alternative build of the same ABI (kernel A/B experiments, tools/build_variant.sh)
 LIB_PATH = os.environ.get("CCST_HIP_LIB") or os.path.join(_HERE, "csrc", "libccst_hip.so")
 
-CONV_RELU, CONV_POOL2, CONV_UPS2, CONV_REFLECT = 1, 2, 4, 8
+CONV_RELU, CONV_POOL2, CONV_UPS2, CONV_REFLECT, CONV_ACCUM = 1, 2, 4, 8, 16
 
 
 class CcstConvDesc(Structure):

@@ -331,6 +331,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
         }
     }
     const bool dense = (p.flags & CONV_DENSE_OUT) != 0;       // &y[m] = y + m*ysW: no (n,oy,ox) decode
+    const bool accum = (p.flags & CCST_CONV_ACCUM) != 0;      // y += conv (host guarantees: no ReLU, no pool)
     if (!POOL && dense && p.ysC == 1 && tm * BM + BM <= p.M && co0 + BN <= p.Cout) {
         // Full tile of a dense NHWC output (every ResNet layer, most of the time): store through a buffer resource
         // on this wave's tile origin -- one per-lane byte offset for the whole epilogue, the row in the scalar
@@ -338,6 +339,17 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
         float* const tile = yb + (long long)(tm * BM + wm * (32 * MT)) * p.ysW + co0 + wn * (32 * NT);
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile, 0, 0x7fffffff, 0x00020000);
         const unsigned lane_off = (unsigned)(4 * lh * p.ysW + li) * 4u;
+        if (accum) {      // y += acc: all loads of a wave tile first (64 in flight), then the adds and stores
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int srow = (mt * 32 + (r & 3) + 8 * (r >> 2)) * p.ysW * 4;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt][r] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_off + nt * 128, srow, 0));
+                }
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -374,7 +386,10 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
                         const int co = co0 + wn * (32 * NT) + nt * 32 + li;
                         float v = acc[mt][nt][r];
                         if (relu) v = fmaxf(v, 0.f);
-                        if (co < p.Cout) yrow[(long long)co * p.ysC] = v;
+                        if (co < p.Cout) {
+                            if (accum) v += yrow[(long long)co * p.ysC];
+                            yrow[(long long)co * p.ysC] = v;
+                        }
                     }
                 }
             }
@@ -573,6 +588,8 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
     CCST_REQUIRE((long long)d->n * d->ho * d->wo < 0x7fffffffLL, "conv: M too large");
     CCST_REQUIRE((long long)d->n * d->xsN < 0x7fffffffLL, "conv: input tensor must have < 2^31 elements (32-bit offsets)");
     const bool pool = (d->flags & CCST_CONV_POOL2) != 0;
+    if (d->flags & CCST_CONV_ACCUM)
+        CCST_REQUIRE(!(d->flags & (CCST_CONV_POOL2 | CCST_CONV_RELU)) && stats == nullptr, "conv: CCST_CONV_ACCUM excludes ReLU / pool / statistics");
     if (d->flags & CCST_CONV_REFLECT) CCST_REQUIRE(d->hi >= 2 && d->wi >= 2, "conv: reflection needs extent >= 2");
     ConvArgs a;
     a.x = x; a.w = w_packed; a.bias = bias; a.y = y;

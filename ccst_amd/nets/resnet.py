@@ -65,9 +65,10 @@ class Conv2d(nn.Conv2d):
             return ops.pack_conv_weight(wv), kwp
         return self._cached("pks", build)
 
-    def forward(self, x, want_stats=False):
+    def forward(self, x, want_stats=False, sink=None):
         """want_stats=True (training only): returns (y, stats) with the BatchNorm batch-statistic partials of y
-        produced in the conv epilogue; pass them to the following BatchNorm2d(..., stats=stats)."""
+        produced in the conv epilogue; pass them to the following BatchNorm2d(..., stats=stats).
+        sink: nn_ops.GradSink whose content this conv's backward-data adds to (residual blocks)."""
         self._check()
         if not x.is_cuda:
             raise RuntimeError("ccst_amd.nets: CUDA (ROCm) tensors only; no CPU fallback")
@@ -75,30 +76,45 @@ class Conv2d(nn.Conv2d):
             y = ops.to_api(nn_ops.StemConvFn.apply(x, self.weight, self))
             return (y, None) if want_stats else y
         if want_stats:
-            y, stats = nn_ops.ConvFn.apply(_to_nhwc(x), self.weight, self, True)
+            y, stats = nn_ops.ConvFn.apply(_to_nhwc(x), self.weight, self, True, sink)
             return ops.to_api(y), stats
-        return ops.to_api(nn_ops.ConvFn.apply(_to_nhwc(x), self.weight, self))
+        return ops.to_api(nn_ops.ConvFn.apply(_to_nhwc(x), self.weight, self, False, sink))
 
 
 class BatchNorm2d(nn.BatchNorm2d):
     """BatchNorm2d fused with an optional residual add and ReLU: y = relu(bn(x) + residual)."""
 
-    def forward(self, x, residual=None, relu=False, stats=None):
+    def forward(self, x, residual=None, relu=False, stats=None, sink=None):
         if not (self.affine and x.is_cuda):
             raise NotImplementedError("ccst_amd.nets: affine CUDA BatchNorm2d only")
         if not self.training and not self.track_running_stats:
             raise NotImplementedError("ccst_amd.nets: eval-mode BatchNorm2d needs running statistics")
         res = _to_nhwc(residual) if residual is not None else None
-        y = nn_ops.BNFn.apply(_to_nhwc(x), self.weight, self.bias, res, self, bool(relu), stats if self.training else None)
+        y = nn_ops.BNFn.apply(_to_nhwc(x), self.weight, self.bias, res, self, bool(relu), stats if self.training else None,
+                              sink if self.training else None)
         return ops.to_api(y)
 
 
-def conv_bn(conv, bn, x, residual=None, relu=False):
-    """bn(conv(x)) [+ residual] [ReLU]; in training the batch statistics come out of the conv epilogue."""
+def conv_bn(conv, bn, x, residual=None, relu=False, sink_in=None, sink_out=None):
+    """bn(conv(x)) [+ residual] [ReLU]; in training the batch statistics come out of the conv epilogue.
+    sink_out / sink_in: the GradSink that this BatchNorm's backward fills with the residual gradient / that this
+    conv's backward-data adds to (a residual block whose identity branch is its input, see _residual_sink)."""
     if bn.training:
-        y, stats = conv(x, want_stats=True)
-        return bn(y, residual=residual, relu=relu, stats=stats)
+        y, stats = conv(x, want_stats=True, sink=sink_in)
+        return bn(y, residual=residual, relu=relu, stats=stats, sink=sink_out)
     return bn(conv(x), residual=residual, relu=relu)
+
+
+USE_GRAD_SINK = os.environ.get("CCST_GRAD_SINK", "1") != "0"
+
+
+def _residual_sink(block, x, first_conv):
+    """A GradSink when the block's identity branch is x itself, x needs a gradient and the first conv has stride 1
+    (then d(identity) and the first conv's dX have the same shape and the conv can add to it in place)."""
+    if USE_GRAD_SINK and block.downsample is None and block.training and torch.is_grad_enabled() and x.requires_grad \
+            and first_conv.stride[0] == 1:
+        return nn_ops.GradSink()
+    return None
 
 
 class ReLU(nn.ReLU):
@@ -159,10 +175,11 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         identity = x
-        out = conv_bn(self.conv1, self.bn1, x, relu=True)
+        sink = _residual_sink(self, x, self.conv1)
+        out = conv_bn(self.conv1, self.bn1, x, relu=True, sink_in=sink)
         if self.downsample is not None:
             identity = conv_bn(self.downsample[0], self.downsample[1], x)
-        return conv_bn(self.conv2, self.bn2, out, residual=identity, relu=True)
+        return conv_bn(self.conv2, self.bn2, out, residual=identity, relu=True, sink_out=sink)
 
 
 class Bottleneck(nn.Module):
@@ -182,11 +199,12 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         identity = x
-        out = conv_bn(self.conv1, self.bn1, x, relu=True)
+        sink = _residual_sink(self, x, self.conv1)
+        out = conv_bn(self.conv1, self.bn1, x, relu=True, sink_in=sink)
         out = conv_bn(self.conv2, self.bn2, out, relu=True)
         if self.downsample is not None:
             identity = conv_bn(self.downsample[0], self.downsample[1], x)
-        return conv_bn(self.conv3, self.bn3, out, residual=identity, relu=True)
+        return conv_bn(self.conv3, self.bn3, out, residual=identity, relu=True, sink_out=sink)
 
 
 class ResNet(nn.Module):

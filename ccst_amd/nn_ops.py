@@ -145,17 +145,24 @@ def _fwd_desc(N, Hs, Ws, Cx, kh, kw, stride, pad, cin_k, cout, n_pad):
     return d, ho, wo
 
 
-def conv_bwd_data(dy, pc_t, x_shape, stride, pad):
+def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None):
     """dX of a zero-padded conv: an implicit GEMM over dY with the transposed packed weight.
-    Stride 1: one launch (iy = oy + pad - ky).  Stride s: one launch per output parity class."""
+    Stride 1: one launch (iy = oy + pad - ky).  Stride s: one launch per output parity class.
+    accumulate_into (stride 1 only): a tensor of x's shape that already holds another gradient contribution (the
+    identity branch of a residual block); the epilogue adds to it in place (CCST_CONV_ACCUM) and it is returned."""
     N, H, W, Cin = x_shape
     _, Ho, Wo, Cout = dy.shape
     kh, kw = pc_t.kh, pc_t.kw
     lib = _lib.load()
     if stride == 1:
-        dx = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
+        if accumulate_into is not None:
+            assert tuple(accumulate_into.shape) == tuple(x_shape) and accumulate_into.is_contiguous()
+            dx = accumulate_into
+        else:
+            dx = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
         classes = [(0, 0)]
     else:
+        assert accumulate_into is None
         dx = torch.zeros(x_shape, device=dy.device, dtype=torch.float32)
         classes = [(py, px) for py in range(stride) for px in range(stride)]
     for py, px in classes:
@@ -173,7 +180,7 @@ def conv_bwd_data(dy, pc_t, x_shape, stride, pad):
         d.tap_base, d.tap_sy, d.tap_sx = ky0 * kw + kx0, stride * kw, stride
         d.xsN, d.xsH, d.xsW = Ho * Wo * Cout, Wo * Cout, Cout
         d.y_off, d.ysN, d.ysH, d.ysW, d.ysC = (py * W + px) * Cin, H * W * Cin, stride * W * Cin, stride * Cin, 1
-        d.flags = 0
+        d.flags = _lib.CONV_ACCUM if (stride == 1 and accumulate_into is not None) else 0
         if ops.TIMING is None:
             check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(dy), ptr(pc_t.w), None, ptr(dx), stream_ptr()), "conv bwd-data")
         else:
@@ -204,14 +211,25 @@ def conv_bwd_weight(d, x, dy, weight_grad_oihw, accumulate=True):
                            "n%d %dx%d cin%d cout%d taps%dx%d splits%d" % (d.n, d.ho, d.wo, d.cin, d.cout, d.nky, d.nkx, splits)))
 
 
+class GradSink(object):
+    """Carries the identity-branch gradient of a residual block from the closing BatchNorm's backward to the block's
+    first convolution, whose backward-data epilogue adds to it in place -- instead of autograd materialising both
+    contributions and running an add kernel (16 per ResNet50 step, 3 passes over the block input each)."""
+    __slots__ = ("grad",)
+
+    def __init__(self):
+        self.grad = None
+
+
 class ConvFn(torch.autograd.Function):
     """Bias-free zero-padded Conv2d on NHWC (nets/resnet.py:160-161 + torchvision blocks)."""
 
     @staticmethod
-    def forward(ctx, x, weight, mod, want_stats=False):
+    def forward(ctx, x, weight, mod, want_stats=False, sink=None):
         pc = mod.packed()
         ctx.save_for_backward(x, weight)
         ctx.mod = mod
+        ctx.sink = sink
         ctx.want_stats = bool(want_stats)
         ctx.set_materialize_grads(False)       # no zero tensor for the non-differentiable stats output
         if want_stats:      # BN batch statistics from the conv epilogue (non-differentiable side output)
@@ -223,7 +241,7 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, *unused):
         if dy is None:
-            return None, None, None, None
+            return None, None, None, None, None
         x, weight = ctx.saved_tensors
         mod = ctx.mod
         dy = dy.contiguous()
@@ -238,8 +256,11 @@ class ConvFn(torch.autograd.Function):
                 conv_bwd_weight(d, x, dy, g)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = conv_bwd_data(dy, mod.packed_t(), tuple(x.shape), stride, pad)
-        return dx, None, None, None
+            into = None
+            if ctx.sink is not None and ctx.sink.grad is not None:
+                into, ctx.sink.grad = ctx.sink.grad, None
+            dx = conv_bwd_data(dy, mod.packed_t(), tuple(x.shape), stride, pad, accumulate_into=into)
+        return dx, None, None, None, None
 
 
 class StemConvFn(torch.autograd.Function):
@@ -300,8 +321,9 @@ class StemConvFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------
 class BNFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, mod, relu, stats=None):
+    def forward(ctx, x, gamma, beta, residual, mod, relu, stats=None, sink=None):
         lib = _lib.load()
+        ctx.sink = sink
         N, H, W, C = x.shape
         M = N * H * W
         y = torch.empty_like(x)
@@ -342,7 +364,9 @@ class BNFn(torch.autograd.Function):
         check(lib.ccst_bn_train_bwd_f32(ptr(dy), ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(save[0]), ptr(save[1]), int(ctx.relu), ptr(dx),
                                         ptr(dres), ptr(_grad_slot(gamma)), ptr(_grad_slot(beta)), 1, M, C, ptr(ws), ws.numel(),
                                         stream_ptr()), "bn_train_bwd")
-        return dx, None, None, dres, None, None, None
+        if ctx.sink is not None and dres is not None:
+            ctx.sink.grad, dres = dres, None        # handed to the block's first conv (GradSink), not to autograd
+        return dx, None, None, dres, None, None, None, None
 
 
 # ---------------------------------------------------------------------------

@@ -59,6 +59,8 @@ const char* ccst_last_error(void);
 #define CCST_CONV_UPS2      4u   /* input is read through a nearest x2 upsample:
                                     x is the SOURCE [N,Hi/2,Wi/2,Cin] tensor         */
 #define CCST_CONV_REFLECT   8u   /* reflection padding (else zero padding)           */
+#define CCST_CONV_ACCUM    16u   /* y += conv(x) (no ReLU/pool): the gradient of a residual
+                                    block input = identity-branch gradient already in y  */
 
 typedef struct CcstConvDesc {
     int32_t n, ho, wo;          /* output pixel grid; GEMM M = n*ho*wo                */
