@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CCST_HIP_LIB points at an alternative build of the same ABI (kernel A/B experiments, tools/build_variant.sh)
 LIB_PATH = os.environ.get("CCST_HIP_LIB") or os.path.join(_HERE, "csrc", "libccst_hip.so")
 
-CONV_RELU, CONV_POOL2, CONV_UPS2, CONV_REFLECT, CONV_ACCUM = 1, 2, 4, 8, 16
+CONV_RELU, CONV_POOL2, CONV_UPS2, CONV_REFLECT, CONV_ACCUM, CONV_FLIP = 1, 2, 4, 8, 16, 32
 
 
 class CcstConvDesc(Structure):
@@ -36,6 +36,8 @@ _SIGNATURES = {
     "ccst_conv2d_igemm_stats_groups": [c_int, c_int, c_int],
     "ccst_conv3x3_halo_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_conv3x3_halo_narrow": [c_int, c_int, c_int, c_int],
+    "ccst_conv3x3_halo_train_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
+    "ccst_conv3x3_halo_stats_groups": [c_int, c_int, c_int],
     "ccst_conv2d_igemm_tile": [c_int, c_int, c_int, c_int],
     "ccst_pack_conv_weights_batch_f32": [_P, c_int, _P],
     "ccst_conv3x3_smallco_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],

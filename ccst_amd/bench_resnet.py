@@ -70,7 +70,7 @@ def layer_table(step):
     for name, flops, e0, e1, info in timing:
         us = e0.elapsed_time(e1) * 1e3
         print("%-44s %-52s %8.1f us %6.1f TF" % (name, info, us, flops / us / 1e6), file=sys.stderr)
-        k = name.split(":")[0] if ":" in name else ("fwd" if name.startswith("conv_igemm") else name)
+        k = name.split(":")[0] if ":" in name else ("fwd" if name.startswith("conv") else name)
         t = tot.setdefault(k, [0.0, 0.0])
         t[0] += us
         t[1] += flops

@@ -39,6 +39,8 @@ struct HaloArgs {
     long long ysN;
     int ysH, ysW;                                 // output strides (of the pooled tensor when POOL)
     int tilesX, tilesY, tilesN;
+    float* stats;        // TRAIN: per-(spatial tile, wave row) (sum, sum^2) partials of the output, or nullptr
+    int flip, accum;     // TRAIN: taps read in reverse order (backward-data); y += conv
 };
 
 // Positions (in groups of 4 MFMAs, 8 groups per k-step) of the staging inside a step; measured sweep in DESIGN.md 3.0.
@@ -62,8 +64,13 @@ __device__ __forceinline__ int reflect_h(int i, int n) {
     return min(max(i, 0), n - 1);
 }
 
-template <int WM, int WN, int NT, bool POOL>
+// TRAIN = true: the ResNet-trunk form (zero padding, no bias/ReLU/pool) with what the train step needs from it --
+// BatchNorm statistics of the output from the epilogue (as ccst_conv2d_igemm_stats_f32), the taps in reverse
+// order (backward-data of a stride-1 3x3 conv = the same conv with flipped taps and the transposed weight), and
+// y += conv (CCST_CONV_ACCUM).  A separate instantiation so the AdaIN kernels carry none of it.
+template <int WM, int WN, int NT, bool POOL, bool TRAIN = false>
 __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) {
+    static_assert(!(TRAIN && POOL), "the train form has no pooled epilogue");
     constexpr int MT = 2;
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     constexpr int TH = BM / 16, HH = TH + 2;
@@ -148,7 +155,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
     f32x4 rh, rb[BR];
 
     auto load_b = [&](int c_, int tap) {
-        const float* wc = p.w + ((long long)tap * (p.Cin / 4) + c_ * (CKH / 4)) * p.CoutPad * 4;   // uniform
+        const int tw = (TRAIN && p.flip) ? 8 - tap : tap;
+        const float* wc = p.w + ((long long)tw * (p.Cin / 4) + c_ * (CKH / 4)) * p.CoutPad * 4;   // uniform
 #pragma unroll
         for (int b = 0; b < BR; ++b) rb[b] = *reinterpret_cast<const f32x4*>(wc + boff[b]);
     };
@@ -263,6 +271,43 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
         const unsigned lane_off = (unsigned)(2 * lh * p.ysW + li);
         const bool interior = (oy0 + TH <= p.H) && (ox0 + 16 <= p.W) && (co0 + BN <= p.Cout);
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile, 0, 0x7fffffff, 0x00020000);
+        if (TRAIN && p.stats != nullptr) {
+            // this wave's 64 pixels x 32*NT channels -> per-channel (sum, sum^2); pixels outside the image excluded
+            const int slab = ((n * p.tilesY + ty) * p.tilesX + tx) * WM + wm;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dy = 2 * (wm * MT + mt) + ((r & 3) >> 1), dx = 4 * (r >> 2) + (r & 1) + 2 * lh;
+                        const float v = (interior || (oy0 + dy < p.H && ox0 + dx < p.W)) ? acc[mt][nt][r] : 0.f;
+                        s1 += v;
+                        s2 += v * v;
+                    }
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                const int co = co0 + cw + nt * 32 + li;
+                if (lh == 0 && co < p.Cout) {
+                    float* o = p.stats + ((long long)slab * p.Cout + co) * 2;
+                    o[0] = s1;
+                    o[1] = s2;
+                }
+            }
+        }
+        if (TRAIN && p.accum && interior) {          // y += acc: the loads of the wave tile first, then adds + stores
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dy = 2 * (wm * MT + mt) + ((r & 3) >> 1), dx = 4 * (r >> 2) + (r & 1);
+                    const int srow = (dy * p.ysH + dx * p.ysW) * 4;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt][r] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_off * 4 + nt * 128, srow, 0));
+                }
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int Tt = wm * MT + mt;
@@ -284,7 +329,10 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
                     for (int nt = 0; nt < NT; ++nt) {
                         float v = acc[mt][nt][r];
                         if (relu) v = fmaxf(v, 0.f);
-                        if (co0 + cw + nt * 32 + li < p.Cout) rowp[lane_off + nt * 32] = v;
+                        if (co0 + cw + nt * 32 + li < p.Cout) {
+                            if (TRAIN && p.accum) v += rowp[lane_off + nt * 32];
+                            rowp[lane_off + nt * 32] = v;
+                        }
                     }
                 }
             }
@@ -330,7 +378,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
     }
 }
 
-template <int WM, int WN, int NT, bool POOL>
+template <int WM, int WN, int NT, bool POOL, bool TRAIN = false>
 int launch_halo(HaloArgs& a, hipStream_t s) {
     constexpr int BM = 64 * WM, BN = 32 * NT * WN, TH = BM / 16;
     a.tilesN = (a.Cout + BN - 1) / BN;
@@ -341,11 +389,13 @@ int launch_halo(HaloArgs& a, hipStream_t s) {
         ccst_set_error("conv3x3_halo: bad grid %lld", grid);
         return CCST_EINVAL;
     }
-    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, WN, NT, POOL>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, WN, NT, POOL, TRAIN>), dim3((unsigned)grid), dim3(256), 0, s, a);
     return ccst_launch_status("conv3x3_halo");
 }
 
 }  // namespace
+
+extern "C" int ccst_conv3x3_halo_narrow(int N, int H, int W, int Cout);
 
 // x: NHWC source [N,Hs,Ws,Cin] (Hs = H/2 if CCST_CONV_UPS2), w: packed [9][Cin/4][cout_pad][4], y: NHWC
 // [N,H,W,Cout] or its 2x2 ceil-pooled form.  flags: CCST_CONV_RELU | POOL2 | UPS2 | REFLECT.
@@ -361,6 +411,7 @@ extern "C" int ccst_conv3x3_halo_f32(const float* x, const float* w_packed, cons
     a.x = x; a.w = w_packed; a.bias = bias; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Hs = ups ? H / 2 : H; a.Ws = ups ? W / 2 : W; a.Cin = Cin; a.Cout = Cout; a.CoutPad = cout_pad;
     a.reflect = (flags & CCST_CONV_REFLECT) ? 1 : 0; a.ups = ups ? 1 : 0; a.relu = (flags & CCST_CONV_RELU) ? 1 : 0;
+    a.stats = nullptr; a.flip = 0; a.accum = 0;
     CCST_REQUIRE((long long)N * a.Hs * a.Ws * Cin < 0x7fffffffLL, "conv3x3_halo: input must have < 2^31 elements");
     const int oh = pool ? (H + 1) / 2 : H, ow = pool ? (W + 1) / 2 : W;
     a.ysW = Cout; a.ysH = ow * Cout; a.ysN = (long long)oh * ow * Cout;
@@ -377,6 +428,31 @@ extern "C" int ccst_conv3x3_halo_f32(const float* x, const float* w_packed, cons
     if (narrow) return pool ? launch_halo<2, 2, 1, true>(a, s) : launch_halo<2, 2, 1, false>(a, s);
     return pool ? launch_halo<2, 2, 2, true>(a, s) : launch_halo<2, 2, 2, false>(a, s);
 }
+
+// The ResNet-trunk form: zero padding, no bias / ReLU / pool; flags: CCST_CONV_FLIP (taps reversed: with the
+// transposed packed weight this is the backward-data of the stride-1 conv) | CCST_CONV_ACCUM (y += conv); stats
+// (may be NULL): [ccst_conv3x3_halo_stats_groups(N,H,W)][Cout][2] (sum, sum^2) partials of y for the next BatchNorm.
+extern "C" int ccst_conv3x3_halo_train_f32(const float* x, const float* w_packed, float* y, float* stats, int N, int H, int W,
+                                           int Cin, int Cout, int cout_pad, uint32_t flags, void* stream) {
+    CCST_REQUIRE(x && w_packed && y, "conv3x3_halo_train: null pointer");
+    CCST_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0, "conv3x3_halo_train: bad shape");
+    CCST_REQUIRE(cout_pad >= Cout && cout_pad % 128 == 0, "conv3x3_halo_train: cout_pad must be a multiple of 128 >= cout");
+    CCST_REQUIRE(!(flags & ~(CCST_CONV_FLIP | CCST_CONV_ACCUM)), "conv3x3_halo_train: only CCST_CONV_FLIP | CCST_CONV_ACCUM");
+    CCST_REQUIRE(!(stats && (flags & CCST_CONV_ACCUM)), "conv3x3_halo_train: statistics are of the conv output, not of y += conv");
+    CCST_REQUIRE((long long)N * H * W * Cin < 0x7fffffffLL, "conv3x3_halo_train: input must have < 2^31 elements");
+    HaloArgs a;
+    a.x = x; a.w = w_packed; a.bias = nullptr; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.Hs = H; a.Ws = W; a.Cin = Cin; a.Cout = Cout; a.CoutPad = cout_pad;
+    a.reflect = 0; a.ups = 0; a.relu = 0;
+    a.stats = stats; a.flip = (flags & CCST_CONV_FLIP) ? 1 : 0; a.accum = (flags & CCST_CONV_ACCUM) ? 1 : 0;
+    a.ysW = Cout; a.ysH = W * Cout; a.ysN = (long long)H * W * Cout;
+    hipStream_t s = (hipStream_t)stream;
+    if (ccst_conv3x3_halo_narrow(N, H, W, Cout)) return launch_halo<2, 2, 1, false, true>(a, s);
+    return launch_halo<2, 2, 2, false, true>(a, s);
+}
+
+// Row groups ccst_conv3x3_halo_train_f32 writes statistics for: two wave rows per 8x16-pixel tile.
+extern "C" int ccst_conv3x3_halo_stats_groups(int N, int H, int W) { return N * ((H + 7) / 8) * ((W + 15) / 16) * 2; }
 
 // 1 if the dispatcher above picks the 128x64 tile (bench.py names kernels with it).
 extern "C" int ccst_conv3x3_halo_narrow(int N, int H, int W, int Cout) {

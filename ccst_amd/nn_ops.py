@@ -154,6 +154,8 @@ def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None):
     _, Ho, Wo, Cout = dy.shape
     kh, kw = pc_t.kh, pc_t.kw
     lib = _lib.load()
+    if stride == 1 and kh == 3 and kw == 3 and pad == 1 and Cout == pc_t.k_pad and ops.halo_train_ok(H, W, Cout, Cin):
+        return ops.conv3x3_halo_train(dy, pc_t, flip=True, accumulate_into=accumulate_into)      # dX = conv(dY, flipped W^T)
     if stride == 1:
         if accumulate_into is not None:
             assert tuple(accumulate_into.shape) == tuple(x_shape) and accumulate_into.is_contiguous()

@@ -28,9 +28,48 @@ def bump_weights_epoch():
 
 # 3x3 reflect-pad convs go through the halo-in-LDS kernel (conv3x3_halo.hip); CCST_CONV_HALO=0 keeps the gather kernel.
 USE_HALO = os.environ.get("CCST_CONV_HALO", "1") != "0"
-# zero-padded 3x3 stride-1 convs (the ResNet trunk: 7x7..56x56 maps) measure the same on either kernel (2279 vs 2276 img/s);
-# they stay on the gather kernel unless CCST_CONV_HALO_ZERO=1
+# The zero-padded 3x3 stride-1 convs of the ResNet trunk (forward with BN statistics, backward-data with flipped taps, y +=)
+# CAN run on the halo kernel too (ccst_conv3x3_halo_train_f32) when its 8x16-pixel tiles cover the map well enough (56x56:
+# 88 %, 28x28 / 14x14: 77 %; 7x7 would be 38 %).  Measured: per layer 97-105 TF vs 90-100 TF on the gather kernel, but
+# the same step time (ResNet50 2837 vs 2839 img/s, ResNet18 within noise) -- short K loops and tile waste eat the
+# advantage -- so the gather kernel stays the default; CCST_CONV_HALO_ZERO=1 switches.
 HALO_ZERO_PAD = os.environ.get("CCST_CONV_HALO_ZERO", "0") != "0"
+HALO_MIN_COVER = float(os.environ.get("CCST_CONV_HALO_COVER", "0.7"))
+
+
+def halo_train_ok(H, W, cin, cout):
+    if not (USE_HALO and HALO_ZERO_PAD) or cin % 16 != 0:
+        return False
+    return H * W >= HALO_MIN_COVER * (round_up(H, 8) * round_up(W, 16))
+
+
+def conv3x3_halo_train(x, pc, want_stats=False, flip=False, accumulate_into=None):
+    """3x3 stride-1 zero-padded bias-free conv on the halo kernel (ResNet trunk).  pc: PackedConv whose K side matches
+    x's channels (the transposed pack + flip=True gives the backward-data).  Returns y or (y, stats)."""
+    N, H, W, Cx = x.shape
+    assert Cx == pc.k_pad and pc.kh == 3 and pc.kw == 3
+    cout = pc.cin if pc.transpose else pc.cout
+    lib = _lib.load()
+    if accumulate_into is not None:
+        assert tuple(accumulate_into.shape) == (N, H, W, cout) and accumulate_into.is_contiguous() and not want_stats
+        y = accumulate_into
+    else:
+        y = torch.empty((N, H, W, cout), device=x.device, dtype=torch.float32)
+    stats = None
+    if want_stats:
+        stats = torch.empty((lib.ccst_conv3x3_halo_stats_groups(N, H, W), cout, 2), device=x.device, dtype=torch.float32)
+    flags = (_lib.CONV_FLIP if flip else 0) | (_lib.CONV_ACCUM if accumulate_into is not None else 0)
+    args = (ptr(x), ptr(pc.w), ptr(y), ptr(stats), N, H, W, Cx, cout, pc.n_pad, flags, stream_ptr())
+    if TIMING is None:
+        check(lib.ccst_conv3x3_halo_train_f32(*args), "conv3x3_halo_train")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.ccst_conv3x3_halo_train_f32(*args), "conv3x3_halo_train")
+        e1.record()
+        TIMING.append((("bwd_data:" if flip else "") + "conv3x3_halo_kernel<%s,train>" % ("2,2,1" if lib.ccst_conv3x3_halo_narrow(N, H, W, cout) else "2,2,2"),
+                       2.0 * N * H * W * cout * Cx * 9, e0, e1, "n%d %dx%d cin%d cout%d taps3x3 s1" % (N, H, W, Cx, cout)))
+    return (y, stats) if want_stats else y
 
 # bench.py sets TIMING = [] to collect (kernel name, algorithmic flops, start event, end event) per conv launch.
 TIMING = None
@@ -171,7 +210,10 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
         (CONV_REFLECT if reflect else 0)
     d.flags = flags
     oh, ow = ((ho + 1) // 2, (wo + 1) // 2) if pool else (ho, wo)
-    if USE_HALO and (reflect or HALO_ZERO_PAD) and pc.kh == 3 and pc.kw == 3 and stride == 1 and pad == 1 and not out_nchw \
+    if not reflect and pc.kh == 3 and pc.kw == 3 and stride == 1 and pad == 1 and not (relu or pool or ups or out_nchw) \
+            and out is None and pc.bias is None and halo_train_ok(Hi, Wi, Cx, pc.cout):
+        return conv3x3_halo_train(x, pc, want_stats=want_stats)
+    if USE_HALO and reflect and pc.kh == 3 and pc.kw == 3 and stride == 1 and pad == 1 and not out_nchw \
             and out is None and not want_stats:
         out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
         lib = _lib.load()

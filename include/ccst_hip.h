@@ -59,6 +59,7 @@ const char* ccst_last_error(void);
 #define CCST_CONV_UPS2      4u   /* input is read through a nearest x2 upsample:
                                     x is the SOURCE [N,Hi/2,Wi/2,Cin] tensor         */
 #define CCST_CONV_REFLECT   8u   /* reflection padding (else zero padding)           */
+#define CCST_CONV_FLIP     32u   /* ccst_conv3x3_halo_train_f32: taps in reverse order */
 #define CCST_CONV_ACCUM    16u   /* y += conv(x) (no ReLU/pool): the gradient of a residual
                                     block input = identity-branch gradient already in y  */
 
@@ -93,6 +94,14 @@ int ccst_conv3x3_halo_f32(const float* x, const float* w_packed, const float* bi
                           int Cin, int Cout, int cout_pad, uint32_t flags, void* stream);
 
 int ccst_conv3x3_halo_narrow(int N, int H, int W, int Cout);   /* 1: the 128x64 tile is dispatched, 0: 128x128 */
+
+/* The same kernel for the ResNet trunk's 3x3 stride-1 zero-padded, bias-free convs (nets/resnet.py:160-161 via the
+ * torchvision blocks), forward AND backward-data: flags = CCST_CONV_FLIP (reverse the taps; with the transposed packed
+ * weight that is dX of the conv) | CCST_CONV_ACCUM (y += conv).  stats (NULL or [groups][Cout][2], groups =
+ * ccst_conv3x3_halo_stats_groups(N,H,W)): (sum, sum of squares) partials of y for the following BatchNorm2d. */
+int ccst_conv3x3_halo_train_f32(const float* x, const float* w_packed, float* y, float* stats, int N, int H, int W,
+                                int Cin, int Cout, int cout_pad, uint32_t flags, void* stream);
+int ccst_conv3x3_halo_stats_groups(int N, int H, int W);
 
 /* The tile code (WM WN NT as decimal digits: 222 = 128x128, 221 = 128x64, 412 = 256x64, 411 = 256x32; 1221 / 1222 =
  * 64x64 with a 16- / 32-channel k-step for grids that cannot fill the chip) ccst_conv2d_igemm_f32 dispatches for

@@ -67,6 +67,35 @@ def test_conv_fwd_bwd(dev, cfg):
     assert relerr(conv.weight.grad, 2 * wr.grad) < 1e-4
 
 
+@pytest.mark.parametrize("shape", [(3, 28, 28, 128, 128), (2, 56, 56, 64, 64), (2, 14, 14, 256, 192), (1, 13, 19, 32, 48)])
+def test_halo_train_form_vs_gather(dev, shape):
+    """ccst_conv3x3_halo_train_f32 (ResNet-trunk form of the halo kernel): forward + BN statistics, backward-data by
+    flipped taps, and y += conv, against the gather kernel's results for the same packed weights."""
+    from ccst_amd import nn_ops, ops
+    N, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, H, W, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(dev)
+    dy = torch.randn(N, H, W, Cout, generator=g).to(dev)
+    base = torch.randn(N, H, W, Cin, generator=g).to(dev)
+    pc, pct = ops.pack_conv_weight(w), ops.pack_conv_weight(w, transpose=True)
+    assert not ops.HALO_ZERO_PAD
+    y_ref, st_ref = ops.conv2d_nhwc(x, pc, stride=1, pad=1, want_stats=True)
+    dx_ref = nn_ops.conv_bwd_data(dy, pct, (N, H, W, Cin), 1, 1)
+    y, st = ops.conv3x3_halo_train(x, pc, want_stats=True)
+    assert float((y - y_ref).abs().max()) < 1e-4 * max(1.0, float(y_ref.abs().max()))
+    tot, tot_ref = st.double().sum(0), st_ref.double().sum(0)          # the partials are grouped differently; totals agree
+    assert float((tot - tot_ref).abs().max()) < 1e-4 * float(tot_ref.abs().max())
+    dx = ops.conv3x3_halo_train(dy, pct, flip=True)
+    assert float((dx - dx_ref).abs().max()) < 1e-4 * max(1.0, float(dx_ref.abs().max()))
+    acc = base.clone()
+    out = ops.conv3x3_halo_train(dy, pct, flip=True, accumulate_into=acc)
+    assert out.data_ptr() == acc.data_ptr() and float((acc - (base + dx_ref)).abs().max()) < 1e-4 * max(1.0, float(dx_ref.abs().max()))
+    acc2 = base.clone()
+    nn_ops.conv_bwd_data(dy, pct, (N, H, W, Cin), 1, 1, accumulate_into=acc2)          # the gather kernel's CCST_CONV_ACCUM
+    assert float((acc2 - (base + dx_ref)).abs().max()) < 1e-5 * max(1.0, float(dx_ref.abs().max()))
+
+
 def test_stem_conv_fwd_bwd(dev):
     from ccst_amd.nets import resnet
     x = rnd((2, 3, 38, 38), 4)
