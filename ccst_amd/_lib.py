@@ -33,12 +33,12 @@ _SIGNATURES = {
     "ccst_last_error": [],
     "ccst_conv2d_igemm_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P],
     "ccst_conv2d_igemm_stats_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P, _P],
-    "ccst_conv2d_igemm_stats_groups": [c_int, c_int, c_int],
+    "ccst_conv2d_igemm_stats_groups": [c_int, c_int, c_int, c_int],
     "ccst_conv3x3_halo_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_conv3x3_halo_narrow": [c_int, c_int, c_int, c_int],
     "ccst_conv3x3_halo_train_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_conv3x3_halo_stats_groups": [c_int, c_int, c_int],
-    "ccst_conv2d_igemm_tile": [c_int, c_int, c_int, c_int],
+    "ccst_conv2d_igemm_tile": [c_int, c_int, c_int, c_int, c_int],
     "ccst_pack_conv_weights_batch_f32": [_P, c_int, _P],
     "ccst_conv3x3_smallco_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "ccst_pack_conv_weight_f32": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],

@@ -532,12 +532,17 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
 // 128x64 tiles; they run on 64x64 tiles (one MFMA tile per wave, code 1221) with a 32-channel k-step (1222) so a
 // step still carries 16 MFMAs per wave: 4x the workgroups, 4 per CU.  Measured on those layers, forward +
 // backward-data: 6.49 -> 6.09 ms per step (7x7 stages -10..14 %, 14x14 stages -1..3 %).
-static int choose_tile(int M, int cout, int cin, bool pool) {
+static int choose_tile(int M, int cout, int cin, int taps, bool pool) {
     int tile;
     const long long g221 = (((long long)M + 127) / 128) * ((cout + 63) / 64);
     if (cout <= 32 && !pool) tile = 411;
-    else if (!pool && g221 < 768) tile = (cin % 32 == 0) ? 1222 : 1221;   // under-filled grid: 64x64 tiles (see below)
-    else if (cout <= 64) tile = 221;     // 128x64: 8-10 % faster than 256x64 on the ResNet Cout=64 layers (56x56, B=64)
+    else if (!pool && (g221 < 768 || M <= 65536 || cout <= 64)) {
+        // 64x64 tiles (see below): under-filled grids, and -- measured per layer on the ResNet50 B=64 shapes, forward
+        // and backward-data -- equal or faster than 128x64 / 128x128 everywhere up to 28x28 maps and on the Cout = 64
+        // layers at 56x56 (-5 %); without a 32-channel k-step (Cin % 32 != 0, the stems) the larger tiles stay.
+        tile = (cin % 32 == 0) ? 1222 : (g221 < 768 ? 1221 : 221);
+    } else if (cout <= 64) tile = 221;     // 128x64: 8-10 % faster than 256x64 on the Cout=64 layers (pooled AdaIN form)
+    else if (!pool && (long long)cin * taps < 1024) tile = 221;   // large maps, short K (ResNet 1x1 at 56x56): 128x64 beats 128x128 (-3..7 %)
     else {
         const double slots = 768.0;
         const long long g222 = (((long long)M + 127) / 128) * ((cout + 127) / 128);
@@ -554,11 +559,11 @@ static int choose_tile(int M, int cout, int cin, bool pool) {
 }
 
 // Tile code (WM WN NT as decimal digits) the dispatcher picks for this problem; bench.py names kernels with it.
-extern "C" int ccst_conv2d_igemm_tile(int M, int cout, int cin, int pool) { return choose_tile(M, cout, cin, pool != 0); }
+extern "C" int ccst_conv2d_igemm_tile(int M, int cout, int cin, int taps, int pool) { return choose_tile(M, cout, cin, taps, pool != 0); }
 
 // Row groups of 64 output rows that ccst_conv2d_igemm_stats_f32 writes for a problem of M rows and cout columns.
-extern "C" int ccst_conv2d_igemm_stats_groups(int M, int cout, int cin) {
-    const int tile = choose_tile(M, cout, cin, false);
+extern "C" int ccst_conv2d_igemm_stats_groups(int M, int cout, int cin, int taps) {
+    const int tile = choose_tile(M, cout, cin, taps, false);
     const int WM = (tile / 100) % 10, BM = (tile >= 1000 ? 32 : 64) * WM;      // one slab per wave row
     return ((M + BM - 1) / BM) * WM;
 }
@@ -606,7 +611,7 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
     a.fastdiv = a.M < (1 << 22);
     a.stats = stats;
     hipStream_t s = (hipStream_t)stream;
-    const int tile = choose_tile(a.M, d->cout, d->cin, pool);
+    const int tile = choose_tile(a.M, d->cout, d->cin, d->nky * d->nkx, pool);
     if (pool) {
         if (tile == 412) return launch_conv<4, 1, 2, true>(a, s);
         if (tile == 221) return launch_conv<2, 2, 1, true>(a, s);

@@ -190,7 +190,7 @@ def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None):
             e0.record()
             check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(dy), ptr(pc_t.w), None, ptr(dx), stream_ptr()), "conv bwd-data")
             e1.record()
-            ops.TIMING.append(("bwd_data:" + ops._conv_kernel_name(Cin, False, N * Hc * Wc, pc_t.k_pad), 2.0 * N * Hc * Wc * Cin * Cout * nky * nkx,
+            ops.TIMING.append(("bwd_data:" + ops._conv_kernel_name(Cin, False, N * Hc * Wc, pc_t.k_pad, nky * nkx), 2.0 * N * Hc * Wc * Cin * Cout * nky * nkx,
                                e0, e1, "n%d %dx%d cin%d cout%d taps%dx%d s%d" % (N, Hc, Wc, Cout, Cin, nky, nkx, stride)))
     return dx
 

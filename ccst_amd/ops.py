@@ -75,9 +75,9 @@ def conv3x3_halo_train(x, pc, want_stats=False, flip=False, accumulate_into=None
 TIMING = None
 
 
-def _conv_kernel_name(cout, pool, M, cin):
+def _conv_kernel_name(cout, pool, M, cin, taps=1):
     """Name of the kernel instance the C dispatcher picks (ccst_conv2d_igemm_tile)."""
-    t = str(_lib.load().ccst_conv2d_igemm_tile(int(M), int(cout), int(cin), int(bool(pool))))
+    t = str(_lib.load().ccst_conv2d_igemm_tile(int(M), int(cout), int(cin), int(taps), int(bool(pool))))
     small = ""
     if len(t) == 4:          # 1xyz: the 64x64 tile (one MFMA tile row per wave)
         small, t = ",mt1" + ("" if t[3] == "1" else ",ck32"), t[1:3] + "1"
@@ -100,7 +100,7 @@ def _launch_conv(d, x, pc, out, flops, pool, what, stats=None):
     e0.record()
     call()
     e1.record()
-    TIMING.append((_conv_kernel_name(pc.cout, pool, d.n * d.ho * d.wo, d.cin), flops, e0, e1,
+    TIMING.append((_conv_kernel_name(pc.cout, pool, d.n * d.ho * d.wo, d.cin, d.nky * d.nkx), flops, e0, e1,
                    "n%d %dx%d cin%d cout%d taps%dx%d flags%d" % (d.n, d.ho, d.wo, d.cin, d.cout, d.nky, d.nkx, d.flags)))
 
 
@@ -242,7 +242,7 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
     stats = None
     if want_stats:
         assert not (relu or pool or out_nchw), "statistics are of the raw dense NHWC conv output"
-        groups = _lib.load().ccst_conv2d_igemm_stats_groups(N * ho * wo, pc.cout, pc.k_pad)
+        groups = _lib.load().ccst_conv2d_igemm_stats_groups(N * ho * wo, pc.cout, pc.k_pad, pc.kh * pc.kw)
         stats = torch.empty((groups, pc.cout, 2), device=x.device, dtype=torch.float32)
     _launch_conv(d, x, pc, out, 2.0 * N * ho * wo * pc.cout * pc.cin * pc.kh * pc.kw, pool, "conv2d_igemm", stats)
     return (out, stats) if want_stats else out

@@ -80,11 +80,11 @@ int ccst_conv2d_igemm_f32(const CcstConvDesc* d, const float* x, const float* w_
                           const float* bias /* may be NULL */, float* y, void* stream);
 /* Same convolution (dense NHWC output, no ReLU / pool), additionally writing per-row-group (64 or 32 rows, one per
  * wave row of the dispatched tile) (sum, sum of squares) partials of the output, stats[groups][cout][2] with
- * groups = ccst_conv2d_igemm_stats_groups(M, cout, cin): the
+ * groups = ccst_conv2d_igemm_stats_groups(M, cout, cin, taps): the
  * batch statistics the following BatchNorm2d needs (nets/resnet.py:138,162), so BN skips its own read pass. */
 int ccst_conv2d_igemm_stats_f32(const CcstConvDesc* d, const float* x, const float* w_packed,
                                 const float* bias, float* y, float* stats, void* stream);
-int ccst_conv2d_igemm_stats_groups(int M, int cout, int cin /* padded, d->cin */);
+int ccst_conv2d_igemm_stats_groups(int M, int cout, int cin /* padded, d->cin */, int taps /* nky*nkx */);
 
 /* 3x3 stride-1 "same" conv (reflection or zero padding) with the input halo staged once per 16-channel
  * chunk in LDS (A-side loads / LDS writes 9x fewer than the gather form): the AdaIN encoder/decoder
@@ -105,8 +105,8 @@ int ccst_conv3x3_halo_stats_groups(int N, int H, int W);
 
 /* The tile code (WM WN NT as decimal digits: 222 = 128x128, 221 = 128x64, 412 = 256x64, 411 = 256x32; 1221 / 1222 =
  * 64x64 with a 16- / 32-channel k-step for grids that cannot fill the chip) ccst_conv2d_igemm_f32 dispatches for
- * M = n*ho*wo output pixels, cout channels and cin (padded) input channels. */
-int ccst_conv2d_igemm_tile(int M, int cout, int cin, int pool);
+ * M = n*ho*wo output pixels, cout channels, cin (padded) input channels and taps = nky*nkx. */
+int ccst_conv2d_igemm_tile(int M, int cout, int cin, int taps, int pool);
 
 /* Direct 3x3 stride-1 conv with 1..4 output channels writing NCHW (the decoder's last layer,
  * net.py:35): x NHWC [N,H,W,Cin] (Cin % 16 == 0), w [3][3][Cin][Cout], y NCHW [N,Cout,H,W].

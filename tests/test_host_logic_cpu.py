@@ -97,9 +97,10 @@ def test_flat_params_arena_views():
 
 def test_bench_conv_kernel_name_mirror():
     from ccst_amd import ops
-    assert ops._conv_kernel_name(256, False, 98304, 256) == "conv_igemm_kernel<2,2,2>"
-    assert ops._conv_kernel_name(64, True, 1572864, 64) == "conv_igemm_kernel<2,2,1,pool>"
-    assert ops._conv_kernel_name(256, False, 24576, 256) == "conv_igemm_kernel<2,2,1>"
-    assert ops._conv_kernel_name(1024, False, 12544, 256) == "conv_igemm_kernel<2,2,1>"      # 784 tiles of 128x128 = 2 rounds
-    assert ops._conv_kernel_name(256, False, 12544, 256) == "conv_igemm_kernel<2,2,1,mt1,ck32>"   # 392 tiles of 128x64: 64x64 tiles
-    assert ops._conv_kernel_name(256, False, 12544, 48) == "conv_igemm_kernel<2,2,1,mt1>"
+    assert ops._conv_kernel_name(256, False, 98304, 256, 9) == "conv_igemm_kernel<2,2,2>"            # large map, long K
+    assert ops._conv_kernel_name(256, False, 200704, 64, 1) == "conv_igemm_kernel<2,2,1>"            # large map, short K
+    assert ops._conv_kernel_name(64, True, 1572864, 64, 9) == "conv_igemm_kernel<2,2,1,pool>"
+    assert ops._conv_kernel_name(64, False, 200704, 256, 1) == "conv_igemm_kernel<2,2,1,mt1,ck32>"   # Cout = 64
+    assert ops._conv_kernel_name(1024, False, 12544, 256, 1) == "conv_igemm_kernel<2,2,1,mt1,ck32>"  # maps up to 28x28 at B=64
+    assert ops._conv_kernel_name(256, False, 12544, 48, 9) == "conv_igemm_kernel<2,2,1,mt1>"         # no 32-channel k-step
+    assert ops._conv_kernel_name(64, False, 1572864, 16, 3) == "conv_igemm_kernel<2,2,1>"            # AdaIN stem
