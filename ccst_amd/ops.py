@@ -142,14 +142,6 @@ def from_api(x, cpad=1):
     return y
 
 
-def to_nchw_contiguous(y_nhwc, C=None):
-    N, H, W, Cs = y_nhwc.shape
-    C = Cs if C is None else C
-    out = torch.empty((N, C, H, W), device=y_nhwc.device, dtype=torch.float32)
-    check(_lib.load().ccst_nhwc_to_nchw_f32(ptr(y_nhwc), ptr(out), N, C, H * W, Cs, stream_ptr()), "nhwc_to_nchw")
-    return out
-
-
 # ---------------------------------------------------------------------------
 # convolution
 # ---------------------------------------------------------------------------
