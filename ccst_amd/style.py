@@ -4,10 +4,38 @@ style_transfer   : CCST_OverallStyleTransfer.py:32-46 (same copy at CCST_SingleS
 calc_sum         : mean_std_computation_effcientMem.py:103-115 / CCST_SingleStyleTransfer.py:55-67
 StyleStatAccumulator : the stage-1 loop and finalisation, mean_std_computation_effcientMem.py:117-137
 """
+import os
+
 import numpy as np
 import torch
 
 from . import ops
+
+# CCST_ADAIN_STREAMS=2: run the two halves of a content batch on two HIP streams, so one half's launch ramps, tails and
+# HBM-bound edges (stem, last decoder layer, AdaIN) overlap the other half's MFMA work: 548 -> 561 images/s at B=6 512x512.
+# Off by default: with kernels of two streams sharing the chip a per-launch duration no longer says anything about the
+# kernel (bench.py's roofline line is measured on the plain single-stream schedule).
+HALF_BATCH_STREAMS = os.environ.get("CCST_ADAIN_STREAMS", "1") == "2"
+_SIDE = {}
+
+
+def _style_transfer_two_streams(vgg, decoder, content, style_stat, alpha):
+    dev = content.device
+    main = torch.cuda.current_stream(dev)
+    side = _SIDE.get(dev.index)
+    if side is None:
+        side = _SIDE[dev.index] = torch.cuda.Stream(device=dev)
+    h = content.shape[0] // 2
+    parts, outs = (content[:h], content[h:]), [None, None]
+    side.wait_stream(main)
+    for i, st in enumerate((main, side)):
+        with torch.cuda.stream(st):
+            f = ops.adain(vgg(parts[i]), style_stat[0], style_stat[1], alpha=alpha)
+            outs[i] = decoder(f)
+    main.wait_stream(side)
+    outs[1].record_stream(main)
+    return torch.cat(outs, 0)
+
 
 
 def style_transfer(vgg, decoder, content, style_stat, alpha=1.0, interpolation_weights=None):
@@ -15,6 +43,8 @@ def style_transfer(vgg, decoder, content, style_stat, alpha=1.0, interpolation_w
     if interpolation_weights:
         # unreachable from the reference CLIs (do_interpolation is never set, CCST_OverallStyleTransfer.py:109)
         raise NotImplementedError("ccst_amd: style interpolation is outside the hot path")
+    if HALF_BATCH_STREAMS and content.shape[0] >= 2 and content.is_cuda:
+        return _style_transfer_two_streams(vgg, decoder, content, style_stat, alpha)
     content_f = vgg(content)
     style_mean, style_std = style_stat
     feat = ops.adain(content_f, style_mean, style_std, alpha=alpha)   # AdaIN + alpha blend in one pass

@@ -387,6 +387,25 @@ def test_cli_scripts_run_end_to_end(dev, tmp_path):
         assert got.shape == (2, 1, 512, 1, 1) and got.dtype == np.float32 and np.allclose(got, ref, rtol=1e-3, atol=1e-4)   # shuffled batches: summation order differs
 
 
+def test_two_stream_half_batches_match(dev, nets, A):
+    """CCST_ADAIN_STREAMS=2 (style.HALF_BATCH_STREAMS): the two halves of the batch on two HIP streams give the same images."""
+    from ccst_amd import style
+    vgg31, dec, _, _ = nets
+    content = A.synth_content(5, 96, 80, seed=21).to(dev)
+    stat = [t.to(dev) for t in A.synth_style_stat(512, seed=7)]
+    with torch.no_grad():
+        ref = style.style_transfer(vgg31, dec, content, stat, 1.0)
+        old, style.HALF_BATCH_STREAMS = style.HALF_BATCH_STREAMS, True
+        try:
+            outs = [style.style_transfer(vgg31, dec, content, stat, 1.0) for _ in range(3)]
+        finally:
+            style.HALF_BATCH_STREAMS = old
+    torch.cuda.synchronize()
+    for o in outs:
+        assert o.shape == ref.shape and float((o - ref).abs().max()) < 1e-4
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
 def test_style_transfer_bitwise_reproducible(dev, nets, A):
     from ccst_amd import style
     vgg31, dec, _, _ = nets
