@@ -125,9 +125,14 @@ def main():
             base, targs = dom[:-1].split("<")
             targs = targs.split(",")
             nums, pooled = ", ".join(a for a in targs if a != "pool"), ("true" if "pool" in targs else "false")
-            key = ("void conv_igemm_kernel<%s, %s, 2, 16>" if base == "conv_igemm_kernel" else "void " + base + "<%s, %s>") % (nums, pooled)
-            if key in tj:
-                traffic = round(tj[key]["total_bytes_per_launch"])
+            if base == "conv_igemm_kernel":
+                keys = ["void conv_igemm_kernel<%s, %s, 2, 16>" % (nums, pooled)]
+            else:       # rocprofv3 prints every template argument: <WM, WN, NT, POOL, TRAIN>
+                keys = ["void %s<%s, %s, false>" % (base, nums, pooled), "void %s<%s, %s>" % (base, nums, pooled)]
+            for key in keys:
+                if key in tj:
+                    traffic = round(tj[key]["total_bytes_per_launch"])
+                    break
         roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "kernel": dom,
                     "launches_per_step": cnt / args.steps, "avg_launch_us": round(sec / cnt * 1e6, 2),
