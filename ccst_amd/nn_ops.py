@@ -165,8 +165,12 @@ def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None):
         classes = [(0, 0)]
     else:
         assert accumulate_into is None
-        dx = torch.zeros(x_shape, device=dy.device, dtype=torch.float32)
         classes = [(py, px) for py in range(stride) for px in range(stride)]
+        # every input pixel belongs to exactly one parity class; the buffer needs zeroing only if some class has no tap
+        # (1x1 stride-2 downsample convs: three of four classes), not for 3x3 stride 2 where every class is written
+        covered = all(len(range((py + pad) % stride, kh, stride)) > 0 and len(range((px + pad) % stride, kw, stride)) > 0
+                      for py, px in classes)
+        dx = (torch.empty if covered else torch.zeros)(x_shape, device=dy.device, dtype=torch.float32)
     for py, px in classes:
         ky0, kx0 = (py + pad) % stride, (px + pad) % stride
         nky, nkx = len(range(ky0, kh, stride)), len(range(kx0, kw, stride))
