@@ -265,40 +265,47 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs p) 
         }
 }
 
-// dw[co][ci][tap] (+)= sum_s ws[s][tap][ci][co].  One output element per thread (8 ci x 32 co tile per
-// workgroup => enough workgroups even for 64x64 weights), the split sum unrolled 8 deep so 8 loads are
-// in flight, fixed summation order; the tile is transposed through LDS so stores run along ci.
+// dw[co][ci][tap] (+)= sum_s ws[s][tap][ci][co].  A workgroup owns (8/NL) ci x 32 co output elements and NL
+// split-lanes per element: lane l sums the slabs l, l+NL, ... (8 loads in flight), the lanes are folded in fixed
+// order through LDS, and the tile is transposed so the stores run along ci.  NL = 4 for the small weight tensors
+// (a 64x256 1x1 layer has only 64 tiles of 8x32 but 256-512 slabs to sum: one element per thread was pure latency).
+// Fixed summation order for a given (problem, NL) => bitwise reproducible.
+template <int NL>
 __global__ __launch_bounds__(256) void bwd_weight_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int ntap, int Cin,
                                                                 int Cout, int splits, int accumulate) {
-    __shared__ float tile[8][33];
+    constexpr int TCI = 8 / NL;                      // ci rows per workgroup
+    __shared__ float part[NL][TCI][33];
     const int tap = blockIdx.z;
-    const int ci0 = blockIdx.y * 8, co0 = blockIdx.x * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int ci0 = blockIdx.y * TCI, co0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = (threadIdx.x >> 5) % TCI, sl = (threadIdx.x >> 5) / TCI;
     {
         const int ci = ci0 + ty, co = co0 + tx;
         float s = 0.f;
         if (ci < Cin && co < Cout) {
             const long long stride = (long long)ntap * Cin * Cout;
             const float* p = ws + ((long long)tap * Cin + ci) * Cout + co;
-            int k = 0;
-            for (; k + 8 <= splits; k += 8) {
+            int k = sl;
+            for (; k + 7 * NL < splits; k += 8 * NL) {
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = p[(long long)(k + j) * stride];
+                for (int j = 0; j < 8; ++j) v[j] = p[(long long)(k + j * NL) * stride];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s += v[j];
             }
-            for (; k < splits; ++k) s += p[(long long)k * stride];
+            for (; k < splits; k += NL) s += p[(long long)k * stride];
         }
-        tile[ty][tx] = s;
+        part[sl][ty][tx] = s;
     }
     __syncthreads();
-    {
-        const int cil = threadIdx.x & 7, col = threadIdx.x >> 3;
+    if (threadIdx.x < TCI * 32) {
+        const int cil = threadIdx.x % TCI, col = threadIdx.x / TCI;
         const int ci = ci0 + cil, co = co0 + col;
         if (ci < Cin && co < Cout) {
+            float s = part[0][cil][col];
+#pragma unroll
+            for (int l = 1; l < NL; ++l) s += part[l][cil][col];
             const long long o = ((long long)co * Cin + ci) * ntap + tap;
-            dw[o] = accumulate ? dw[o] + tile[cil][col] : tile[cil][col];
+            dw[o] = accumulate ? dw[o] + s : s;
         }
     }
 }
@@ -373,8 +380,15 @@ extern "C" int ccst_conv2d_bwd_weight_f32(const CcstConvDesc* d, const float* x,
     else if (!pw && ntap > 1 && d->cin <= 32) rc = launch<1, 1, 32, false, true>(a, s);      // two taps per ci tile
     else rc = pw ? launch<1, 1, 32, true>(a, s) : launch<1, 1, 32, false>(a, s);
     if (rc) return rc;
-    dim3 grid((d->cout + 31) / 32, (d->cin + 7) / 8, ntap);
-    hipLaunchKernelGGL(bwd_weight_reduce_kernel, grid, dim3(256), 0, s, (const float*)ws, dw_oihw, ntap, d->cin, d->cout, splits,
-                       accumulate);
+    const long long tiles8 = (long long)((d->cout + 31) / 32) * ((d->cin + 7) / 8) * ntap;
+    if (tiles8 >= 1024) {
+        dim3 grid((d->cout + 31) / 32, (d->cin + 7) / 8, ntap);
+        hipLaunchKernelGGL(bwd_weight_reduce_kernel<1>, grid, dim3(256), 0, s, (const float*)ws, dw_oihw, ntap, d->cin, d->cout, splits,
+                           accumulate);
+    } else {
+        dim3 grid((d->cout + 31) / 32, (d->cin + 1) / 2, ntap);
+        hipLaunchKernelGGL(bwd_weight_reduce_kernel<4>, grid, dim3(256), 0, s, (const float*)ws, dw_oihw, ntap, d->cin, d->cout, splits,
+                           accumulate);
+    }
     return ccst_launch_status("bwd_weight_reduce");
 }
