@@ -36,6 +36,9 @@ _SIGNATURES = {
     "ccst_conv2d_igemm_stats_groups": [c_int, c_int, c_int, c_int],
     "ccst_conv3x3_halo_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_conv3x3_halo_narrow": [c_int, c_int, c_int, c_int],
+    "ccst_wino_weight_floats": [c_int, c_int],
+    "ccst_pack_conv_weight_wino_f32": [_P, _P, c_int, c_int, c_int, _P],
+    "ccst_conv3x3_wino_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_conv3x3_halo_train_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_conv3x3_halo_stats_groups": [c_int, c_int, c_int],
     "ccst_conv2d_igemm_tile": [c_int, c_int, c_int, c_int, c_int],
@@ -67,7 +70,8 @@ _SIGNATURES = {
     "ccst_sgd_f32": [_P, _P, c_float, c_int64, _P],
     "ccst_scale_f32": [_P, c_float, c_int64, _P],
 }
-_RESTYPES = {"ccst_last_error": c_char_p, "ccst_stats_workspace_bytes": c_int64, "ccst_bn_workspace_bytes": c_int64}
+_RESTYPES = {"ccst_last_error": c_char_p, "ccst_stats_workspace_bytes": c_int64, "ccst_bn_workspace_bytes": c_int64,
+             "ccst_wino_weight_floats": c_int64}
 EXPORTS = tuple(_SIGNATURES)
 
 _lib = None

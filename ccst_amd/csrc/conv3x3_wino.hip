@@ -1,0 +1,329 @@
+// 3x3 stride-1 "same" convolution as fused Winograd F(2x2, 3x3) on the fp32-input MFMA.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A   per 2x2 output tile, summed over input channels: 16 multiplies per 4 outputs
+//   and input channel instead of 36 -- the direct form's MFMA bound (621.6 images/s for the AdaIN path) does not apply.
+//
+// Mapping (one workgroup = 8x16 output pixels = 32 Winograd tiles, x 32 output channels, 4 waves):
+//   * the raw input halo (10x18 pixels x 16 channels per k-step) is staged in LDS exactly as in conv3x3_halo.hip
+//     (reflection / zero padding and the nearest-x2 upsample live in that loader);
+//   * wave r owns row r of the 4x4 transform domain: its four positions (r,0..3) are four 32x32 MFMA accumulators
+//     [tile][cout].  Row r of B^T d B needs only two rows of the 4x4 input patch, so a lane (tile = lane&31, channel
+//     half = lane>>5) reads 8 pixels x 8 channels from the halo (16 ds_read_b128) and builds its A operands with 64 adds;
+//   * the transformed weights U[chunk][r][q][half][cout][8] are packed once (ccst_pack_conv_weight_wino_f32) so that a
+//     lane's eight k-values of one position are 32 contiguous bytes; no two waves share weights, so they stream from
+//     L2 straight into registers (no LDS);
+//   * 32 MFMAs per wave per 16-channel step, one barrier per step (halo double buffer);
+//   * epilogue: each wave applies (.)A to its row locally (4 -> 2 columns), the A^T(.) combination across the four waves
+//     goes through LDS (the halo buffers are free by then), then bias / ReLU / optional 2x2 max-pool (a Winograd tile IS
+//     a pooling window) and NHWC stores.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+struct WinoArgs {
+    const float* x;
+    const float* u;
+    const float* bias;
+    float* y;
+    int N, H, W, Hs, Ws, Cin, Cout, CoutPad;      // H,W: conv (= output) extent; Hs,Ws: source extent (H/2,W/2 if ups)
+    int reflect, ups, relu;
+    long long ysN;
+    int ysH, ysW;                                  // output strides (of the pooled tensor when POOL)
+    int tilesX, tilesY, tilesN;
+};
+
+constexpr int CKW = 16, PITCHW = CKW + 4, HWW = 18, THW = 8, HHW = THW + 2, HPIXW = HHW * HWW;
+constexpr int HUNITSW = HPIXW * (CKW / 4), HRW = (HUNITSW + 255) / 256;
+
+__device__ __forceinline__ int reflect_w(int i, int n) {
+    i = (i < 0) ? -i : i;
+    i = (i >= n) ? 2 * n - 2 - i : i;
+    return min(max(i, 0), n - 1);
+}
+
+template <bool POOL>
+__global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs p) {
+    __shared__ __attribute__((aligned(16))) float Hs_[2][HPIXW * PITCHW];      // 2 x 14.4 KB; reused by the epilogue
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wr = __builtin_amdgcn_readfirstlane(tid >> 6);                    // wave = transform row r
+    const int li = lane & 31, lh = lane >> 5;
+
+    int bid = ccst_xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % p.tilesN;
+    bid /= p.tilesN;
+    const int tx = bid % p.tilesX;
+    bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int n = bid / p.tilesY;
+    const int co0 = tn * 32;
+    const int oy0 = ty * THW, ox0 = tx * 16;
+
+    // ---- halo load units of this thread (as conv3x3_halo.hip) ------------------------------------------
+    unsigned hoff[HRW];
+    bool hok[HRW];
+#pragma unroll
+    for (int i = 0; i < HRW; ++i) {
+        const int u = min(tid + 256 * i, HUNITSW - 1);
+        const int pix = u >> 2, part = u & 3;
+        const int hy = pix / HWW, hx = pix - hy * HWW;
+        int gy = oy0 + hy - 1, gx = ox0 + hx - 1;
+        bool ok = true;
+        if (p.reflect) {
+            gy = reflect_w(gy, p.H);
+            gx = reflect_w(gx, p.W);
+        } else {
+            ok = (gy >= 0) & (gy < p.H) & (gx >= 0) & (gx < p.W);
+            gy = min(max(gy, 0), p.H - 1);
+            gx = min(max(gx, 0), p.W - 1);
+        }
+        gy >>= p.ups;
+        gx >>= p.ups;
+        hok[i] = ok;
+        hoff[i] = (unsigned)(((n * p.Hs + gy) * p.Ws + gx) * p.Cin + part * 4);
+    }
+
+    // ---- A side: this lane's tile and the two patch rows its wave needs ---------------------------------
+    // W = B^T d rows: r0 = d0 - d2, r1 = d1 + d2, r2 = d2 - d1, r3 = d1 - d3
+    const int rowA = (wr == 0) ? 0 : (wr == 2 ? 2 : 1);
+    const int rowB = (wr == 0) ? 2 : (wr == 1 ? 2 : (wr == 2 ? 1 : 3));
+    const float sgn = (wr == 1) ? 1.f : -1.f;
+    const int tyy = li >> 3, txx = li & 7;
+    const int aA = ((2 * tyy + rowA) * HWW + 2 * txx) * PITCHW + lh * 8;
+    const int aB = ((2 * tyy + rowB) * HWW + 2 * txx) * PITCHW + lh * 8;
+
+    // ---- B side: U[chunk][r][q][half][cout_pad][8] --------------------------------------------------------
+    const int nchunks = p.Cin / CKW;
+    const long long uq = (long long)2 * p.CoutPad * 8;                         // floats per (chunk, r, q)
+    const float* ub = p.u + ((long long)wr * 4) * uq + ((long long)lh * p.CoutPad + co0 + li) * 8;
+    const long long uchunk = 16 * uq;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    f32x4 rh[HRW];
+    f32x4 bq[2][4][2];          // [buffer][q][half of the 8 k-values]
+    auto load_b = [&](int buf, int c) {
+        const float* uc = ub + (long long)c * uchunk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bq[buf][q][0] = *reinterpret_cast<const f32x4*>(uc + q * uq);
+            bq[buf][q][1] = *reinterpret_cast<const f32x4*>(uc + q * uq + 4);
+        }
+    };
+    auto load_h = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < HRW; ++i) rh[i] = *reinterpret_cast<const f32x4*>(p.x + hoff[i] + c * CKW);
+    };
+    auto store_h = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < HRW; ++i) {
+            const int u = tid + 256 * i;
+            if (u < HUNITSW) {
+                f32x4 v = rh[i];
+                if (!hok[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(&Hs_[buf][(u >> 2) * PITCHW + (u & 3) * 4]) = v;
+            }
+        }
+    };
+
+    // one k-step: transform this lane's A operands for row wr from Hs_[hbuf], then 32 MFMAs against bq[bbuf]
+    auto step = [&](int hbuf, int bbuf) {
+        const float* ha = &Hs_[hbuf][aA];
+        const float* hb = &Hs_[hbuf][aB];
+        float w[4][8];
+#pragma unroll
+        for (int col = 0; col < 4; ++col) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ha + col * PITCHW);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(ha + col * PITCHW + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(hb + col * PITCHW);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(hb + col * PITCHW + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                w[col][j] = fmaf(sgn, b0[j], a0[j]);
+                w[col][4 + j] = fmaf(sgn, b1[j], a1[j]);
+            }
+        }
+        float v[4][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[0][j] = w[0][j] - w[2][j];
+            v[1][j] = w[1][j] + w[2][j];
+            v[2][j] = w[2][j] - w[1][j];
+            v[3][j] = w[1][j] - w[3][j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[q][j], bq[bbuf][q][j >> 2][j & 3], acc[q], 0, 0, 0);
+    };
+
+    // ---- prologue ------------------------------------------------------------------------------------------
+    load_h(0);
+    load_b(0, 0);
+    store_h(0);
+    __syncthreads();
+
+    // ---- main loop: one 16-channel chunk per step -----------------------------------------------------------
+    for (int c = 0; c < nchunks; c += 2) {
+        {   // even step: halo buffer 0, weights buffer 0
+            const int cn = min(c + 1, nchunks - 1);
+            load_b(1, cn);
+            load_h(cn);
+            step(0, 0);
+            store_h(1);
+            __syncthreads();
+        }
+        if (c + 1 < nchunks) {
+            const int cn = min(c + 2, nchunks - 1);
+            load_b(0, cn);
+            load_h(cn);
+            step(1, 1);
+            store_h(0);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: (.)A locally, A^T(.) across the four waves through LDS ----------------------------------------
+    // A^T = [[1,1,1,0],[0,1,-1,-1]]
+    f32x16 ma[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        ma[0][r] = acc[0][r] + acc[1][r] + acc[2][r];
+        ma[1][r] = acc[1][r] - acc[2][r] - acc[3][r];
+    }
+    float* ex = &Hs_[0][0];                                   // [4 waves][32 tiles][33] floats = 16.9 KB <= 28.8 KB
+    float yv[4][2][2];                                        // [tile of this lane][out row i][out col j]
+    const int rbase = 8 * wr + 4 * lh;                        // this lane finalises tiles rbase .. rbase+3, channel co0+li
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+        if (cc == 1) __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            ex[(wr * 32 + row) * 33 + li] = ma[cc][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = rbase + k;
+            const float m0 = ex[(0 * 32 + row) * 33 + li], m1 = ex[(1 * 32 + row) * 33 + li];
+            const float m2 = ex[(2 * 32 + row) * 33 + li], m3 = ex[(3 * 32 + row) * 33 + li];
+            yv[k][0][cc] = m0 + m1 + m2;
+            yv[k][1][cc] = m1 - m2 - m3;
+        }
+    }
+
+    const int co = co0 + li;
+    if (co >= p.Cout) return;
+    const float bias = (p.bias != nullptr) ? p.bias[co] : 0.f;
+    const bool relu = p.relu != 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = rbase + k, t_y = t >> 3, t_x = t & 7;
+        const int oy = oy0 + 2 * t_y, ox = ox0 + 2 * t_x;
+        if (!POOL) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (oy + i < p.H && ox + j < p.W) {
+                        float v = yv[k][i][j] + bias;
+                        if (relu) v = fmaxf(v, 0.f);
+                        p.y[(long long)n * p.ysN + (long long)(oy + i) * p.ysH + (long long)(ox + j) * p.ysW + co] = v;
+                    }
+        } else {
+            if (oy < p.H && ox < p.W) {                        // ceil mode: a window at the edge holds 1 or 2 valid pixels
+                float v = yv[k][0][0];
+                if (ox + 1 < p.W) v = fmaxf(v, yv[k][0][1]);
+                if (oy + 1 < p.H) {
+                    v = fmaxf(v, yv[k][1][0]);
+                    if (ox + 1 < p.W) v = fmaxf(v, yv[k][1][1]);
+                }
+                v += bias;
+                if (relu) v = fmaxf(v, 0.f);
+                p.y[(long long)n * p.ysN + (long long)(oy >> 1) * p.ysH + (long long)(ox >> 1) * p.ysW + co] = v;
+            }
+        }
+    }
+}
+
+// OIHW 3x3 -> U[chunk][r][q][half][cout_pad][8], U = G g G^T, channel ci = chunk*16 + half*8 + j
+__global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ u, int cout, int cin, int cin_pad, int cout_pad) {
+    const long long total = (long long)(cin_pad / 16) * 16 * 2 * cout_pad * 8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        long long t = i >> 3;
+        const int co = (int)(t % cout_pad);
+        t /= cout_pad;
+        const int half = (int)(t & 1);
+        t >>= 1;
+        const int q = (int)(t & 3);
+        t >>= 2;
+        const int r = (int)(t & 3);
+        const int chunk = (int)(t >> 2);
+        const int ci = chunk * 16 + half * 8 + j;
+        float val = 0.f;
+        if (co < cout && ci < cin) {
+            const float* g = w + ((long long)co * cin + ci) * 9;
+            float gg[3];                                       // row r of G g
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                const float g0 = g[0 * 3 + cc], g1 = g[1 * 3 + cc], g2 = g[2 * 3 + cc];
+                gg[cc] = (r == 0) ? g0 : (r == 1) ? 0.5f * (g0 + g1 + g2) : (r == 2) ? 0.5f * (g0 - g1 + g2) : g2;
+            }
+            val = (q == 0) ? gg[0] : (q == 1) ? 0.5f * (gg[0] + gg[1] + gg[2]) : (q == 2) ? 0.5f * (gg[0] - gg[1] + gg[2]) : gg[2];
+        }
+        u[i] = val;
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t ccst_wino_weight_floats(int cin, int cout_pad) { return (int64_t)((cin + 15) / 16) * 16 * 2 * cout_pad * 8; }
+
+extern "C" int ccst_pack_conv_weight_wino_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, void* stream) {
+    CCST_REQUIRE(w_oihw && u && cout > 0 && cin > 0, "pack_wino: bad args");
+    CCST_REQUIRE(cout_pad >= cout && cout_pad % 32 == 0, "pack_wino: cout_pad must be a multiple of 32 >= cout");
+    const int cin_pad = (cin + 15) / 16 * 16;
+    const long long total = ccst_wino_weight_floats(cin, cout_pad);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(pack_weight_wino_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, u, cout, cin, cin_pad, cout_pad);
+    return ccst_launch_status("pack_weight_wino");
+}
+
+// x: NHWC source [N,Hs,Ws,Cin] (Hs = H/2 if CCST_CONV_UPS2), u: ccst_pack_conv_weight_wino_f32 output, y: NHWC [N,H,W,Cout] or
+// its 2x2 ceil-pooled form.  flags: CCST_CONV_RELU | POOL2 | UPS2 | REFLECT.
+extern "C" int ccst_conv3x3_wino_f32(const float* x, const float* u_packed, const float* bias, float* y, int N, int H, int W, int Cin,
+                                     int Cout, int cout_pad, uint32_t flags, void* stream) {
+    CCST_REQUIRE(x && u_packed && y, "conv3x3_wino: null pointer");
+    CCST_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0, "conv3x3_wino: bad shape");
+    CCST_REQUIRE(cout_pad >= Cout && cout_pad % 32 == 0, "conv3x3_wino: cout_pad must be a multiple of 32 >= cout");
+    const bool pool = (flags & CCST_CONV_POOL2) != 0, ups = (flags & CCST_CONV_UPS2) != 0;
+    if (ups) CCST_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv3x3_wino: upsampled extent must be even");
+    if (flags & CCST_CONV_REFLECT) CCST_REQUIRE(H >= 2 && W >= 2, "conv3x3_wino: reflection needs extent >= 2");
+    WinoArgs a;
+    a.x = x; a.u = u_packed; a.bias = bias; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.Hs = ups ? H / 2 : H; a.Ws = ups ? W / 2 : W; a.Cin = Cin; a.Cout = Cout; a.CoutPad = cout_pad;
+    a.reflect = (flags & CCST_CONV_REFLECT) ? 1 : 0; a.ups = ups ? 1 : 0; a.relu = (flags & CCST_CONV_RELU) ? 1 : 0;
+    CCST_REQUIRE((long long)N * a.Hs * a.Ws * Cin < 0x7fffffffLL, "conv3x3_wino: input must have < 2^31 elements");
+    const int oh = pool ? (H + 1) / 2 : H, ow = pool ? (W + 1) / 2 : W;
+    a.ysW = Cout; a.ysH = ow * Cout; a.ysN = (long long)oh * ow * Cout;
+    a.tilesN = (Cout + 31) / 32;
+    a.tilesY = (H + THW - 1) / THW;
+    a.tilesX = (W + 15) / 16;
+    const long long grid = (long long)N * a.tilesY * a.tilesX * a.tilesN;
+    if (grid <= 0 || grid > 0x7fffffffLL) {
+        ccst_set_error("conv3x3_wino: bad grid %lld", grid);
+        return CCST_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (pool) hipLaunchKernelGGL(conv3x3_wino_kernel<true>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(conv3x3_wino_kernel<false>, dim3((unsigned)grid), dim3(256), 0, s, a);
+    return ccst_launch_status("conv3x3_wino");
+}

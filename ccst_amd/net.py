@@ -121,7 +121,7 @@ def _compile(mods):
             else:
                 pool = at(j) is not None and _is_pool2(at(j)) and conv.out_channels % 16 == 0
                 j += int(pool)
-                steps.append(_Step("conv", pc=ops.pack_conv_weight(conv.weight.detach(), conv.bias), pad=1, reflect=True,
+                steps.append(_Step("conv", pc=ops.pack_conv_weight(conv.weight.detach(), conv.bias, wino=ops.USE_WINO), pad=1, reflect=True,
                                    relu=relu, pool=pool, ups=pending_up))
                 pending_up = False
             i = j

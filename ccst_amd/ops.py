@@ -146,16 +146,24 @@ def from_api(x, cpad=1):
 # convolution
 # ---------------------------------------------------------------------------
 class PackedConv(object):
-    """Device-resident packed weight [kh*kw][K/4][n_pad][4] (+ optional bias)."""
-    __slots__ = ("w", "bias", "cin", "cout", "kh", "kw", "k_pad", "n_pad", "transpose")
+    """Device-resident packed weight [kh*kw][K/4][n_pad][4] (+ optional bias).  `u` / `u_pad`: the Winograd-transformed
+    copy (ccst_pack_conv_weight_wino_f32) of a 3x3 weight, built by pack_conv_weight(..., wino=True)."""
+    __slots__ = ("w", "bias", "cin", "cout", "kh", "kw", "k_pad", "n_pad", "transpose", "u", "u_pad")
 
     def __init__(self, w, bias, cin, cout, kh, kw, k_pad, n_pad, transpose):
         self.w, self.bias, self.cin, self.cout, self.kh, self.kw = w, bias, cin, cout, kh, kw
         self.k_pad, self.n_pad, self.transpose = k_pad, n_pad, transpose
+        self.u, self.u_pad = None, 0
 
 
-def pack_conv_weight(w_oihw, bias=None, transpose=False, out=None):
-    """OIHW checkpoint tensor -> PackedConv.  transpose=True builds the backward-data operand."""
+# Fused Winograd F(2x2,3x3) for the reflect-padded 3x3 stride-1 layers (conv3x3_wino.hip); CCST_CONV_WINO=0 keeps the direct
+# halo kernel.
+USE_WINO = os.environ.get("CCST_CONV_WINO", "0") != "0"
+
+
+def pack_conv_weight(w_oihw, bias=None, transpose=False, out=None, wino=False):
+    """OIHW checkpoint tensor -> PackedConv.  transpose=True builds the backward-data operand; wino=True also builds the
+    Winograd-transformed copy of a 3x3 weight."""
     _require_cuda(w_oihw, "weight")
     w = w_oihw.contiguous()
     cout, cin, kh, kw = w.shape
@@ -169,7 +177,13 @@ def pack_conv_weight(w_oihw, bias=None, transpose=False, out=None):
     if bias is not None:
         _require_cuda(bias, "bias")
         b = bias.detach().contiguous()
-    return PackedConv(out, b, cin, cout, kh, kw, k_pad, n_pad, transpose)
+    pc = PackedConv(out, b, cin, cout, kh, kw, k_pad, n_pad, transpose)
+    if wino and kh == 3 and kw == 3 and not transpose:
+        lib = _lib.load()
+        pc.u_pad = round_up(cout, 32)
+        pc.u = torch.empty(int(lib.ccst_wino_weight_floats(cin, pc.u_pad)), device=w.device, dtype=torch.float32)
+        check(lib.ccst_pack_conv_weight_wino_f32(ptr(w), ptr(pc.u), cout, cin, pc.u_pad, stream_ptr()), "pack_conv_weight_wino")
+    return pc
 
 
 def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, ups=False, out_nchw=False, out=None,
@@ -205,6 +219,20 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
     if not reflect and pc.kh == 3 and pc.kw == 3 and stride == 1 and pad == 1 and not (relu or pool or ups or out_nchw) \
             and out is None and pc.bias is None and halo_train_ok(Hi, Wi, Cx, pc.cout):
         return conv3x3_halo_train(x, pc, want_stats=want_stats)
+    if USE_WINO and pc.u is not None and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats:
+        out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
+        lib = _lib.load()
+        args = (ptr(x), ptr(pc.u), ptr(pc.bias), ptr(out), N, Hi, Wi, Cx, pc.cout, pc.u_pad, flags, stream_ptr())
+        if TIMING is None:
+            check(lib.ccst_conv3x3_wino_f32(*args), "conv3x3_wino")
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib.ccst_conv3x3_wino_f32(*args), "conv3x3_wino")
+            e1.record()
+            TIMING.append(("conv3x3_wino_kernel<%s>" % ("pool" if pool else "nopool"), 2.0 * N * ho * wo * pc.cout * pc.cin * 9, e0, e1,
+                           "n%d %dx%d cin%d cout%d taps3x3 flags%d" % (N, ho, wo, pc.cin, pc.cout, flags)))
+        return out
     if USE_HALO and reflect and pc.kh == 3 and pc.kw == 3 and stride == 1 and pad == 1 and not out_nchw \
             and out is None and not want_stats:
         out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)

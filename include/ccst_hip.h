@@ -95,6 +95,15 @@ int ccst_conv3x3_halo_f32(const float* x, const float* w_packed, const float* bi
 
 int ccst_conv3x3_halo_narrow(int N, int H, int W, int Cout);   /* 1: the 128x64 tile is dispatched, 0: 128x128 */
 
+/* The same convolution as fused Winograd F(2x2,3x3) (16 multiplies per 2x2 output tile and input channel instead of
+ * 36): transformed weights from ccst_pack_conv_weight_wino_f32 (ccst_wino_weight_floats(cin, cout_pad) floats,
+ * cout_pad a multiple of 32), same x / y / flags contract as ccst_conv3x3_halo_f32.  fp32 throughout; differs from the
+ * direct form by Winograd's rounding (~1e-6 relative). */
+int64_t ccst_wino_weight_floats(int cin, int cout_pad);
+int ccst_pack_conv_weight_wino_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, void* stream);
+int ccst_conv3x3_wino_f32(const float* x, const float* u_packed, const float* bias, float* y, int N, int H, int W,
+                          int Cin, int Cout, int cout_pad, uint32_t flags, void* stream);
+
 /* The same kernel for the ResNet trunk's 3x3 stride-1 zero-padded, bias-free convs (nets/resnet.py:160-161 via the
  * torchvision blocks), forward AND backward-data: flags = CCST_CONV_FLIP (reverse the taps; with the transposed packed
  * weight that is dX of the conv) | CCST_CONV_ACCUM (y += conv).  stats (NULL or [groups][Cout][2], groups =

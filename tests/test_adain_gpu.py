@@ -138,6 +138,31 @@ def test_conv3x3_halo_vs_gather(dev, case, halo):
     assert maxdiff(got, ref) < 1e-4
 
 
+@pytest.mark.parametrize("case", [(2, 32, 48, 64, 64, False, False), (1, 17, 23, 32, 96, False, False), (2, 24, 24, 128, 40, True, False),
+                                  (1, 22, 38, 64, 64, False, True), (1, 16, 32, 256, 256, False, False), (1, 9, 7, 16, 33, True, False)])
+@pytest.mark.parametrize("reflect", [True, False])
+def test_conv3x3_winograd_vs_direct(dev, case, reflect):
+    """ccst_conv3x3_wino_f32 (fused Winograd F(2x2,3x3)) against the direct halo kernel: same flags, odd sizes, pool, upsample."""
+    from ccst_amd import _lib, ops
+    from ccst_amd._lib import check, ptr, stream_ptr
+    N, H, W, Cin, Cout, pool, ups = case
+    g = torch.Generator().manual_seed(9)
+    Hs, Ws = (H // 2, W // 2) if ups else (H, W)
+    if ups:
+        H, W = 2 * Hs, 2 * Ws
+    x = torch.randn(N, Hs, Ws, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(dev)
+    b = (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    pc = ops.pack_conv_weight(w, b, wino=True)
+    assert pc.u is not None
+    ref = ops.conv2d_nhwc(x, pc, stride=1, pad=1, reflect=reflect, relu=True, pool=pool, ups=ups)     # direct (USE_WINO off by default)
+    flags = 1 | (2 if pool else 0) | (4 if ups else 0) | (8 if reflect else 0)
+    out = torch.empty_like(ref)
+    check(_lib.load().ccst_conv3x3_wino_f32(ptr(x), ptr(pc.u), ptr(pc.bias), ptr(out), N, H, W, Cin, Cout, pc.u_pad, flags, stream_ptr()),
+          "conv3x3_wino")
+    assert float((out - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+
+
 def test_conv_out_nchw(dev):
     from ccst_amd import ops
     x = rnd((2, 64, 12, 10), 8)
