@@ -33,8 +33,18 @@ struct WinoArgs {
     int tilesX, tilesY, tilesN;
 };
 
-constexpr int CKW = 16, PITCHW = CKW + 4, HWW = 18, THW = 8, HHW = THW + 2, HPIXW = HHW * HWW;
+#ifndef WINO_SUBS
+#define WINO_SUBS 1                 // 16-channel sub-steps per barrier (halo chunk = 16*WINO_SUBS channels)
+#endif
+constexpr int SUBS = WINO_SUBS;
+constexpr int CKW = 16 * SUBS, PITCHW = CKW + 4, HWW = 18, THW = 8, HHW = THW + 2, HPIXW = HHW * HWW;
 constexpr int HUNITSW = HPIXW * (CKW / 4), HRW = (HUNITSW + 255) / 256;
+// LDS image of the halo: even and odd pixel columns in separate planes, so that a tile step (2 pixels) is ONE pixel
+// pitch (80 B = 5 sixteen-byte slots, odd => 8 tiles of a row hit 8 distinct slots), and rows padded by 32 B so that two
+// rows shift by 8 slots mod 16 => the 16 lanes of a ds_read_b128 group (2 tile rows x 8 tiles) hit 16 distinct slots.
+// (The plain [row][col] image measured 68 % of the LDS-active cycles as bank conflicts.)
+constexpr int PLANEW = (HWW / 2) * PITCHW, ROWPW = 2 * PLANEW + 8, HIMGW = HHW * ROWPW;
+__device__ __forceinline__ int halo_addr(int hy, int hx) { return hy * ROWPW + (hx & 1) * PLANEW + (hx >> 1) * PITCHW; }
 
 __device__ __forceinline__ int reflect_w(int i, int n) {
     i = (i < 0) ? -i : i;
@@ -42,9 +52,18 @@ __device__ __forceinline__ int reflect_w(int i, int n) {
     return min(max(i, 0), n - 1);
 }
 
+#ifdef WINO_PIN_LOADS
+#define WINO_PIN __builtin_amdgcn_sched_barrier(0)
+#else
+#define WINO_PIN
+#endif
+#ifndef WINO_WAVES
+#define WINO_WAVES 2
+#endif
+
 template <bool POOL>
-__global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs p) {
-    __shared__ __attribute__((aligned(16))) float Hs_[2][HPIXW * PITCHW];      // 2 x 14.4 KB; reused by the epilogue
+__global__ __launch_bounds__(256, WINO_WAVES) void conv3x3_wino_kernel(const WinoArgs p) {
+    __shared__ __attribute__((aligned(16))) float Hs_[2][HIMGW];               // 2 x 14.7 KB; reused by the epilogue
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wr = __builtin_amdgcn_readfirstlane(tid >> 6);                    // wave = transform row r
@@ -66,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs p) 
 #pragma unroll
     for (int i = 0; i < HRW; ++i) {
         const int u = min(tid + 256 * i, HUNITSW - 1);
-        const int pix = u >> 2, part = u & 3;
+        const int pix = u / (CKW / 4), part = u % (CKW / 4);
         const int hy = pix / HWW, hx = pix - hy * HWW;
         int gy = oy0 + hy - 1, gx = ox0 + hx - 1;
         bool ok = true;
@@ -90,14 +109,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs p) 
     const int rowB = (wr == 0) ? 2 : (wr == 1 ? 2 : (wr == 2 ? 1 : 3));
     const float sgn = (wr == 1) ? 1.f : -1.f;
     const int tyy = li >> 3, txx = li & 7;
-    const int aA = ((2 * tyy + rowA) * HWW + 2 * txx) * PITCHW + lh * 8;
-    const int aB = ((2 * tyy + rowB) * HWW + 2 * txx) * PITCHW + lh * 8;
+    const int aA = halo_addr(2 * tyy + rowA, 2 * txx) + lh * 8;      // patch column c: + (c&1)*PLANEW + (c>>1)*PITCHW
+    const int aB = halo_addr(2 * tyy + rowB, 2 * txx) + lh * 8;
 
     // ---- B side: U[chunk][r][q][half][cout_pad][8] --------------------------------------------------------
-    const int nchunks = p.Cin / CKW;
+    const int nchunks = p.Cin / CKW;            // halo chunks (barriers); each holds SUBS 16-channel sub-steps
     const long long uq = (long long)2 * p.CoutPad * 8;                         // floats per (chunk, r, q)
     const float* ub = p.u + ((long long)wr * 4) * uq + ((long long)lh * p.CoutPad + co0 + li) * 8;
-    const long long uchunk = 16 * uq;
+    const long long uchunk = 16 * uq;                                         // per 16-channel sub-step
 
     f32x16 acc[4];
 #pragma unroll
@@ -126,22 +145,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs p) 
             if (u < HUNITSW) {
                 f32x4 v = rh[i];
                 if (!hok[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4*>(&Hs_[buf][(u >> 2) * PITCHW + (u & 3) * 4]) = v;
+                const int pix = u / (CKW / 4);
+                *reinterpret_cast<f32x4*>(&Hs_[buf][halo_addr(pix / HWW, pix % HWW) + (u % (CKW / 4)) * 4]) = v;
             }
         }
     };
 
     // one k-step: transform this lane's A operands for row wr from Hs_[hbuf], then 32 MFMAs against bq[bbuf]
-    auto step = [&](int hbuf, int bbuf) {
-        const float* ha = &Hs_[hbuf][aA];
-        const float* hb = &Hs_[hbuf][aB];
+    auto step = [&](int hbuf, int bbuf, int sub) {
+        const float* ha = &Hs_[hbuf][aA + sub * 16];
+        const float* hb = &Hs_[hbuf][aB + sub * 16];
         float w[4][8];
 #pragma unroll
         for (int col = 0; col < 4; ++col) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ha + col * PITCHW);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(ha + col * PITCHW + 4);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(hb + col * PITCHW);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(hb + col * PITCHW + 4);
+            const int co_ = (col & 1) * PLANEW + (col >> 1) * PITCHW;
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ha + co_);
+            const f32x4 a1 = *reinterpret_cast<const f32x4*>(ha + co_ + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(hb + co_);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(hb + co_ + 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 w[col][j] = fmaf(sgn, b0[j], a0[j]);
@@ -169,26 +190,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(const WinoArgs p) 
     store_h(0);
     __syncthreads();
 
-    // ---- main loop: one 16-channel chunk per step -----------------------------------------------------------
+    // ---- main loop: one halo chunk (16*SUBS channels) per barrier, SUBS 16-channel sub-steps of 32 MFMAs each; the
+    // weights of sub-step s+1 are fetched into the other register buffer while sub-step s computes, the next chunk's halo
+    // is fetched at the top of the chunk and written to the other LDS buffer at its end. ----------------------------
+    const int nsub = nchunks * SUBS;
+#ifdef ABLATE_LOOP_REPEAT
+    for (int rep_ = 0; rep_ < ABLATE_LOOP_REPEAT; ++rep_)
+#endif
     for (int c = 0; c < nchunks; c += 2) {
-        {   // even step: halo buffer 0, weights buffer 0
-            const int cn = min(c + 1, nchunks - 1);
-            load_b(1, cn);
-            load_h(cn);
-            step(0, 0);
-            store_h(1);
-            __syncthreads();
-        }
-        if (c + 1 < nchunks) {
-            const int cn = min(c + 2, nchunks - 1);
-            load_b(0, cn);
-            load_h(cn);
-            step(1, 1);
-            store_h(0);
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            if (par == 1 && c + 1 >= nchunks) break;
+            const int cc = c + par;
+            load_h(min(cc + 1, nchunks - 1));
+#pragma unroll
+            for (int sub = 0; sub < SUBS; ++sub) {
+                const int sidx = cc * SUBS + sub;                    // global sub-step index; weights buffer = sidx & 1
+                load_b((par * SUBS + sub + 1) & 1, min(sidx + 1, nsub - 1));
+                WINO_PIN;
+                step(par, (par * SUBS + sub) & 1, sub);
+                WINO_PIN;
+            }
+            store_h(par ^ 1);
             __syncthreads();
         }
     }
 
+#ifdef ABLATE_NO_EPILOGUE       // timing experiments only
+    {
+        float t_ = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t_ += acc[q][r];
+        if (t_ == 123.456f) p.y[0] = t_;
+        return;
+    }
+#endif
     // ---- epilogue: (.)A locally, A^T(.) across the four waves through LDS ----------------------------------------
     // A^T = [[1,1,1,0],[0,1,-1,-1]]
     f32x16 ma[2];
