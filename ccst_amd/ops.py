@@ -156,9 +156,9 @@ class PackedConv(object):
         self.u, self.u_pad = None, 0
 
 
-# Fused Winograd F(2x2,3x3) for the reflect-padded 3x3 stride-1 layers (conv3x3_wino.hip); CCST_CONV_WINO=0 keeps the direct
-# halo kernel.
-USE_WINO = os.environ.get("CCST_CONV_WINO", "0") != "0"
+# Fused Winograd F(2x2,3x3) for the 3x3 stride-1 layers of the AdaIN encoder / decoder (conv3x3_wino.hip): 2.25x fewer
+# multiplies than the direct form, 549 -> 865 images/s on the metric; CCST_CONV_WINO=0 keeps the direct halo kernel.
+USE_WINO = os.environ.get("CCST_CONV_WINO", "1") != "0"
 
 
 def pack_conv_weight(w_oihw, bias=None, transpose=False, out=None, wino=False):

@@ -155,7 +155,7 @@ def test_conv3x3_winograd_vs_direct(dev, case, reflect):
     b = (torch.randn(Cout, generator=g) * 0.1).to(dev)
     pc = ops.pack_conv_weight(w, b, wino=True)
     assert pc.u is not None
-    ref = ops.conv2d_nhwc(x, pc, stride=1, pad=1, reflect=reflect, relu=True, pool=pool, ups=ups)     # direct (USE_WINO off by default)
+    ref = ops.conv2d_nhwc(x, ops.pack_conv_weight(w, b), stride=1, pad=1, reflect=reflect, relu=True, pool=pool, ups=ups)   # direct kernels
     flags = 1 | (2 if pool else 0) | (4 if ups else 0) | (8 if reflect else 0)
     out = torch.empty_like(ref)
     check(_lib.load().ccst_conv3x3_wino_f32(ptr(x), ptr(pc.u), ptr(pc.bias), ptr(out), N, H, W, Cin, Cout, pc.u_pad, flags, stream_ptr()),
