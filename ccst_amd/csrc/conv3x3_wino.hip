@@ -125,14 +125,11 @@ __global__ __launch_bounds__(256, WINO_WAVES) void conv3x3_wino_kernel(const Win
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
     f32x4 rh[HRW];
-    f32x4 bq[2][4][2];          // [buffer][q][half of the 8 k-values]
-    auto load_b = [&](int buf, int c) {
-        const float* uc = ub + (long long)c * uchunk;
+    f32x4 bq[4][2];             // [q][half of the 8 k-values]: ONE buffer, each half re-loaded right after its last MFMA
+    auto load_b_half = [&](int c, int h) {
+        const float* uc = ub + (long long)c * uchunk + h * 4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            bq[buf][q][0] = *reinterpret_cast<const f32x4*>(uc + q * uq);
-            bq[buf][q][1] = *reinterpret_cast<const f32x4*>(uc + q * uq + 4);
-        }
+        for (int q = 0; q < 4; ++q) bq[q][h] = *reinterpret_cast<const f32x4*>(uc + q * uq);
     };
     auto load_h = [&](int c) {
 #pragma unroll
@@ -151,48 +148,46 @@ __global__ __launch_bounds__(256, WINO_WAVES) void conv3x3_wino_kernel(const Win
         }
     };
 
-    // one k-step: transform this lane's A operands for row wr from Hs_[hbuf], then 32 MFMAs against bq[bbuf]
-    auto step = [&](int hbuf, int bbuf, int sub) {
-        const float* ha = &Hs_[hbuf][aA + sub * 16];
-        const float* hb = &Hs_[hbuf][aB + sub * 16];
-        float w[4][8];
+    // half h (4 of the lane's 8 channels) of one k-step: 8 ds_read_b128, the row transform (32 adds), 16 MFMAs
+    auto half_step = [&](int hbuf, int sub, int h) {
+        const float* ha = &Hs_[hbuf][aA + sub * 16 + h * 4];
+        const float* hb = &Hs_[hbuf][aB + sub * 16 + h * 4];
+        f32x4 w[4];
 #pragma unroll
         for (int col = 0; col < 4; ++col) {
             const int co_ = (col & 1) * PLANEW + (col >> 1) * PITCHW;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(ha + co_);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(ha + co_ + 4);
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(hb + co_);
-            const f32x4 b1 = *reinterpret_cast<const f32x4*>(hb + co_ + 4);
+            const f32x4 a = *reinterpret_cast<const f32x4*>(ha + co_);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(hb + co_);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                w[col][j] = fmaf(sgn, b0[j], a0[j]);
-                w[col][4 + j] = fmaf(sgn, b1[j], a1[j]);
-            }
+            for (int j = 0; j < 4; ++j) w[col][j] = fmaf(sgn, b[j], a[j]);
         }
-        float v[4][8];
+        f32x4 v[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < 4; ++j) {
             v[0][j] = w[0][j] - w[2][j];
             v[1][j] = w[1][j] + w[2][j];
             v[2][j] = w[2][j] - w[1][j];
             v[3][j] = w[1][j] - w[3][j];
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[q][j], bq[bbuf][q][j >> 2][j & 3], acc[q], 0, 0, 0);
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[q][j], bq[q][h][j], acc[q], 0, 0, 0);
     };
 
     // ---- prologue ------------------------------------------------------------------------------------------
     load_h(0);
-    load_b(0, 0);
+    load_b_half(0, 0);
+    load_b_half(0, 1);
     store_h(0);
     __syncthreads();
 
-    // ---- main loop: one halo chunk (16*SUBS channels) per barrier, SUBS 16-channel sub-steps of 32 MFMAs each; the
-    // weights of sub-step s+1 are fetched into the other register buffer while sub-step s computes, the next chunk's halo
-    // is fetched at the top of the chunk and written to the other LDS buffer at its end. ----------------------------
+    // ---- main loop: one halo chunk (16*SUBS channels) per barrier, SUBS 16-channel sub-steps of 2 x 16 MFMAs.  Order of
+    // a sub-step, pinned with sched_barrier: [next chunk's halo fetch] 16 MFMAs | fetch the next sub-step's first weight
+    // half into the registers just consumed | 16 MFMAs | fetch its second half -- every global load overlaps this wave's own
+    // MFMAs (left alone, hipcc put all of them behind the MFMAs, right in front of the wait) and the weights need no second
+    // register buffer; the halo goes to the other LDS buffer at the end of the chunk. --------------------------------------
     const int nsub = nchunks * SUBS;
 #ifdef ABLATE_LOOP_REPEAT
     for (int rep_ = 0; rep_ < ABLATE_LOOP_REPEAT; ++rep_)
@@ -203,13 +198,18 @@ __global__ __launch_bounds__(256, WINO_WAVES) void conv3x3_wino_kernel(const Win
             if (par == 1 && c + 1 >= nchunks) break;
             const int cc = c + par;
             load_h(min(cc + 1, nchunks - 1));
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int sub = 0; sub < SUBS; ++sub) {
-                const int sidx = cc * SUBS + sub;                    // global sub-step index; weights buffer = sidx & 1
-                load_b((par * SUBS + sub + 1) & 1, min(sidx + 1, nsub - 1));
-                WINO_PIN;
-                step(par, (par * SUBS + sub) & 1, sub);
-                WINO_PIN;
+                const int nxt = min(cc * SUBS + sub + 1, nsub - 1);
+                half_step(par, sub, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                load_b_half(nxt, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                half_step(par, sub, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                load_b_half(nxt, 1);
+                __builtin_amdgcn_sched_barrier(0);
             }
             store_h(par ^ 1);
             __syncthreads();
