@@ -92,7 +92,7 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    assert bool(torch.isfinite(out).all())
+    assert os.environ.get("CCST_BENCH_NO_ASSERT") == "1" or bool(torch.isfinite(out).all())      # (kernel timing ablations produce garbage)
 
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed

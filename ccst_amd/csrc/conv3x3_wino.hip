@@ -124,23 +124,44 @@ __global__ __launch_bounds__(256, WINO_WAVES) void conv3x3_wino_kernel(const Win
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
-    f32x4 rh[HRW];
+    f32x4 rh[(HRW + SUBS - 1) / SUBS];
     f32x4 bq[4][2];             // [q][half of the 8 k-values]: ONE buffer, each half re-loaded right after its last MFMA
     auto load_b_half = [&](int c, int h) {
         const float* uc = ub + (long long)c * uchunk + h * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[q][h] = *reinterpret_cast<const f32x4*>(uc + q * uq);
     };
-    auto load_h = [&](int c) {
+    // timing experiments only (tools/build_variant.sh): drop one ingredient of the main loop
+#ifdef ABL_NO_B
+#define LOOP_LOAD_B(c, h)
+#else
+#define LOOP_LOAD_B(c, h) load_b_half(c, h)
+#endif
+#ifdef ABL_NO_HALO
+#define LOOP_LOAD_H(c, s)
+#define LOOP_STORE_H(b, s)
+#else
+#define LOOP_LOAD_H(c, s) load_h(c, s)
+#define LOOP_STORE_H(b, s) store_h(b, s)
+#endif
+#ifdef ABL_NO_BARRIER
+#define LOOP_BARRIER()
+#else
+#define LOOP_BARRIER() __syncthreads()
+#endif
+    // the halo chunk is fetched / written in SUBS slices (one per 16-channel sub-step) through the same HRS registers
+    constexpr int HRS = (HRW + SUBS - 1) / SUBS;
+    auto load_h = [&](int c, int slice) {
 #pragma unroll
-        for (int i = 0; i < HRW; ++i) rh[i] = *reinterpret_cast<const f32x4*>(p.x + hoff[i] + c * CKW);
+        for (int i = slice * HRS; i < (slice + 1) * HRS && i < HRW; ++i)
+            rh[i - slice * HRS] = *reinterpret_cast<const f32x4*>(p.x + hoff[i] + c * CKW);
     };
-    auto store_h = [&](int buf) {
+    auto store_h = [&](int buf, int slice) {
 #pragma unroll
-        for (int i = 0; i < HRW; ++i) {
+        for (int i = slice * HRS; i < (slice + 1) * HRS && i < HRW; ++i) {
             const int u = tid + 256 * i;
             if (u < HUNITSW) {
-                f32x4 v = rh[i];
+                f32x4 v = rh[i - slice * HRS];
                 if (!hok[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 const int pix = u / (CKW / 4);
                 *reinterpret_cast<f32x4*>(&Hs_[buf][halo_addr(pix / HWW, pix % HWW) + (u % (CKW / 4)) * 4]) = v;
@@ -162,6 +183,10 @@ __global__ __launch_bounds__(256, WINO_WAVES) void conv3x3_wino_kernel(const Win
             for (int j = 0; j < 4; ++j) w[col][j] = fmaf(sgn, b[j], a[j]);
         }
         f32x4 v[4];
+#ifdef ABL_NO_XFORM
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = w[q];
+#else
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             v[0][j] = w[0][j] - w[2][j];
@@ -169,6 +194,7 @@ __global__ __launch_bounds__(256, WINO_WAVES) void conv3x3_wino_kernel(const Win
             v[2][j] = w[2][j] - w[1][j];
             v[3][j] = w[1][j] - w[3][j];
         }
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -177,10 +203,13 @@ __global__ __launch_bounds__(256, WINO_WAVES) void conv3x3_wino_kernel(const Win
     };
 
     // ---- prologue ------------------------------------------------------------------------------------------
-    load_h(0);
     load_b_half(0, 0);
     load_b_half(0, 1);
-    store_h(0);
+#pragma unroll
+    for (int sl = 0; sl < SUBS; ++sl) {
+        load_h(0, sl);
+        store_h(0, sl);
+    }
     __syncthreads();
 
     // ---- main loop: one halo chunk (16*SUBS channels) per barrier, SUBS 16-channel sub-steps of 2 x 16 MFMAs.  Order of
@@ -197,22 +226,22 @@ __global__ __launch_bounds__(256, WINO_WAVES) void conv3x3_wino_kernel(const Win
         for (int par = 0; par < 2; ++par) {
             if (par == 1 && c + 1 >= nchunks) break;
             const int cc = c + par;
-            load_h(min(cc + 1, nchunks - 1));
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int sub = 0; sub < SUBS; ++sub) {
                 const int nxt = min(cc * SUBS + sub + 1, nsub - 1);
+                LOOP_LOAD_H(min(cc + 1, nchunks - 1), sub);
+                __builtin_amdgcn_sched_barrier(0);
                 half_step(par, sub, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                load_b_half(nxt, 0);
+                LOOP_LOAD_B(nxt, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 half_step(par, sub, 1);
                 __builtin_amdgcn_sched_barrier(0);
-                load_b_half(nxt, 1);
+                LOOP_LOAD_B(nxt, 1);
                 __builtin_amdgcn_sched_barrier(0);
+                LOOP_STORE_H(par ^ 1, sub);
             }
-            store_h(par ^ 1);
-            __syncthreads();
+            LOOP_BARRIER();
         }
     }
 
