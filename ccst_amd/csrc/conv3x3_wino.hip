@@ -31,6 +31,8 @@ struct WinoArgs {
     long long ysN;
     int ysH, ysW;                                  // output strides (of the pooled tensor when POOL)
     int tilesX, tilesY, tilesN;
+    float* stats;          // train form: [spatial tile * 8 + wave * 2 + lane half][Cout][2] (sum, sum^2) partials of y, or nullptr
+    int accum;             // train form: y += conv
 };
 
 #ifndef WINO_SUBS
@@ -290,6 +292,25 @@ __global__ __launch_bounds__(256, WINO_WAVES) void conv3x3_wino_kernel(const Win
     if (co >= p.Cout) return;
     const float bias = (p.bias != nullptr) ? p.bias[co] : 0.f;
     const bool relu = p.relu != 0;
+    if (!POOL && p.stats != nullptr) {      // BatchNorm statistics of the raw output: this lane's 16 pixels of channel co
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int t = rbase + k, oy = oy0 + 2 * (t >> 3), ox = ox0 + 2 * (t & 7);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float v = (oy + i < p.H && ox + j < p.W) ? yv[k][i][j] : 0.f;
+                    s1 += v;
+                    s2 += v * v;
+                }
+        }
+        const int slab = (((n * p.tilesY + ty) * p.tilesX + tx) * 4 + wr) * 2 + lh;
+        float* o = p.stats + ((long long)slab * p.Cout + co) * 2;
+        o[0] = s1;
+        o[1] = s2;
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int t = rbase + k, t_y = t >> 3, t_x = t & 7;
@@ -302,7 +323,9 @@ __global__ __launch_bounds__(256, WINO_WAVES) void conv3x3_wino_kernel(const Win
                     if (oy + i < p.H && ox + j < p.W) {
                         float v = yv[k][i][j] + bias;
                         if (relu) v = fmaxf(v, 0.f);
-                        p.y[(long long)n * p.ysN + (long long)(oy + i) * p.ysH + (long long)(ox + j) * p.ysW + co] = v;
+                        float* o = p.y + (long long)n * p.ysN + (long long)(oy + i) * p.ysH + (long long)(ox + j) * p.ysW + co;
+                        if (p.accum) v += *o;
+                        *o = v;
                     }
         } else {
             if (oy < p.H && ox < p.W) {                        // ceil mode: a window at the edge holds 1 or 2 valid pixels
@@ -321,7 +344,10 @@ __global__ __launch_bounds__(256, WINO_WAVES) void conv3x3_wino_kernel(const Win
 }
 
 // OIHW 3x3 -> U[chunk][r][q][half][cout_pad][8], U = G g G^T, channel ci = chunk*16 + half*8 + j
-__global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ u, int cout, int cin, int cin_pad, int cout_pad) {
+// bwd != 0: the backward-data operand -- the conv whose input is dY: g'[ci][co][ky][kx] = g[co][ci][2-ky][2-kx], i.e. the roles of
+// cout / cin are those of the BACKWARD conv (cout = forward Cin, cin = forward Cout) and w is still the forward OIHW tensor.
+__global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ u, int cout, int cin, int cin_pad, int cout_pad,
+                                        int bwd) {
     const long long total = (long long)(cin_pad / 16) * 16 * 2 * cout_pad * 8;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(i & 7);
@@ -337,11 +363,13 @@ __global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __re
         const int ci = chunk * 16 + half * 8 + j;
         float val = 0.f;
         if (co < cout && ci < cin) {
-            const float* g = w + ((long long)co * cin + ci) * 9;
+            // forward: g = w[co][ci]; backward-data: g = flip(w[ci][co]) (w's leading dim is then `cin`, its second `cout`)
+            const float* g = bwd ? w + ((long long)ci * cout + co) * 9 : w + ((long long)co * cin + ci) * 9;
             float gg[3];                                       // row r of G g
 #pragma unroll
             for (int cc = 0; cc < 3; ++cc) {
-                const float g0 = g[0 * 3 + cc], g1 = g[1 * 3 + cc], g2 = g[2 * 3 + cc];
+                const int c_ = bwd ? 2 - cc : cc;
+                const float g0 = g[(bwd ? 2 : 0) * 3 + c_], g1 = g[1 * 3 + c_], g2 = g[(bwd ? 0 : 2) * 3 + c_];
                 gg[cc] = (r == 0) ? g0 : (r == 1) ? 0.5f * (g0 + g1 + g2) : (r == 2) ? 0.5f * (g0 - g1 + g2) : g2;
             }
             val = (q == 0) ? gg[0] : (q == 1) ? 0.5f * (gg[0] + gg[1] + gg[2]) : (q == 2) ? 0.5f * (gg[0] - gg[1] + gg[2]) : gg[2];
@@ -354,20 +382,53 @@ __global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __re
 
 extern "C" int64_t ccst_wino_weight_floats(int cin, int cout_pad) { return (int64_t)((cin + 15) / 16) * 16 * 2 * cout_pad * 8; }
 
+static int pack_wino_impl(const float* w_oihw, float* u, int cout, int cin, int cout_pad, int bwd, void* stream);
+
 extern "C" int ccst_pack_conv_weight_wino_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, void* stream) {
+    return pack_wino_impl(w_oihw, u, cout, cin, cout_pad, 0, stream);
+}
+
+// The backward-data operand of a stride-1 3x3 conv with forward weight w_oihw [cout][cin][3][3]: the transformed weights of the
+// conv dY -> dX (its output channels = cin, its input channels = cout; cin_pad a multiple of 32 >= cin).
+extern "C" int ccst_pack_conv_weight_wino_bwd_f32(const float* w_oihw, float* u, int cout, int cin, int cin_pad, void* stream) {
+    return pack_wino_impl(w_oihw, u, cin, cout, cin_pad, 1, stream);
+}
+
+static int pack_wino_impl(const float* w_oihw, float* u, int cout, int cin, int cout_pad, int bwd, void* stream) {
     CCST_REQUIRE(w_oihw && u && cout > 0 && cin > 0, "pack_wino: bad args");
     CCST_REQUIRE(cout_pad >= cout && cout_pad % 32 == 0, "pack_wino: cout_pad must be a multiple of 32 >= cout");
     const int cin_pad = (cin + 15) / 16 * 16;
     const long long total = ccst_wino_weight_floats(cin, cout_pad);
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(pack_weight_wino_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, u, cout, cin, cin_pad, cout_pad);
+    hipLaunchKernelGGL(pack_weight_wino_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, u, cout, cin, cin_pad, cout_pad, bwd);
     return ccst_launch_status("pack_weight_wino");
 }
 
 // x: NHWC source [N,Hs,Ws,Cin] (Hs = H/2 if CCST_CONV_UPS2), u: ccst_pack_conv_weight_wino_f32 output, y: NHWC [N,H,W,Cout] or
 // its 2x2 ceil-pooled form.  flags: CCST_CONV_RELU | POOL2 | UPS2 | REFLECT.
+static int wino_impl(const float* x, const float* u_packed, const float* bias, float* y, float* stats, int N, int H, int W, int Cin,
+                     int Cout, int cout_pad, uint32_t flags, void* stream);
+
 extern "C" int ccst_conv3x3_wino_f32(const float* x, const float* u_packed, const float* bias, float* y, int N, int H, int W, int Cin,
                                      int Cout, int cout_pad, uint32_t flags, void* stream) {
+    CCST_REQUIRE(!(flags & CCST_CONV_ACCUM), "conv3x3_wino: CCST_CONV_ACCUM belongs to ccst_conv3x3_wino_train_f32");
+    return wino_impl(x, u_packed, bias, y, nullptr, N, H, W, Cin, Cout, cout_pad, flags, stream);
+}
+
+// The ResNet-trunk form (zero padding, no bias / ReLU / pool): flags = 0 | CCST_CONV_ACCUM (y += conv); stats (may be NULL):
+// [ccst_conv3x3_wino_stats_groups(N,H,W)][Cout][2] (sum, sum^2) partials of y for the following BatchNorm2d.  Backward-data =
+// this entry point with the weights from ccst_pack_conv_weight_wino_bwd_f32 and x = dY.
+extern "C" int ccst_conv3x3_wino_train_f32(const float* x, const float* u_packed, float* y, float* stats, int N, int H, int W, int Cin,
+                                           int Cout, int cout_pad, uint32_t flags, void* stream) {
+    CCST_REQUIRE(!(flags & ~CCST_CONV_ACCUM), "conv3x3_wino_train: only CCST_CONV_ACCUM");
+    CCST_REQUIRE(!(stats && (flags & CCST_CONV_ACCUM)), "conv3x3_wino_train: statistics are of the conv output, not of y += conv");
+    return wino_impl(x, u_packed, nullptr, y, stats, N, H, W, Cin, Cout, cout_pad, flags, stream);
+}
+
+extern "C" int ccst_conv3x3_wino_stats_groups(int N, int H, int W) { return N * ((H + THW - 1) / THW) * ((W + 15) / 16) * 8; }
+
+static int wino_impl(const float* x, const float* u_packed, const float* bias, float* y, float* stats, int N, int H, int W, int Cin,
+                     int Cout, int cout_pad, uint32_t flags, void* stream) {
     CCST_REQUIRE(x && u_packed && y, "conv3x3_wino: null pointer");
     CCST_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0, "conv3x3_wino: bad shape");
     CCST_REQUIRE(cout_pad >= Cout && cout_pad % 32 == 0, "conv3x3_wino: cout_pad must be a multiple of 32 >= cout");
@@ -378,6 +439,8 @@ extern "C" int ccst_conv3x3_wino_f32(const float* x, const float* u_packed, cons
     a.x = x; a.u = u_packed; a.bias = bias; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Hs = ups ? H / 2 : H; a.Ws = ups ? W / 2 : W; a.Cin = Cin; a.Cout = Cout; a.CoutPad = cout_pad;
     a.reflect = (flags & CCST_CONV_REFLECT) ? 1 : 0; a.ups = ups ? 1 : 0; a.relu = (flags & CCST_CONV_RELU) ? 1 : 0;
+    a.stats = stats; a.accum = (flags & CCST_CONV_ACCUM) ? 1 : 0;
+    CCST_REQUIRE(!(a.accum && (pool || a.relu)) && !(a.stats && (pool || a.relu || a.accum)), "conv3x3_wino: ACCUM / statistics exclude ReLU and pool");
     CCST_REQUIRE((long long)N * a.Hs * a.Ws * Cin < 0x7fffffffLL, "conv3x3_wino: input must have < 2^31 elements");
     const int oh = pool ? (H + 1) / 2 : H, ow = pool ? (W + 1) / 2 : W;
     a.ysW = Cout; a.ysH = ow * Cout; a.ysN = (long long)oh * ow * Cout;

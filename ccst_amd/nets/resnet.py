@@ -52,6 +52,16 @@ class Conv2d(nn.Conv2d):
     def packed_t(self):
         return self._cached("pkt", lambda w, prev: ops.pack_conv_weight(w, transpose=True, out=self._reuse(prev)))
 
+    def wino_ok(self, H, W):
+        return self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and \
+            ops.wino_train_ok(H, W, self.in_channels, self.out_channels)
+
+    def wino_fwd(self):
+        return self._cached("wu", lambda w, prev: ops.pack_wino(w, out=None if prev is None else prev[0]))
+
+    def wino_bwd(self):
+        return self._cached("wut", lambda w, prev: ops.pack_wino(w, bwd=True, out=None if prev is None else prev[0]))
+
     def prepack(self):
         """Refresh the packed copies now (called on the side stream right after the optimiser step)."""
         if self.in_channels > 4 and "_ccst_pk" in self.__dict__:

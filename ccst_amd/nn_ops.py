@@ -238,10 +238,16 @@ class ConvFn(torch.autograd.Function):
         ctx.sink = sink
         ctx.want_stats = bool(want_stats)
         ctx.set_materialize_grads(False)       # no zero tensor for the non-differentiable stats output
+        ctx.wino = mod.wino_ok(x.shape[1], x.shape[2])
         if want_stats:      # BN batch statistics from the conv epilogue (non-differentiable side output)
-            y, stats = ops.conv2d_nhwc(x, pc, stride=mod.stride[0], pad=mod.padding[0], want_stats=True)
+            if ctx.wino:
+                y, stats = ops.conv3x3_wino_train(x, mod.wino_fwd(), want_stats=True)
+            else:
+                y, stats = ops.conv2d_nhwc(x, pc, stride=mod.stride[0], pad=mod.padding[0], want_stats=True)
             ctx.mark_non_differentiable(stats)
             return y, stats
+        if ctx.wino:
+            return ops.conv3x3_wino_train(x, mod.wino_fwd())
         return ops.conv2d_nhwc(x, pc, stride=mod.stride[0], pad=mod.padding[0])
 
     @staticmethod
@@ -265,7 +271,10 @@ class ConvFn(torch.autograd.Function):
             into = None
             if ctx.sink is not None and ctx.sink.grad is not None:
                 into, ctx.sink.grad = ctx.sink.grad, None
-            dx = conv_bwd_data(dy, mod.packed_t(), tuple(x.shape), stride, pad, accumulate_into=into)
+            if ctx.wino:
+                dx = ops.conv3x3_wino_train(dy, mod.wino_bwd(), accumulate_into=into, tag="bwd_data:")
+            else:
+                dx = conv_bwd_data(dy, mod.packed_t(), tuple(x.shape), stride, pad, accumulate_into=into)
         return dx, None, None, None, None
 
 

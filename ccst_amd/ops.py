@@ -43,6 +43,60 @@ def halo_train_ok(H, W, cin, cout):
     return H * W >= HALO_MIN_COVER * (round_up(H, 8) * round_up(W, 16))
 
 
+# ResNet trunk: 3x3 stride-1 convs (forward with BN statistics, backward-data) on the Winograd kernel when its 8x16-pixel tiles
+# cover the map well enough; CCST_RESNET_WINO=0 keeps the gather kernel.
+RESNET_WINO = os.environ.get("CCST_RESNET_WINO", "1") != "0"
+RESNET_WINO_COVER = float(os.environ.get("CCST_RESNET_WINO_COVER", "0.7"))
+
+
+def wino_train_ok(H, W, cin, cout):
+    return RESNET_WINO and cin % 16 == 0 and cout % 16 == 0 and H * W >= RESNET_WINO_COVER * (round_up(H, 8) * round_up(W, 16))
+
+
+def pack_wino(w_oihw, bwd=False, out=None):
+    """Winograd-transformed copy of a 3x3 OIHW weight: (u, cout_pad, cout) of the forward conv, or with bwd=True of the
+    backward-data conv dY -> dX (its `cout` is the forward Cin)."""
+    cout, cin = w_oihw.shape[0], w_oihw.shape[1]
+    lib = _lib.load()
+    n_out, n_in = (cin, cout) if bwd else (cout, cin)
+    pad = round_up(n_out, 32)
+    nfl = int(lib.ccst_wino_weight_floats(n_in, pad))
+    u = out if out is not None and out.numel() == nfl else torch.empty(nfl, device=w_oihw.device, dtype=torch.float32)
+    w = w_oihw.contiguous()
+    if bwd:
+        check(lib.ccst_pack_conv_weight_wino_bwd_f32(ptr(w), ptr(u), cout, cin, pad, stream_ptr()), "pack_wino_bwd")
+    else:
+        check(lib.ccst_pack_conv_weight_wino_f32(ptr(w), ptr(u), cout, cin, pad, stream_ptr()), "pack_wino")
+    return u, pad, n_out
+
+
+def conv3x3_wino_train(x, packed, want_stats=False, accumulate_into=None, tag=""):
+    """3x3 stride-1 zero-padded bias-free conv on the Winograd kernel (ResNet trunk).  packed = pack_wino(...)."""
+    u, pad, cout = packed
+    N, H, W, Cx = x.shape
+    lib = _lib.load()
+    if accumulate_into is not None:
+        assert tuple(accumulate_into.shape) == (N, H, W, cout) and accumulate_into.is_contiguous() and not want_stats
+        y = accumulate_into
+    else:
+        y = torch.empty((N, H, W, cout), device=x.device, dtype=torch.float32)
+    stats = None
+    if want_stats:
+        stats = torch.empty((lib.ccst_conv3x3_wino_stats_groups(N, H, W), cout, 2), device=x.device, dtype=torch.float32)
+    flags = _lib.CONV_ACCUM if accumulate_into is not None else 0
+    args = (ptr(x), ptr(u), ptr(y), ptr(stats), N, H, W, Cx, cout, pad, flags, stream_ptr())
+    if TIMING is None:
+        check(lib.ccst_conv3x3_wino_train_f32(*args), "conv3x3_wino_train")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.ccst_conv3x3_wino_train_f32(*args), "conv3x3_wino_train")
+        e1.record()
+        TIMING.append((tag + "conv3x3_wino_kernel<train>", 2.0 * N * H * W * cout * Cx * 9, e0, e1,
+                       "n%d %dx%d cin%d cout%d taps3x3 s1" % (N, H, W, Cx, cout)))
+    return (y, stats) if want_stats else y
+
+
 def conv3x3_halo_train(x, pc, want_stats=False, flip=False, accumulate_into=None):
     """3x3 stride-1 zero-padded bias-free conv on the halo kernel (ResNet trunk).  pc: PackedConv whose K side matches
     x's channels (the transposed pack + flip=True gives the backward-data).  Returns y or (y, stats)."""

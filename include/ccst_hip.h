@@ -103,6 +103,13 @@ int64_t ccst_wino_weight_floats(int cin, int cout_pad);
 int ccst_pack_conv_weight_wino_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, void* stream);
 int ccst_conv3x3_wino_f32(const float* x, const float* u_packed, const float* bias, float* y, int N, int H, int W,
                           int Cin, int Cout, int cout_pad, uint32_t flags, void* stream);
+/* The Winograd kernel for the ResNet trunk's 3x3 stride-1 zero-padded bias-free convs (forward with the BatchNorm statistics
+ * epilogue, backward-data with the weights from ccst_pack_conv_weight_wino_bwd_f32 and x = dY, optional y += with
+ * CCST_CONV_ACCUM).  stats: NULL or [ccst_conv3x3_wino_stats_groups(N,H,W)][Cout][2]. */
+int ccst_pack_conv_weight_wino_bwd_f32(const float* w_oihw, float* u, int cout, int cin, int cin_pad, void* stream);
+int ccst_conv3x3_wino_train_f32(const float* x, const float* u_packed, float* y, float* stats, int N, int H, int W,
+                                int Cin, int Cout, int cout_pad, uint32_t flags, void* stream);
+int ccst_conv3x3_wino_stats_groups(int N, int H, int W);
 
 /* The same kernel for the ResNet trunk's 3x3 stride-1 zero-padded, bias-free convs (nets/resnet.py:160-161 via the
  * torchvision blocks), forward AND backward-data: flags = CCST_CONV_FLIP (reverse the taps; with the transposed packed

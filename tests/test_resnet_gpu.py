@@ -458,3 +458,28 @@ def test_train_step_bitwise_reproducible(dev):
     a, b = run(), run()
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("shape", [(3, 28, 28, 128, 128), (2, 56, 56, 64, 64), (2, 14, 14, 256, 192), (1, 13, 19, 32, 48)])
+def test_wino_train_form_vs_gather(dev, shape):
+    """ccst_conv3x3_wino_train_f32: forward + BN statistics, backward-data through the transposed / flipped weight transform,
+    and y += conv, against the gather kernel."""
+    from ccst_amd import nn_ops, ops
+    N, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(N, H, W, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(dev)
+    dy = torch.randn(N, H, W, Cout, generator=g).to(dev)
+    base = torch.randn(N, H, W, Cin, generator=g).to(dev)
+    pc, pct = ops.pack_conv_weight(w), ops.pack_conv_weight(w, transpose=True)
+    y_ref, st_ref = ops.conv2d_nhwc(x, pc, stride=1, pad=1, want_stats=True)
+    dx_ref = nn_ops.conv_bwd_data(dy, pct, (N, H, W, Cin), 1, 1)
+    y, st = ops.conv3x3_wino_train(x, ops.pack_wino(w), want_stats=True)
+    assert float((y - y_ref).abs().max()) < 3e-5 * max(1.0, float(y_ref.abs().max()))
+    tot, tot_ref = st.double().sum(0), st_ref.double().sum(0)
+    assert float((tot - tot_ref).abs().max()) < 1e-4 * float(tot_ref.abs().max())
+    dx = ops.conv3x3_wino_train(dy, ops.pack_wino(w, bwd=True))
+    assert float((dx - dx_ref).abs().max()) < 3e-5 * max(1.0, float(dx_ref.abs().max()))
+    acc = base.clone()
+    ops.conv3x3_wino_train(dy, ops.pack_wino(w, bwd=True), accumulate_into=acc)
+    assert float((acc - (base + dx_ref)).abs().max()) < 3e-5 * max(1.0, float(dx_ref.abs().max()))
