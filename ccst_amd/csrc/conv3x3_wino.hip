@@ -378,7 +378,51 @@ __global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __re
     }
 }
 
+// the same for many weight tensors in one launch: jobs[j] = {src, dst, cout, cin, cin_pad, cout_pad, bwd, 0} (int64, device)
+__global__ void pack_weight_wino_batch_kernel(const long long* __restrict__ jobs) {
+    const long long* jb = jobs + (long long)blockIdx.y * 8;
+    const float* __restrict__ w = reinterpret_cast<const float*>(jb[0]);
+    float* __restrict__ u = reinterpret_cast<float*>(jb[1]);
+    const int cout = (int)jb[2], cin = (int)jb[3], cin_pad = (int)jb[4], cout_pad = (int)jb[5], bwd = (int)jb[6];
+    const long long total = (long long)(cin_pad / 16) * 16 * 2 * cout_pad * 8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i & 7);
+        long long t = i >> 3;
+        const int co = (int)(t % cout_pad);
+        t /= cout_pad;
+        const int half = (int)(t & 1);
+        t >>= 1;
+        const int q = (int)(t & 3);
+        t >>= 2;
+        const int r = (int)(t & 3);
+        const int chunk = (int)(t >> 2);
+        const int ci = chunk * 16 + half * 8 + j;
+        float val = 0.f;
+        if (co < cout && ci < cin) {
+            const float* g = bwd ? w + ((long long)ci * cout + co) * 9 : w + ((long long)co * cin + ci) * 9;
+            float gg[3];
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+                const int c_ = bwd ? 2 - cc : cc;
+                const float g0 = g[(bwd ? 2 : 0) * 3 + c_], g1 = g[1 * 3 + c_], g2 = g[(bwd ? 0 : 2) * 3 + c_];
+                gg[cc] = (r == 0) ? g0 : (r == 1) ? 0.5f * (g0 + g1 + g2) : (r == 2) ? 0.5f * (g0 - g1 + g2) : g2;
+            }
+            val = (q == 0) ? gg[0] : (q == 1) ? 0.5f * (gg[0] + gg[1] + gg[2]) : (q == 2) ? 0.5f * (gg[0] - gg[1] + gg[2]) : gg[2];
+        }
+        u[i] = val;
+    }
+}
+
 }  // namespace
+
+// ccst_pack_conv_weight_wino(_bwd)_f32 for many tensors in one launch (the per-step refresh after ccst_sgd_f32).
+// jobs_device: [njobs][8] int64 {src OIHW, dst, n_out, n_in, n_in_pad16, n_out_pad32, bwd, 0} with (n_out, n_in) = (cout, cin) of
+// the conv the transform is for (the backward-data conv has them swapped).
+extern "C" int ccst_pack_conv_weights_wino_batch_f32(const int64_t* jobs_device, int njobs, void* stream) {
+    CCST_REQUIRE(jobs_device && njobs > 0 && njobs <= 65535, "pack_wino_batch: bad job table");
+    hipLaunchKernelGGL(pack_weight_wino_batch_kernel, dim3(64, njobs), dim3(256), 0, (hipStream_t)stream, (const long long*)jobs_device);
+    return ccst_launch_status("pack_weight_wino_batch");
+}
 
 extern "C" int64_t ccst_wino_weight_floats(int cin, int cout_pad) { return (int64_t)((cin + 15) / 16) * 16 * 2 * cout_pad * 8; }
 

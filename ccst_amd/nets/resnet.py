@@ -63,11 +63,17 @@ class Conv2d(nn.Conv2d):
         return self._cached("wut", lambda w, prev: ops.pack_wino(w, bwd=True, out=None if prev is None else prev[0]))
 
     def prepack(self):
-        """Refresh the packed copies now (called on the side stream right after the optimiser step)."""
-        if self.in_channels > 4 and "_ccst_pk" in self.__dict__:
-            self.packed()
-            if "_ccst_pkt" in self.__dict__:
+        """Refresh every packed copy this conv holds now (a key compare when they are current)."""
+        if self.in_channels > 4:
+            d = self.__dict__
+            if "_ccst_pk" in d:
+                self.packed()
+            if "_ccst_pkt" in d:
                 self.packed_t()
+            if "_ccst_wu" in d:
+                self.wino_fwd()
+            if "_ccst_wut" in d:
+                self.wino_bwd()
 
     def packed_stem(self):
         def build(w, prev):

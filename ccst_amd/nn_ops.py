@@ -68,51 +68,74 @@ _PREPACK_PENDING = set()
 
 
 def _prepack_jobs(model, convs):
-    """Device table for ccst_pack_conv_weights_batch_f32 covering every packed copy the model's convs hold.  Rebuilt
+    """Device tables for the batched re-pack launches covering every packed copy the model's convs hold: the direct
+    layouts (ccst_pack_conv_weights_batch_f32) and the Winograd transforms (ccst_pack_conv_weights_wino_batch_f32).  Rebuilt
     only if a weight or a packed buffer moved (the key is the tuple of their addresses)."""
-    slots = []
+    slots, wslots = [], []
     for m in convs:
+        if m.in_channels <= 4:
+            continue
         for name, transpose in (("_ccst_pk", 0), ("_ccst_pkt", 1)):
             slot = m.__dict__.get(name)
-            if slot is not None and m.in_channels > 4:
+            if slot is not None:
                 slots.append((m, name, slot[1], transpose))
-    sig = tuple((m.weight.data_ptr(), pc.w.data_ptr()) for m, _n, pc, _t in slots)
+        for name, bwd in (("_ccst_wu", 0), ("_ccst_wut", 1)):
+            slot = m.__dict__.get(name)
+            if slot is not None:
+                wslots.append((m, name, slot[1], bwd))
+    sig = tuple((m.weight.data_ptr(), pc.w.data_ptr()) for m, _n, pc, _t in slots) + \
+        tuple((m.weight.data_ptr(), pk[0].data_ptr()) for m, _n, pk, _b in wslots)
     cached = model.__dict__.get("_ccst_prepack_jobs")
-    if not slots:
-        return (sig, None, slots)
+    if not slots and not wslots:
+        return (sig, None, slots, None, wslots)
     if cached is None or cached[0] != sig:
-        rows = [[m.weight.data_ptr(), pc.w.data_ptr(), m.out_channels, m.in_channels, pc.kh * pc.kw, t, pc.k_pad, pc.n_pad]
-                for m, _n, pc, t in slots]
-        dev = slots[0][0].weight.device
-        table = torch.tensor(rows, dtype=torch.int64).to(dev)
-        cached = (sig, table, slots)
+        dev = (slots or wslots)[0][0].weight.device
+        table = wtable = None
+        if slots:
+            rows = [[m.weight.data_ptr(), pc.w.data_ptr(), m.out_channels, m.in_channels, pc.kh * pc.kw, t, pc.k_pad, pc.n_pad]
+                    for m, _n, pc, t in slots]
+            table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        if wslots:
+            rows = []
+            for m, _n, (u, pad, n_out), bwd in wslots:
+                n_in = m.out_channels if bwd else m.in_channels
+                rows.append([m.weight.data_ptr(), u.data_ptr(), n_out, n_in, (n_in + 15) // 16 * 16, pad, bwd, 0])
+            wtable = torch.tensor(rows, dtype=torch.int64).to(dev)
+        cached = (sig, table, slots, wtable, wslots)
         model.__dict__["_ccst_prepack_jobs"] = cached
     return cached
 
 
 def prepack_on_side(model):
-    """After an optimiser step: refresh every packed conv weight (into the existing buffers) with ONE batched launch on
-    the side stream, so it overlaps the next step's stem / first BN / max-pool instead of preceding them."""
+    """After an optimiser step: refresh every packed conv weight (into the existing buffers) with ONE batched launch per
+    layout on the side stream, so it overlaps the next step's stem / first BN / max-pool instead of preceding them."""
     convs = model.__dict__.get("_ccst_convs")
     if convs is None:
         convs = model.__dict__["_ccst_convs"] = [m for m in model.modules() if hasattr(m, "prepack")]
     if not convs:
         return
     device = convs[0].weight.device
-    _sig, table, slots = _prepack_jobs(model, convs)
-    if table is None:
+    _sig, table, slots, wtable, wslots = _prepack_jobs(model, convs)
+    if table is None and wtable is None:
         return
+
+    def launch():
+        lib = _lib.load()
+        if table is not None:
+            check(lib.ccst_pack_conv_weights_batch_f32(ptr(table), len(slots), stream_ptr()), "pack_weights_batch")
+        if wtable is not None:
+            check(lib.ccst_pack_conv_weights_wino_batch_f32(ptr(wtable), len(wslots), stream_ptr()), "pack_weights_wino_batch")
     if SIDE_STREAM:
         side = _side_stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
-            check(_lib.load().ccst_pack_conv_weights_batch_f32(ptr(table), len(slots), stream_ptr()), "pack_weights_batch")
+            launch()
         _PREPACK_PENDING.add(device.index)
     else:
-        check(_lib.load().ccst_pack_conv_weights_batch_f32(ptr(table), len(slots), stream_ptr()), "pack_weights_batch")
-    for m, name, pc, _t in slots:           # the packed copies now match the weights of this epoch
+        launch()
+    for m, name, pk, _t in slots + wslots:           # the packed copies now match the weights of this epoch
         w = m.weight
-        m.__dict__[name] = ((w._version, w.data_ptr(), ops.WEIGHTS_EPOCH), pc)
+        m.__dict__[name] = ((w._version, w.data_ptr(), ops.WEIGHTS_EPOCH), pk)
 
 
 def join_prepack(device):

@@ -110,6 +110,9 @@ int ccst_pack_conv_weight_wino_bwd_f32(const float* w_oihw, float* u, int cout, 
 int ccst_conv3x3_wino_train_f32(const float* x, const float* u_packed, float* y, float* stats, int N, int H, int W,
                                 int Cin, int Cout, int cout_pad, uint32_t flags, void* stream);
 int ccst_conv3x3_wino_stats_groups(int N, int H, int W);
+/* many Winograd weight transforms in one launch: jobs_device [njobs][8] int64 {src OIHW, dst, n_out, n_in, n_in rounded up to 16,
+ * n_out rounded up to 32, bwd, 0}, (n_out, n_in) = channels of the conv the transform serves. */
+int ccst_pack_conv_weights_wino_batch_f32(const int64_t* jobs_device, int njobs, void* stream);
 
 /* The same kernel for the ResNet trunk's 3x3 stride-1 zero-padded, bias-free convs (nets/resnet.py:160-161 via the
  * torchvision blocks), forward AND backward-data: flags = CCST_CONV_FLIP (reverse the taps; with the transposed packed
