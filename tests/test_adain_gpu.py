@@ -446,3 +446,27 @@ def test_no_cpu_fallback(nets):
     vgg31, _, _, _ = nets
     with pytest.raises(RuntimeError):
         vgg31(torch.zeros(1, 3, 16, 16))
+
+
+def test_conv3x3_winograd_conditioning(dev):
+    """Winograd F(2x2,3x3) in fp32 against an fp64 convolution on inputs with a wide dynamic range (values from 1e-3 to 1e3 with
+    mixed signs): the error stays within 2e-6 of the sum of |terms|, i.e. the transform adds no cancellation beyond fp32 rounding."""
+    from ccst_amd import _lib, ops
+    from ccst_amd._lib import check, ptr, stream_ptr
+    N, H, W, Cin, Cout = 1, 24, 40, 64, 32
+    g = torch.Generator().manual_seed(31)
+    mag = 10.0 ** (torch.rand(N, H, W, Cin, generator=g) * 6 - 3)
+    x = (mag * torch.sign(torch.randn(N, H, W, Cin, generator=g))).float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).float()
+    xr = F.pad(x.permute(0, 3, 1, 2).double(), (1, 1, 1, 1), mode="reflect")
+    ref = F.conv2d(xr, w.double()).permute(0, 2, 3, 1)
+    scale = F.conv2d(xr.abs(), w.double().abs()).permute(0, 2, 3, 1)                 # sum of |terms| per output
+    xd, wd = x.to(dev), w.to(dev)
+    pc = ops.pack_conv_weight(wd, None, wino=True)
+    out = torch.empty((N, H, W, Cout), device=dev, dtype=torch.float32)
+    check(_lib.load().ccst_conv3x3_wino_f32(ptr(xd), ptr(pc.u), None, ptr(out), N, H, W, Cin, Cout, pc.u_pad, 8, stream_ptr()), "conv3x3_wino")
+    err = (out.cpu().double() - ref).abs() / scale
+    direct = ops.conv2d_nhwc(xd, ops.pack_conv_weight(wd, None), stride=1, pad=1, reflect=True)
+    err_d = (direct.cpu().double() - ref).abs() / scale
+    assert float(err.max()) < 2e-6, float(err.max())
+    assert float(err.max()) < 8 * max(float(err_d.max()), 1e-7)          # same order as the direct fp32 kernel
