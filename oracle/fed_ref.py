@@ -44,9 +44,11 @@ def communication_fedbn(server_model, models, client_weights):
     return server_model, models
 
 
-def train_epoch(model, loader, lr, loss_fun):
-    """federated/fed_run.py:31-88 without logging/device moves: returns
-    (train_loss, train_acc) = (sum loss / n_batches, correct / num_data)."""
+def train_epoch(model, loader, lr, loss_fun, log=None):
+    """federated/fed_run.py:31-88 without device moves: returns (train_loss, train_acc) =
+    (sum loss / n_batches, correct / num_data).  `log`, when a list, receives what the reference hands its
+    logger per iteration (:72-75): (loss, samples right, batch size).  Pinned bit-for-bit against the
+    reference's own train() by tests/golden/fed_loop.npz (tools/make_golden.py)."""
     model.train()
     num_data, correct, loss_all, it = 0, 0, 0.0, -1
     for it, (img, lab) in enumerate(loader):
@@ -55,8 +57,11 @@ def train_epoch(model, loader, lr, loss_fun):
         logit = model(img)
         loss = loss_fun(logit, lab)
         loss_all += loss.item()
-        correct += int((logit.max(dim=1)[1] == lab).sum())
+        right = int((logit.max(dim=1)[1] == lab).sum())
+        correct += right
         num_data += img.size(0)
+        if log is not None:
+            log.append((loss.item(), right, img.shape[0]))
         loss.backward()
         with torch.no_grad():
             for p in model.parameters():
@@ -65,7 +70,7 @@ def train_epoch(model, loader, lr, loss_fun):
 
 
 def test_epoch(model, loader, loss_fun):
-    """federated/fed_run.py:214-259 (IN_test off): eval-mode forward."""
+    """federated/fed_run.py:214-259 (IN_test off): eval-mode forward.  Pinned by tests/golden/fed_loop.npz."""
     model.eval()
     num_data, correct, loss_all, it = 0, 0, 0.0, -1
     with torch.no_grad():

@@ -120,14 +120,28 @@ def resnet50(classes):
     return ResNet(Bottleneck, [3, 4, 6, 3], classes=classes)     # nets/resnet.py:359
 
 
-def seeded_state_dict(model, seed):
+def seeded_state_dict(model, seed, residual_gamma=1.0, fc_gain=1.0):
     """Deterministic (numpy RandomState) re-initialisation with the reference's
     init law (kaiming-normal fan_out for convs, BN gamma=1 beta=0, Linear
     U(-1/sqrt(fan_in), 1/sqrt(fan_in))) so fixtures need not store weights.
     BN gammas are perturbed around 1 and betas around 0 so that parity tests
-    are sensitive to the affine path."""
+    are sensitive to the affine path.
+
+    ``residual_gamma`` scales the gamma of each block's CLOSING BatchNorm (bn3 of a Bottleneck, bn2 of a
+    BasicBlock) and ``fc_gain`` the classifier weight.  With gamma ~ 1 everywhere a randomly initialised
+    50-layer net doubles its activation / gradient scale at every block: the reference's own fp32 and fp64
+    runs of one train step then differ by 1e-3 in the post-step logits and 2 % in conv1's gradient (measured,
+    tools/make_golden.py "noise/*"), so no fp32 implementation can be held to 1e-3 on it.  The reference
+    trains from ImageNet weights (nets/resnet.py:364-369), whose closing gammas are small; residual_gamma=0.25
+    restores that conditioning (fp32-vs-fp64 <= 1e-6 on logits) and fc_gain keeps the logits O(1)."""
     rs = np.random.RandomState(seed)
     sd = {}
+    closing = {}
+    for name, mod in model.named_modules():
+        if isinstance(mod, Bottleneck):
+            closing[name + ".bn3.weight"] = True
+        elif isinstance(mod, BasicBlock):
+            closing[name + ".bn2.weight"] = True
     for k, v in model.state_dict().items():
         if k.endswith("num_batches_tracked"):
             sd[k] = torch.zeros_like(v)
@@ -136,14 +150,15 @@ def seeded_state_dict(model, seed):
             sd[k] = torch.from_numpy(rs.normal(0, np.sqrt(2.0 / fan_out), tuple(v.shape)).astype(np.float32))
         elif v.dim() == 2:
             b = 1.0 / np.sqrt(v.shape[1])
-            sd[k] = torch.from_numpy(rs.uniform(-b, b, tuple(v.shape)).astype(np.float32))
+            sd[k] = torch.from_numpy((rs.uniform(-b, b, tuple(v.shape)) * fc_gain).astype(np.float32))
         elif k.endswith("running_var"):
             sd[k] = torch.ones_like(v)
         elif k.endswith("running_mean"):
             sd[k] = torch.zeros_like(v)
         elif "bn" in k.split(".")[-2] or "downsample.1" in k:
             if k.endswith("weight"):
-                sd[k] = torch.from_numpy(rs.uniform(0.8, 1.2, tuple(v.shape)).astype(np.float32))
+                gam = residual_gamma if k in closing else 1.0
+                sd[k] = torch.from_numpy((rs.uniform(0.8, 1.2, tuple(v.shape)) * gam).astype(np.float32))
             else:
                 sd[k] = torch.from_numpy(rs.normal(0, 0.05, tuple(v.shape)).astype(np.float32))
         else:   # linear bias

@@ -68,7 +68,7 @@ def test_style_transfer_odd(golden):
 
 def _resnet_case(g, model):
     seed, classes, nb = int(g["seed"]), int(g["classes"]), int(g["nb"])
-    model.load_state_dict(R.seeded_state_dict(model, seed))
+    model.load_state_dict(R.seeded_state_dict(model, seed, float(g["residual_gamma"]), float(g["fc_gain"])))
     x, y = R.synth_batch(nb, 222, classes, seed=seed + 1)
     model.eval()
     with torch.no_grad():
@@ -145,3 +145,30 @@ def test_communication_fedbn(golden):
     assert shared == [bool(b) for b in g["shared"]] == ['bn' not in k for k in fkeys]
     assert shared[fkeys.index("layer2.0.downsample.1.weight")] and not shared[fkeys.index("bn1.weight")]
     assert torch.equal(clients[1].state_dict()["bn1.weight"].flatten()[:16], t(g["bn1_weight_client1"]))
+
+
+def test_fed_train_test_loops(golden):
+    """oracle.fed_ref.train_epoch / test_epoch vs the reference's own train() / test() (fed_run.py:31-88, :214-259,
+    AST-extracted and run by tools/make_golden.py with a stub logger): two epochs over a ragged 3-batch loader with
+    one optimiser (fed_run.py:657), a test pass on held-out batches and one on the training batches -- bit for bit."""
+    g = golden("fed_loop")
+    model = R.ResNet(R.BasicBlock, [1, 1, 1, 1], classes=3)
+    model.load_state_dict(R.seeded_state_dict(model, int(g["seed"])))
+    train_loader = [R.synth_batch(int(n), 222, 3, seed=int(s)) for s, n in zip(g["train_seeds"], g["train_sizes"])]
+    test_loader = [R.synth_batch(int(n), 222, 3, seed=int(s)) for s, n in zip(g["test_seeds"], g["test_sizes"])]
+    ce, lr = nn.CrossEntropyLoss(), float(g["lr"])
+    log = []
+    tr1 = Fd.train_epoch(model, train_loader, lr, ce, log=log)
+    te1 = Fd.test_epoch(model, test_loader, ce)
+    tr2 = Fd.train_epoch(model, train_loader, lr, ce, log=log)
+    te2 = Fd.test_epoch(model, train_loader, ce)
+    for got, key in ((tr1, "train1"), (te1, "test1"), (tr2, "train2"), (te2, "test2")):
+        assert np.array_equal(np.array(got, dtype=np.float64), g[key]), (key, got, g[key])
+    assert np.array_equal(np.array([r[0] for r in log], dtype=np.float64), g["log_loss"])
+    assert [r[1] for r in log] == list(g["log_right"]) and [r[2] for r in log] == list(g["log_total"])
+    sd = model.state_dict()
+    assert torch.equal(sd["conv1.weight"].flatten()[:64], t(g["conv1_head"]))
+    assert torch.equal(sd["class_classifier.weight"], t(g["fc_weight"])) and torch.equal(sd["class_classifier.bias"], t(g["fc_bias"]))
+    assert torch.equal(sd["bn1.running_mean"], t(g["bn1_running_mean"])) and torch.equal(sd["bn1.running_var"], t(g["bn1_running_var"]))
+    assert int(sd["bn1.num_batches_tracked"]) == int(g["nbt"]) == 6
+    assert np.array_equal(np.array([float(v.double().sum()) for v in sd.values()]), g["key_sum"])

@@ -185,21 +185,23 @@ def test_pools_linear_ce(dev):
 
 
 def _model_case(dev, g, arch):
-    """One train step vs the reference's own outputs.  Tolerance: 1e-3 (BASELINE.json) plus 8x the
-    problem's conditioning noise |reference fp32 - reference fp64| stored with each probe
-    (tools/make_golden.py): tiny-batch train-mode BN + ReLU/max-pool masks make some gradient
-    probes of the randomly initialised ResNet-50 ill-conditioned for ANY fp32 implementation."""
+    """One train step vs the reference's own outputs (tests/golden/resnet*_step.npz).  Logits (eval, train, post-step) and
+    the loss are held to BASELINE.json's 1e-3 flat: the fixture's weights are conditioned like a trained net (small closing-BN
+    gammas, oracle.resnet_ref.seeded_state_dict), so the reference's own fp32-vs-fp64 difference on them is <= 1e-5 and is
+    asserted to be.  Gradient PROBES (single elements of conv1 / early-layer gradients behind ~50 ReLU / max-pool masks) keep a
+    term scaled by the reference's own |fp32 - fp64| on the probed elements."""
     from ccst_amd import fed
     from ccst_amd.nets import models
     from oracle import resnet_ref as R
     seed, classes, nb, lr = int(g["seed"]), int(g["classes"]), int(g["nb"]), float(g["lr"])
 
     def tol(key):
-        return 1e-3 + 8.0 * float(g["noise/" + key])
+        assert float(g["noise/" + key]) < 1e-4, ("fixture is ill-conditioned", key, float(g["noise/" + key]))
+        return 1e-3
 
     model = models.get_network(arch)(ARGS, pretrained=False, classes=classes)
     oracle = R.resnet18(classes) if arch == "resnet18" else R.resnet50(classes)
-    model.load_state_dict(R.seeded_state_dict(oracle, seed))
+    model.load_state_dict(R.seeded_state_dict(oracle, seed, float(g["residual_gamma"]), float(g["fc_gain"])))
     model.to(dev)
     x, y = R.synth_batch(nb, 222, classes, seed=seed + 1)
     x, y = x.to(dev), y.to(dev)
@@ -256,6 +258,49 @@ def test_resnet18_step_golden(dev, golden):
 
 def test_resnet50_step_golden(dev, golden):
     _model_case(dev, golden("resnet50_step"), "resnet50")
+
+
+def test_resnet50_full_size_step_vs_oracle(dev):
+    """BASELINE config 4 at its own size -- ResNet50, B=64, 222x222, SGD lr 0.001 (SURVEY 8d "Synthetic inputs 2") -- one
+    whole train step against ONE step of the CPU oracle (pinned bit-for-bit to the reference's ResNet / train(), see
+    tests/test_oracle_golden.py): train-mode logits, loss, accuracy count, every BN's running statistics and the post-step
+    eval-mode logits, all at 1e-3."""
+    from ccst_amd import fed
+    from ccst_amd.nets import models
+    from oracle import resnet_ref as R
+    torch.set_num_threads(max(1, len(__import__("os").sched_getaffinity(0))))
+    classes, nb, lr = 7, 64, 0.001
+    oracle = R.resnet50(classes)
+    sd = R.seeded_state_dict(oracle, 77, residual_gamma=0.25, fc_gain=8.0)
+    oracle.load_state_dict(sd)
+    x, y = R.synth_batch(nb, 222, classes, seed=78)
+    loss_ref, logit_ref = R.train_step(oracle, x, y, lr)
+    oracle.eval()
+    with torch.no_grad():
+        after_ref = oracle(x[:16])
+    model = models.get_network("resnet50")(ARGS, pretrained=False, classes=classes)
+    model.load_state_dict(sd)
+    model.to(dev).train()
+    opt, ce = fed.SGD(model, lr=lr), fed.CrossEntropyLoss()
+    opt.zero_grad()
+    logit = model(x.to(dev))
+    loss = ce(logit, y.to(dev))
+    loss.backward()
+    opt.step()
+    assert float(logit_ref.abs().max()) > 0.5                                      # the 1e-3 below is not vacuous
+    assert float((logit.detach().cpu() - logit_ref).abs().max()) < 1e-3
+    assert abs(float(loss.detach()) - float(loss_ref)) < 1e-3
+    assert int(ce.correct) == int((logit_ref.argmax(1) == y).sum())
+    osd, msd = oracle.state_dict(), model.state_dict()
+    for k, v in osd.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert float((msd[k].cpu() - v).abs().max()) < 1e-3 * max(1.0, float(v.abs().max())), k
+    worst = max(float((msd[k].cpu() - v).abs().max()) for k, v in osd.items() if v.dtype == torch.float32)
+    assert worst < 1e-3, worst                                                     # every updated weight
+    model.eval()
+    with torch.no_grad():
+        after = model(x[:16].to(dev))
+    assert float((after.cpu() - after_ref).abs().max()) < 1e-3
 
 
 def test_communication_golden(dev, golden):
@@ -327,26 +372,50 @@ def test_communication_fedbn_golden(dev, golden):
     assert [int(server.state_dict()[k]) for k in nbt] == list(g["nbt_server"])
 
 
-def test_train_and_test_loops(dev):
-    """train()/test() (fed_run.py:31-88,214-259) on a tiny synthetic loader vs the oracle loops."""
+def test_train_and_test_loops(dev, golden):
+    """train()/test() vs THE REFERENCE'S OWN train()/test() (fed_run.py:31-88,214-259, run by tools/make_golden.py ->
+    tests/golden/fed_loop.npz): two epochs over a ragged 3-batch loader with one optimiser, a held-out test pass and
+    a test pass over the training batches; per-iteration logger rows, epoch returns and the post-epoch state."""
     from ccst_amd import fed
     from ccst_amd.nets import resnet
-    from oracle import fed_ref, resnet_ref as R
+    from oracle import resnet_ref as R
+    g = golden("fed_loop")
     classes = 3
     ours = resnet.ResNet(resnet.BasicBlock, [1, 1, 1, 1], classes=classes)
-    ref = R.ResNet(R.BasicBlock, [1, 1, 1, 1], classes=classes)
-    sd = R.seeded_state_dict(ref, 91)
-    ours.load_state_dict(sd)
-    ref.load_state_dict(sd)
-    loader = [R.synth_batch(4, 222, classes, seed=100 + i) for i in range(2)]
-    rl, ra = fed_ref.train_epoch(ref, loader, 0.001, nn.CrossEntropyLoss())
+    ours.load_state_dict(R.seeded_state_dict(R.ResNet(R.BasicBlock, [1, 1, 1, 1], classes=classes), int(g["seed"])))
+    train_loader = [R.synth_batch(int(n), 222, classes, seed=int(s)) for s, n in zip(g["train_seeds"], g["train_sizes"])]
+    test_loader = [R.synth_batch(int(n), 222, classes, seed=int(s)) for s, n in zip(g["test_seeds"], g["test_sizes"])]
+
+    class Log(object):
+        rows = []
+
+        def log(self, it, iters, losses, samples_right, total_samples):
+            self.rows.append((it, iters, float(losses["train_loss"]), int(samples_right["class_acc"]), int(total_samples)))
+
+    logger = Log()
     ours.to(dev)
-    opt = fed.SGD(ours, lr=0.001)
-    tl, ta = fed.train(ours, loader, opt, fed.CrossEntropyLoss(), 0, dev, ARGS, 0, None)
-    assert abs(tl - rl) < 1e-3 and abs(ta - ra) < 1e-6
-    el, ea = fed.test(ours, loader, fed.CrossEntropyLoss(), dev, ARGS)
-    rel, rea = fed_ref.test_epoch(ref, loader, nn.CrossEntropyLoss())
-    assert abs(el - rel) < 2e-3 and abs(ea - rea) < 1e-6, (el, rel)
+    opt = fed.SGD(ours, lr=float(g["lr"]))                       # one optimiser for both epochs, as fed_run.py:657-664
+    ce = fed.CrossEntropyLoss()
+    tr1 = fed.train(ours, train_loader, opt, ce, 3, dev, ARGS, 0, logger)
+    te1 = fed.test(ours, test_loader, ce, dev, ARGS)
+    tr2 = fed.train(ours, train_loader, opt, ce, 3, dev, ARGS, 1, logger)
+    te2 = fed.test(ours, train_loader, ce, dev, ARGS)
+    for got, key in ((tr1, "train1"), (te1, "test1"), (tr2, "train2"), (te2, "test2")):
+        assert abs(got[0] - float(g[key][0])) < 1e-3, (key, got, g[key])
+        assert got[1] == float(g[key][1]), (key, got, g[key])                 # accuracies are exact ratios
+    assert [r[0] for r in logger.rows] == list(g["log_it"]) and [r[1] for r in logger.rows] == list(g["log_iters"])
+    assert [r[3] for r in logger.rows] == list(g["log_right"]) and [r[4] for r in logger.rows] == list(g["log_total"])
+    assert np.abs(np.array([r[2] for r in logger.rows]) - g["log_loss"]).max() < 1e-3
+    sd = ours.state_dict()
+    for key, name in (("conv1_head", "conv1.weight"), ("fc_weight", "class_classifier.weight"), ("fc_bias", "class_classifier.bias"),
+                      ("bn1_running_mean", "bn1.running_mean"), ("bn1_running_var", "bn1.running_var"),
+                      ("l4_bn2_weight", "layer4.0.bn2.weight")):
+        ref = torch.from_numpy(g[key]).flatten()
+        got = sd[name].flatten()[:ref.numel()].cpu()
+        assert float((got - ref).abs().max()) < 1e-3 * max(1.0, float(ref.abs().max())), key
+    assert int(sd["bn1.num_batches_tracked"]) == int(g["nbt"])
+    kabs = np.array([float(v.double().abs().sum()) for v in sd.values()])
+    assert np.allclose(kabs, g["key_abs"], rtol=1e-3)
 
 
 def test_train_hip_graph_matches_eager(dev):

@@ -6,7 +6,7 @@ Runs only where /root/reference exists (the build container).  It
   * AST-extracts (and exec's, unmodified) the script-level functions
     ``style_transfer`` (CCST_OverallStyleTransfer.py:32), ``calc_sum``
     (mean_std_computation_effcientMem.py:103 and CCST_SingleStyleTransfer.py:55)
-    and ``train`` / ``test`` / ``communication`` (federated/fed_run.py:31,214,385)
+    and ``train`` / ``test`` / ``communication`` (federated/fed_run.py:31,214,385; ``train``/``test`` with a stub logger)
     because the scripts themselves execute argparse/model loading on import and
     need torchvision,
   * imports nets/resnet.py behind a stub ``torchvision.models.resnet`` that
@@ -53,8 +53,12 @@ def extract_functions(path, names, namespace):
 ONLY = set(sys.argv[1:])      # e.g. `python tools/make_golden.py communication_fedbn` rewrites just that fixture
 
 
+def wanted(name):
+    return not ONLY or name in ONLY
+
+
 def save(name, **arrs):
-    if ONLY and name not in ONLY:
+    if not wanted(name):
         print("skipped", name)
         return
     out = {}
@@ -179,10 +183,13 @@ def _run_case(model, x, y, lr):
     return logit_eval, logit_train, loss, g, logit_after, model.state_dict()
 
 
-def resnet_case(name, block, layers, classes, nb, seed, lr=0.001):
+def resnet_case(name, block, layers, classes, nb, seed, lr=0.001, residual_gamma=0.25, fc_gain=8.0):
+    if not wanted(name):
+        return
     model = ref_resnet.ResNet(block, layers, classes=classes)
     ours = R.ResNet(block, layers, classes=classes)
-    sd = R.seeded_state_dict(ours, seed)
+    # conditioned like a trained net (small closing-BN gammas), see oracle.resnet_ref.seeded_state_dict
+    sd = R.seeded_state_dict(ours, seed, residual_gamma=residual_gamma, fc_gain=fc_gain)
     model.load_state_dict(sd)
     x, y = R.synth_batch(nb, 222, classes, seed=seed + 1)
     model.eval()
@@ -228,12 +235,12 @@ def resnet_case(name, block, layers, classes, nb, seed, lr=0.001):
             # the 16-element head is a small sample of the tensor's error distribution: also keep the reference's own
             # worst fp32 error over the WHOLE gradient tensor (same conditioning, far steadier estimate)
             probe["noise_full/grad/" + n_] = (g[n_].double() - g64[n_]).abs().max()
-    save(name, seed=seed, classes=classes, nb=nb, lr=lr, logit_eval=logit_eval, logit_train=logit_train,
+    save(name, seed=seed, classes=classes, nb=nb, lr=lr, residual_gamma=residual_gamma, fc_gain=fc_gain, logit_eval=logit_eval, logit_train=logit_train,
          loss=loss, logit_after=logit_after, **probe)
 
 
-resnet_case("resnet18_step", R.BasicBlock, [2, 2, 2, 2], 2, 4, seed=50)
-resnet_case("resnet50_step", R.Bottleneck, [3, 4, 6, 3], 7, 8, seed=60)
+resnet_case("resnet18_step", R.BasicBlock, [2, 2, 2, 2], 2, 8, seed=50)
+resnet_case("resnet50_step", R.Bottleneck, [3, 4, 6, 3], 7, 16, seed=60)
 
 # communication() on 3 perturbed clients (fed_run.py:385-455, fedavg branch)
 nsf = {"torch": torch, "nn": nn}
@@ -291,4 +298,46 @@ save("communication_fedbn", seed=70, weights=weights, keys=np.array(fkeys),
      ds_bn_weight_client1=clients[1].state_dict()["layer2.0.downsample.1.weight"].flatten()[:16],
      nbt_server=[int(server.state_dict()[k]) for k in keys if "num_batches_tracked" in k],
      nbt_clients=[[int(c.state_dict()[k]) for k in keys if "num_batches_tracked" in k] for c in clients])
+# train() / test() (fed_run.py:31-88, :214-259): the reference's own loops, AST-extracted, on a 3-batch seeded loader with a
+# ragged last batch (4, 4, 3 images).  The reference's ResNet class carries the oracle's restated blocks (see above).
+import math  # noqa: E402
+from collections import OrderedDict  # noqa: E402
+
+
+class _StubLogger(object):
+    """utils/Logger.py needs tensorflow; train() only calls .log(it, n, losses, samples_right, total_samples)."""
+
+    def __init__(self):
+        self.rows = []
+
+    def log(self, it, iters, losses, samples_right, total_samples):
+        self.rows.append((it, iters, float(losses["train_loss"]), int(samples_right["class_acc"]), int(total_samples)))
+
+
+nsl = {"torch": torch, "nn": nn, "copy": copy, "math": math, "OrderedDict": OrderedDict}
+extract_functions(os.path.join(REF, "federated/fed_run.py"), {"train", "test"}, nsl)
+largs = types.SimpleNamespace(dg_method="no_DG", network="resnet18", n_classes=3, IN_test=False, jig_weight=0.0)
+lmodel = ref_resnet.ResNet(R.BasicBlock, [1, 1, 1, 1], classes=3)
+lmodel.load_state_dict(R.seeded_state_dict(R.ResNet(R.BasicBlock, [1, 1, 1, 1], classes=3), 91))
+train_loader = [R.synth_batch(n, 222, 3, seed=100 + i) for i, n in enumerate((4, 4, 3))]
+test_loader = [R.synth_batch(n, 222, 3, seed=200 + i) for i, n in enumerate((4, 2))]
+logger = _StubLogger()
+opt = torch.optim.SGD(params=lmodel.parameters(), lr=0.01)                      # fed_run.py:657
+loss_fun = nn.CrossEntropyLoss()                                                # fed_run.py:554
+tr1 = nsl["train"](lmodel, train_loader, opt, loss_fun, 3, torch.device("cpu"), largs, 0, logger)
+te1 = nsl["test"](lmodel, test_loader, loss_fun, torch.device("cpu"), largs)
+tr2 = nsl["train"](lmodel, train_loader, opt, loss_fun, 3, torch.device("cpu"), largs, 1, logger)
+te2 = nsl["test"](lmodel, train_loader, loss_fun, torch.device("cpu"), largs)
+lsd = lmodel.state_dict()
+save("fed_loop", seed=91, train_seeds=[100, 101, 102], train_sizes=[4, 4, 3], test_seeds=[200, 201], test_sizes=[4, 2], lr=0.01,
+     train1=np.array(tr1, dtype=np.float64), test1=np.array(te1, dtype=np.float64),
+     train2=np.array(tr2, dtype=np.float64), test2=np.array(te2, dtype=np.float64),
+     log_loss=np.array([r[2] for r in logger.rows], dtype=np.float64), log_right=np.array([r[3] for r in logger.rows]),
+     log_total=np.array([r[4] for r in logger.rows]), log_it=np.array([r[0] for r in logger.rows]),
+     log_iters=np.array([r[1] for r in logger.rows]),
+     conv1_head=lsd["conv1.weight"].flatten()[:64], fc_weight=lsd["class_classifier.weight"], fc_bias=lsd["class_classifier.bias"],
+     bn1_running_mean=lsd["bn1.running_mean"], bn1_running_var=lsd["bn1.running_var"],
+     l4_bn2_weight=lsd["layer4.0.bn2.weight"], nbt=int(lsd["bn1.num_batches_tracked"]),
+     key_sum=np.array([float(v.double().sum()) for v in lsd.values()]),
+     key_abs=np.array([float(v.double().abs().sum()) for v in lsd.values()]))
 print("done")
