@@ -26,6 +26,12 @@ class CcstConvDesc(Structure):
                 ("flags", c_uint32)]
 
 
+class CcstImageXform(Structure):
+    _fields_ = [("src_off", c_int64), ("src_w", c_int32), ("crop_i", c_int32), ("crop_j", c_int32), ("crop_h", c_int32),
+                ("crop_w", c_int32), ("flip", c_int32), ("kx", c_int32), ("ky", c_int32),
+                ("bounds_x", c_int32), ("coefs_x", c_int32), ("bounds_y", c_int32), ("coefs_y", c_int32)]
+
+
 _P = c_void_p
 # name -> argtypes (restype is int unless listed in _RESTYPES).  Every symbol of include/ccst_hip.h.
 _SIGNATURES = {
@@ -54,6 +60,8 @@ _SIGNATURES = {
     "ccst_nchw_to_nhwc_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "ccst_nhwc_to_nchw_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "ccst_quantize_u8_hwc_f32": [_P, _P, c_int, c_int, c_int, _P],
+    "ccst_image_plan": [c_int, _P, c_int, c_int, _P, c_int64],
+    "ccst_crop_resize_norm_u8_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P],
     "ccst_conv2d_bwd_weight_f32": [POINTER(CcstConvDesc), _P, _P, _P, c_int, c_int, _P, c_int64, _P],
     "ccst_conv2d_bwd_weight_splits": [c_int, c_int, c_int, c_int],
     "ccst_calc_mean_std_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, c_int64, _P],
@@ -75,7 +83,7 @@ _SIGNATURES = {
     "ccst_scale_f32": [_P, c_float, c_int64, _P],
 }
 _RESTYPES = {"ccst_last_error": c_char_p, "ccst_stats_workspace_bytes": c_int64, "ccst_bn_workspace_bytes": c_int64,
-             "ccst_wino_weight_floats": c_int64}
+             "ccst_wino_weight_floats": c_int64, "ccst_image_plan": c_int64}
 EXPORTS = tuple(_SIGNATURES)
 
 _lib = None

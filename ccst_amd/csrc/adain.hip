@@ -1,9 +1,14 @@
 // AdaIN feature statistics and normalisation (HBM-bound; gfx950).
 //
 //   partials : per-(n, split, c) fp32 sum and sum of squares over a slice of the H*W plane
-//              (each thread adds <= a few dozen values in fp32; wide 16-B loads)
-//   finalize : combines the split partials in fp64 -> mean, sqrt(var_unbiased+eps)   (calc_mean_std,
-//              function.py:4-13) or per-channel totals over N too (calc_sum, mean_std...py:103-115)
+//              (each thread adds <= a few dozen values in fp32; wide 16-B loads).  For calc_mean_std / AdaIN
+//              (SHIFT) the sums are of d = x - pivot, pivot = the slice's own first element of that channel:
+//              the reference computes a two-pass variance (function.py:9), and raw fp32 sum(x^2) loses it
+//              entirely once |mean| >> sigma (100 +- 0.01: ulp(1e4) = 1e-3 vs var = 1e-4) or the plane is
+//              constant; shifted sums keep |d| ~ sigma, and a constant slice gives exactly 0.
+//   finalize : per slice mean_k = pivot_k + sum d / n_k, M2_k = sum d^2 - (sum d)^2 / n_k, merged over the
+//              slices in fp64 (Chan et al.) -> mean, sqrt(M2/(HW-1)+eps)   (calc_mean_std, function.py:4-13);
+//              or raw per-channel totals over N too (calc_sum, mean_std...py:103-115: fp32 sums as the reference).
 //   apply    : y = ((x-mu_c)/sigma_c)*sigma_s+mu_s, then y*alpha + x*(1-alpha)      (function.py:26-33,
 //              CCST_OverallStyleTransfer.py:45), one read + one write of the tensor.
 // layout 0 = NCHW planes (API tensors), 1 = NHWC (the pipeline's internal layout).
@@ -14,6 +19,7 @@ namespace {
 constexpr int TPB = 256;
 
 // ---- NHWC: x[n][p][c]; thread = one float4 channel group, PL pixel lanes per block -----------
+template <bool SHIFT>
 __global__ __launch_bounds__(TPB) void partials_nhwc_kernel(const float* __restrict__ x, float* __restrict__ part, int HW, int C,
                                                             int S, int cgb, int PL) {
     __shared__ f32x4 red[2][TPB];
@@ -24,10 +30,12 @@ __global__ __launch_bounds__(TPB) void partials_nhwc_kernel(const float* __restr
     const int per = (HW + S - 1) / S;
     const int p0 = split * per, p1 = min(HW, p0 + per);
     f32x4 s = {0, 0, 0, 0}, q = {0, 0, 0, 0};
-    if (pl < PL && cg * 4 < C) {
+    if (pl < PL && cg * 4 < C && p0 < p1) {
         const float* base = x + ((long long)n * HW) * C + cg * 4;
+        f32x4 pv = {0, 0, 0, 0};
+        if (SHIFT) pv = *reinterpret_cast<const f32x4*>(base + (long long)p0 * C);
         for (int p = p0 + pl; p < p1; p += PL) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)p * C);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)p * C) - pv;
             s += v;
             q += v * v;
         }
@@ -51,6 +59,7 @@ __global__ __launch_bounds__(TPB) void partials_nhwc_kernel(const float* __restr
 }
 
 // ---- NCHW: plane (n,c) contiguous; block = (plane, split) -----------------------------------
+template <bool SHIFT>
 __global__ __launch_bounds__(TPB) void partials_nchw_kernel(const float* __restrict__ x, float* __restrict__ part, int HW, int C,
                                                             int S) {
     __shared__ float red[2][TPB / 64];
@@ -60,8 +69,9 @@ __global__ __launch_bounds__(TPB) void partials_nchw_kernel(const float* __restr
     const int p0 = split * per, p1 = min(HW, p0 + per);
     const float* base = x + (long long)plane * HW;
     float s = 0.f, q = 0.f;
+    const float pv = (SHIFT && p0 < p1) ? base[p0] : 0.f;
     for (int p = p0 + threadIdx.x; p < p1; p += TPB) {
-        const float v = base[p];
+        const float v = base[p] - pv;
         s += v;
         q += v * v;
     }
@@ -84,37 +94,58 @@ __global__ __launch_bounds__(TPB) void partials_nchw_kernel(const float* __restr
     }
 }
 
-// mean/std per (n,c) from the split partials, combined in fp64.  A workgroup owns 16 consecutive (n,c) pairs;
-// 16 split-lanes per pair each sum every 16th partial (coalesced: consecutive threads read consecutive channels of
-// one split), then the lanes are folded in fixed order through LDS -- the serial loop over <= 256 splits that this
-// replaces was 43 us of pure latency per batch.
-__global__ __launch_bounds__(256) void finalize_mean_std_kernel(const float* __restrict__ part, float* __restrict__ mean,
-                                                                float* __restrict__ stdv, int N, int C, int S, int HW, float eps) {
-    __shared__ double red[2][16][17];
+// mean/std per (n,c) from the SHIFTED split partials, merged in fp64.  A workgroup owns 16 consecutive (n,c) pairs;
+// 16 split-lanes per pair each fold every 16th slice (coalesced: consecutive threads read consecutive channels of
+// one split), then the lanes are folded in fixed order through LDS.  Two rounds: the plane mean (sum n_k * mean_k),
+// then M2 = sum M2_k + n_k (mean_k - mean)^2.
+__global__ __launch_bounds__(256) void finalize_mean_std_kernel(const float* __restrict__ x, const float* __restrict__ part,
+                                                                float* __restrict__ mean, float* __restrict__ stdv, int N, int C, int S,
+                                                                int HW, int layout, float eps) {
+    __shared__ double red[16][17];
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + cl;
-    double s = 0.0, q = 0.0;
-    if (i < N * C) {
-        const int n = i / C, c = i - n * C;
+    const bool live = i < N * C;
+    const int n = live ? i / C : 0, c = live ? i - n * C : 0;
+    const int per = (HW + S - 1) / S;
+    auto slice = [&](int k, double& cnt, double& mk, double& m2k) {
+        const int p0 = k * per, p1 = min(HW, p0 + per);
+        cnt = (double)max(0, p1 - p0);
+        if (p1 <= p0) { mk = 0.0; m2k = 0.0; return; }
+        const float2 o = *reinterpret_cast<const float2*>(part + (((long long)n * S + k) * C + c) * 2);
+        const double pv = (double)(layout == 1 ? x[((long long)n * HW + p0) * C + c] : x[((long long)n * C + c) * HW + p0]);
+        const double sd = (double)o.x, qd = (double)o.y;
+        mk = pv + sd / cnt;
+        m2k = qd - sd * sd / cnt;
+        if (m2k < 0.0) m2k = 0.0;
+    };
+    double acc = 0.0;
+    if (live)
         for (int k = sl; k < S; k += 16) {
-            const float2 o = *reinterpret_cast<const float2*>(part + (((long long)n * S + k) * C + c) * 2);
-            s += (double)o.x;
-            q += (double)o.y;
+            double cnt, mk, m2k;
+            slice(k, cnt, mk, m2k);
+            acc += cnt * mk;
         }
-    }
-    red[0][sl][cl] = s;
-    red[1][sl][cl] = q;
+    red[sl][cl] = acc;
     __syncthreads();
-    if (sl == 0 && i < N * C) {
+    double tot = 0.0;
 #pragma unroll
-        for (int k = 1; k < 16; ++k) {
-            s += red[0][k][cl];
-            q += red[1][k][cl];
+    for (int k = 0; k < 16; ++k) tot += red[k][cl];
+    const double mu = tot / (double)HW;
+    __syncthreads();
+    acc = 0.0;
+    if (live)
+        for (int k = sl; k < S; k += 16) {
+            double cnt, mk, m2k;
+            slice(k, cnt, mk, m2k);
+            acc += m2k + cnt * (mk - mu) * (mk - mu);
         }
-        const double cnt = (double)HW;
-        const double mu = s / cnt;
-        double var = (q - s * mu) / (cnt - 1.0);   // unbiased, function.py:9 (HW==1 -> NaN like the reference)
-        if (var < 0.0) var = 0.0;
+    red[sl][cl] = acc;
+    __syncthreads();
+    if (sl == 0 && live) {
+        double m2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) m2 += red[k][cl];
+        const double var = m2 / ((double)HW - 1.0);   // unbiased, function.py:9 (HW==1 -> NaN like the reference)
         mean[i] = (float)mu;
         stdv[i] = sqrtf((float)var + eps);
     }
@@ -136,8 +167,9 @@ __global__ void finalize_chan_sums_kernel(const float* __restrict__ part, float*
 }
 
 __device__ __forceinline__ float adain_one(float x, float mu, float sd, float sm, float ss, float alpha, bool blend) {
-    float t = ((x - mu) / sd) * ss + sm;          // evaluation order of function.py:31-33
-    if (blend) t = t * alpha + x * (1.f - alpha); // CCST_OverallStyleTransfer.py:45
+    // evaluation order AND rounding of function.py:31-33 (sub, div, mul, add as four separately rounded tensor ops: no FMA)
+    float t = __fadd_rn(__fmul_rn(__fdiv_rn(__fsub_rn(x, mu), sd), ss), sm);
+    if (blend) t = __fadd_rn(__fmul_rn(t, alpha), __fmul_rn(x, 1.f - alpha)); // CCST_OverallStyleTransfer.py:45
     return t;
 }
 
@@ -190,16 +222,17 @@ int pick_splits(int N, int C, int HW, int layout) {
     return (int)s;
 }
 
+template <bool SHIFT>
 int run_partials(const float* x, float* part, int N, int C, int HW, int layout, int S, hipStream_t st) {
     if (layout == 1) {
         const int cg = C / 4;
         const int cgb = cg < TPB ? cg : TPB;
         const int PL = TPB / cgb;
         dim3 grid(S, (cg + cgb - 1) / cgb, N);
-        hipLaunchKernelGGL(partials_nhwc_kernel, grid, dim3(TPB), 0, st, x, part, HW, C, S, cgb, PL);
+        hipLaunchKernelGGL(partials_nhwc_kernel<SHIFT>, grid, dim3(TPB), 0, st, x, part, HW, C, S, cgb, PL);
     } else {
         dim3 grid(S, N * C);
-        hipLaunchKernelGGL(partials_nchw_kernel, grid, dim3(TPB), 0, st, x, part, HW, C, S);
+        hipLaunchKernelGGL(partials_nchw_kernel<SHIFT>, grid, dim3(TPB), 0, st, x, part, HW, C, S);
     }
     return ccst_launch_status("stats partials");
 }
@@ -234,9 +267,9 @@ extern "C" int ccst_calc_mean_std_f32(const float* x, float* mean, float* stdv, 
     hipStream_t st = (hipStream_t)stream;
     const int S = pick_splits(N, C, HW, layout);
     float* part = (float*)ws;
-    rc = run_partials(x, part, N, C, HW, layout, S, st);
+    rc = run_partials<true>(x, part, N, C, HW, layout, S, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(finalize_mean_std_kernel, dim3((N * C + 15) / 16), dim3(256), 0, st, part, mean, stdv, N, C, S, HW, eps);
+    hipLaunchKernelGGL(finalize_mean_std_kernel, dim3((N * C + 15) / 16), dim3(256), 0, st, x, part, mean, stdv, N, C, S, HW, layout, eps);
     return ccst_launch_status("finalize_mean_std");
 }
 
@@ -281,7 +314,7 @@ extern "C" int ccst_chan_sums_f32(const float* x, float* sum, float* sqsum, int 
     hipStream_t st = (hipStream_t)stream;
     const int S = pick_splits(N, C, HW, layout);
     float* part = (float*)ws;
-    rc = run_partials(x, part, N, C, HW, layout, S, st);
+    rc = run_partials<false>(x, part, N, C, HW, layout, S, st);
     if (rc) return rc;
     hipLaunchKernelGGL(finalize_chan_sums_kernel, dim3((C + 63) / 64), dim3(64), 0, st, part, sum, sqsum, N, C, S);
     return ccst_launch_status("finalize_chan_sums");

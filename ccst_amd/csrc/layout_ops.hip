@@ -97,7 +97,7 @@ __global__ void quantize_u8_hwc_kernel(const float* __restrict__ x, unsigned cha
         const long long n = i / HW;
         const int p = (int)(i - n * HW);
         for (int c = 0; c < C; ++c) {
-            float v = x[(n * C + c) * HW + p] * 255.f + 0.5f;
+            float v = __fadd_rn(__fmul_rn(x[(n * C + c) * HW + p], 255.f), 0.5f);     // mul(255).add_(0.5): two roundings, never an FMA
             v = fminf(fmaxf(v, 0.f), 255.f);
             y[i * C + c] = (unsigned char)v;
         }

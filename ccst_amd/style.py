@@ -99,14 +99,13 @@ class StyleStatAccumulator(object):
 
 def domain_style_stat(vgg, loader, device, world=1, rank=0, progress=None):
     """Stage 1 as a function (mean_std_computation_effcientMem.py:117-137): stream one domain's loader through
-    vgg[:31], accumulate the per-channel sums (this rank's share of the batches), all-reduce the additive triple,
-    finalise.  Returns ([mean, std] as stage 2 consumes them, accumulator).  Used by the stage-1 CLI and by stage
+    vgg[:31], accumulate the per-channel sums, all-reduce the additive triple, finalise.  Under torchrun `loader` is
+    already this rank's shard of the domain's list (data.get_train_dataloader(..., rank, world)): the shards partition
+    the list whatever each rank's RNG does, so every image is counted exactly once.  Returns ([mean, std] as stage 2 consumes them, accumulator).  Used by the stage-1 CLI and by stage
     2's --fuse_stats, which skips the .npy round trip and keeps the file only as a cache."""
     acc = StyleStatAccumulator()
     with torch.no_grad():
         for it, (batch, _) in enumerate(loader):
-            if it % world != rank:
-                continue
             acc.update(vgg(batch.to(device)))
             if progress is not None:
                 progress(it, len(loader))

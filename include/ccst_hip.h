@@ -163,6 +163,31 @@ int ccst_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int HW, int Cs
  * NCHW float -> NHWC uint8 with v*255+0.5 clamped to [0,255]. */
 int ccst_quantize_u8_hwc_f32(const float* x_nchw, uint8_t* y_nhwc, int N, int C, int HW, void* stream);
 
+/* Image input edge on the GPU.  Replaces, per image, the CPU transform chain of
+ * data/data_helper.py:161-181 (train: RandomResizedCrop -> ToTensor -> Normalize -> RandomHorizontalFlip; val:
+ * Resize -> ToTensor -> Normalize) and style_transfer/AdaIN/cjm_util/data_helper.py:46-49 (Resize -> ToTensor):
+ *   out[n,c,oy,ox'] = ((PIL_bilinear_resize(crop(src_n))[oy,ox,c] / 255) - mean[c]) / std[c],  ox' = flip ? W-1-ox : ox
+ * byte-identical to PIL's uint8 resize (libImaging/Resample.c fixed-point tables, built on the host by
+ * ccst_image_plan) and bit-identical to the fp32 ToTensor/Normalize arithmetic.
+ * The caller fills src_off, src_w, crop_i..crop_w and flip of every CcstImageXform; ccst_image_plan, a HOST function that needs no GPU, fills
+ * kx/ky and the table offsets and writes the int32 tables; it returns the number of int32 used (call it with
+ * tables == NULL to size the buffer), or a negative CCST_E* code.  xf and tables are then copied to the device
+ * for ccst_crop_resize_norm_u8_f32: src = packed uint8 HWC (3-channel) decoded images, dst_nchw fp32 [n,3,H,W]
+ * and/or dst_u8_nhwc uint8 [n,H,W,3] (the un-normalised resize, either may be NULL); mean3/std3 are HOST
+ * pointers to three floats (NULL = 0 / 1, i.e. ToTensor only). */
+typedef struct CcstImageXform {
+    int64_t src_off;                            /* byte offset of the image's first pixel in src             */
+    int32_t src_w;                              /* decoded width (row pitch = 3*src_w bytes)                 */
+    int32_t crop_i, crop_j, crop_h, crop_w;     /* torchvision F.resized_crop rectangle: top, left, h, w     */
+    int32_t flip;                               /* horizontal flip of the OUTPUT                             */
+    int32_t kx, ky;                             /* (plan) taps per output column / row                       */
+    int32_t bounds_x, coefs_x, bounds_y, coefs_y; /* (plan) int32 offsets into tables                        */
+} CcstImageXform;
+int64_t ccst_image_plan(int n, CcstImageXform* xf, int out_h, int out_w, int32_t* tables, int64_t cap);
+int ccst_crop_resize_norm_u8_f32(const uint8_t* src, const CcstImageXform* xf, const int32_t* tables, float* dst_nchw,
+                                 uint8_t* dst_u8_nhwc, int n, int out_h, int out_w, const float* mean3,
+                                 const float* std3, void* stream);
+
 /* Backward-weight: dW[tap][ci][co] = sum_m X[n, oy*ay+ky*by+cy, ox*ax+kx*bx+cx, ci] * dY[m, co]
  * (zero padding; x indexed with d's x strides, dY dense [M][cout]), split over `splits` pixel
  * ranges into ws[splits][ntap][cin][cout] partial slabs, then summed in fixed order (bitwise

@@ -2,8 +2,8 @@
 """Drop-in for the reference's style_transfer/AdaIN/CCST_OverallStyleTransfer.py (stage 2, overall
 mode): for every other domain's {style}_mean_std.npy, encoder -> AdaIN(stat) -> alpha blend -> decoder
 on every content batch, save the images under all_style_transferred_Overall (:138-175).  Same flags
-(:49-93).  Under torchrun, content batches are sharded over ranks (images are independent: no
-collective).
+(:49-93).  Under torchrun the content LIST is sharded over ranks by entry (disjoint and complete whatever each
+rank's shuffle would have drawn; images are independent: no collective).
 
 --fuse_stats (addition): stage 1 and stage 2 in one process -- a style domain whose
 {style}_mean_std.npy is absent (or every domain with --refresh_stats) has its statistics computed here by
@@ -38,7 +38,7 @@ if world > 1 and args.fuse_stats:
     dist.init_process_group(backend="nccl", device_id=device)       # only the fused statistics need a collective
 
 vgg, decoder = load_networks(args, device)
-data_loader = data.get_train_dataloader(args, args.txt_root)
+data_loader = data.get_train_dataloader(args, args.txt_root, rank, world)      # this rank's shard of the content list
 
 
 def style_stat_of(style_name):
@@ -47,7 +47,7 @@ def style_stat_of(style_name):
         return style.load_style_stat(path, device)                    # :140-144
     sargs = copy.copy(args)
     sargs.target = style_name
-    stat, acc = style.domain_style_stat(vgg, data.get_train_dataloader(sargs, args.txt_root), device, world, rank)
+    stat, acc = style.domain_style_stat(vgg, data.get_train_dataloader(sargs, args.txt_root, rank, world), device, world, rank)
     print(f"    computed style statistics of {style_name} from {acc.images} images")
     if rank == 0:
         os.makedirs(os.path.dirname(path), exist_ok=True)
@@ -61,8 +61,6 @@ for style_name in style_domains:
     start_time = datetime.now()
     img_count = 0
     for it, (batch, fpaths) in enumerate(data_loader):
-        if it % world != rank:
-            continue
         img_count += len(batch)
         with torch.no_grad():
             output = style.style_transfer(vgg, decoder, batch.to(device), style_stat, args.alpha)

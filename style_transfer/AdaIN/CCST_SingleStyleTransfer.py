@@ -35,27 +35,24 @@ world = int(os.environ.get("WORLD_SIZE", "1"))
 rank = int(os.environ.get("RANK", "0"))
 
 vgg, decoder = load_networks(args, device)
-data_loader = data.get_train_dataloader(args, args.txt_root)
+data_loader = data.get_train_dataloader(args, args.txt_root, rank, world)      # this rank's shard of the content list
 
 
 def load_style_image(path):
     if args.synthetic:
         g = torch.Generator().manual_seed(abs(hash(path)) % (2 ** 31))
         return torch.rand(3, args.style_size, args.style_size, generator=g)
-    from PIL import Image
-    img = Image.open(str(path)).convert('RGB')
-    w, h = img.size
+    u8 = data.decode_rgb_u8(str(path))
+    h, w = int(u8.shape[0]), int(u8.shape[1])
     s = args.style_size
+    oh, ow = h, w
     if s:                                   # transforms.Resize(size): shorter side -> size (:29-30)
-        if w <= h:
-            img = img.resize((s, max(1, int(s * h / w))), Image.BILINEAR)
-        else:
-            img = img.resize((max(1, int(s * w / h)), s), Image.BILINEAR)
-    if args.crop:
-        w, h = img.size
-        l, t = (w - s) // 2, (h - s) // 2
-        img = img.crop((l, t, l + s, t + s))
-    return data._to_tensor(img)
+        oh, ow = (max(1, int(s * h / w)), s) if w <= h else (s, max(1, int(s * w / h)))
+    img = data.gpu_transform([u8], [(0, 0, h, w, 0)], (oh, ow), device)[0]      # PIL-exact resize + ToTensor on the GPU
+    if args.crop:                           # transforms.CenterCrop(size) (:31-32)
+        t, l = int(round((oh - s) / 2.0)), int(round((ow - s) / 2.0))
+        img = img[:, t:t + s, l:l + s]
+    return img
 
 
 for style_name in style_domains:
@@ -69,9 +66,7 @@ for style_name in style_domains:
     start_time = datetime.now()
     img_count = 0
     for it, (batch, fpaths) in enumerate(data_loader):
-        style_img_path = random.choice(style_img_list)          # drawn on every rank so the streams stay in step
-        if it % world != rank:
-            continue
+        style_img_path = random.choice(style_img_list)
         img_count += len(batch)
         print(f"    Style: {style_name}, Iteration: {it}/{len(data_loader)}")
         with torch.no_grad():

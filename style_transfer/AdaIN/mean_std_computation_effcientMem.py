@@ -26,7 +26,7 @@ if world > 1:
     dist.init_process_group(backend="nccl", device_id=device)
 
 vgg, decoder = load_networks(args, device)
-data_loader = data.get_train_dataloader(args, args.txt_root)
+data_loader = data.get_train_dataloader(args, args.txt_root, rank, world)      # this rank's shard of the list
 start_time = datetime.now()
 (feat_mean, feat_std), acc = style.domain_style_stat(vgg, data_loader, device, world, rank,
                                                      progress=lambda it, n: print(f"{it}/{n}"))

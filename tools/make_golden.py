@@ -340,4 +340,132 @@ save("fed_loop", seed=91, train_seeds=[100, 101, 102], train_sizes=[4, 4, 3], te
      l4_bn2_weight=lsd["layer4.0.bn2.weight"], nbt=int(lsd["bn1.num_batches_tracked"]),
      key_sum=np.array([float(v.double().sum()) for v in lsd.values()]),
      key_abs=np.array([float(v.double().abs().sum()) for v in lsd.values()]))
+# --------------------------------------------------------------------------
+# Data plane lists (data/data_helper.py:46-159, data/ImageLoader.py:13-47): the reference's own get_train_dataloader /
+# get_test_dataloader / creat_train_loader_list / get_random_subset, AST-extracted, with the image datasets replaced by
+# name-capturing stubs (the list logic never touches a pixel) and the stray pdb.set_trace() at :76 neutralised.
+# --------------------------------------------------------------------------
+if wanted("data_lists"):
+    import json
+    import random
+    import tempfile
+    from os.path import dirname, join
+
+    def extract_defs(path, names, namespace):
+        with open(path) as f:
+            tree = ast.parse(f.read(), filename=path)
+        for node in tree.body:
+            if isinstance(node, (ast.FunctionDef, ast.ClassDef)) and node.name in names:
+                exec(compile(ast.Module(body=[node], type_ignores=[]), path, "exec"), namespace)
+        return namespace
+
+    class _CapDataset(torch.utils.data.Dataset):
+        def __init__(self, names, labels, img_transformer=None):
+            self.names, self.labels = names, labels
+
+        def __len__(self):
+            return len(self.names)
+
+        def __getitem__(self, i):
+            return self.names[i], int(self.labels[i])
+
+    class _Train(_CapDataset):
+        kind = "train"
+
+    class _Test(_CapDataset):
+        kind = "test"
+
+    pdb_stub = types.ModuleType("pdb")
+    pdb_stub.set_trace = lambda *a, **k: None
+    real_pdb = sys.modules.get("pdb")
+    sys.modules["pdb"] = pdb_stub
+    tmp = tempfile.mkdtemp()
+    nsd = {"sample": random.sample}
+    extract_defs(os.path.join(REF, "data/ImageLoader.py"), {"get_random_subset", "_dataset_info", "get_split_dataset_info"}, nsd)
+    nsd.update({"torch": torch, "join": join, "dirname": dirname, "__file__": os.path.join(tmp, "data_helper.py"),
+                "get_train_transformers": lambda a: None, "get_val_transformer": lambda a: None,
+                "ImageDataset": _Train, "ImageTestDataset": _Test})
+    extract_defs(os.path.join(REF, "data/data_helper.py"),
+                 {"get_train_dataloader", "get_test_dataloader", "creat_train_loader_list", "Subset"}, nsd)
+
+    domains = ["art_painting", "cartoon", "photo", "sketch"]
+    classes = ["dog", "elephant", "giraffe"]
+    rsl = np.random.RandomState(5)
+
+    def make_lists(root, fusion_mode, target, sources):
+        """Lists shaped like the shipped ones (data/txt_lists/pacs/*.txt; expanded '-K' lists as data_list_generator.py writes them)."""
+        files = {}
+        for d in domains:
+            rows = []
+            for ci, c in enumerate(classes):
+                for k in range(int(rsl.randint(5, 9))):
+                    rows.append(("/disk1/x/CCST/data/PACS/kfold/%s/%s/pic_%03d.jpg" % (d, c, k), ci))
+            files[d] = rows
+        base = os.path.join(root, "txt_lists", "pacs")
+        os.makedirs(base, exist_ok=True)
+        for d in domains:
+            for split in ("train", "test"):
+                with open(os.path.join(base, "%s_%s.txt" % (d, split)), "w") as f:
+                    for n_, l_ in files[d]:
+                        f.write("%s %d\n" % (n_, l_))
+        sub = os.path.join(root, "txt_lists", "pacs_%s" % fusion_mode, target)
+        os.makedirs(sub, exist_ok=True)
+        for d in sources:
+            with open(os.path.join(sub, "%s_train.txt" % d), "w") as f:
+                for n_, l_ in files[d]:
+                    if "-K" in fusion_mode:
+                        style = fusion_mode.split("-")[1]
+                        outp = n_.replace("kfold/", "kfold_adain-%s-multi/%s/" % (style, target))
+                        K = int(fusion_mode[-1])
+                        for t_ in list(rsl.choice(sources, K, replace=False)):
+                            f.write("%s %d\n" % (outp if t_ == d else outp.replace(".", "_" + t_ + "."), l_))
+                    else:
+                        f.write("%s %d\n" % (n_, l_))
+        return files
+
+    cases = []
+    for fusion_mode, mode, limit_source, limit_target in [("no_fusion", "fedavg", None, None), ("adain-overall-K3", "fedavg", None, None),
+                                                           ("adain-single-K2", "fedavg", None, 7), ("adain-overall-K1", "deepall", None, None),
+                                                           ("adain-overall-K2", "fedavg", 11, None), ("no_fusion", "deepall", 13, 5)]:
+        target = "photo"
+        sources = [d for d in domains if d != target]
+        root = os.path.join(tmp, "%s_%s_%s" % (fusion_mode, mode, limit_source))
+        os.makedirs(root)
+        make_lists(root, fusion_mode, target, sources)
+        nsd["__file__"] = os.path.join(root, "data_helper.py")
+        a = types.SimpleNamespace(source=list(sources), target=target, dataset="pacs", fusion_mode=fusion_mode, mode=mode, val_size=0.1,
+                                  dg_method="no_DG", limit_source=limit_source, limit_target=limit_target, batch=4, image_size=222,
+                                  min_scale=0.8, max_scale=1.0, random_horiz_flip=0.0)
+        random.seed(a=1)
+        torch.manual_seed(1)
+        loaders, val_loaders = nsd["get_train_dataloader"](a)
+        test_loader = nsd["get_test_dataloader"](a)
+
+        def describe(loader):
+            ds = loader.dataset
+            idx = None
+            if hasattr(ds, "indices"):
+                idx, ds = [int(i) for i in ds.indices], ds.dataset
+            return {"names": list(ds.names), "labels": [int(l_) for l_ in ds.labels], "indices": idx, "kind": ds.kind,
+                    "batch_size": loader.batch_size, "shuffle": isinstance(loader.sampler, torch.utils.data.RandomSampler)}
+        cases.append({"fusion_mode": fusion_mode, "mode": mode, "limit_source": limit_source, "limit_target": limit_target,
+                      "target": target, "source": sources, "root": os.path.relpath(root, tmp),
+                      "lists": {os.path.relpath(os.path.join(dp, fn), root): open(os.path.join(dp, fn)).read()
+                                for dp, _, fns in os.walk(root) for fn in fns},
+                      "train": [describe(l_) for l_ in loaders], "val": [describe(l_) for l_ in val_loaders], "test": describe(test_loader)})
+    # creat_train_loader_list on the modes the CLI cannot reach but the function handles ('multi' expansion, :128-143)
+    direct = []
+    for fusion_mode in ["no_fusion", "adain-overall-K3", "adain-single-K1", "adain-overall-multi", "adain-single-multi", "multi"]:
+        names_in = ["/d/PACS/kfold/%s/%s/p%d.jpg" % (d, c, k) for d in ("cartoon", "sketch") for c in classes for k in range(2)]
+        labels_in = [classes.index(n_.split("/")[-2]) for n_ in names_in]
+        n_out, l_out = nsd["creat_train_loader_list"](list(names_in), list(labels_in), fusion_mode, ["art_painting", "cartoon", "sketch"], "photo")
+        direct.append({"mode": fusion_mode, "names_in": names_in, "labels_in": labels_in, "names": n_out, "labels": [int(x_) for x_ in l_out]})
+    random.seed(a=1)
+    split = nsd["get_random_subset"](["n%d" % i for i in range(57)], [i % 7 for i in range(57)], 0.1)
+    blob = json.dumps({"cases": cases, "direct": direct, "split57": [list(x_) for x_ in split]})
+    save("data_lists", json=np.frombuffer(blob.encode(), dtype=np.uint8))
+    if real_pdb is not None:
+        sys.modules["pdb"] = real_pdb
+    else:
+        del sys.modules["pdb"]
 print("done")
