@@ -100,8 +100,8 @@ def decode_rgb_u8(path):
     """Image.open(path).convert('RGB') as a contiguous uint8 [H,W,3] tensor (the only per-pixel CPU work left)."""
     from PIL import Image
     with Image.open(path) as im:
-        a = np.asarray(im.convert('RGB'), dtype=np.uint8)
-    return torch.from_numpy(np.ascontiguousarray(a))
+        a = np.array(im.convert('RGB'), dtype=np.uint8)      # a writable, contiguous copy
+    return torch.from_numpy(a)
 
 
 def random_resized_crop_params(height, width, scale, ratio=(3.0 / 4.0, 4.0 / 3.0)):

@@ -53,15 +53,56 @@ class FlatParams(object):
                 b.data = self.flat[off:off + n].view(b.shape)
                 off += al(n)
         self.params = params
+        self.bufs = bufs
         self.model = model
         model.__dict__["_ccst_arena"] = self
+        model.__dict__.pop("_ccst_graph_steps", None)     # captured train steps hold the old tensors' addresses
+
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(model) clones every parameter into storage of its own (fed_run.py:577 makes the clients that way), so a
+        copied arena would alias nothing: the copy gets none and builds its own on first use."""
+        return None
+
+    def valid(self, full=False):
+        """Do the model's tensors still live in this arena?  model.to('cpu') / .to(device) (fed_run.py:32,85 -- the
+        ``offload_models`` path), load-by-assignment or a deepcopy replace p.data; kernels fed from a stale arena would
+        silently stop training the model."""
+        p0 = self.params[0]
+        if p0.device != self.flat.device or p0.data_ptr() != self.flat.data_ptr():
+            return False
+        if full:
+            base, off = self.flat.data_ptr(), 0
+            for t in list(self.params) + list(self.bufs):
+                if t.data_ptr() != base + 4 * off or t.device != self.flat.device:
+                    return False
+                off += (t.numel() + 3) // 4 * 4
+            live = [p for p in self.model.parameters()]
+            if len(live) != len(self.params) or any(a is not b for a, b in zip(live, self.params)):
+                return False
+        return True
 
     @staticmethod
     def of(model):
+        """The model's arena, rebuilt from the tensors the modules currently hold whenever they no longer alias it."""
         a = model.__dict__.get("_ccst_arena")
-        if a is None:
+        if a is None or a.model is not model or not a.valid(full=True):
             a = FlatParams(model)
         return a
+
+    def require_cuda(self, what):
+        if not self.flat.is_cuda:
+            raise RuntimeError("ccst_amd.fed: %s runs on the GPU and the model is on %s; move it with model.to(device) first "
+                               "(there is no CPU fallback)" % (what, self.flat.device))
+
+    def state_dict_of(self, flat):
+        """An OrderedDict view of a flat buffer laid out like this arena (another client's gathered state): fp32 entries only."""
+        from collections import OrderedDict
+        out, off = OrderedDict(), 0
+        named = [(k, v) for k, v in self.model.named_parameters()] + [(k, b) for k, b in self.model.named_buffers() if b.dtype == torch.float32]
+        for k, v in named:
+            out[k] = flat[off:off + v.numel()].view(v.shape)
+            off += (v.numel() + 3) // 4 * 4
+        return out
 
     def zero_grad(self):
         self.grad.zero_()
@@ -98,19 +139,31 @@ class SGD(object):
 
     def __init__(self, model_or_params, lr):
         if isinstance(model_or_params, nn.Module):
-            self.arena = FlatParams.of(model_or_params)
+            self.model = model_or_params
         elif isinstance(model_or_params, FlatParams):
-            self.arena = model_or_params
+            self.model = model_or_params.model
         else:
             raise TypeError("ccst_amd.fed.SGD takes the model (or its FlatParams), e.g. SGD(model, lr=args.lr)")
+        self._arena = FlatParams.of(self.model)
         self.lr = float(lr)
-        self.param_groups = [{"lr": self.lr, "params": self.arena.params}]
+        self.param_groups = [{"lr": self.lr, "params": self._arena.params}]
+
+    @property
+    def arena(self):
+        """The optimiser is created before train() moves the model (fed_run.py:657 then :32): re-resolve the arena when the
+        model's tensors have moved since (cheap pointer check per call, full check + rebuild only on a mismatch)."""
+        a = self._arena
+        if self.model.__dict__.get("_ccst_arena") is not a or not a.valid():
+            a = self._arena = FlatParams.of(self.model)
+            self.param_groups[0]["params"] = a.params
+        return a
 
     def zero_grad(self, set_to_none=False):
         self.arena.zero_grad()
 
     def step(self):
         a = self.arena
+        a.require_cuda("SGD.step")
         check(_lib.load().ccst_sgd_f32(ptr(a.flat), ptr(a.grad), float(self.param_groups[0]["lr"]), a.n_param, stream_ptr()), "sgd")
         ops.bump_weights_epoch()
         nn_ops.prepack_on_side(a.model)
@@ -288,9 +341,13 @@ def communication(args, server_model, models, client_weights):
     models on one GPU) for API parity; see communication_distributed for the one-client-per-GPU form."""
     mode = (getattr(args, "mode", "fedavg") or "fedavg").lower()
     with torch.no_grad():
+        dev = next(models[0].parameters()).device
+        for m in [server_model] + list(models):          # the reference averages on the CPU after train() moved the clients back
+            if next(m.parameters()).device != dev:       # (fed_run.py:85); here everything meets on the clients' GPU
+                m.to(dev)
         arenas = [FlatParams.of(m) for m in [server_model] + list(models)]
-        if arenas[0].flat.is_cuda:
-            nn_ops.join_prepack(arenas[0].flat.device)      # side-stream re-packs still read the client weights
+        arenas[0].require_cuda("communication()")
+        nn_ops.join_prepack(arenas[0].flat.device)      # side-stream re-packs still read the client weights
         srv, clients = arenas[0], arenas[1:]
         if any(c.n_total != srv.n_total for c in clients):
             raise ValueError("communication: client and server models differ in size")
@@ -312,6 +369,59 @@ def communication(args, server_model, models, client_weights):
             if 'num_batches_tracked' in key:
                 ssd[key].data.copy_(c0[key])
     return server_model, models
+
+
+def test_fedbn(server_model, models, test_loader, loss_fun, device, args):
+    """fed_run.py:350-381 (``--test`` of a ``--mode fedbn`` checkpoint): the server takes client 0's ``num_batches_tracked`` and, for
+    every other entry whose key contains 'bn', the 1/K average of the clients' local entries; then an ordinary test() pass."""
+    client_num = len(models)
+    w = float(1. / client_num)
+    with torch.no_grad():
+        for m in [server_model] + list(models):
+            m.to(device)
+        srv = FlatParams.of(server_model)
+        srv.require_cuda("test_fedbn()")
+        nn_ops.join_prepack(srv.flat.device)
+        clients = [FlatParams.of(m) for m in models]
+        for a, b in srv.key_ranges(lambda k: 'bn' in k):
+            srv.flat[a:b].zero_()
+            for c in clients:
+                _axpy(srv.flat[a:b], c.flat[a:b], w)
+        ops.bump_weights_epoch()
+        ssd, c0 = server_model.state_dict(), models[0].state_dict()
+        for key in ssd.keys():
+            if 'num_batches_tracked' in key:
+                ssd[key].data.copy_(c0[key])
+    return test(server_model, test_loader, loss_fun, device, args)
+
+
+def gather_client_states(model, group=None, dst=0):
+    """One client per rank: rank `dst` receives every client's full state (flat fp32 arena over RCCL + the int64 counters) and
+    returns [state_dict_0, ..., state_dict_{K-1}] on the CPU -- what the fedbn checkpoint stores as 'model_{k}' (fed_run.py:735-739);
+    other ranks return None."""
+    import torch.distributed as dist
+    from collections import OrderedDict
+    arena = FlatParams.of(model)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    nn_ops.join_prepack(arena.flat.device) if arena.flat.is_cuda else None
+    keys = list(model.state_dict().keys())
+    ints = [v for k, v in model.state_dict().items() if v.dtype != torch.float32]
+    cnt = torch.stack([v.reshape(()).to(arena.flat.device, torch.int64) for v in ints]) if ints else torch.zeros(0, dtype=torch.int64, device=arena.flat.device)
+    flats = [torch.empty_like(arena.flat) for _ in range(world)] if rank == dst else None
+    cnts = [torch.empty_like(cnt) for _ in range(world)] if rank == dst else None
+    dist.gather(arena.flat, flats, dst=dst, group=group)
+    dist.gather(cnt, cnts, dst=dst, group=group)
+    if rank != dst:
+        return None
+    out = []
+    for k in range(world):
+        fl = arena.state_dict_of(flats[k].cpu())
+        it = iter(cnts[k].cpu())
+        sd = OrderedDict()
+        for key in keys:
+            sd[key] = fl[key].clone() if key in fl else next(it).clone()
+        out.append(sd)
+    return out
 
 
 def _hip_scale(flat, w, n):

@@ -291,15 +291,19 @@ class ResNet(nn.Module):
 
 
 def _maybe_pretrained(model, name, pretrained):
-    """nets/resnet.py:340-344,364-369 load ImageNet weights through model_zoo (network access).  Here:
-    load from $CCST_PRETRAINED_DIR/<name>.pth if present, else keep the reference's kaiming init."""
+    """nets/resnet.py:340-344,364-369 load ImageNet weights through model_zoo (network access; ``strict=False`` because the
+    head is ``class_classifier``, not ``fc``).  Here the same state dict is read from $CCST_PRETRAINED_DIR/<name>.pth; asking for
+    pretrained weights that are not there is an error, never a silent random initialisation."""
     if not pretrained:
         return model
     d = os.environ.get("CCST_PRETRAINED_DIR", "")
     path = os.path.join(d, name + ".pth")
-    if d and os.path.exists(path):
-        model.load_state_dict(torch.load(path, map_location="cpu"), strict=False)
-        print("Use pretrained %s" % name)
+    if not (d and os.path.exists(path)):
+        raise FileNotFoundError("ccst_amd.nets: pretrained=True but %s does not exist (set CCST_PRETRAINED_DIR to a directory holding "
+                                "torchvision's %s state dict as %s.pth; there is no network access to download it). Pass "
+                                "pretrained=False for the reference's kaiming initialisation." % (path or "<CCST_PRETRAINED_DIR>/%s.pth" % name, name, name))
+    model.load_state_dict(torch.load(path, map_location="cpu"), strict=False)
+    print("Use pretrained %s" % name)
     return model
 
 

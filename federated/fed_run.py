@@ -72,8 +72,21 @@ def parse():
     parser.add_argument('--txt_root', type=str, default='data/txt_lists')
     parser.add_argument('--hip_graph', action='store_true',
                         help='capture the train iteration into a HIP graph and replay it per batch (launch-bound models: ResNet18, small batches)')
-    parser.add_argument('--pretrained', action='store_true', help='load $CCST_PRETRAINED_DIR/<network>.pth (no network access here)')
+    parser.add_argument('--pretrained', action='store_true',
+                        help='ImageNet initialisation from $CCST_PRETRAINED_DIR/<network>.pth (the reference downloads it, nets/resnet.py:364-369; '
+                             'there is no network here, so it is opt-in and fails loudly when the file is missing)')
+    parser.add_argument('--workers', type=int, default=0, help='DataLoader decode workers (the reference uses 0)')
     return parser.parse_args()
+
+
+def restore(checkpoint, server_model, models, fedbn):
+    """fed_run.py:626-640 (--resume) / :585-589 (--test): the server model from 'server_model'; every client from its own
+    'model_{k}' under --mode fedbn (local BN weights and running statistics survive the restart), else from the server's.
+    `models` maps client index -> model (one entry per rank under torchrun).  Returns the iteration to resume at."""
+    server_model.load_state_dict(checkpoint['server_model'])
+    for ci, m in models.items():
+        m.load_state_dict(checkpoint['model_{}'.format(ci)] if fedbn else checkpoint['server_model'])
+    return int(checkpoint['a_iter']) + 1
 
 
 def main():
@@ -104,6 +117,9 @@ def main():
     logfile = open(os.path.join(args.save_path, '{}.log'.format(args.mode)), 'a') if (args.log and rank == 0) else None
 
     print("Building server's model...")
+    if not args.pretrained:
+        print("NOTE: random (kaiming) initialisation; the reference starts from ImageNet weights -- pass --pretrained with "
+              "CCST_PRETRAINED_DIR set to reproduce that")
     server_model = get_network(args.network)(args, pretrained=args.pretrained, classes=args.n_classes)
     loss_fun = fed.CrossEntropyLoss()
     print("Preparing data...")
@@ -117,19 +133,24 @@ def main():
     server_model.to(device)
     models = {ci: copy.deepcopy(server_model) for ci in my_clients}
 
-    if args.test:
+    fedbn = args.mode.lower() == 'fedbn'
+    if args.test:                                                    # fed_run.py:582-596
         print('Loading snapshots...')
-        server_model.load_state_dict(torch.load(SAVE_PATH)['server_model'])
-        _, test_acc = fed.test(server_model, target_test_loader, loss_fun, device, args)
-        print(' {:<11s}| Test  Acc: {:.4f}'.format(args.target, test_acc))
+        checkpoint = torch.load(SAVE_PATH, map_location='cpu')
+        if fedbn and world > 1:
+            raise SystemExit("--test of a fedbn checkpoint averages every client's BN entries: run it as one process")
+        restore(checkpoint, server_model, models if fedbn else {}, fedbn)
+        if fedbn:
+            _, test_acc = fed.test_fedbn(server_model, [models[ci] for ci in my_clients], target_test_loader, loss_fun, device, args)
+            print(' {:<11s}| Test  Acc: {:.4f}'.format(datasets[my_clients[-1]], test_acc))       # the reference prints the last client's name
+        else:
+            _, test_acc = fed.test(server_model, target_test_loader, loss_fun, device, args)
+            print(' {:<11s}| Test  Acc: {:.4f}'.format(args.target, test_acc))
         return
     resume_iter = 0
-    if args.resume:
-        checkpoint = torch.load(SAVE_PATH + '_latest')
-        server_model.load_state_dict(checkpoint['server_model'])
-        for m in models.values():
-            m.load_state_dict(checkpoint['server_model'])
-        resume_iter = int(checkpoint['a_iter']) + 1
+    if args.resume:                                                  # fed_run.py:626-640
+        checkpoint = torch.load(SAVE_PATH + '_latest', map_location='cpu')
+        resume_iter = restore(checkpoint, server_model, models, fedbn)
         print('Resume training from epoch {}'.format(resume_iter))
 
     def log(msg):
@@ -152,7 +173,6 @@ def main():
                 log(' {:<11s}| Train Loss: {:.4f}'.format(datasets[ci], train_loss))
                 log(' {:<11s}| Train Class Acc: {:.4f}'.format(datasets[ci], train_acc))
         with torch.no_grad():
-            fedbn = args.mode.lower() == 'fedbn'
             if world > 1 and fedbn:
                 fed.communication_distributed(args, models[rank], client_weights[rank], server_model=server_model)
                 srv = server_model                    # the average lives in this rank's server replica
@@ -175,15 +195,22 @@ def main():
                 dist.all_reduce(t)
                 val_acc_sum = float(t)
             val_class_acc_average = val_acc_sum / client_num
+            client_states = None
+            if fedbn and world > 1:     # one client per rank: rank 0 collects every client's state for the checkpoint (:735-739)
+                client_states = fed.gather_client_states(models[rank])
             if rank == 0:
                 print("-------------Test server model on target domain testset----------------")
                 test_loss, test_acc = fed.test(srv, target_test_loader, loss_fun, device, args)
                 log(' {:<11s}| Global Test Loss: {:.4f}'.format(args.target, test_loss))
                 log(' {:<11s}| Global Test Class Acc: {:.4f}'.format(args.target, test_acc))
                 ckpt = {'server_model': {k: v.detach().cpu() for k, v in srv.state_dict().items()}, 'a_iter': a_iter}
-                if fedbn:       # :735-739 -- one process holds every client only in the single-process form
-                    for ci in my_clients:
-                        ckpt['model_{}'.format(ci)] = {k: v.detach().cpu() for k, v in models[ci].state_dict().items()}
+                if fedbn:       # :735-739
+                    if client_states is not None:
+                        for ci, sd in enumerate(client_states):
+                            ckpt['model_{}'.format(ci)] = sd
+                    else:
+                        for ci in my_clients:
+                            ckpt['model_{}'.format(ci)] = {k: v.detach().cpu() for k, v in models[ci].state_dict().items()}
                 if a_iter % args.save_freq == 0 and a_iter > 0:
                     torch.save(ckpt, SAVE_PATH + '_latest')
                 if val_class_acc_average > best_val_class_acc:

@@ -80,3 +80,20 @@ def test_epoch(model, loader, loss_fun):
             correct += int((logit.max(dim=1)[1] == lab).sum())
             num_data += img.size(0)
     return loss_all / (it + 1), float(correct) / num_data
+
+
+def test_fedbn_merge(server_model, models):
+    """federated/fed_run.py:350-362, the state merge test_fedbn() does before its evaluation loop: the server takes client 0's
+    num_batches_tracked and, for every OTHER key containing 'bn', the 1/K average of the clients' entries."""
+    client_num = len(models)
+    client_weights = [float(1. / client_num) for _ in range(client_num)]
+    with torch.no_grad():
+        for key in models[0].state_dict().keys():
+            if 'num_batches_tracked' in key:
+                server_model.state_dict()[key].data.copy_(models[0].state_dict()[key])
+            if 'bn' in key and 'num_batches_tracked' not in key:
+                temp = torch.zeros_like(server_model.state_dict()[key])
+                for ci in range(client_num):
+                    temp += client_weights[ci] * models[ci].state_dict()[key]
+                server_model.state_dict()[key].data.copy_(temp)
+    return server_model

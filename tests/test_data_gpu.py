@@ -138,7 +138,7 @@ def test_save_images_writes_the_quantised_bytes(dev, tmp_path):
     from ccst_amd import data
     g = torch.Generator().manual_seed(2)
     out = torch.rand(2, 3, 33, 47, generator=g) * 1.2 - 0.1
-    paths = [str(tmp_path / "a" / "b" / "x_%d.png" % i) for i in range(2)]
+    paths = [str(tmp_path / "a" / "b" / ("x_%d.png" % i)) for i in range(2)]
     data.save_images(out.to(dev), paths)
     for i, p in enumerate(paths):
         assert np.array_equal(np.asarray(Image.open(p)), I.save_image_bytes(out[i]))

@@ -54,6 +54,20 @@ def _worker(rank, world, initfile, outdir):
     acc.count, acc.images = 100 * (rank + 1), rank + 1
     acc.all_reduce()
     torch.save({"sum": acc.sum, "sq": acc.sqsum, "count": acc.count, "images": acc.images}, os.path.join(outdir, "st_%d.pt" % rank))
+    # fedbn checkpoints under torchrun: rank 0 gathers every client's full state (flat arena + int64 counters)
+    third = resnet.ResNet(resnet.BasicBlock, [1, 1, 1, 1], classes=3)
+    third.load_state_dict(_client_state(rank).state_dict())
+    states = fed.gather_client_states(third)
+    if rank == 0:
+        torch.save(states, os.path.join(outdir, "gathered.pt"))
+    else:
+        assert states is None
+    # AdaIN content list sharded by entry over the ranks dist reports, each rank with its own RNG state
+    from ccst_amd import data
+    torch.manual_seed(1000 + rank)
+    a = types.SimpleNamespace(dataset="pacs", target="photo", batch=4, image_size=32, synthetic=0)
+    ld = data.get_train_dataloader(a, outdir, rank=dist.get_rank(), world=dist.get_world_size())
+    torch.save(list(ld.dataset.names), os.path.join(outdir, "shard_%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -61,7 +75,21 @@ def _worker(rank, world, initfile, outdir):
 def test_fedavg_and_style_stats_world2():
     with tempfile.TemporaryDirectory() as d:
         initfile = os.path.join(d, "init")
+        os.makedirs(os.path.join(d, "pacs"))
+        rows = ["/x/PACS/kfold/photo/dog/p%03d.jpg 0" % i for i in range(37)]
+        with open(os.path.join(d, "pacs", "photo_train.txt"), "w") as f:
+            f.write("\n".join(rows) + "\n")
         mp.spawn(_worker, args=(2, initfile, d), nprocs=2, join=True)
+        shards = [torch.load(os.path.join(d, "shard_%d.pt" % r), weights_only=False) for r in range(2)]
+        assert not set(shards[0]) & set(shards[1])                                   # disjoint ...
+        assert sorted(shards[0] + shards[1]) == sorted(r.split(" ")[0] for r in rows)   # ... and complete
+        gathered = torch.load(os.path.join(d, "gathered.pt"), weights_only=False)
+        assert len(gathered) == 2
+        for r in range(2):
+            want = _client_state(r).state_dict()
+            assert list(gathered[r].keys()) == list(want.keys())
+            for k, v in want.items():
+                assert gathered[r][k].dtype == v.dtype and torch.equal(gathered[r][k], v), k
         r0 = torch.load(os.path.join(d, "fed_0.pt"), weights_only=False)
         r1 = torch.load(os.path.join(d, "fed_1.pt"), weights_only=False)
         server = _client_state(0)

@@ -104,3 +104,85 @@ def test_bench_conv_kernel_name_mirror():
     assert ops._conv_kernel_name(1024, False, 12544, 256, 1) == "conv_igemm_kernel<2,2,1,mt1,ck32>"  # maps up to 28x28 at B=64
     assert ops._conv_kernel_name(256, False, 12544, 48, 9) == "conv_igemm_kernel<2,2,1,mt1>"         # no 32-channel k-step
     assert ops._conv_kernel_name(64, False, 1572864, 16, 3) == "conv_igemm_kernel<2,2,1>"            # AdaIN stem
+
+
+def test_flat_params_follow_the_model():
+    """an arena whose tensors the model no longer holds (deepcopy, .to() round trip, assignment) is rebuilt, never
+    silently updated in place of the model; kernels that need the GPU refuse a CPU arena."""
+    import copy
+    import pytest
+    from ccst_amd import fed
+    from ccst_amd.nets import resnet
+    m = resnet.ResNet(resnet.BasicBlock, [1, 1, 1, 1], classes=3)
+    a = fed.FlatParams.of(m)
+    m2 = copy.deepcopy(m)                               # fed_run.py:577 builds the clients like this
+    assert m2.__dict__.get("_ccst_arena") is None
+    a2 = fed.FlatParams.of(m2)
+    assert a2 is not a and a2.valid(full=True) and a.valid(full=True)
+    a2.flat.fill_(3.0)
+    assert float(m2.conv1.weight[0, 0, 0, 0]) == 3.0 and float(m.conv1.weight[0, 0, 0, 0]) != 3.0
+    # what model.to('cpu') -> .to(device) does to every parameter: a fresh tensor
+    opt = fed.SGD(m, lr=0.1)
+    for p in m.parameters():
+        p.data = p.data.clone()
+    for b in m.buffers():
+        b.data = b.data.clone()
+    assert not a.valid()
+    a3 = opt.arena
+    assert a3 is not a and a3.valid(full=True) and fed.FlatParams.of(m) is a3 and opt.param_groups[0]["params"] is a3.params
+    a3.flat[:a3.n_param].fill_(5.0)
+    assert float(m.class_classifier.bias[0]) == 5.0
+    with pytest.raises(RuntimeError, match="GPU"):
+        opt.step()
+    import types
+    with pytest.raises(RuntimeError, match="GPU"):
+        fed.communication(types.SimpleNamespace(mode="fedavg"), m, [m2], [1.0])
+
+
+def test_pretrained_weights_must_exist(tmp_path, monkeypatch):
+    import types
+    import pytest
+    from ccst_amd.nets import models
+    args = types.SimpleNamespace(dg_method="no_DG")
+    monkeypatch.delenv("CCST_PRETRAINED_DIR", raising=False)
+    with pytest.raises(FileNotFoundError):
+        models.get_network("resnet18")(args, classes=7)                  # the reference's default is pretrained=True
+    monkeypatch.setenv("CCST_PRETRAINED_DIR", str(tmp_path))
+    with pytest.raises(FileNotFoundError):
+        models.get_network("resnet18")(args, pretrained=True, classes=7)
+    ref = models.get_network("resnet18")(args, pretrained=False, classes=1000)
+    sd = {k.replace("class_classifier", "fc"): v + 1.0 if v.dtype == torch.float32 else v for k, v in ref.state_dict().items()}
+    torch.save(sd, str(tmp_path / "resnet18.pth"))
+    m = models.get_network("resnet18")(args, pretrained=True, classes=7)     # strict=False: the 1000-way 'fc' head is ignored
+    assert torch.equal(m.conv1.weight, ref.conv1.weight + 1.0) and m.class_classifier.weight.shape == (7, 512)
+
+
+def test_resume_restores_every_clients_own_model_under_fedbn():
+    """fed_run.py:626-640: --resume under --mode fedbn loads 'model_{k}' into client k (the server average used to
+    overwrite the local BN state); other modes load the server model everywhere."""
+    import importlib.util
+    import os
+    from ccst_amd.nets import resnet
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("ccst_fed_run", os.path.join(root, "federated", "fed_run.py"))
+    fr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fr)
+
+    def mk(seed):
+        torch.manual_seed(seed)
+        m = resnet.ResNet(resnet.BasicBlock, [1, 1, 1, 1], classes=3)
+        with torch.no_grad():
+            m.bn1.running_mean.normal_()
+        return m
+    ck = {"server_model": mk(1).state_dict(), "a_iter": 4, "model_0": mk(2).state_dict(), "model_1": mk(3).state_dict()}
+    server, models = mk(9), {0: mk(10), 1: mk(11)}
+    assert fr.restore(ck, server, models, fedbn=True) == 5
+    assert torch.equal(server.bn1.running_mean, ck["server_model"]["bn1.running_mean"])
+    for ci in (0, 1):
+        assert torch.equal(models[ci].bn1.running_mean, ck["model_%d" % ci]["bn1.running_mean"])
+        assert torch.equal(models[ci].conv1.weight, ck["model_%d" % ci]["conv1.weight"])
+    only1 = {1: mk(12)}                                     # torchrun: rank 1 holds only client 1
+    fr.restore(ck, server, only1, fedbn=True)
+    assert torch.equal(only1[1].bn1.running_mean, ck["model_1"]["bn1.running_mean"])
+    fr.restore(ck, server, models, fedbn=False)
+    assert torch.equal(models[1].bn1.running_mean, ck["server_model"]["bn1.running_mean"])
