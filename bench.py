@@ -8,10 +8,15 @@ rank per GPU) every rank stylises its own batch (content images are independent:
 collective), timing is barrier-bracketed and the max over ranks.
 
 Prints ONE JSON line on rank 0 (see the bench contract) including
-  roofline     : the dominant kernel (the 128x128-tile implicit-GEMM conv instance), algorithmic
-                 FLOPs of its launches / their HIP-event durations inside the timed region
+  roofline     : the dominant kernel (the Winograd 3x3 conv), HIP-event timed inside the timed region.
+                 ``achieved`` / ``frac`` are the FLOPs the MFMA pipe EXECUTES (Winograd F(2x2,3x3) = algorithmic / 2.25)
+                 against the fp32-MFMA peak -- a fraction of a real bound, <= 1; ``algorithmic_tflops`` is the
+                 convolution's 2*M*Cout*Cin*9 rate, and ``bound_images_per_s`` the whole-path ceilings of SURVEY 8d
+                 (direct form) and of the algorithm in use
+  adain_step   : the statistics + normalise step against its HBM roofline (100.66 MB algorithmic per B=6 batch)
+  end_to_end   : images/sec including the H2D of the content batch and the D2H of the result (never ``value``)
   cpu_baseline : the CPU oracle (a port of the reference path) timed on the host cores, rank 0, N=1
-  secondary    : ResNet50 train-step images/sec @222x222 B=64 (second half of the metric), if built
+  secondary    : ResNet50 train-step images/sec @222x222 B=64 (second half of the metric) with its MFMA / HBM rooflines
 """
 import argparse
 import json
@@ -26,6 +31,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md, HBM3E
+GFLOP_PER_IMAGE_512 = 253.07      # 19 convs, encoder 126.54 + decoder 126.53
+WINO_GFLOP_PER_IMAGE_512 = 1.812  # the two layers that do not run on the Winograd kernel (conv1_1 stem, last decoder 64->3)
 
 
 def parse():
@@ -78,16 +86,21 @@ def main():
     if distributed:
         dist.barrier()
         torch.cuda.synchronize()
-    ops.TIMING = []                       # per-launch HIP events for the conv kernels
+    ops.TIMING = []                       # per-launch HIP events for the conv kernels and the AdaIN step
+    step_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        step_ev[i][0].record()
         out = step()
+        step_ev[i][1].record()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timing, ops.TIMING = ops.TIMING, None
+    step_ms = sorted(a.elapsed_time(b) for a, b in step_ev)
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     if distributed:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -95,7 +108,40 @@ def main():
     assert os.environ.get("CCST_BENCH_NO_ASSERT") == "1" or bool(torch.isfinite(out).all())      # (kernel timing ablations produce garbage)
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * B * args.steps / elapsed
+    n_ranks_seen = dist.get_world_size() if distributed else 1
+    value = n_ranks_seen * B * args.steps / elapsed
+
+    # ---- end to end: H2D of the content batch + the step + D2H of the result, as the reference's loop does per batch
+    # (data.to(device) ... output.cpu(), CCST_OverallStyleTransfer.py:152-157).  Reported beside `value`, never as it.
+    e2e = None
+    if rank == 0:
+        host_in = content.cpu().pin_memory()
+        host_out = torch.empty(out.shape, dtype=out.dtype).pin_memory()
+        from ccst_amd import data as cdata
+        host_u8 = torch.empty((B, S, S, 3), dtype=torch.uint8).pin_memory()
+        reps = max(5, min(20, args.steps))
+
+        def e2e_f32():
+            with torch.no_grad():
+                o = style.style_transfer(vgg31, dec, host_in.to(dev, non_blocking=True), stat, 1.0)
+            host_out.copy_(o, non_blocking=True)
+            torch.cuda.synchronize()
+
+        def e2e_u8():       # f1: quantise on the GPU (save_image's bytes), 4x smaller D2H
+            with torch.no_grad():
+                o = style.style_transfer(vgg31, dec, host_in.to(dev, non_blocking=True), stat, 1.0)
+            host_u8.copy_(cdata.quantize_u8(o), non_blocking=True)
+            torch.cuda.synchronize()
+        rates = []
+        for fn in (e2e_f32, e2e_u8):
+            fn()
+            c0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            rates.append(reps * B / (time.perf_counter() - c0))
+        e2e = {"images_per_s": round(rates[0], 2), "images_per_s_u8_output": round(rates[1], 2), "batches": reps,
+               "h2d_bytes_per_batch": int(host_in.numel() * 4), "d2h_bytes_per_batch": int(host_out.numel() * 4),
+               "note": "serial per batch: pinned H2D -> style_transfer -> D2H -> sync; u8 variant = save_image quantisation on the GPU"}
 
     # ---- roofline of the dominant kernel ------------------------------------------------
     per_kernel = {}
@@ -104,7 +150,11 @@ def main():
         for name, flops, e0, e1, info in timing[-per_step:]:
             us = e0.elapsed_time(e1) * 1e3
             print("%-32s %-48s %9.1f us %7.1f TF" % (name, info, us, flops / us / 1e6), file=sys.stderr)
+    adain_us = []
     for name, flops, e0, e1, _info in timing:
+        if name == "adain_step":
+            adain_us.append(e0.elapsed_time(e1) * 1e3)
+            continue
         k = per_kernel.setdefault(name, [0, 0.0, 0.0])
         k[0] += 1
         k[1] += flops
@@ -114,19 +164,27 @@ def main():
     for name, (cnt, fl, sec) in per_kernel.items():
         kernels[name] = {"launches_per_step": cnt / args.steps, "avg_us": sec / cnt * 1e6,
                          "gflop_per_launch": fl / cnt / 1e9, "tflops": fl / sec / 1e12}
+    scale = S * S / 512.0 / 512.0
+    wino_share = 1.0 - WINO_GFLOP_PER_IMAGE_512 / GFLOP_PER_IMAGE_512
+    # whole-path ceilings per GPU: every FLOP at the fp32-MFMA peak, and the same with the 3x3 layers' multiplies
+    # divided by 2.25 (F(2x2,3x3)); the two non-Winograd layers are HBM-bound and priced at their MFMA time only
+    bound_direct = PEAK_F32_MFMA_TFLOPS * 1e3 / (GFLOP_PER_IMAGE_512 * scale)
+    bound_wino = PEAK_F32_MFMA_TFLOPS * 1e3 / ((GFLOP_PER_IMAGE_512 * wino_share / 2.25 + WINO_GFLOP_PER_IMAGE_512) * scale)
     if per_kernel:
         dom = max(per_kernel, key=lambda n: per_kernel[n][2])
         cnt, fl, sec = per_kernel[dom]
-        ach = fl / sec / 1e12
+        alg = fl / sec / 1e12
+        wino = dom.startswith("conv3x3_wino_kernel")
+        executed = alg / 2.25 if wino else alg
         traffic, tsrc = None, os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tsrc):      # HBM bytes/launch from the separate rocprofv3 --pmc passes (tools/profile_bench.sh)
             with open(tsrc) as fh:
                 tj = json.load(fh)
             base, targs = dom[:-1].split("<")
             targs = targs.split(",")
-            nums, pooled = ", ".join(a for a in targs if a != "pool"), ("true" if "pool" in targs else "false")
+            nums, pooled = ", ".join(a for a in targs if a not in ("pool", "nopool")), ("true" if "pool" in targs else "false")
             if base == "conv3x3_wino_kernel":
-                keys = ["void conv3x3_wino_kernel<%s>" % pooled]
+                keys = [k for k in tj if k.startswith("void conv3x3_wino_kernel<") and k.rstrip(">").split("<")[1].split(",")[0].strip() == pooled]
             elif base == "conv_igemm_kernel":
                 keys = ["void conv_igemm_kernel<%s, %s, 2, 16>" % (nums, pooled)]
             else:       # rocprofv3 prints every template argument: <WM, WN, NT, POOL, TRAIN>
@@ -135,30 +193,39 @@ def main():
                 if key in tj:
                     traffic = round(tj[key]["total_bytes_per_launch"])
                     break
-        roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "kernel": dom,
+        roofline = {"bound": "mfma", "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "kernel": dom,
                     "launches_per_step": cnt / args.steps, "avg_launch_us": round(sec / cnt * 1e6, 2),
-                    "gflop_per_launch": round(fl / cnt / 1e9, 3)}
-        if dom.startswith("conv3x3_wino_kernel"):
-            # `achieved` counts the ALGORITHMIC FLOPs of the convolution (2*M*Cout*Cin*9); Winograd F(2x2,3x3)
-            # executes 16/36 of those multiplies, so frac can exceed 1.  The MFMA pipe itself runs at executed_frac.
-            roofline["algorithm"] = "winograd F(2x2,3x3): executes 1/2.25 of the algorithmic multiplies"
-            roofline["executed_tflops"] = round(ach / 2.25, 2)
-            roofline["executed_frac"] = round(ach / 2.25 / PEAK_F32_MFMA_TFLOPS, 4)
+                    "gflop_per_launch": round(fl / cnt / 1e9, 3), "algorithmic_tflops": round(alg, 2),
+                    "algorithm": ("winograd F(2x2,3x3): the MFMA pipe executes gflop_per_launch / 2.25; achieved and frac are the EXECUTED rate"
+                                  if wino else "direct"),
+                    "executed_gflop_per_launch": round(fl / cnt / 1e9 / (2.25 if wino else 1.0), 3),
+                    "bound_images_per_s": {"direct": round(bound_direct, 1), "winograd_f2x2": round(bound_wino, 1)},
+                    "path_frac_of_bound": round(value / n_ranks_seen / (bound_wino if wino else bound_direct), 4)}
+    adain_step = None
+    if adain_us:
+        nbytes = 2 * 4 * B * 512 * (S // 8) * (S // 8)       # read x once + write y once (SURVEY 8d "AdaIN-step roofline")
+        us = sorted(adain_us)[len(adain_us) // 2]
+        adain_step = {"bound": "hbm", "bytes": nbytes, "median_us": round(us, 2), "achieved": round(nbytes / us / 1e3, 1),
+                      "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(nbytes / us / 1e3 / PEAK_HBM_GBPS, 4),
+                      "kernels": "partials + finalize + apply (3 launches, HIP events around ccst_adain_f32)"}
 
     result = {
         "metric": "AdaIN stylised images/sec @512x512 B=6", "value": round(value, 3), "unit": "images/sec",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "median_ms_per_step": round(median_ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "CCST_OverallStyleTransfer PACS %dx%d batch=%d (encoder->AdaIN->decoder)" % (S, S, B),
                    "batch_per_gpu": B, "image_size": S, "sharding": "content batches per rank, no collective"},
         "roofline": roofline,
-        "whole_path_tflops": round(253.07e9 * (S * S / 512.0 / 512.0) * B * world * args.steps / elapsed / 1e12, 2),
+        "adain_step": adain_step,
+        "end_to_end": e2e,
+        "whole_path_tflops": round(GFLOP_PER_IMAGE_512 * 1e9 * scale * B * n_ranks_seen * args.steps / elapsed / 1e12, 2),
         "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in kernels.items()},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from ccst_amd.bench_resnet import host_cores
+        from bench_resnet import host_cores
         torch.set_num_threads(host_cores())
         cpu_content = A.synth_content(B, S, S, seed=1)
         cpu_stat = A.synth_style_stat(512, seed=7)
@@ -175,7 +242,7 @@ def main():
         result["max_abs_diff_vs_cpu"] = float((out.cpu() - ref).abs().max())
 
     if not args.no_secondary:           # second half of the BASELINE metric; every rank takes part
-        from ccst_amd import bench_resnet
+        import bench_resnet
         del out, content
         torch.cuda.empty_cache()
         sec = bench_resnet.run(dev, world, steps=max(3, args.steps // 2), warmup=2,

@@ -2,18 +2,27 @@
 federated/fed_run.py:49-80: zero_grad -> forward -> CrossEntropy -> backward -> SGD step), synthetic
 data resident in HBM.  Called by bench.py (``secondary``) and runnable on its own:
 
-    python -m ccst_amd.bench_resnet [--steps K] [--warmup W] [--batch B] [--arch resnet50] [--graph]
+    python bench_resnet.py [--steps K] [--warmup W] [--batch B] [--arch resnet50] [--graph]
+
+Lives next to bench.py, outside the ``ccst_amd`` package: its ``cpu_baseline`` leg imports the oracle, which nothing under
+``ccst_amd/`` may do.
 """
 import argparse
 import json
 import os
+import sys
 import time
 import types
 
 import torch
 
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
 GFLOP_PER_IMAGE = {"resnet50": 24.51, "resnet18": 10.87}      # SURVEY.md 8d (fwd + bwd-data + bwd-weight), 222x222
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBPS = 8000.0                                      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def host_cores():
@@ -31,8 +40,8 @@ def host_cores():
 
 
 def build(dev, arch="resnet50", classes=7, batch=64, size=222, lr=0.001, seed=1):
-    from . import fed
-    from .nets import models
+    from ccst_amd import fed
+    from ccst_amd.nets import models
     torch.manual_seed(seed)                                   # fed_run.py:495,510-514
     args = types.SimpleNamespace(dg_method="")
     model = models.get_network(arch)(args, pretrained=False, classes=classes).to(dev)
@@ -52,7 +61,7 @@ def make_step(model, opt, loss_fun, x, y, join_side=False):
         loss.backward()
         opt.step()
         if join_side:         # graph capture: every forked stream must re-join before the capture ends
-            from . import nn_ops
+            from ccst_amd import nn_ops
             nn_ops.join_prepack(x.device)
         return loss
     return step
@@ -60,8 +69,7 @@ def make_step(model, opt, loss_fun, x, y, join_side=False):
 
 def layer_table(step):
     """Per-launch conv table of one train step (HIP events), to stderr."""
-    import sys
-    from . import ops
+    from ccst_amd import ops
     ops.TIMING = []
     step()
     torch.cuda.synchronize()
@@ -78,61 +86,97 @@ def layer_table(step):
         print("TOTAL %-12s %9.1f us  %7.1f GFLOP  %6.1f TF" % (k, us, fl / 1e9, fl / us / 1e6), file=sys.stderr)
 
 
-def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False, cpu_baseline=False, layers=False):
+def hbm_traffic_per_step(arch, batch):
+    """HBM bytes one train step moves, from the separate rocprofv3 --pmc passes over this same script (FETCH_SIZE x2 per the
+    gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, summed over every kernel of a step; tools/profile_resnet.sh writes
+    profiles/traffic_resnet.json).  None when no profile for this arch/batch is committed."""
+    f = os.path.join(ROOT, "profiles", "traffic_resnet.json")
+    if not os.path.exists(f):
+        return None
+    with open(f) as fh:
+        tj = json.load(fh)
+    key = "%s_b%d" % (arch, batch)
+    return tj.get(key)
+
+
+def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False, cpu_baseline=False, layers=False,
+        build_fn=None, scale_fn=None, sync=None):
     """One client per rank (weak scaling).  With world > 1 (torch.distributed already initialised by the
     caller) the timed region is K local train steps followed by ONE FedAvg all-reduce of the flat state
-    (fed_run.py's round: local epoch(s) then communication()), barrier-bracketed, max over ranks."""
+    (fed_run.py's round: local epoch(s) then communication()), barrier-bracketed, max over ranks.
+    build_fn / scale_fn / sync are injection points for the CPU (gloo) test of this protocol: a stand-in model + step,
+    a host pre-scale instead of the HIP one, and a no-op instead of torch.cuda.synchronize."""
     import torch.distributed as dist
-    from . import fed
+    from ccst_amd import fed
+    sync = sync or torch.cuda.synchronize
     if graph and os.environ.get("CCST_GRAPH_SIDE", "1") == "0":       # single-stream capture
-        from . import nn_ops
+        from ccst_amd import nn_ops
         nn_ops.SIDE_STREAM = False
     distributed = world > 1 and dist.is_available() and dist.is_initialized()
     rank = dist.get_rank() if distributed else 0
-    model, opt, loss_fun, x, y = build(dev, arch=arch, batch=batch, seed=1 + rank)
+    n_ranks_seen = dist.get_world_size() if distributed else 1
+    model, opt, loss_fun, x, y = (build_fn or build)(dev, arch=arch, batch=batch, seed=1 + rank)
     step = make_step(model, opt, loss_fun, x, y, join_side=graph)
     args = types.SimpleNamespace(mode="fedavg")
+    comm_kw = {"scale_fn": scale_fn} if scale_fn is not None else {}
     for _ in range(warmup):
         loss = step()
     if distributed:
-        fed.communication_distributed(args, model, 1.0 / world)
-    torch.cuda.synchronize()
+        fed.communication_distributed(args, model, 1.0 / world, **comm_kw)
+    sync()
     if layers:
         layer_table(step)
     if graph:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             loss = step()
-        torch.cuda.synchronize()
+        sync()
         run_step = g.replay
     else:
         run_step = step
     if distributed:
         dist.barrier()
-        torch.cuda.synchronize()
+        sync()
     t0 = time.perf_counter()
     for _ in range(steps):
         run_step()
+    allreduce_ms = None
     if distributed:
-        fed.communication_distributed(args, model, 1.0 / world)
-    torch.cuda.synchronize()
+        sync()
+        ta = time.perf_counter()
+        fed.communication_distributed(args, model, 1.0 / world, **comm_kw)
+        sync()
+        allreduce_ms = (time.perf_counter() - ta) * 1e3
+    sync()
     if distributed:
         dist.barrier()
-        torch.cuda.synchronize()
+        sync()
     total = time.perf_counter() - t0
     if distributed:
-        tt = torch.tensor([total], device=dev, dtype=torch.float64)
+        tt = torch.tensor([total, allreduce_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        total = float(tt.item())
+        total, allreduce_ms = float(tt[0].item()), float(tt[1].item())
     dt = total / steps
     gflop = GFLOP_PER_IMAGE.get(arch, 0.0) * batch
-    out = {"metric": "%s train images/sec @222x222 B=%d" % (arch, batch), "value": round(world * batch / dt, 2), "unit": "images/sec",
-           "n_gpus": world, "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup, "dtype": "f32",
+    tf = gflop / dt / 1e3
+    traffic = hbm_traffic_per_step(arch, batch)
+    out = {"metric": "%s train images/sec @222x222 B=%d" % (arch, batch), "value": round(n_ranks_seen * batch / dt, 2), "unit": "images/sec",
+           "n_gpus": world, "n_ranks_seen": n_ranks_seen, "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup, "dtype": "f32",
            "hip_graph": bool(graph), "scaling": "weak",
            "config": {"workload": "fed_run.py train() body, %s classes=7, SGD lr 0.001, one client per GPU%s"
                       % (arch, ", + 1 FedAvg all-reduce (RCCL) per %d steps" % steps if distributed else "")},
-           "tflops_per_gpu": round(gflop / dt / 1e3, 2), "frac_of_f32_mfma_peak": round(gflop / dt / 1e3 / PEAK_F32_MFMA_TFLOPS, 4),
+           "tflops_per_gpu": round(tf, 2), "frac_of_f32_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+           # the step is bounded by the fp32 MFMA time of its 3 GEMMs per conv (SURVEY 8d "Roofline 2"); the BN / element-wise
+           # kernels are HBM work on top: traffic = measured HBM bytes per step (PMC), hbm_frac = traffic / step time / 8 TB/s
+           "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "bound_images_per_s": round(PEAK_F32_MFMA_TFLOPS * 1e3 / GFLOP_PER_IMAGE.get(arch, 1.0), 1),
+                        "traffic": traffic,
+                        "achieved_GBps": round(traffic / dt / 1e9, 1) if traffic else None,
+                        "hbm_frac": round(traffic / dt / 1e9 / PEAK_HBM_GBPS, 4) if traffic else None},
            "final_loss": round(float(loss.detach()), 5)}
+    if distributed:
+        out["fedavg_allreduce_ms"] = round(allreduce_ms, 3)
+        out["fedavg_bytes"] = int(fed.FlatParams.of(model).n_total * 4)
     if cpu_baseline and rank == 0 and world == 1:
         from oracle import resnet_ref as R
         torch.set_num_threads(host_cores())

@@ -494,8 +494,15 @@ def adain(feat, style_mean, style_std, alpha=1.0, eps=1e-5):
         raise RuntimeError("ccst_amd: style statistics must have C or N*C elements")
     out = torch.empty_like(buf)
     ws, nb = _stats_ws(N, C, H * W, feat.device)
-    check(_lib.load().ccst_adain_f32(ptr(buf), ptr(sm), ptr(ss), per_n, float(alpha), ptr(out), N, C, H * W, layout, eps,
-                                     ptr(ws), nb, stream_ptr()), "adain")
+    args = (ptr(buf), ptr(sm), ptr(ss), per_n, float(alpha), ptr(out), N, C, H * W, layout, eps, ptr(ws), nb, stream_ptr())
+    if TIMING is None:
+        check(_lib.load().ccst_adain_f32(*args), "adain")
+    else:       # bench.py: the whole statistics + normalise step (3 launches), HBM-bound: algorithmic bytes = read x + write y
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().ccst_adain_f32(*args), "adain")
+        e1.record()
+        TIMING.append(("adain_step", 0.0, e0, e1, "n%d c%d hw%d bytes%d" % (N, C, H * W, 2 * 4 * N * C * H * W)))
     return out if layout == NCHW else to_api(out)
 
 

@@ -123,3 +123,39 @@ def test_fedavg_and_style_stats_world2():
         e0 = np.random.RandomState(5).uniform(1, 2, (1, 8, 1, 1)).astype(np.float32)
         e1 = np.random.RandomState(6).uniform(1, 2, (1, 8, 1, 1)).astype(np.float32)
         assert np.allclose(s0["sum"].numpy(), e0 + e1, rtol=1e-6) and torch.equal(s0["sum"], s1["sum"])
+
+
+def _bench_worker(rank, world, initfile, outdir):
+    """bench_resnet.run's distributed branch (what `bench.py --gpus N` executes for the FedAvg half of the metric) on gloo:
+    K local steps, ONE all-reduce of the flat state, barrier-bracketed timing, value = ranks x batch / max-over-ranks time."""
+    import json
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    dist.init_process_group("gloo", init_method="file://" + initfile, rank=rank, world_size=world)
+    import bench_resnet
+    from torch import nn
+
+    def build_fn(dev, arch, batch, seed):
+        torch.manual_seed(seed)
+        model = nn.Sequential(nn.Linear(12, 16), nn.ReLU(), nn.Linear(16, 7))
+        opt = torch.optim.SGD(model.parameters(), lr=0.05)
+        x, y = torch.randn(batch, 12), torch.randint(0, 7, (batch,))
+        return model, opt, nn.CrossEntropyLoss(), x, y
+    out = bench_resnet.run(torch.device("cpu"), world=world, steps=3, warmup=1, batch=8, arch="resnet50", build_fn=build_fn,
+                           scale_fn=lambda flat, w, n: flat.mul_(float(w)), sync=lambda: None)
+    with open(os.path.join(outdir, "bench_%d.json" % rank), "w") as f:
+        json.dump(out, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_fedavg_round_world4():
+    import json
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_bench_worker, args=(4, os.path.join(d, "init"), d), nprocs=4, join=True)
+        outs = [json.load(open(os.path.join(d, "bench_%d.json" % r))) for r in range(4)]
+        for o in outs:
+            assert o["n_gpus"] == 4 and o["n_ranks_seen"] == 4 and o["scaling"] == "weak" and o["steps"] == 3
+            assert o["fedavg_allreduce_ms"] > 0 and o["fedavg_bytes"] == 4 * ((12 * 16) + 16 + (16 * 7 + 3) // 4 * 4 + (7 + 3) // 4 * 4)
+            assert abs(o["value"] - 4 * 8 / (o["ms_per_step"] * 1e-3)) < 1e-2 * o["value"]          # whole-job rate: ranks x batch / time
+            assert "FedAvg all-reduce" in o["config"]["workload"]
+        assert len({o["ms_per_step"] for o in outs}) == 1                                            # the MAX over ranks, on every rank

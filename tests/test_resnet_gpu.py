@@ -418,6 +418,64 @@ def test_train_and_test_loops(dev, golden):
     assert np.allclose(kabs, g["key_abs"], rtol=1e-3)
 
 
+def test_offload_models_round_trip_keeps_training(dev):
+    """args.offload_models=True reproduces fed_run.py:85,258 (model.to('cpu') after every train()/test()).  Every parameter tensor is
+    replaced on each round trip; the optimiser created BEFORE the moves (fed_run.py:657) must keep updating the model the
+    modules hold (it used to update a stale arena).  Result: bit-identical to the resident run."""
+    from ccst_amd import fed
+    from ccst_amd.nets import resnet
+    from oracle import resnet_ref as R
+    loader = [R.synth_batch(4, 222, 3, seed=500 + i) for i in range(2)]
+    out = {}
+    for offload in (False, True):
+        args = types.SimpleNamespace(dg_method="", mode="fedavg", offload_models=offload)
+        m = resnet.ResNet(resnet.BasicBlock, [1, 1, 1, 1], classes=3)
+        m.load_state_dict(R.seeded_state_dict(R.ResNet(R.BasicBlock, [1, 1, 1, 1], classes=3), 92))
+        opt = fed.SGD(m, lr=0.01)                       # model still on the CPU here, as in fed_run.py:657
+        ce = fed.CrossEntropyLoss()
+        r = [fed.train(m, loader, opt, ce, 1, dev, args, 0, None), fed.test(m, loader, ce, dev, args),
+             fed.train(m, loader, opt, ce, 1, dev, args, 1, None)]
+        assert next(m.parameters()).device.type == ("cpu" if offload else "cuda")
+        out[offload] = (r, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    assert out[False][0] == out[True][0]
+    assert out[True][0][2][0] != out[True][0][0][0]                    # the second epoch saw updated weights
+    for k, v in out[False][1].items():
+        assert torch.equal(v, out[True][1][k]), k
+
+
+def test_test_fedbn_merge_and_eval(dev):
+    """fed.test_fedbn vs the reference's merge (fed_run.py:350-362, restated in oracle.fed_ref.test_fedbn_merge) + eval loop."""
+    from ccst_amd import fed
+    from ccst_amd.nets import resnet
+    from oracle import fed_ref, resnet_ref as R
+
+    def make(cls, blk):
+        server = cls(blk, [1, 1, 1, 1], classes=3)
+        server.load_state_dict(R.seeded_state_dict(R.ResNet(R.BasicBlock, [1, 1, 1, 1], classes=3), 70))
+        clients = [copy.deepcopy(server) for _ in range(3)]
+        for ci, c in enumerate(clients):
+            rs = np.random.RandomState(81 + ci)
+            with torch.no_grad():
+                for k, v in c.state_dict().items():
+                    if "num_batches_tracked" in k:
+                        v.fill_(5 + ci)
+                    elif "running_var" in k:
+                        v += torch.from_numpy(rs.uniform(0, 0.2, tuple(v.shape)).astype(np.float32))
+                    else:
+                        v += torch.from_numpy(rs.normal(0, 0.02, tuple(v.shape)).astype(np.float32))
+        return server, clients
+    loader = [R.synth_batch(4, 222, 3, seed=600 + i) for i in range(2)]
+    rs_, rc = make(R.ResNet, R.BasicBlock)
+    fed_ref.test_fedbn_merge(rs_, rc)
+    ref = fed_ref.test_epoch(rs_, loader, nn.CrossEntropyLoss())
+    server, clients = make(resnet.ResNet, resnet.BasicBlock)
+    got = fed.test_fedbn(server, clients, loader, fed.CrossEntropyLoss(), dev, ARGS)
+    for k, v in rs_.state_dict().items():
+        d = (server.state_dict()[k].cpu().double() - v.double()).abs().max()
+        assert float(d) <= 1e-6 * max(1.0, float(v.double().abs().max())), k
+    assert abs(got[0] - ref[0]) < 1e-3 and got[1] == ref[1]
+
+
 def test_train_hip_graph_matches_eager(dev):
     """fed.train(..., args.hip_graph=True): iterations 3.. are HIP-graph replays; same losses, accuracies and -- bit for
     bit -- the same weights / BN statistics as the eager loop, across two calls with a FedAvg-style weight rewrite between."""
@@ -496,6 +554,29 @@ def test_fed_run_cli_fedbn(dev, tmp_path):
     srv, m1 = ck["server_model"], ck["model_1"]
     assert torch.equal(srv["conv1.weight"], m1["conv1.weight"]) and torch.equal(srv["layer2.0.downsample.1.weight"], m1["layer2.0.downsample.1.weight"])
     assert not torch.equal(srv["bn1.running_mean"], m1["bn1.running_mean"])
+    # --resume: every client continues from ITS model_k; --test: test_fedbn (fed_run.py:585-590)
+    if not (d / "fedbn").exists():
+        import shutil
+        shutil.copy(str(d / "fedbn_latest"), str(d / "fedbn"))
+    out2 = subprocess.check_output(cmd[:-1] + ["3", "--resume"], cwd=str(tmp_path), env=env, text=True)
+    assert "Resume training from epoch 2" in out2
+    out3 = subprocess.check_output(cmd + ["--test"], cwd=str(tmp_path), env=env, text=True)
+    assert "| Test  Acc:" in out3 and out3.strip().splitlines()[-1].startswith(" sketch")
+
+
+def test_fed_run_cli_deepall(dev, tmp_path):
+    """--mode deepall (data/data_helper.py:66-121, fed_run.py:570-575): ONE client trained on every source's data."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    cmd = [sys.executable, os.path.join(root, "federated", "fed_run.py"), "--mode", "deepall", "--fusion_mode", "no_fusion",
+           "--source", "art_painting", "cartoon", "sketch", "--target", "photo", "--n_classes", "7", "--network", "resnet18",
+           "--lr", "0.001", "--image_size", "222", "--batch", "4", "--synthetic", "8", "--save_path", str(tmp_path / "ckpt"),
+           "--iters", "2"]
+    out = subprocess.check_output(cmd, cwd=str(tmp_path), env=env, text=True)
+    assert out.count("| Train Loss:") == 2 and out.count("| Global Val Class Acc:") == 2          # one client per round
 
 
 def test_train_step_bitwise_reproducible(dev):

@@ -5,7 +5,7 @@ import pstats
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from ccst_amd import bench_resnet as B
+import bench_resnet as B
 dev = torch.device("cuda:0")
 arch = sys.argv[1] if len(sys.argv) > 1 else "resnet50"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64

@@ -1,0 +1,38 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): the ResNet50 train step (bench_resnet.py) under rocprofv3 -- kernel-trace stats, then
+# separate PMC passes for FETCH_SIZE and WRITE_SIZE -> gpurun_out/prof_<tag>/{summary.txt,traffic_resnet.json}
+# Usage: tools/profile_resnet.sh <tag> [arch] [batch]
+set -u
+TAG=${1:-r2}; ARCH=${2:-resnet50}; BATCH=${3:-64}
+STEPS=5; WARM=2
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="$ROOT/bench_resnet.py --steps $STEPS --warmup $WARM --arch $ARCH --batch $BATCH"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/bench_trace.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/bench_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/bench_write.log 2>&1
+cd $ROOT
+python3 tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
+python3 - "$OUT" "$ARCH" "$BATCH" "$((STEPS + WARM))" <<'PY'
+import csv, glob, json, os, sys
+out, arch, batch, nsteps = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+tot = {}
+for sub, ctr, mult in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SIZE", 1.0)):     # gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md)
+    fs = glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True)
+    if not fs:
+        continue
+    s = 0.0
+    with open(fs[0]) as fh:
+        for r in csv.DictReader(fh):
+            if r.get("Counter_Name") == ctr:
+                s += float(r["Counter_Value"])
+    tot[ctr] = s * mult * 1024.0 / nsteps          # counters are in KB; every launch of the run / (warm-up + timed) steps
+if tot:
+    res = {"%s_b%d" % (arch, batch): round(sum(tot.values())), "detail_bytes_per_step": {k: round(v) for k, v in tot.items()},
+           "steps_in_run": nsteps, "note": "FETCH_SIZE x2 + WRITE_SIZE over every kernel of the run / steps (includes the one-off weight packs of step 0)"}
+    json.dump(res, open(os.path.join(out, "traffic_resnet.json"), "w"), indent=1)
+    print(json.dumps(res))
+PY
+head -40 $OUT/summary.txt

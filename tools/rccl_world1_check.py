@@ -6,7 +6,8 @@ import torch.distributed as dist
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 dev = torch.device("cuda:0"); torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-from ccst_amd import fed, bench_resnet, style
+import bench_resnet
+from ccst_amd import fed, style
 from ccst_amd.nets import models
 args = types.SimpleNamespace(mode="fedavg", dg_method="no_DG")
 m = models.get_network("resnet18")(args, pretrained=False, classes=7).to(dev)
