@@ -45,6 +45,9 @@ _SIGNATURES = {
     "ccst_wino_weight_floats": [c_int, c_int],
     "ccst_pack_conv_weight_wino_f32": [_P, _P, c_int, c_int, c_int, _P],
     "ccst_conv3x3_wino_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
+    "ccst_wino4_weight_floats": [c_int, c_int],
+    "ccst_pack_conv_weight_wino4_f32": [_P, _P, c_int, c_int, c_int, _P],
+    "ccst_conv3x3_wino4_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_pack_conv_weight_wino_bwd_f32": [_P, _P, c_int, c_int, c_int, _P],
     "ccst_conv3x3_wino_train_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_conv3x3_wino_stats_groups": [c_int, c_int, c_int],
@@ -83,7 +86,8 @@ _SIGNATURES = {
     "ccst_scale_f32": [_P, c_float, c_int64, _P],
 }
 _RESTYPES = {"ccst_last_error": c_char_p, "ccst_stats_workspace_bytes": c_int64, "ccst_bn_workspace_bytes": c_int64,
-             "ccst_wino_weight_floats": c_int64, "ccst_image_plan": c_int64}
+             "ccst_wino_weight_floats": c_int64, "ccst_image_plan": c_int64,
+             "ccst_wino4_weight_floats": c_int64}
 EXPORTS = tuple(_SIGNATURES)
 
 _lib = None

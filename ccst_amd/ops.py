@@ -202,17 +202,25 @@ def from_api(x, cpad=1):
 class PackedConv(object):
     """Device-resident packed weight [kh*kw][K/4][n_pad][4] (+ optional bias).  `u` / `u_pad`: the Winograd-transformed
     copy (ccst_pack_conv_weight_wino_f32) of a 3x3 weight, built by pack_conv_weight(..., wino=True)."""
-    __slots__ = ("w", "bias", "cin", "cout", "kh", "kw", "k_pad", "n_pad", "transpose", "u", "u_pad")
+    __slots__ = ("w", "bias", "cin", "cout", "kh", "kw", "k_pad", "n_pad", "transpose", "u", "u_pad", "u4")
 
     def __init__(self, w, bias, cin, cout, kh, kw, k_pad, n_pad, transpose):
         self.w, self.bias, self.cin, self.cout, self.kh, self.kw = w, bias, cin, cout, kh, kw
         self.k_pad, self.n_pad, self.transpose = k_pad, n_pad, transpose
         self.u, self.u_pad = None, 0
+        self.u4 = None              # F(4x4,3x3) transform (ccst_pack_conv_weight_wino4_f32), same u_pad
 
 
 # Fused Winograd F(2x2,3x3) for the 3x3 stride-1 layers of the AdaIN encoder / decoder (conv3x3_wino.hip): 2.25x fewer
 # multiplies than the direct form, 549 -> 865 images/s on the metric; CCST_CONV_WINO=0 keeps the direct halo kernel.
 USE_WINO = os.environ.get("CCST_CONV_WINO", "1") != "0"
+# CCST_CONV_WINO=4: F(4x4,3x3) (conv3x3_wino4.hip, 2.25 multiplies per output instead of 4) on the layers wino4_ok() admits.
+WINO_F4 = os.environ.get("CCST_CONV_WINO", "1") == "4"
+WINO_F4_MIN_CIN = int(os.environ.get("CCST_WINO4_MIN_CIN", "16"))
+
+
+def wino4_ok(cin, cout, H, W):
+    return WINO_F4 and cin % 16 == 0 and cin >= WINO_F4_MIN_CIN
 
 
 def pack_conv_weight(w_oihw, bias=None, transpose=False, out=None, wino=False):
@@ -237,7 +245,30 @@ def pack_conv_weight(w_oihw, bias=None, transpose=False, out=None, wino=False):
         pc.u_pad = round_up(cout, 32)
         pc.u = torch.empty(int(lib.ccst_wino_weight_floats(cin, pc.u_pad)), device=w.device, dtype=torch.float32)
         check(lib.ccst_pack_conv_weight_wino_f32(ptr(w), ptr(pc.u), cout, cin, pc.u_pad, stream_ptr()), "pack_conv_weight_wino")
+        if wino == 4 or (WINO_F4 and cin >= WINO_F4_MIN_CIN):
+            pc.u4 = torch.empty(int(lib.ccst_wino4_weight_floats(cin, pc.u_pad)), device=w.device, dtype=torch.float32)
+            check(lib.ccst_pack_conv_weight_wino4_f32(ptr(w), ptr(pc.u4), cout, cin, pc.u_pad, stream_ptr()), "pack_conv_weight_wino4")
     return pc
+
+
+def conv3x3_wino4(x, pc, flags=0):
+    """3x3 stride-1 pad-1 conv on the F(4x4,3x3) kernel; x NHWC [N,Hs,Ws,Cin], pc packed with wino=4.  flags: CONV_* bits."""
+    N, Hs, Ws, Cx = x.shape
+    ups, pool = bool(flags & CONV_UPS2), bool(flags & CONV_POOL2)
+    Hi, Wi = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
+    oh, ow = ((Hi + 1) // 2, (Wi + 1) // 2) if pool else (Hi, Wi)
+    out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
+    args = (ptr(x), ptr(pc.u4), ptr(pc.bias), ptr(out), N, Hi, Wi, Cx, pc.cout, pc.u_pad, flags, stream_ptr())
+    if TIMING is None:
+        check(_lib.load().ccst_conv3x3_wino4_f32(*args), "conv3x3_wino4")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().ccst_conv3x3_wino4_f32(*args), "conv3x3_wino4")
+        e1.record()
+        TIMING.append(("conv3x3_wino4_kernel<%s>" % ("pool" if pool else "nopool"), 2.0 * N * Hi * Wi * pc.cout * pc.cin * 9, e0, e1,
+                       "n%d %dx%d cin%d cout%d taps3x3 flags%d" % (N, Hi, Wi, pc.cin, pc.cout, flags)))
+    return out
 
 
 def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, ups=False, out_nchw=False, out=None,
@@ -273,6 +304,9 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
     if not reflect and pc.kh == 3 and pc.kw == 3 and stride == 1 and pad == 1 and not (relu or pool or ups or out_nchw) \
             and out is None and pc.bias is None and halo_train_ok(Hi, Wi, Cx, pc.cout):
         return conv3x3_halo_train(x, pc, want_stats=want_stats)
+    if pc.u4 is not None and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats \
+            and wino4_ok(pc.cin, pc.cout, Hi, Wi):
+        return conv3x3_wino4(x, pc, flags)
     if USE_WINO and pc.u is not None and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats:
         out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
         lib = _lib.load()

@@ -103,6 +103,14 @@ int64_t ccst_wino_weight_floats(int cin, int cout_pad);
 int ccst_pack_conv_weight_wino_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, void* stream);
 int ccst_conv3x3_wino_f32(const float* x, const float* u_packed, const float* bias, float* y, int N, int H, int W,
                           int Cin, int Cout, int cout_pad, uint32_t flags, void* stream);
+
+/* Fused Winograd F(4x4,3x3): same contract as ccst_conv3x3_wino_f32 (3x3 stride-1 "same" conv of net.py:6-36,38-69: reflection or
+ * zero padding, fused bias / ReLU / nearest-x2 upsample on read / 2x2 ceil max-pool), 2.25 multiplies per output instead of 4.
+ * u_packed from ccst_pack_conv_weight_wino4_f32 ([Cin/16][36][2][cout_pad][8] floats = ccst_wino4_weight_floats). */
+int64_t ccst_wino4_weight_floats(int cin, int cout_pad);
+int ccst_pack_conv_weight_wino4_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, void* stream);
+int ccst_conv3x3_wino4_f32(const float* x, const float* u_packed, const float* bias, float* y, int N, int H, int W, int Cin,
+                           int Cout, int cout_pad, uint32_t flags, void* stream);
 /* The Winograd kernel for the ResNet trunk's 3x3 stride-1 zero-padded bias-free convs (forward with the BatchNorm statistics
  * epilogue, backward-data with the weights from ccst_pack_conv_weight_wino_bwd_f32 and x = dY, optional y += with
  * CCST_CONV_ACCUM).  stats: NULL or [ccst_conv3x3_wino_stats_groups(N,H,W)][Cout][2]. */
