@@ -167,15 +167,18 @@ def main():
     scale = S * S / 512.0 / 512.0
     wino_share = 1.0 - WINO_GFLOP_PER_IMAGE_512 / GFLOP_PER_IMAGE_512
     # whole-path ceilings per GPU: every FLOP at the fp32-MFMA peak, and the same with the 3x3 layers' multiplies
-    # divided by 2.25 (F(2x2,3x3)); the two non-Winograd layers are HBM-bound and priced at their MFMA time only
+    # divided by 2.25 (F(2x2,3x3)) or 4 (F(4x4,3x3)); the two non-Winograd layers are HBM-bound and priced at their MFMA time only
     bound_direct = PEAK_F32_MFMA_TFLOPS * 1e3 / (GFLOP_PER_IMAGE_512 * scale)
-    bound_wino = PEAK_F32_MFMA_TFLOPS * 1e3 / ((GFLOP_PER_IMAGE_512 * wino_share / 2.25 + WINO_GFLOP_PER_IMAGE_512) * scale)
+    bound_w2 = PEAK_F32_MFMA_TFLOPS * 1e3 / ((GFLOP_PER_IMAGE_512 * wino_share / 2.25 + WINO_GFLOP_PER_IMAGE_512) * scale)
+    bound_w4 = PEAK_F32_MFMA_TFLOPS * 1e3 / ((GFLOP_PER_IMAGE_512 * wino_share / 4.0 + WINO_GFLOP_PER_IMAGE_512) * scale)
     if per_kernel:
         dom = max(per_kernel, key=lambda n: per_kernel[n][2])
         cnt, fl, sec = per_kernel[dom]
         alg = fl / sec / 1e12
-        wino = dom.startswith("conv3x3_wino_kernel")
-        executed = alg / 2.25 if wino else alg
+        wfac = 4.0 if dom.startswith("conv3x3_wino4_kernel") else 2.25 if dom.startswith("conv3x3_wino_kernel") else 1.0
+        wino = wfac != 1.0
+        bound_wino = bound_w4 if wfac == 4.0 else bound_w2
+        executed = alg / wfac
         traffic, tsrc = None, os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tsrc):      # HBM bytes/launch from the separate rocprofv3 --pmc passes (tools/profile_bench.sh)
             with open(tsrc) as fh:
@@ -183,8 +186,8 @@ def main():
             base, targs = dom[:-1].split("<")
             targs = targs.split(",")
             nums, pooled = ", ".join(a for a in targs if a not in ("pool", "nopool")), ("true" if "pool" in targs else "false")
-            if base == "conv3x3_wino_kernel":
-                keys = [k for k in tj if k.startswith("void conv3x3_wino_kernel<") and k.rstrip(">").split("<")[1].split(",")[0].strip() == pooled]
+            if base in ("conv3x3_wino_kernel", "conv3x3_wino4_kernel"):
+                keys = [k for k in tj if k.startswith("void %s<" % base) and k.rstrip(">").split("<")[1].split(",")[0].strip() == pooled]
             elif base == "conv_igemm_kernel":
                 keys = ["void conv_igemm_kernel<%s, %s, 2, 16>" % (nums, pooled)]
             else:       # rocprofv3 prints every template argument: <WM, WN, NT, POOL, TRAIN>
@@ -197,10 +200,10 @@ def main():
                     "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "kernel": dom,
                     "launches_per_step": cnt / args.steps, "avg_launch_us": round(sec / cnt * 1e6, 2),
                     "gflop_per_launch": round(fl / cnt / 1e9, 3), "algorithmic_tflops": round(alg, 2),
-                    "algorithm": ("winograd F(2x2,3x3): the MFMA pipe executes gflop_per_launch / 2.25; achieved and frac are the EXECUTED rate"
-                                  if wino else "direct"),
-                    "executed_gflop_per_launch": round(fl / cnt / 1e9 / (2.25 if wino else 1.0), 3),
-                    "bound_images_per_s": {"direct": round(bound_direct, 1), "winograd_f2x2": round(bound_wino, 1)},
+                    "algorithm": ("winograd F(%s,3x3): the MFMA pipe executes gflop_per_launch / %.4g; achieved and frac are the EXECUTED rate"
+                                  % ("4x4" if wfac == 4.0 else "2x2", wfac) if wino else "direct"),
+                    "executed_gflop_per_launch": round(fl / cnt / 1e9 / wfac, 3),
+                    "bound_images_per_s": {"direct": round(bound_direct, 1), "winograd_f2x2": round(bound_w2, 1), "winograd_f4x4": round(bound_w4, 1)},
                     "path_frac_of_bound": round(value / n_ranks_seen / (bound_wino if wino else bound_direct), 4)}
     adain_step = None
     if adain_us:

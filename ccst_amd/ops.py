@@ -211,11 +211,12 @@ class PackedConv(object):
         self.u4 = None              # F(4x4,3x3) transform (ccst_pack_conv_weight_wino4_f32), same u_pad
 
 
-# Fused Winograd F(2x2,3x3) for the 3x3 stride-1 layers of the AdaIN encoder / decoder (conv3x3_wino.hip): 2.25x fewer
-# multiplies than the direct form, 549 -> 865 images/s on the metric; CCST_CONV_WINO=0 keeps the direct halo kernel.
-USE_WINO = os.environ.get("CCST_CONV_WINO", "1") != "0"
-# CCST_CONV_WINO=4: F(4x4,3x3) (conv3x3_wino4.hip, 2.25 multiplies per output instead of 4) on the layers wino4_ok() admits.
-WINO_F4 = os.environ.get("CCST_CONV_WINO", "1") == "4"
+# Fused Winograd for the 3x3 stride-1 layers of the AdaIN encoder / decoder.  CCST_CONV_WINO = 4 (default): F(4x4,3x3)
+# (conv3x3_wino4.hip, 2.25 multiplies per output); 2 (or 1): F(2x2,3x3) (conv3x3_wino.hip, 4 per output: 549 -> 880 images/s over
+# the direct form); 0: the direct halo kernel (9 per output).
+_WINO_MODE = os.environ.get("CCST_CONV_WINO", "4")
+USE_WINO = _WINO_MODE != "0"
+WINO_F4 = _WINO_MODE == "4"
 WINO_F4_MIN_CIN = int(os.environ.get("CCST_WINO4_MIN_CIN", "16"))
 
 

@@ -21,6 +21,8 @@ LAYERS = [(512, 512, 64, 64, True, False), (256, 256, 64, 128, False, False), (2
           (128, 128, 256, 256, False, False), (128, 128, 256, 128, False, False), (256, 256, 128, 128, False, True),
           (256, 256, 128, 64, False, False), (512, 512, 64, 64, False, True)]
 g = torch.Generator().manual_seed(1)
+if os.environ.get('WINO_LAYER'):
+    LAYERS = [LAYERS[int(i)] for i in os.environ['WINO_LAYER'].split(',')]
 tot2 = tot4 = 0.0
 for (H, W, Cin, Cout, pool, ups) in LAYERS:
     Hs, Ws = (H // 2, W // 2) if ups else (H, W)
