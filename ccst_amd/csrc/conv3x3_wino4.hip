@@ -68,7 +68,12 @@ __device__ __forceinline__ f32x2 hi2(f32x4 a) { return f32x2{a[2], a[3]}; }
 // +2.0-2.6 ns per v_fma_f32, +2.6 ns per v_pk_fma_f32), so the transform's cost is its INSTRUCTION COUNT, and a v_pk_* does two
 // lanes' worth for one slot.  hipcc splits packed fp32 instructions next to MFMAs back into scalar ones (it assumes they co-execute);
 // assembly keeps them packed.  Constants come from scalar register pairs (one scalar operand per instruction).
-__device__ __forceinline__ f32x2 pk_fma_vsv(f32x2 a, f32x2 k, f32x2 c) {      // a * k + c, k in SGPRs
+typedef unsigned long long k64;                                               // a coefficient pair (k, k) as the 64 bits of an SGPR pair
+__device__ __forceinline__ k64 splat_k(float k) {
+    const unsigned b = __builtin_amdgcn_readfirstlane(__float_as_uint(k));
+    return ((k64)b << 32) | b;
+}
+__device__ __forceinline__ f32x2 pk_fma_vsv(f32x2 a, k64 k, f32x2 c) {        // a * k + c, k in an SGPR pair
     f32x2 d;
     asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c));
     return d;
@@ -143,8 +148,8 @@ __device__ __forceinline__ void wino4_body(const Wino4Args& p, float* __restrict
         k3 = 1.f;
     }
     // coefficient pairs in scalar registers; the last row's coefficient is always 1, so the chain starts from that row
-    const f32x2 K0 = {k0, k0}, K1 = {k1, k1}, K2 = {k2, k2};
-    const f32x2 C4 = {4.f, 4.f}, CM5 = {-5.f, -5.f}, CM4 = {-4.f, -4.f}, C2 = {2.f, 2.f}, CM2 = {-2.f, -2.f};
+    const k64 K0 = splat_k(k0), K1 = splat_k(k1), K2 = splat_k(k2);
+    const k64 C4 = splat_k(4.f), CM5 = splat_k(-5.f), CM4 = splat_k(-4.f), C2 = splat_k(2.f), CM2 = splat_k(-2.f);
     (void)k3;
     const int rfirst = FOUR ? 1 : (wr == 0 ? 0 : 1), rstep = FOUR ? 1 : 2;
     const int tyy = li >> 3, txx = li & 7;
