@@ -55,10 +55,12 @@ def build(dev, arch="resnet50", classes=7, batch=64, size=222, lr=0.001, seed=1)
 
 
 def make_step(model, opt, loss_fun, x, y, join_side=False):
+    from ccst_amd import fed
+
     def step():
         opt.zero_grad()
         loss = loss_fun(model(x), y)
-        loss.backward()
+        fed.backward(loss) if x.is_cuda else loss.backward()
         opt.step()
         if join_side:         # graph capture: every forked stream must re-join before the capture ends
             from ccst_amd import nn_ops

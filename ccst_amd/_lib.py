@@ -84,6 +84,10 @@ _SIGNATURES = {
     "ccst_softmax_ce_f32": [_P, _P, _P, _P, _P, c_int, c_int, _P],
     "ccst_sgd_f32": [_P, _P, c_float, c_int64, _P],
     "ccst_scale_f32": [_P, c_float, c_int64, _P],
+    "ccst_fill_f32": [_P, c_float, c_int64, _P],
+    "ccst_add_i64": [_P, c_int64, c_int, _P],
+    "ccst_mul_scalar_f32": [_P, _P, _P, c_int64, _P],
+    "ccst_stem_grad_unfold_f32": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
 }
 _RESTYPES = {"ccst_last_error": c_char_p, "ccst_stats_workspace_bytes": c_int64, "ccst_bn_workspace_bytes": c_int64,
              "ccst_wino_weight_floats": c_int64, "ccst_image_plan": c_int64,

@@ -346,8 +346,8 @@ __global__ __launch_bounds__(256, WINO_WAVES) void conv3x3_wino_kernel(const Win
 // OIHW 3x3 -> U[chunk][r][q][half][cout_pad][8], U = G g G^T, channel ci = chunk*16 + half*8 + j
 // bwd != 0: the backward-data operand -- the conv whose input is dY: g'[ci][co][ky][kx] = g[co][ci][2-ky][2-kx], i.e. the roles of
 // cout / cin are those of the BACKWARD conv (cout = forward Cin, cin = forward Cout) and w is still the forward OIHW tensor.
-__global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ u, int cout, int cin, int cin_pad, int cout_pad,
-                                        int bwd) {
+__device__ __forceinline__ void pack_weight_wino_body(const float* __restrict__ w, float* __restrict__ u, int cout, int cin, int cin_pad,
+                                                      int cout_pad, int bwd) {
     const long long total = (long long)(cin_pad / 16) * 16 * 2 * cout_pad * 8;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(i & 7);
@@ -378,39 +378,16 @@ __global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __re
     }
 }
 
+__global__ void pack_weight_wino_kernel(const float* __restrict__ w, float* __restrict__ u, int cout, int cin, int cin_pad, int cout_pad,
+                                        int bwd) {
+    pack_weight_wino_body(w, u, cout, cin, cin_pad, cout_pad, bwd);
+}
+
 // the same for many weight tensors in one launch: jobs[j] = {src, dst, cout, cin, cin_pad, cout_pad, bwd, 0} (int64, device)
 __global__ void pack_weight_wino_batch_kernel(const long long* __restrict__ jobs) {
     const long long* jb = jobs + (long long)blockIdx.y * 8;
-    const float* __restrict__ w = reinterpret_cast<const float*>(jb[0]);
-    float* __restrict__ u = reinterpret_cast<float*>(jb[1]);
-    const int cout = (int)jb[2], cin = (int)jb[3], cin_pad = (int)jb[4], cout_pad = (int)jb[5], bwd = (int)jb[6];
-    const long long total = (long long)(cin_pad / 16) * 16 * 2 * cout_pad * 8;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int j = (int)(i & 7);
-        long long t = i >> 3;
-        const int co = (int)(t % cout_pad);
-        t /= cout_pad;
-        const int half = (int)(t & 1);
-        t >>= 1;
-        const int q = (int)(t & 3);
-        t >>= 2;
-        const int r = (int)(t & 3);
-        const int chunk = (int)(t >> 2);
-        const int ci = chunk * 16 + half * 8 + j;
-        float val = 0.f;
-        if (co < cout && ci < cin) {
-            const float* g = bwd ? w + ((long long)ci * cout + co) * 9 : w + ((long long)co * cin + ci) * 9;
-            float gg[3];
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) {
-                const int c_ = bwd ? 2 - cc : cc;
-                const float g0 = g[(bwd ? 2 : 0) * 3 + c_], g1 = g[1 * 3 + c_], g2 = g[(bwd ? 0 : 2) * 3 + c_];
-                gg[cc] = (r == 0) ? g0 : (r == 1) ? 0.5f * (g0 + g1 + g2) : (r == 2) ? 0.5f * (g0 - g1 + g2) : g2;
-            }
-            val = (q == 0) ? gg[0] : (q == 1) ? 0.5f * (gg[0] + gg[1] + gg[2]) : (q == 2) ? 0.5f * (gg[0] - gg[1] + gg[2]) : gg[2];
-        }
-        u[i] = val;
-    }
+    pack_weight_wino_body(reinterpret_cast<const float*>(jb[0]), reinterpret_cast<float*>(jb[1]), (int)jb[2], (int)jb[3], (int)jb[4],
+                          (int)jb[5], (int)jb[6]);
 }
 
 }  // namespace

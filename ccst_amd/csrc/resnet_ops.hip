@@ -407,6 +407,35 @@ __global__ __launch_bounds__(TPB) void scale_kernel(float* __restrict__ p, float
     for (long long i = (n4 << 2) + (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) p[i] *= s;
 }
 
+// small helpers that keep ATen's own elementwise kernels out of the train step
+__global__ __launch_bounds__(TPB) void fill_kernel(float* __restrict__ p, float v, long long n) {
+    // head up to the first 16-byte boundary, body as float4, tail
+    const long long head = min(n, (long long)(((16 - ((uintptr_t)p & 15)) & 15) >> 2));
+    float* q = p + head;
+    const long long n4 = (n - head) >> 2;
+    const f32x4 vv = {v, v, v, v};
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long long)gridDim.x * TPB) reinterpret_cast<f32x4*>(q)[i] = vv;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < head; i += (long long)gridDim.x * TPB) p[i] = v;
+    for (long long i = head + (n4 << 2) + (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) p[i] = v;
+}
+__global__ void add_i64_kernel(long long* __restrict__ p, long long d, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] += d;
+}
+__global__ __launch_bounds__(TPB) void mul_scalar_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ s, long long n) {
+    const float sv = s[0];
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) y[i] = x[i] * sv;
+}
+// stem weight gradient: virtual-pixel form gv[co][kx*4+c][ky] -> OIHW g[co][c][ky][kx] += (nn_ops.StemConvFn)
+__global__ void stem_grad_unfold_kernel(const float* __restrict__ gv, float* __restrict__ g, int cout, int kwp, int kh, int kw, int C, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = cout * C * kh * kw;
+    if (i >= total) return;
+    const int kx = i % kw, ky = (i / kw) % kh, c = (i / (kw * kh)) % C, co = i / (kw * kh * C);
+    const float v = gv[((long long)co * kwp * 4 + kx * 4 + c) * kh + ky];
+    g[i] = accumulate ? g[i] + v : v;
+}
+
 int grid_for(long long total) {
     long long g = (total + TPB - 1) / TPB;
     return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -582,6 +611,27 @@ extern "C" int ccst_sgd_f32(float* p, const float* g, float lr, int64_t n, void*
     CCST_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0), "sgd: arenas must be 16-byte aligned");
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4 + 1)), dim3(TPB), 0, (hipStream_t)stream, p, g, lr, (long long)n);
     return ccst_launch_status("sgd");
+}
+extern "C" int ccst_fill_f32(float* p, float value, int64_t n, void* stream) {
+    CCST_REQUIRE(p && n > 0 && ((uintptr_t)p % 4 == 0), "fill: bad args");
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n / 4 + 1)), dim3(TPB), 0, (hipStream_t)stream, p, value, (long long)n);
+    return ccst_launch_status("fill");
+}
+extern "C" int ccst_add_i64(int64_t* p, int64_t delta, int n, void* stream) {
+    CCST_REQUIRE(p && n > 0, "add_i64: bad args");
+    hipLaunchKernelGGL(add_i64_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (long long*)p, (long long)delta, n);
+    return ccst_launch_status("add_i64");
+}
+extern "C" int ccst_mul_scalar_f32(float* y, const float* x, const float* s_dev, int64_t n, void* stream) {
+    CCST_REQUIRE(y && x && s_dev && n > 0, "mul_scalar: bad args");
+    hipLaunchKernelGGL(mul_scalar_kernel, dim3(grid_for(n)), dim3(TPB), 0, (hipStream_t)stream, y, x, s_dev, (long long)n);
+    return ccst_launch_status("mul_scalar");
+}
+extern "C" int ccst_stem_grad_unfold_f32(const float* gv, float* g_oihw, int cout, int kwp, int kh, int kw, int C, int accumulate, void* stream) {
+    CCST_REQUIRE(gv && g_oihw && cout > 0 && kwp >= kw && kh > 0 && kw > 0 && C > 0 && C <= 4, "stem_grad_unfold: bad args");
+    const int total = cout * C * kh * kw;
+    hipLaunchKernelGGL(stem_grad_unfold_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, gv, g_oihw, cout, kwp, kh, kw, C, accumulate);
+    return ccst_launch_status("stem_grad_unfold");
 }
 extern "C" int ccst_scale_f32(float* p, float s, int64_t n, void* stream) {
     CCST_REQUIRE(p && n > 0, "scale: bad args");

@@ -105,7 +105,7 @@ class FlatParams(object):
         return out
 
     def zero_grad(self):
-        self.grad.zero_()
+        nn_ops.fill_(self.grad) if self.grad.is_cuda else self.grad.zero_()
         for p, off in self._slots():
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * off:
                 p.grad = self.grad[off:off + p.numel()].view(p.shape)
@@ -169,6 +169,19 @@ class SGD(object):
         nn_ops.prepack_on_side(a.model)
 
 
+_ONES = {}
+
+
+def backward(loss):
+    """loss.backward() with a cached root gradient of one: autograd otherwise materialises ones_like(loss) with an ATen fill
+    kernel on every step."""
+    key = (loss.device, loss.dtype, tuple(loss.shape))
+    one = _ONES.get(key)
+    if one is None:
+        one = _ONES[key] = torch.ones(loss.shape, device=loss.device, dtype=loss.dtype)
+    loss.backward(one)
+
+
 class CrossEntropyLoss(nn.Module):
     """nn.CrossEntropyLoss() (mean).  The last call's argmax==label count is kept in ``correct``
     (a device int32), so train()/test() need no second pass over the logits."""
@@ -212,7 +225,7 @@ class _GraphedTrainStep(object):
             loss = loss_fun(model(self.x), self.y)
             self.loss_all += loss.detach()
             self.correct_all += loss_fun.correct[0]
-            loss.backward()
+            backward(loss)
             optimizer.step()
             nn_ops.join_prepack(dev)            # every forked stream re-joins before the capture ends
 
@@ -283,7 +296,7 @@ def train(model, train_loader, optimizer, loss_fun, client_num, device, args, it
         correct_all += batch_correct
         if logger is not None:
             logger.log(it, len(train_loader), {"train_loss": loss.item()}, {"class_acc": int(batch_correct)}, img.shape[0])
-        loss.backward()
+        backward(loss)
         optimizer.step()
         del img, class_l
     if use_graph:

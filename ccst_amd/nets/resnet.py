@@ -124,6 +124,13 @@ def conv_bn(conv, bn, x, residual=None, relu=False, sink_in=None, sink_out=None)
 USE_GRAD_SINK = os.environ.get("CCST_GRAD_SINK", "1") != "0"
 
 
+def _pair_sink(block, x):
+    """The GradSink shared by the two convolutions that read x in a block with a downsample branch (see nn_ops.GradSink)."""
+    if USE_GRAD_SINK and block.downsample is not None and block.training and torch.is_grad_enabled() and x.requires_grad:
+        return nn_ops.GradSink(pair=True)
+    return None
+
+
 def _residual_sink(block, x, first_conv):
     """A GradSink when the block's identity branch is x itself, x needs a gradient and the first conv has stride 1
     (then d(identity) and the first conv's dX have the same shape and the conv can add to it in place)."""
@@ -192,9 +199,12 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         identity = x
         sink = _residual_sink(self, x, self.conv1)
-        out = conv_bn(self.conv1, self.bn1, x, relu=True, sink_in=sink)
+        pair = _pair_sink(self, x)
         if self.downsample is not None:
-            identity = conv_bn(self.downsample[0], self.downsample[1], x)
+            # evaluated FIRST so that its backward runs LAST (autograd runs later-created nodes first): the main branch's dense dX is
+            # deposited in `pair`, and the strided downsample conv adds its (sparser) dX to it in place -- no zero-filled temporary
+            identity = conv_bn(self.downsample[0], self.downsample[1], x, sink_in=pair)
+        out = conv_bn(self.conv1, self.bn1, x, relu=True, sink_in=sink if sink is not None else pair)
         return conv_bn(self.conv2, self.bn2, out, residual=identity, relu=True, sink_out=sink)
 
 
@@ -216,10 +226,11 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         identity = x
         sink = _residual_sink(self, x, self.conv1)
-        out = conv_bn(self.conv1, self.bn1, x, relu=True, sink_in=sink)
+        pair = _pair_sink(self, x)
+        if self.downsample is not None:         # first, so that its backward runs last and adds to the main branch's dX (BasicBlock)
+            identity = conv_bn(self.downsample[0], self.downsample[1], x, sink_in=pair)
+        out = conv_bn(self.conv1, self.bn1, x, relu=True, sink_in=sink if sink is not None else pair)
         out = conv_bn(self.conv2, self.bn2, out, relu=True)
-        if self.downsample is not None:
-            identity = conv_bn(self.downsample[0], self.downsample[1], x)
         return conv_bn(self.conv3, self.bn3, out, residual=identity, relu=True, sink_out=sink)
 
 
@@ -264,13 +275,19 @@ class ResNet(nn.Module):
         return False
 
     def _bump_counters(self):
-        # BatchNorm2d.num_batches_tracked += 1 for every BN, as one fused launch
-        cs = self.__dict__.get("_ccst_nbt")
-        if cs is None:
-            cs = [m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
-            self.__dict__["_ccst_nbt"] = cs
-        if cs:
-            torch._foreach_add_(cs, 1)
+        # BatchNorm2d.num_batches_tracked += 1 for every BN: the int64 counters are re-homed into one small arena (as FlatParams
+        # does for the fp32 state) and bumped by ONE HIP launch
+        arena = self.__dict__.get("_ccst_nbt")
+        cs = [m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
+        if not cs:
+            return
+        if arena is None or arena.device != cs[0].device or any(c.data_ptr() != arena.data_ptr() + 8 * i for i, c in enumerate(cs)):
+            arena = torch.stack([c.detach().reshape(()) for c in cs]).to(torch.int64).contiguous()
+            for i, c in enumerate(cs):
+                c.data = arena[i]
+            self.__dict__["_ccst_nbt"] = arena
+        from .._lib import check, load, ptr, stream_ptr
+        check(load().ccst_add_i64(ptr(arena), 1, arena.numel(), stream_ptr()), "bump num_batches_tracked")
 
     def forward(self, x, **kwargs):
         if self.training:

@@ -144,10 +144,16 @@ def join_prepack(device):
         torch.cuda.current_stream(device).wait_stream(_side_stream(device))
 
 
+def fill_(t, value=0.0):
+    """t.fill_(value) as a HIP launch (contiguous fp32 tensors)."""
+    check(_lib.load().ccst_fill_f32(ptr(t), float(value), t.numel(), stream_ptr()), "fill")
+    return t
+
+
 def _grad_slot(p):
     """Return (tensor to write, accumulate flag) for parameter p."""
     if p.grad is None:
-        p.grad = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        p.grad = fill_(torch.empty_like(p, memory_format=torch.contiguous_format))
     return p.grad
 
 
@@ -187,13 +193,18 @@ def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None):
             dx = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
         classes = [(0, 0)]
     else:
-        assert accumulate_into is None
         classes = [(py, px) for py in range(stride) for px in range(stride)]
-        # every input pixel belongs to exactly one parity class; the buffer needs zeroing only if some class has no tap
-        # (1x1 stride-2 downsample convs: three of four classes), not for 3x3 stride 2 where every class is written
-        covered = all(len(range((py + pad) % stride, kh, stride)) > 0 and len(range((px + pad) % stride, kw, stride)) > 0
-                      for py, px in classes)
-        dx = (torch.empty if covered else torch.zeros)(x_shape, device=dy.device, dtype=torch.float32)
+        if accumulate_into is not None:     # y += over the parity classes that have taps; the others add nothing
+            assert tuple(accumulate_into.shape) == tuple(x_shape) and accumulate_into.is_contiguous()
+            dx = accumulate_into
+        else:
+            # every input pixel belongs to exactly one parity class; the buffer needs zeroing only if some class has no tap
+            # (1x1 stride-2 downsample convs: three of four classes), not for 3x3 stride 2 where every class is written
+            covered = all(len(range((py + pad) % stride, kh, stride)) > 0 and len(range((px + pad) % stride, kw, stride)) > 0
+                          for py, px in classes)
+            dx = torch.empty(x_shape, device=dy.device, dtype=torch.float32)
+            if not covered:
+                fill_(dx)
     for py, px in classes:
         ky0, kx0 = (py + pad) % stride, (px + pad) % stride
         nky, nkx = len(range(ky0, kh, stride)), len(range(kx0, kw, stride))
@@ -209,7 +220,7 @@ def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None):
         d.tap_base, d.tap_sy, d.tap_sx = ky0 * kw + kx0, stride * kw, stride
         d.xsN, d.xsH, d.xsW = Ho * Wo * Cout, Wo * Cout, Cout
         d.y_off, d.ysN, d.ysH, d.ysW, d.ysC = (py * W + px) * Cin, H * W * Cin, stride * W * Cin, stride * Cin, 1
-        d.flags = _lib.CONV_ACCUM if (stride == 1 and accumulate_into is not None) else 0
+        d.flags = _lib.CONV_ACCUM if accumulate_into is not None else 0
         if ops.TIMING is None:
             check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(dy), ptr(pc_t.w), None, ptr(dx), stream_ptr()), "conv bwd-data")
         else:
@@ -244,10 +255,14 @@ class GradSink(object):
     """Carries the identity-branch gradient of a residual block from the closing BatchNorm's backward to the block's
     first convolution, whose backward-data epilogue adds to it in place -- instead of autograd materialising both
     contributions and running an add kernel (16 per ResNet50 step, 3 passes over the block input each)."""
-    __slots__ = ("grad",)
+    __slots__ = ("grad", "pair")
 
-    def __init__(self):
+    def __init__(self, pair=False):
         self.grad = None
+        # pair=True: TWO convolutions read the same block input (the first conv and the downsample conv of a block that changes
+        # shape, nets/resnet.py:156-165).  Whichever backward runs first leaves its dX here and reports no gradient; the second
+        # adds to it in its epilogue and reports the sum -- instead of autograd adding the two tensors with an ATen kernel.
+        self.pair = pair
 
 
 class ConvFn(torch.autograd.Function):
@@ -291,13 +306,18 @@ class ConvFn(torch.autograd.Function):
                 conv_bwd_weight(d, x, dy, g)
         dx = None
         if ctx.needs_input_grad[0]:
-            into = None
-            if ctx.sink is not None and ctx.sink.grad is not None:
-                into, ctx.sink.grad = ctx.sink.grad, None
+            into, deposit = None, False
+            if ctx.sink is not None:
+                if ctx.sink.grad is not None:
+                    into, ctx.sink.grad = ctx.sink.grad, None
+                elif ctx.sink.pair:
+                    deposit = True
             if ctx.wino:
                 dx = ops.conv3x3_wino_train(dy, mod.wino_bwd(), accumulate_into=into, tag="bwd_data:")
             else:
                 dx = conv_bwd_data(dy, mod.packed_t(), tuple(x.shape), stride, pad, accumulate_into=into)
+            if deposit:
+                ctx.sink.grad, dx = dx, None
         return dx, None, None, None, None
 
 
@@ -349,8 +369,8 @@ class StemConvFn(torch.autograd.Function):
             gv = torch.empty((cout, kwp * 4, kh, 1), device=dy.device, dtype=torch.float32)    # virtual-pixel gradient
             conv_bwd_weight(d, xp, dy.contiguous(), gv, accumulate=False)
             # un-fold (kx, ci) <- virtual channel kx*4+ci : 9.4k floats of glue
-            g = gv.reshape(cout, kwp, 4, kh)[:, :kw, :C, :].permute(0, 2, 3, 1)
-            _grad_slot(weight).add_(g)
+            check(_lib.load().ccst_stem_grad_unfold_f32(ptr(gv), ptr(_grad_slot(weight)), cout, kwp, kh, kw, C, 1, stream_ptr()),
+                  "stem_grad_unfold")
         return None, None, None
 
 
@@ -493,4 +513,6 @@ class CrossEntropyFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dlog,) = ctx.saved_tensors
-        return dlog * g, None, None
+        out = torch.empty_like(dlog)
+        check(_lib.load().ccst_mul_scalar_f32(ptr(out), ptr(dlog), ptr(g.contiguous()), dlog.numel(), stream_ptr()), "ce_backward_scale")
+        return out, None, None

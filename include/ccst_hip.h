@@ -272,6 +272,15 @@ int ccst_softmax_ce_f32(const float* logits, const int64_t* labels, float* loss,
 /* SGD p -= lr*g over a flat arena (fed_run.py:657,80), and the FedAvg pre-scale p *= s. */
 int ccst_sgd_f32(float* p, const float* g, float lr, int64_t n, void* stream);
 int ccst_scale_f32(float* p, float s, int64_t n, void* stream);
+/* Glue the reference gets from ATen, as HIP launches so that no framework kernel runs inside a train step:
+ * optimizer.zero_grad() (fed_run.py:58) as one fill of the flat gradient arena; BatchNorm2d's num_batches_tracked += 1
+ * over the re-homed int64 counters; the chain-rule scale of CrossEntropyLoss's saved dlogits by the incoming gradient
+ * (a device scalar); the stem conv's weight gradient from its virtual-pixel form [cout][kwp*4][kh] to OIHW (+=). */
+int ccst_fill_f32(float* p, float value, int64_t n, void* stream);
+int ccst_add_i64(int64_t* p, int64_t delta, int n, void* stream);
+int ccst_mul_scalar_f32(float* y, const float* x, const float* s_dev, int64_t n, void* stream);
+int ccst_stem_grad_unfold_f32(const float* gv, float* g_oihw, int cout, int kwp, int kh, int kw, int C, int accumulate,
+                              void* stream);
 /* elementwise helpers: y = relu(a + b) and its backward mask are folded into the BN calls above. */
 
 #ifdef __cplusplus
