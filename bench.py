@@ -211,7 +211,8 @@ def main():
         us = sorted(adain_us)[len(adain_us) // 2]
         adain_step = {"bound": "hbm", "bytes": nbytes, "median_us": round(us, 2), "achieved": round(nbytes / us / 1e3, 1),
                       "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(nbytes / us / 1e3 / PEAK_HBM_GBPS, 4),
-                      "kernels": "partials + finalize + apply (3 launches, HIP events around ccst_adain_f32)"}
+                      "kernels": "adain_fused_nhwc_kernel: two-pass statistics on register-resident planes + normalise, one read and one write, "
+                                 "ONE launch (HIP events around ccst_adain_f32)"}
 
     result = {
         "metric": "AdaIN stylised images/sec @512x512 B=6", "value": round(value, 3), "unit": "images/sec",

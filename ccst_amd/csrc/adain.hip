@@ -210,6 +210,102 @@ __global__ __launch_bounds__(TPB) void adain_apply_nchw_kernel(const float* __re
     for (int p = blockIdx.x * TPB + threadIdx.x; p < HW; p += gridDim.x * TPB) yb[p] = adain_one(xb[p], mu, sd, sm, ss, alpha, blend);
 }
 
+// ---- single-pass AdaIN (NHWC, H*W <= 4096): statistics AND normalise with the tensor read once and written once ------------------
+// One workgroup of 512 threads owns image n x 16 channels x ALL pixels: thread (pixel lane = t >> 2 of 128, channel quad = t & 3)
+// keeps its <= 32 pixels x 4 channels in registers (<= 128 VGPRs), so the reference's own TWO-PASS statistics (mean, then the
+// unbiased variance of x - mean, function.py:9-13) cost no second trip to memory: wavefront reductions over the 16 pixel lanes of a
+// wave (xor-shuffles that keep the channel quad), then over the 8 waves through LDS in fixed order (fp64), twice.  The normalise
+// (function.py:31-33, four separately rounded operations) and the alpha blend run on the registers; 64 contiguous bytes per pixel
+// in and out.  Algorithmic traffic = the HBM roofline's 2 * N*C*H*W*4 bytes, in ONE launch.
+#ifndef FP_CQ
+#define FP_CQ 4                      // channel quads per workgroup (16 channels = 64 contiguous bytes per pixel)
+#endif
+#ifndef FP_THREADS
+#define FP_THREADS 512
+#endif
+constexpr int FP_T = FP_THREADS, FP_PL = FP_T / FP_CQ, FP_PPT = 4096 / FP_PL, FP_W = FP_T / 64;
+
+__device__ __forceinline__ f32x4 quad_lane_sum(f32x4 v) {       // sum over the lanes of a wave that share lane % FP_CQ
+#pragma unroll
+    for (int o = FP_CQ; o < 64; o <<= 1)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += __shfl_xor(v[j], o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(FP_T) void adain_fused_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                const float* __restrict__ smean, const float* __restrict__ sstd,
+                                                                int style_per_n, float alpha, int HW, int C, float eps,
+                                                                float* __restrict__ mean_out, float* __restrict__ std_out) {
+    __shared__ double red[2][FP_W][FP_CQ][4];
+    const int t = threadIdx.x, cq = t % FP_CQ, pl = t / FP_CQ, wave = t >> 6;
+    const int n = blockIdx.y, c0 = blockIdx.x * (4 * FP_CQ) + cq * 4;
+    const float* xb = x + ((long long)n * HW) * C + c0;
+    float* yb = y + ((long long)n * HW) * C + c0;
+    f32x4 v[FP_PPT];
+#pragma unroll
+    for (int i = 0; i < FP_PPT; ++i) {
+        const int p = pl + i * FP_PL;
+        v[i] = (p < HW) ? *reinterpret_cast<const f32x4*>(xb + (long long)p * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // pass 1: mean
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < FP_PPT; ++i) s += v[i];
+    s = quad_lane_sum(s);
+    if ((t & 63) < FP_CQ)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[0][wave][cq][j] = (double)s[j];
+    __syncthreads();
+    f32x4 mu;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double a = 0.0;
+#pragma unroll
+        for (int w = 0; w < FP_W; ++w) a += red[0][w][cq][j];
+        mu[j] = (float)(a / (double)HW);
+    }
+    // pass 2: unbiased variance of x - mean (registers only)
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < FP_PPT; ++i) {
+        if (pl + i * FP_PL < HW) {
+            const f32x4 d = v[i] - mu;
+            q += d * d;
+        }
+    }
+    q = quad_lane_sum(q);
+    if ((t & 63) < FP_CQ)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[1][wave][cq][j] = (double)q[j];
+    __syncthreads();
+    f32x4 sd;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double a = 0.0;
+#pragma unroll
+        for (int w = 0; w < FP_W; ++w) a += red[1][w][cq][j];
+        sd[j] = sqrtf((float)(a / ((double)HW - 1.0)) + eps);
+    }
+    if (mean_out != nullptr && pl == 0) {
+        *reinterpret_cast<f32x4*>(mean_out + n * C + c0) = mu;
+        *reinterpret_cast<f32x4*>(std_out + n * C + c0) = sd;
+    }
+    const int so = (style_per_n ? n * C : 0) + c0;
+    const f32x4 sm = *reinterpret_cast<const f32x4*>(smean + so), ss = *reinterpret_cast<const f32x4*>(sstd + so);
+    const bool blend = (alpha != 1.f);
+#pragma unroll
+    for (int i = 0; i < FP_PPT; ++i) {
+        const int p = pl + i * FP_PL;
+        if (p < HW) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = adain_one(v[i][j], mu[j], sd[j], sm[j], ss[j], alpha, blend);
+            *reinterpret_cast<f32x4*>(yb + (long long)p * C) = o;
+        }
+    }
+}
+
 int pick_splits(int N, int C, int HW, int layout) {
     // aim for ~1024 workgroups, at least ~8 pixels (NHWC) / 1024 elements (NCHW) per split
     long long units = (layout == 1) ? (long long)N * ((C / 4 + 255) / 256) : (long long)N * C;
@@ -287,6 +383,11 @@ extern "C" int ccst_adain_f32(const float* x, const float* style_mean, const flo
     float* part = (float*)ws;
     float* mean = part + (int64_t)N * 256 * C * 2;
     float* stdv = mean + (int64_t)N * C;
+    if (layout == 1 && C % (4 * FP_CQ) == 0 && HW >= 2 && HW <= FP_PL * FP_PPT && N <= 65535) {      // the metric's shape: one pass, one launch
+        hipLaunchKernelGGL(adain_fused_nhwc_kernel, dim3(C / (4 * FP_CQ), N), dim3(FP_T), 0, st, x, y, style_mean, style_std, style_per_n, alpha, HW,
+                           C, eps, mean, stdv);
+        return ccst_launch_status("adain_fused");
+    }
     rc = ccst_calc_mean_std_f32(x, mean, stdv, N, C, HW, layout, eps, ws, ws_bytes, stream);
     if (rc) return rc;
     if (layout == 1) {

@@ -287,7 +287,7 @@ def test_calc_mean_std_ill_conditioned_planes(dev, A, channels_last):
     assert float((((s - s_ref.view(2, 8)).abs() / s_ref.view(2, 8))[ok]).max()) < 1e-3
 
 
-@pytest.mark.parametrize("channels_last", [False, True])
+@pytest.mark.parametrize("channels_last", [False, True, "fused16"])
 def test_adain_ill_conditioned_planes(dev, A, channels_last):
     """adaIN_StyleStat_ContentFeat on the same planes.  (x - mu)/sigma amplifies the fp32 rounding of mu by |mu|/sigma, so where that
     ratio is 1e4 ANY fp32 result (the reference's included) carries ~1e-3 * sigma_s of noise: the gate is 1e-3 against the oracle on
@@ -296,10 +296,14 @@ def test_adain_ill_conditioned_planes(dev, A, channels_last):
     x = _edge_planes()
     rs = np.random.RandomState(22)
     stat = [torch.from_numpy(rs.normal(0.5, 0.3, (1, 8, 1, 1)).astype(np.float32)), torch.from_numpy(rs.uniform(0.5, 1.5, (1, 8, 1, 1)).astype(np.float32))]
+    if channels_last == "fused16":      # 16 channels, NHWC, H*W = 4096: the single-pass kernel (two-pass statistics in registers)
+        x = torch.cat([x, x.flip(1)], 1)
+        stat = [torch.cat([t, t.flip(1)], 1) for t in stat]
+    C = x.shape[1]
     ref = A.adain_style_stat(x, stat)
     x64 = x.double()
     mu = x64.mean((2, 3), keepdim=True)
-    sd = (x64.view(2, 8, -1).var(2).view(2, 8, 1, 1) + 1e-5).sqrt()
+    sd = (x64.view(2, C, -1).var(2).view(2, C, 1, 1) + 1e-5).sqrt()
     truth = (x64 - mu) / sd * stat[1].double() + stat[0].double()
     xd = x.to(dev)
     if channels_last:
@@ -309,10 +313,30 @@ def test_adain_ill_conditioned_planes(dev, A, channels_last):
     err_ref = (ref.double() - truth).abs().amax((2, 3))
     assert bool((err <= 2.0 * err_ref + 1e-4).all()), (err, err_ref)
     well = err_ref < 1e-4
-    assert int(well.sum()) >= 11
+    assert int(well.sum()) >= 11 * C // 8
     d = (out - ref).abs().amax((2, 3))
     assert float(d[well].max()) < 1e-3
     assert torch.equal(out[0, 0], ref[0, 0]) and torch.equal(out[1, 0], ref[1, 0])       # constant planes: (x - x)/sqrt(eps)*s + m, bit for bit
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 37, 29), (1, 16, 64, 64), (2, 48, 1, 2), (2, 512, 64, 64)])
+def test_adain_single_pass_kernel(dev, A, shape):
+    """The single-pass AdaIN kernel (NHWC, C % 16 == 0, H*W <= 4096: statistics and normalise with one read and one write) on ragged
+    plane sizes, per-image style statistics and the alpha blend, against the oracle (function.py:16-33 + CCST_OverallStyleTransfer.py:45)."""
+    from ccst_amd import function, ops
+    N, C, H, W = shape
+    rs = np.random.RandomState(33)
+    x = torch.from_numpy(np.abs(rs.normal(0.2, 0.7, shape)).astype(np.float32))
+    sf = torch.from_numpy(np.abs(rs.normal(0.3, 0.9, (N, C, 5, 7))).astype(np.float32))
+    stat = A.synth_style_stat(C, seed=8)
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last)
+    assert maxdiff(function.adaIN_StyleStat_ContentFeat(xd, [t.to(dev) for t in stat]), A.adain_style_stat(x, stat)) < 1e-4
+    sd = sf.to(dev).contiguous(memory_format=torch.channels_last)
+    assert maxdiff(function.adaptive_instance_normalization(xd, sd), A.adain(x, sf)) < 1e-4
+    t = A.adain_style_stat(x, stat)
+    out = ops.adain(xd, stat[0].to(dev), stat[1].to(dev), alpha=0.3)
+    assert maxdiff(out, t * 0.3 + x * (1 - 0.3)) < 1e-4
+    assert out.is_contiguous(memory_format=torch.channels_last) or C == 1
 
 
 def test_function_asserts(dev):
