@@ -283,7 +283,16 @@ __device__ __forceinline__ void wino4_body(const Wino4Args& p, float* __restrict
     // One half-step: the 12 MFMAs of the CURRENT quad (operands v[], bq[.][h]) two at a time, between them the LDS reads (one
     // patch column ahead) and the row pass of the NEXT quad (buffer hs, channel quad hn); the order is pinned with sched_barrier
     // (left alone, hipcc bunches the MFMAs and even lifts them over the workgroup barrier).
-    auto half_step = [&](int h, const float* __restrict__ hs, int hn) {
+    // `stage` (half-step A only): the LDS stores of chunk c+1 (fetched a whole chunk ago) and the fetch of chunk c+2 sit BETWEEN the
+    // MFMA groups instead of in front of the barrier, where every wave would wait for its own ds_write_b128 to drain.
+    auto store_h2 = [&](float* __restrict__ dst, int i0) {
+#ifdef ABL4_NO_HALO
+        return;
+#endif
+#pragma unroll
+        for (int i = i0; i < i0 + 2 && i < HR4; ++i) *reinterpret_cast<f32x4*>(dst + hdst[i]) = rh[i];
+    };
+    auto half_step = [&](int h, const float* __restrict__ hs, int hn, float* __restrict__ stage, int c2) {
         read_col(hs, hn, 0, 0);
         W4_SB;
         W4_MFMA2(h, 0);
@@ -292,10 +301,12 @@ __device__ __forceinline__ void wino4_body(const Wino4Args& p, float* __restrict
         row_col(0, 0);
         W4_MFMA2(h, 1);
         read_col(hs, hn, 2, 0);
+        if (stage) store_h2(stage, 0);
         W4_SB;
         row_col(1, 1);
         W4_MFMA2(h, 2);
         read_col(hs, hn, 3, 1);
+        if (stage) store_h2(stage, 2);
         W4_SB;
         row_col(2, 0);
         W4_MFMA2(h, 3);
@@ -303,6 +314,7 @@ __device__ __forceinline__ void wino4_body(const Wino4Args& p, float* __restrict
         W4_SB;
         row_col(3, 1);
         W4_MFMA2(h, 4);
+        if (stage) load_h(c2);
         W4_SB;
         row_col(4, 0);
         W4_MFMA2(h, 5);
@@ -336,16 +348,22 @@ __device__ __forceinline__ void wino4_body(const Wino4Args& p, float* __restrict
         const float* cur = (c & 1) ? Hs1 : Hs0;
         float* nxt = (c & 1) ? Hs0 : Hs1;
         const int c1 = min(c + 1, last), c2 = min(c + 2, last);
-        half_step(0, cur, 1);
+#ifdef W4_STAGE_LATE
+        half_step(0, cur, 1, nullptr, 0);
         load_b_half(c1, 0);
         col_pass();
         store_h(nxt);
         load_h(c2);
+#else
+        half_step(0, cur, 1, nxt, c2);
+        load_b_half(c1, 0);
+        col_pass();
+#endif
 #ifndef ABL4_NO_BARRIER
         __syncthreads();
 #endif
         W4_SB;
-        half_step(1, nxt, 0);
+        half_step(1, nxt, 0, nullptr, 0);
         load_b_half(c1, 1);
         col_pass();
         W4_SB;
