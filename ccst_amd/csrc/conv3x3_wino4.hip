@@ -21,6 +21,7 @@
 //     the twelve waves goes through LDS (two passes of two output columns in the freed halo buffers); bias, ReLU, optional 2x2
 //     ceil-mode max-pool (a 4x4 tile holds four pooling windows), NHWC stores.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -292,7 +293,7 @@ __device__ __forceinline__ void wino4_body(const Wino4Args& p, float* __restrict
 #pragma unroll
         for (int i = i0; i < i0 + 2 && i < HR4; ++i) *reinterpret_cast<f32x4*>(dst + hdst[i]) = rh[i];
     };
-    auto half_step = [&](int h, const float* __restrict__ hs, int hn, float* __restrict__ stage, int c2) {
+    auto half_step = [&](int h, const float* __restrict__ hs, int hn, auto do_stage, float* __restrict__ stage, int c2) {
         read_col(hs, hn, 0, 0);
         W4_SB;
         W4_MFMA2(h, 0);
@@ -301,12 +302,12 @@ __device__ __forceinline__ void wino4_body(const Wino4Args& p, float* __restrict
         row_col(0, 0);
         W4_MFMA2(h, 1);
         read_col(hs, hn, 2, 0);
-        if (stage) store_h2(stage, 0);
+        if (decltype(do_stage)::value) store_h2(stage, 0);
         W4_SB;
         row_col(1, 1);
         W4_MFMA2(h, 2);
         read_col(hs, hn, 3, 1);
-        if (stage) store_h2(stage, 2);
+        if (decltype(do_stage)::value) store_h2(stage, 2);
         W4_SB;
         row_col(2, 0);
         W4_MFMA2(h, 3);
@@ -314,7 +315,7 @@ __device__ __forceinline__ void wino4_body(const Wino4Args& p, float* __restrict
         W4_SB;
         row_col(3, 1);
         W4_MFMA2(h, 4);
-        if (stage) load_h(c2);
+        if (decltype(do_stage)::value) load_h(c2);
         W4_SB;
         row_col(4, 0);
         W4_MFMA2(h, 5);
@@ -349,13 +350,13 @@ __device__ __forceinline__ void wino4_body(const Wino4Args& p, float* __restrict
         float* nxt = (c & 1) ? Hs0 : Hs1;
         const int c1 = min(c + 1, last), c2 = min(c + 2, last);
 #ifdef W4_STAGE_LATE
-        half_step(0, cur, 1, nullptr, 0);
+        half_step(0, cur, 1, std::false_type{}, nullptr, 0);
         load_b_half(c1, 0);
         col_pass();
         store_h(nxt);
         load_h(c2);
 #else
-        half_step(0, cur, 1, nxt, c2);
+        half_step(0, cur, 1, std::true_type{}, nxt, c2);
         load_b_half(c1, 0);
         col_pass();
 #endif
@@ -363,7 +364,7 @@ __device__ __forceinline__ void wino4_body(const Wino4Args& p, float* __restrict
         __syncthreads();
 #endif
         W4_SB;
-        half_step(1, nxt, 0, nullptr, 0);
+        half_step(1, nxt, 0, std::false_type{}, nullptr, 0);
         load_b_half(c1, 1);
         col_pass();
         W4_SB;
@@ -426,6 +427,38 @@ __device__ __forceinline__ void wino4_body(const Wino4Args& p, float* __restrict
     if (co >= p.Cout) return;
     const float bias = (p.bias != nullptr) ? p.bias[co] : 0.f;
     const bool relu = p.relu != 0;
+    // interior tiles (every pixel inside the image): buffer stores -- one per-lane byte offset per tile, the pixel in the scalar offset,
+    // no bounds test and no 64-bit address arithmetic per store (vector instructions are not free next to MFMAs, see the header)
+    if ((oy0 + TH4 <= p.H) && (ox0 + TW4 <= p.W)) {
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y + (long long)n * p.ysN, 0, (int)(p.ysN * 4), 0x00020000);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int t = t0 + kk;
+            const int oy = oy0 + 4 * (t >> 3), ox = ox0 + 4 * (t & 7);
+            if (!POOL) {
+                const unsigned voff = (unsigned)((oy * p.ysH + ox * p.ysW + co) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = yv[kk][i][j] + bias;
+                        if (relu) v = fmaxf(v, 0.f);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, voff, (unsigned)((i * p.ysH + j * p.ysW) * 4), 0);
+                    }
+            } else {
+                const unsigned voff = (unsigned)(((oy >> 1) * p.ysH + (ox >> 1) * p.ysW + co) * 4);
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        float v = fmaxf(fmaxf(yv[kk][2 * a][2 * b], yv[kk][2 * a][2 * b + 1]), fmaxf(yv[kk][2 * a + 1][2 * b], yv[kk][2 * a + 1][2 * b + 1])) + bias;
+                        if (relu) v = fmaxf(v, 0.f);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, voff, (unsigned)((a * p.ysH + b * p.ysW) * 4), 0);
+                    }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         const int t = t0 + kk;
