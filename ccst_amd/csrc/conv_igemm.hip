@@ -308,18 +308,32 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
         // BatchNorm statistics for free: this wave's 64 rows x 32*NT columns -> per-column (sum, sum^2) partials,
         // slab index = tile row * WM + wave row.  Rows beyond M are excluded; the fp64 combine happens in the BN
         // finalize kernel, so the result does not depend on the tiling beyond fp32 partial-sum rounding.
+        // (vector instructions are paid on top of the MFMA time on gfx950: the rows-beyond-M mask, three instructions per accumulator,
+        //  is only applied to the last, partial row tile)
+        const bool full_rows = (tm * BM + BM <= p.M);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             float s1 = 0.f, s2 = 0.f;
+            if (full_rows) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * (32 * MT) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float v = (tm * BM + row < p.M) ? acc[mt][nt][r] : 0.f;
-                    s1 += v;
-                    s2 += v * v;
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[mt][nt][r];
+                        s1 += v;
+                        s2 += v * v;
+                    }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wm * (32 * MT) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const float v = (tm * BM + row < p.M) ? acc[mt][nt][r] : 0.f;
+                        s1 += v;
+                        s2 += v * v;
+                    }
+            }
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             const int co = co0 + wn * (32 * NT) + nt * 32 + li;
@@ -350,17 +364,22 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
                         acc[mt][nt][r] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, lane_off + nt * 128, srow, 0));
                 }
         }
+        if (relu) {       // one uniform branch, not a max + select per accumulator
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = fmaxf(acc[mt][nt][r], 0.f);
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int srow = (mt * 32 + (r & 3) + 8 * (r >> 2)) * p.ysW * 4;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    float v = acc[mt][nt][r];
-                    if (relu) v = fmaxf(v, 0.f);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, lane_off + nt * 128, srow, 0);
-                }
+                for (int nt = 0; nt < NT; ++nt)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mt][nt][r]), rsrc, lane_off + nt * 128, srow, 0);
             }
     } else if (!POOL) {
         const int HW = p.Ho * p.Wo;
