@@ -142,3 +142,105 @@ def test_save_images_writes_the_quantised_bytes(dev, tmp_path):
     data.save_images(out.to(dev), paths)
     for i, p in enumerate(paths):
         assert np.array_equal(np.asarray(Image.open(p)), I.save_image_bytes(out[i]))
+
+
+def _write_pacs_tree(root, size=40):
+    """A miniature PACS: root/PACS/kfold/<domain>/<class>/pic_<k>.png + list files in both CLIs' layouts; returns the list roots."""
+    import os
+    from PIL import Image
+    rs = np.random.RandomState(9)
+    domains, classes = ["art_painting", "cartoon", "photo", "sketch"], ["dog", "house"]
+    rows = {d: [] for d in domains}
+    for d in domains:
+        for ci, c in enumerate(classes):
+            os.makedirs(os.path.join(root, "PACS", "kfold", d, c), exist_ok=True)
+            for k in range(3):
+                p = os.path.join(root, "PACS", "kfold", d, c, "pic_%03d.png" % k)
+                Image.fromarray(_img(rs, size + 3 * k, size + ci, smooth=(k == 1))).save(p)
+                rows[d].append((p, ci))       # absolute paths, as in the reference's lists (the loaders prepend one more '/', ImageLoader.py:57)
+    for sub in ("adain_lists/pacs", "fed_lists/pacs", "fed_lists/pacs_no_fusion/photo"):
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
+    for d in domains:
+        text = "".join("%s %d\n" % r for r in rows[d])
+        for name in ("%s_train.txt" % d, "%s_test.txt" % d):
+            open(os.path.join(root, "adain_lists/pacs", name), "w").write(text)
+            open(os.path.join(root, "fed_lists/pacs", name), "w").write(text)
+        if d != "photo":
+            open(os.path.join(root, "fed_lists/pacs_no_fusion/photo", "%s_train.txt" % d), "w").write(text)
+    return rows
+
+
+def test_adain_clis_on_real_files_vs_oracle(dev, tmp_path):
+    """Stage 1 + stage 2 (Overall and Single) on image FILES through the drop-in CLIs: list parsing, decode, GPU resize, encoder /
+    AdaIN / decoder, GPU quantise, PNG write, output naming.  A stylised image is compared, byte for byte up to +-1 level, with the
+    oracle run on the same file (PIL Resize -> ToTensor -> the oracle's style_transfer -> save_image's bytes)."""
+    import os
+    import subprocess
+    import sys
+    from PIL import Image
+    from oracle import adain_ref as A
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "style_transfer", "AdaIN")
+    rows = _write_pacs_tree(str(tmp_path))
+    env = dict(os.environ, PYTHONPATH=root)
+    common = ["--dataset", "pacs", "--random_weights", "--batch", "4", "--image_size", "64", "--txt_root", str(tmp_path / "adain_lists"),
+              "--output", str(tmp_path / "out")]
+    for dom in ("cartoon", "photo", "sketch"):
+        subprocess.check_call([sys.executable, os.path.join(d, "mean_std_computation_effcientMem.py"), "--target", dom] + common,
+                              cwd=str(tmp_path), env=env, stdout=subprocess.DEVNULL)
+    subprocess.check_call([sys.executable, os.path.join(d, "CCST_OverallStyleTransfer.py"), "--target", "art_painting"] + common,
+                          cwd=str(tmp_path), env=env, stdout=subprocess.DEVNULL)
+    subprocess.check_call([sys.executable, os.path.join(d, "CCST_SingleStyleTransfer.py"), "--target", "art_painting", "--style_size", "48"] + common,
+                          cwd=str(tmp_path), env=env, stdout=subprocess.DEVNULL)
+    src = rows["art_painting"][1][0]
+    out_overall = ("/" + src).replace("kfold", "all_style_transferred_Overall").replace("art_painting", "art_painting/cartoon").replace(".png", "_cartoon.png")
+    out_single = ("/" + src).replace("kfold", "all_style_transferred_Single").replace("art_painting", "art_painting/sketch").replace(".png", "_sketch.png")
+    assert os.path.exists(out_overall) and os.path.exists(out_single), (out_overall, os.listdir(str(tmp_path)))
+    n_out = sum(len(fs) for _, _, fs in os.walk(str(tmp_path / "PACS" / "all_style_transferred_Overall")))
+    assert n_out == 3 * 6                                           # 3 style domains x 6 content images
+    # the oracle on the same file: the CLI's --random_weights are seeded He-normal in module order (_common.load_networks)
+    g = torch.Generator().manual_seed(1234)
+    vgg_w, dec_w = {}, {}
+    for table, wd in ((A.VGG_TABLE, vgg_w), (A.DECODER_TABLE, dec_w)):
+        for idx, cin, cout, k in A.conv_keys(table):
+            wd["%d.weight" % idx] = torch.randn((cout, cin, k, k), generator=g) * (2.0 / (cin * k * k)) ** 0.5
+            wd["%d.bias" % idx] = torch.randn((cout,), generator=g) * 0.05
+    stat = np.load(str(tmp_path / "style_stats" / "pacs" / "cartoon_mean_std.npy"))
+    content = I.val_transform(Image.open(src).convert("RGB"), 64).unsqueeze(0)
+    with torch.no_grad():
+        ref = A.style_transfer(vgg_w, dec_w, content, [torch.from_numpy(stat[0]), torch.from_numpy(stat[1])], 1.0)
+    want = I.save_image_bytes(ref[0]).astype(np.int32)
+    got = np.asarray(Image.open(out_overall).convert("RGB")).astype(np.int32)
+    assert got.shape == want.shape == (64, 64, 3)
+    assert np.abs(got - want).max() <= 1 and (got != want).mean() < 0.02      # fp32 differences of <= 1e-3 can flip a rounding at a level boundary
+    # ... and the style statistics file against the oracle's stage-1 loop over the cartoon files (list order, batch 4)
+    batches, cur = [], []
+    for name, _ in rows["cartoon"]:
+        cur.append(I.val_transform(Image.open(name).convert("RGB"), 64))
+        if len(cur) == 4:
+            batches.append(torch.stack(cur))
+            cur = []
+    if cur:
+        batches.append(torch.stack(cur))
+    with torch.no_grad():
+        mean, std = A.overall_style_stats(batches, vgg_w)
+    assert np.abs(stat[0] - mean.numpy()).max() < 1e-3 and np.abs(stat[1] - std.numpy()).max() < 1e-3
+
+
+def test_fed_run_cli_on_real_files(dev, tmp_path):
+    """federated/fed_run.py on image files: the reference's list layout (txt_lists/<dataset>_<fusion>/<target>/<source>_train.txt),
+    the random disjoint validation split, GPU-side train / val transforms inside train() / test(), two rounds of FedAvg."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _write_pacs_tree(str(tmp_path), size=230)
+    env = dict(os.environ, PYTHONPATH=root)
+    cmd = [sys.executable, os.path.join(root, "federated", "fed_run.py"), "--mode", "fedavg", "--fusion_mode", "no_fusion",
+           "--source", "art_painting", "cartoon", "sketch", "--target", "photo", "--n_classes", "2", "--network", "resnet18",
+           "--lr", "0.001", "--image_size", "222", "--batch", "4", "--val_size", "0.34", "--random_horiz_flip", "0.5",
+           "--txt_root", str(tmp_path / "fed_lists"), "--save_path", str(tmp_path / "ckpt"), "--iters", "2"]
+    out = subprocess.check_output(cmd, cwd=str(tmp_path), env=env, text=True)
+    assert out.count("| Train Loss:") == 6 and out.count("| Global Val Class Acc:") == 6 and "| Global Test Class Acc:" in out
+    losses = [float(l.split(":")[1]) for l in out.splitlines() if "| Train Loss:" in l]
+    assert all(np.isfinite(losses)) and all(0.0 < x < 5.0 for x in losses)
