@@ -63,6 +63,7 @@ _SIGNATURES = {
     "ccst_nchw_to_nhwc_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "ccst_nhwc_to_nchw_f32": [_P, _P, c_int, c_int, c_int, c_int, _P],
     "ccst_quantize_u8_hwc_f32": [_P, _P, c_int, c_int, c_int, _P],
+    "ccst_resize_bilinear_nchw_f32": [_P, _P, c_int, c_int, c_int, c_int, c_int, _P],
     "ccst_image_plan": [c_int, _P, c_int, c_int, _P, c_int64],
     "ccst_crop_resize_norm_u8_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P],
     "ccst_conv2d_bwd_weight_f32": [POINTER(CcstConvDesc), _P, _P, _P, c_int, c_int, _P, c_int64, _P],

@@ -104,6 +104,28 @@ __global__ void quantize_u8_hwc_kernel(const float* __restrict__ x, unsigned cha
     }
 }
 
+// transforms.Resize(size) applied to the stylised TENSOR before save_image (CCST_OverallStyleTransfer.py:154-157): on tensors
+// torchvision (0.8 .. 0.16) calls torch.nn.functional.interpolate(mode='bilinear', align_corners=False) without antialiasing.
+// Source index = scale * (dst + 0.5) - 0.5 clamped at 0, scale = in / out (ATen area_pixel_compute_source_index).
+__global__ void resize_bilinear_planes_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int oh, int ow, float sy,
+                                              float sx, long long total) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % ow);
+        const long long t = i / ow;
+        const int oy = (int)(t % oh);
+        const long long plane = t / oh;
+        float fy = sy * ((float)oy + 0.5f) - 0.5f, fx = sx * ((float)ox + 0.5f) - 0.5f;
+        fy = fy < 0.f ? 0.f : fy;
+        fx = fx < 0.f ? 0.f : fx;
+        const int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
+        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float* p = x + plane * (long long)H * W;
+        const float a = p[(long long)y0 * W + x0], b = p[(long long)y0 * W + x1], c = p[(long long)y1 * W + x0], d = p[(long long)y1 * W + x1];
+        y[i] = (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * c + lx * d);
+    }
+}
+
 int grid_for(long long total) {
     long long g = (total + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -123,6 +145,14 @@ extern "C" int ccst_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int
     dim3 grid((HW + 31) / 32, (C + 31) / 32, N);
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, C, HW, Cs);
     return ccst_launch_status("nhwc_to_nchw");
+}
+
+extern "C" int ccst_resize_bilinear_nchw_f32(const float* x, float* y, int planes, int H, int W, int oh, int ow, void* stream) {
+    CCST_REQUIRE(x && y && planes > 0 && H > 0 && W > 0 && oh > 0 && ow > 0, "resize_bilinear: bad args");
+    const long long total = (long long)planes * oh * ow;
+    hipLaunchKernelGGL(resize_bilinear_planes_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, H, W, oh, ow,
+                       (float)H / (float)oh, (float)W / (float)ow, total);
+    return ccst_launch_status("resize_bilinear");
 }
 
 extern "C" int ccst_quantize_u8_hwc_f32(const float* x_nchw, uint8_t* y_nhwc, int N, int C, int HW, void* stream) {

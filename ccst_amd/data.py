@@ -330,19 +330,34 @@ def quantize_u8(images):
     return y
 
 
+def resize_tensor(images, size):
+    """transforms.Resize(size) on a float tensor batch, as CCST_OverallStyleTransfer.py:154-157 applies it to the stylised output:
+    the smaller edge becomes `size` (aspect kept; torchvision's int-size rule), bilinear, align_corners=False, no antialiasing."""
+    x = images.contiguous()
+    N, C, H, W = x.shape
+    if W <= H:
+        ow, oh = size, int(size * H / W)
+    else:
+        oh, ow = size, int(size * W / H)
+    if (oh, ow) == (H, W):
+        return x
+    y = torch.empty((N, C, oh, ow), device=x.device, dtype=torch.float32)
+    check(_lib.load().ccst_resize_bilinear_nchw_f32(ptr(x), ptr(y), N * C, H, W, oh, ow, stream_ptr()), "resize_bilinear")
+    return y
+
+
 def save_images(output, paths, output_size=-1):
-    """torchvision.utils.save_image per image (CCST_OverallStyleTransfer.py:158-167): quantise on the
-    GPU, copy uint8 to the host, encode with PIL.  `paths` are the final file names."""
+    """torchvision.utils.save_image per image (CCST_OverallStyleTransfer.py:154-167): the optional tensor resize, the uint8
+    quantisation on the GPU, copy to the host, encode with PIL.  `paths` are the final file names."""
     from PIL import Image
+    if output_size and output_size > 0:
+        output = resize_tensor(output, output_size)
     u8 = quantize_u8(output).cpu().numpy()
     for arr, name in zip(u8, paths):
         d = os.path.dirname(name)
         if d and not os.path.exists(d):
             os.makedirs(d)
-        img = Image.fromarray(arr)
-        if output_size and output_size > 0:
-            img = img.resize((output_size, output_size), Image.BILINEAR)   # transforms.Resize(output_size) (:154-155)
-        img.save(name)
+        Image.fromarray(arr).save(name)
 
 
 # ---------------------------------------------------------------------------

@@ -170,6 +170,9 @@ int ccst_nhwc_to_nchw_f32(const float* x, float* y, int N, int C, int HW, int Cs
 /* Image output edge (CCST_OverallStyleTransfer.py:156-167, torchvision save_image semantics):
  * NCHW float -> NHWC uint8 with v*255+0.5 clamped to [0,255]. */
 int ccst_quantize_u8_hwc_f32(const float* x_nchw, uint8_t* y_nhwc, int N, int C, int HW, void* stream);
+/* --output_size (CCST_OverallStyleTransfer.py:154-157): transforms.Resize on the stylised float TENSOR = bilinear interpolation,
+ * align_corners=False, no antialiasing, of `planes` = N*C planes [H,W] -> [oh,ow]. */
+int ccst_resize_bilinear_nchw_f32(const float* x, float* y, int planes, int H, int W, int oh, int ow, void* stream);
 
 /* Image input edge on the GPU.  Replaces, per image, the CPU transform chain of
  * data/data_helper.py:161-181 (train: RandomResizedCrop -> ToTensor -> Normalize -> RandomHorizontalFlip; val:

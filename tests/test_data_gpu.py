@@ -244,3 +244,25 @@ def test_fed_run_cli_on_real_files(dev, tmp_path):
     assert out.count("| Train Loss:") == 6 and out.count("| Global Val Class Acc:") == 6 and "| Global Test Class Acc:" in out
     losses = [float(l.split(":")[1]) for l in out.splitlines() if "| Train Loss:" in l]
     assert all(np.isfinite(losses)) and all(0.0 < x < 5.0 for x in losses)
+
+
+def test_output_size_resizes_the_tensor_like_the_reference(dev, tmp_path):
+    """--output_size (CCST_OverallStyleTransfer.py:154-157): transforms.Resize on the float tensor BEFORE save_image = F.interpolate
+    (bilinear, align_corners=False, no antialias); up- and down-scaling, non-square."""
+    import torch.nn.functional as F
+    from PIL import Image
+    from ccst_amd import data
+    g = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 3, 40, 56, generator=g) * 1.2 - 0.1
+    for size in (24, 40, 77):
+        got = data.resize_tensor(x.to(dev), size).cpu()
+        oh, ow = (size, int(size * 56 / 40))
+        ref = F.interpolate(x, size=(oh, ow), mode="bilinear", align_corners=False)
+        assert got.shape == ref.shape and float((got - ref).abs().max()) < 2e-6
+    paths = [str(tmp_path / ("o_%d.png" % i)) for i in range(2)]
+    data.save_images(x.to(dev), paths, output_size=24)
+    ref = F.interpolate(x, size=(24, 33), mode="bilinear", align_corners=False)
+    for i, p in enumerate(paths):
+        got = np.asarray(Image.open(p)).astype(np.int32)
+        want = I.save_image_bytes(ref[i]).astype(np.int32)
+        assert got.shape == want.shape and np.abs(got - want).max() <= 1 and (got != want).mean() < 0.01
