@@ -63,6 +63,7 @@ __device__ __forceinline__ int fdiv(int m, int d, float inv, int fast) {
 }
 
 constexpr unsigned CONV_DENSE_OUT = 0x80000000u;   // internal flag: output rows are m*ysW apart
+constexpr unsigned CONV_DENSE_IN = 0x40000000u;    // internal flag: 1x1 stride-1 unpadded conv of a dense NHWC input: row m reads x + m*xsW
 constexpr int CK_MIN = 16;        // smallest k-step (input channels of one tap per step)
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {
@@ -120,6 +121,14 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
             ox = ptx * 16 + 2 * (i >> 2) + (i & 1);
             oy = min(oy, p.Ho - 1);
             ox = min(ox, p.Wo - 1);
+        } else if (p.flags & CONV_DENSE_IN) {
+            // pointwise conv (two thirds of the ResNet50 trunk, forward and backward-data): no (n, oy, ox) decode, no bounds --
+            // vector instructions are paid on top of the MFMA time, and these tiles have as few as 2 k-steps to amortise them over
+            const int m = min(tm * BM + r, p.M - 1);
+            rowIy[a] = 0;
+            rowIx[a] = 0;
+            rowBase[a] = (unsigned)(m * p.xsW + part * 4);
+            continue;
         } else {
             int m = tm * BM + r;
             m = min(m, p.M - 1);
@@ -163,6 +172,14 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
     int ky = 0, kx = 0, c = 0;
 
     auto tap_offsets = [&](int ky_, int kx_) {
+        if (p.flags & CONV_DENSE_IN) {
+#pragma unroll
+            for (int a = 0; a < AR; ++a) {
+                aok[a] = true;
+                aoff[a] = rowBase[a];
+            }
+            return;
+        }
 #pragma unroll
         for (int a = 0; a < AR; ++a) {
             int iy = rowIy[a] + ky_ * p.by, ix = rowIx[a] + kx_ * p.bx;
@@ -624,6 +641,9 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
     a.y_off = d->y_off; a.ysN = d->ysN; a.ysH = d->ysH; a.ysW = d->ysW; a.ysC = d->ysC;
     a.flags = d->flags & 0xffu;
     if (!pool && d->ysH == (long long)d->wo * d->ysW && d->ysN == (long long)d->ho * d->wo * d->ysW) a.flags |= CONV_DENSE_OUT;
+    if (!pool && d->nky == 1 && d->nkx == 1 && d->ay == 1 && d->ax == 1 && d->cy == 0 && d->cx == 0 && d->hi == d->ho && d->wi == d->wo &&
+        !(d->flags & (CCST_CONV_UPS2 | CCST_CONV_REFLECT)) && d->xsH == (long long)d->wi * d->xsW && d->xsN == (long long)d->hi * d->wi * d->xsW)
+        a.flags |= CONV_DENSE_IN;
     a.M = d->n * d->ho * d->wo;
     a.invHW = 1.0f / (float)(d->ho * d->wo);
     a.invWo = 1.0f / (float)d->wo;
