@@ -115,7 +115,7 @@ def _compile(mods):
                 steps.append(_Step("stem", pc=ops.pack_conv_weight(wv, conv.bias), kw=3, kwp=kwp, pad=1, reflect=True, relu=relu))
             elif conv.out_channels <= 4 and conv.in_channels % 16 == 0 and not pending_up:
                 # image edge of the decoder (net.py:35): direct VALU kernel writing NCHW
-                steps.append(_Step("smallco", w_small=conv.weight.detach().permute(2, 3, 1, 0).contiguous(),
+                steps.append(_Step("smallco", w_small=conv.weight.detach().permute(2, 3, 0, 1).contiguous(),
                                    b_small=None if conv.bias is None else conv.bias.detach().contiguous(),
                                    cout=conv.out_channels, reflect=True, relu=relu))
             else:

@@ -357,14 +357,14 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
     return (out, stats) if want_stats else out
 
 
-def conv3x3_smallco_nchw(x, w_tap_ci_co, bias, cout, reflect=True, relu=False):
+def conv3x3_smallco_nchw(x, w_tap_co_ci, bias, cout, reflect=True, relu=False):
     """Direct 3x3 conv with <= 4 output channels: NHWC in, contiguous NCHW out (decoder's last layer)."""
     _require_cuda(x, "activation")
     assert x.is_contiguous() and x.dim() == 4
     N, H, W, Cin = x.shape
     out = torch.empty((N, cout, H, W), device=x.device, dtype=torch.float32)
     lib = _lib.load()
-    args = (ptr(x), ptr(w_tap_ci_co), ptr(bias), ptr(out), N, H, W, Cin, cout, int(reflect), int(relu), stream_ptr())
+    args = (ptr(x), ptr(w_tap_co_ci), ptr(bias), ptr(out), N, H, W, Cin, cout, int(reflect), int(relu), stream_ptr())
     if TIMING is None:
         check(lib.ccst_conv3x3_smallco_f32(*args), "conv3x3_smallco")
     else:

@@ -136,9 +136,9 @@ int ccst_conv3x3_halo_stats_groups(int N, int H, int W);
 int ccst_conv2d_igemm_tile(int M, int cout, int cin, int taps, int pool);
 
 /* Direct 3x3 stride-1 conv with 1..4 output channels writing NCHW (the decoder's last layer,
- * net.py:35): x NHWC [N,H,W,Cin] (Cin % 16 == 0), w [3][3][Cin][Cout], y NCHW [N,Cout,H,W].
+ * net.py:35): x NHWC [N,H,W,Cin] (Cin % 16 == 0), w [3][3][Cout][Cin], y NCHW [N,Cout,H,W].
  * HBM-bound (13 FLOP/B), so it runs on the VALU rather than padding Cout to an MFMA tile. */
-int ccst_conv3x3_smallco_f32(const float* x, const float* w_tap_ci_co, const float* bias, float* y,
+int ccst_conv3x3_smallco_f32(const float* x, const float* w_tap_co_ci, const float* bias, float* y,
                              int N, int H, int W, int Cin, int Cout, int reflect, int relu, void* stream);
 
 /* OIHW [cout][cin][kh][kw] -> packed [kh*kw][cin/4][cout_pad][4] (transpose=0), or the

@@ -212,7 +212,7 @@ def test_conv3x3_smallco(dev, shape, reflect):
         ref = F.conv2d(F.pad(x, (1,) * 4, mode="reflect"), w, b)
     else:
         ref = F.conv2d(x, w, b, padding=1)
-    y = ops.conv3x3_smallco_nchw(ops.from_api(x.to(dev), 16), w.to(dev).permute(2, 3, 1, 0).contiguous(), b.to(dev), Cout,
+    y = ops.conv3x3_smallco_nchw(ops.from_api(x.to(dev), 16), w.to(dev).permute(2, 3, 0, 1).contiguous(), b.to(dev), Cout,
                                  reflect=reflect)
     assert y.is_contiguous() and tuple(y.shape) == tuple(ref.shape)
     assert maxdiff(y, ref) < 1e-4
