@@ -7,7 +7,7 @@
 namespace {
 
 constexpr int TPB = 256;
-constexpr int MAXS = 256;   // max row-splits of a per-channel reduction
+constexpr int MAXS = 1024;  // max row-splits of a per-channel reduction
 
 // ------------------------------------------------------------------------------------------
 // per-channel partial reductions over rows of x[M][C].
@@ -41,24 +41,48 @@ __global__ __launch_bounds__(TPB) void chan_partials_kernel(const float* __restr
                 be = *reinterpret_cast<const f32x4*>(beta + cg * 4);
             }
         }
-        for (long long r = r0 + pl; r < r1; r += PL) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + cg * 4);
+        // two rows in flight per thread (the loop is a chain of HBM-latency loads otherwise); same summation order as one at a time
+        auto fold = [&](const f32x4 v, f32x4 g, const f32x4 o_in) {
             if (MODE == 0) {
                 a += v;
                 b += v * v;
             } else {
-                f32x4 g = *reinterpret_cast<const f32x4*>(dy + r * C + cg * 4);
                 const f32x4 xh = (v - mu) * is;
                 if (MASK != 0) {
-                    f32x4 o;
-                    if (MASK == 1) o = *reinterpret_cast<const f32x4*>(y + r * C + cg * 4);
-                    else o = xh * ga + be;
+                    const f32x4 o = (MASK == 1) ? o_in : xh * ga + be;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
                 }
                 a += g;
                 b += g * xh;
             }
+        };
+        const f32x4 z4 = {0, 0, 0, 0};
+        long long r = r0 + pl;
+        for (; r + PL < r1; r += 2 * PL) {
+            const long long o0 = r * C + cg * 4, o1 = (r + PL) * C + cg * 4;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + o0), v1 = *reinterpret_cast<const f32x4*>(x + o1);
+            f32x4 g0 = z4, g1 = z4, y0 = z4, y1 = z4;
+            if (MODE == 1) {
+                g0 = *reinterpret_cast<const f32x4*>(dy + o0);
+                g1 = *reinterpret_cast<const f32x4*>(dy + o1);
+                if (MASK == 1) {
+                    y0 = *reinterpret_cast<const f32x4*>(y + o0);
+                    y1 = *reinterpret_cast<const f32x4*>(y + o1);
+                }
+            }
+            fold(v0, g0, y0);
+            fold(v1, g1, y1);
+        }
+        if (r < r1) {
+            const long long o0 = r * C + cg * 4;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + o0);
+            f32x4 g0 = z4, y0 = z4;
+            if (MODE == 1) {
+                g0 = *reinterpret_cast<const f32x4*>(dy + o0);
+                if (MASK == 1) y0 = *reinterpret_cast<const f32x4*>(y + o0);
+            }
+            fold(v0, g0, y0);
         }
     }
     red[0][t] = a;
@@ -181,12 +205,13 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__
     }
 }
 
+template <int NCH>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, float* __restrict__ sums, int C, int S,
                                                               int accumulate) {
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * NCH + (threadIdx.x % NCH), sl = threadIdx.x / NCH;
     double a, b;
-    reduce_partials<16>(part, C, S, c, sl, a, b);
+    reduce_partials<NCH>(part, C, S, c, sl, a, b);
     if (sl != 0 || c >= C) return;
     sums[c] = (float)a;          // sum dy'
     sums[C + c] = (float)b;      // sum dy' * xhat
@@ -463,8 +488,8 @@ Split pick_split(long long M, int C) {
     sp.cgb = cg < TPB ? cg : TPB;
     sp.PL = TPB / sp.cgb;
     sp.gy = (cg + sp.cgb - 1) / sp.cgb;
-    long long s = 1024 / sp.gy;                        // ~1024 workgroups
-    const long long smax = (M + 8LL * sp.PL - 1) / (8LL * sp.PL);   // >= 8 rows per row lane
+    long long s = 2048 / sp.gy;                        // ~2048 workgroups (8 per CU: these loops are latency chains)
+    const long long smax = (M + 4LL * sp.PL - 1) / (4LL * sp.PL);   // >= 4 rows per row lane
     if (s > smax) s = smax;
     if (s > MAXS) s = MAXS;
     if (s < 1) s = 1;
@@ -552,7 +577,10 @@ extern "C" int ccst_bn_train_bwd_f32(const float* dy, const float* x, const floa
     else if (mask == 1) CCST_PARTIALS1(1);
     else CCST_PARTIALS1(2);
 #undef CCST_PARTIALS1
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, dgamma, dbeta, sums, C, sp.S, accumulate);
+    if (sp.S > 512)
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3((C + 3) / 4), dim3(256), 0, st, part, dgamma, dbeta, sums, C, sp.S, accumulate);
+    else
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<16>, dim3((C + 15) / 16), dim3(256), 0, st, part, dgamma, dbeta, sums, C, sp.S, accumulate);
     const long long total4 = (long long)M * (C / 4);
 #define CCST_BWD_APPLY(MK)                                                                                                          \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<MK>), dim3(grid_for(total4)), dim3(TPB), 0, st, dy, x, y, gamma, beta, save_mean, save_invstd, \
