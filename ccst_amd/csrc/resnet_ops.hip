@@ -17,12 +17,15 @@ constexpr int MAXS = 1024;  // max row-splits of a per-channel reduction
 // ------------------------------------------------------------------------------------------
 // relu mask: from the saved output y (y > 0) or, when y == nullptr (no residual was added), recomputed from x:
 // z = (x-mean)*invstd*gamma + beta > 0 -- one tensor read less in both backward passes.
-template <int MODE, int MASK = 0>      // MASK: 0 no ReLU, 1 mask from the saved output y, 2 mask recomputed from x
+// MASK: 0 no ReLU, 1 mask from the saved output y, 2 mask recomputed from x, 3 mask from the forward's byte mask (bit j of
+// byte i <-> element 4 i + j; written by bn_apply_kernel: 1/16 of a tensor read instead of a whole one)
+template <int MODE, int MASK = 0>
 __global__ __launch_bounds__(TPB) void chan_partials_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ y, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, int relu, float* __restrict__ part,
-                                                            long long M, int C, int S, int cgb, int PL) {
+                                                            long long M, int C, int S, int cgb, int PL,
+                                                            const unsigned char* __restrict__ rmask = nullptr) {
     __shared__ f32x4 red[2][TPB];
     const int split = blockIdx.x, t = threadIdx.x;
     const int cgl = t % cgb, pl = t / cgb;
@@ -42,13 +45,16 @@ __global__ __launch_bounds__(TPB) void chan_partials_kernel(const float* __restr
             }
         }
         // two rows in flight per thread (the loop is a chain of HBM-latency loads otherwise); same summation order as one at a time
-        auto fold = [&](const f32x4 v, f32x4 g, const f32x4 o_in) {
+        auto fold = [&](const f32x4 v, f32x4 g, const f32x4 o_in, unsigned bits) {
             if (MODE == 0) {
                 a += v;
                 b += v * v;
             } else {
                 const f32x4 xh = (v - mu) * is;
-                if (MASK != 0) {
+                if (MASK == 3) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[j] = ((bits >> j) & 1u) ? g[j] : 0.f;
+                } else if (MASK != 0) {
                     const f32x4 o = (MASK == 1) ? o_in : xh * ga + be;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
@@ -63,6 +69,7 @@ __global__ __launch_bounds__(TPB) void chan_partials_kernel(const float* __restr
             const long long o0 = r * C + cg * 4, o1 = (r + PL) * C + cg * 4;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + o0), v1 = *reinterpret_cast<const f32x4*>(x + o1);
             f32x4 g0 = z4, g1 = z4, y0 = z4, y1 = z4;
+            unsigned b0 = 0, b1 = 0;
             if (MODE == 1) {
                 g0 = *reinterpret_cast<const f32x4*>(dy + o0);
                 g1 = *reinterpret_cast<const f32x4*>(dy + o1);
@@ -70,19 +77,25 @@ __global__ __launch_bounds__(TPB) void chan_partials_kernel(const float* __restr
                     y0 = *reinterpret_cast<const f32x4*>(y + o0);
                     y1 = *reinterpret_cast<const f32x4*>(y + o1);
                 }
+                if (MASK == 3) {
+                    b0 = rmask[o0 >> 2];
+                    b1 = rmask[o1 >> 2];
+                }
             }
-            fold(v0, g0, y0);
-            fold(v1, g1, y1);
+            fold(v0, g0, y0, b0);
+            fold(v1, g1, y1, b1);
         }
         if (r < r1) {
             const long long o0 = r * C + cg * 4;
             const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + o0);
             f32x4 g0 = z4, y0 = z4;
+            unsigned b0 = 0;
             if (MODE == 1) {
                 g0 = *reinterpret_cast<const f32x4*>(dy + o0);
                 if (MASK == 1) y0 = *reinterpret_cast<const f32x4*>(y + o0);
+                if (MASK == 3) b0 = rmask[o0 >> 2];
             }
-            fold(v0, g0, y0);
+            fold(v0, g0, y0, b0);
         }
     }
     red[0][t] = a;
@@ -177,7 +190,8 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ shift, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ rmean,
                                                        const float* __restrict__ rvar, float eps, const float* __restrict__ residual,
-                                                       int relu, float* __restrict__ y, long long total4, int C) {
+                                                       int relu, float* __restrict__ y, long long total4, int C,
+                                                       unsigned char* __restrict__ rmask = nullptr) {
     const int cg = C / 4;
     for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total4; i += (long long)gridDim.x * TPB) {
         const int c = (int)(i % cg) * 4;
@@ -198,6 +212,7 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__
         v = v * sc + sh;
         if (residual) v += *reinterpret_cast<const f32x4*>(residual + i * 4);
         if (relu) {
+            if (rmask) rmask[i] = (unsigned char)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
         }
@@ -231,7 +246,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ beta, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ sums, int relu,
                                                            float* __restrict__ dx, float* __restrict__ dres, long long total4, int C,
-                                                           float invM) {
+                                                           float invM, const unsigned char* __restrict__ rmask = nullptr) {
     const int cg = C / 4;
     for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total4; i += (long long)gridDim.x * TPB) {
         const int c = (int)(i % cg) * 4;
@@ -240,7 +255,11 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
         const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
         const f32x4 xh = (v - mu) * is;
-        if (MASK != 0) {
+        if (MASK == 3) {
+            const unsigned bits = rmask[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = ((bits >> j) & 1u) ? g[j] : 0.f;
+        } else if (MASK != 0) {
             f32x4 o;
             if (MASK == 1) o = *reinterpret_cast<const f32x4*>(y + i * 4);
             else o = xh * ga + *reinterpret_cast<const f32x4*>(beta + c);
@@ -504,10 +523,11 @@ extern "C" int64_t ccst_bn_workspace_bytes(int64_t M, int C) {
     return ((int64_t)MAXS * C * 2 + 4LL * C) * 4;     // partials + scale/shift (fwd) or sums (bwd)
 }
 
-extern "C" int ccst_bn_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                     float momentum, float eps, const float* residual, int relu, float* y, float* save_mean,
-                                     float* save_invstd, int64_t M, int C, const float* stats_in, int stats_groups, void* ws,
-                                     int64_t ws_bytes, void* stream) {
+extern "C" int ccst_bn_train_fwd_mask_f32(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                          float momentum, float eps, const float* residual, int relu, float* y, uint8_t* relu_mask,
+                                          float* save_mean, float* save_invstd, int64_t M, int C, const float* stats_in, int stats_groups,
+                                          void* ws, int64_t ws_bytes, void* stream) {
+    CCST_REQUIRE(!relu_mask || relu, "bn_train_fwd: a ReLU mask needs relu=1");
     CCST_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && ws, "bn_train_fwd: null pointer");
     CCST_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_train_fwd: need M>0 and C %% 4 == 0 (C=%d)", C);
     CCST_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_train_fwd: running stats must come together");
@@ -538,8 +558,16 @@ extern "C" int ccst_bn_train_fwd_f32(const float* x, const float* gamma, const f
                            running_var, momentum, eps, save_mean, save_invstd, scale, shift, (long long)M, C, S);
     const long long total4 = (long long)M * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(TPB), 0, st, x, scale, shift, nullptr, nullptr, nullptr, nullptr,
-                       eps, residual, relu, y, total4, C);
+                       eps, residual, relu, y, total4, C, relu_mask);
     return ccst_launch_status("bn_train_fwd");
+}
+
+extern "C" int ccst_bn_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                     float momentum, float eps, const float* residual, int relu, float* y, float* save_mean,
+                                     float* save_invstd, int64_t M, int C, const float* stats_in, int stats_groups, void* ws,
+                                     int64_t ws_bytes, void* stream) {
+    return ccst_bn_train_fwd_mask_f32(x, gamma, beta, running_mean, running_var, momentum, eps, residual, relu, y, nullptr, save_mean,
+                                      save_invstd, M, C, stats_in, stats_groups, ws, ws_bytes, stream);
 }
 
 extern "C" int ccst_bn_eval_fwd_f32(const float* x, const float* gamma, const float* beta, const float* running_mean,
@@ -553,13 +581,13 @@ extern "C" int ccst_bn_eval_fwd_f32(const float* x, const float* gamma, const fl
     return ccst_launch_status("bn_eval_fwd");
 }
 
-extern "C" int ccst_bn_train_bwd_f32(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
-                                     const float* save_mean, const float* save_invstd, int relu, float* dx, float* d_residual,
-                                     float* dgamma, float* dbeta, int accumulate, int64_t M, int C, void* ws, int64_t ws_bytes,
-                                     void* stream) {
+extern "C" int ccst_bn_train_bwd_mask_f32(const float* dy, const float* x, const float* y, const uint8_t* relu_mask, const float* gamma,
+                                          const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dx,
+                                          float* d_residual, float* dgamma, float* dbeta, int accumulate, int64_t M, int C, void* ws,
+                                          int64_t ws_bytes, void* stream) {
     CCST_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws, "bn_train_bwd: null pointer");
-    CCST_REQUIRE(!relu || y || beta, "bn_train_bwd: relu=1 needs the saved output y, or beta to recompute the mask from x");
-    CCST_REQUIRE(!(relu && d_residual && !y), "bn_train_bwd: with a residual the ReLU mask must come from the saved output y");
+    CCST_REQUIRE(!relu || y || relu_mask || beta, "bn_train_bwd: relu=1 needs the forward's mask, the saved output y, or beta to recompute the mask from x");
+    CCST_REQUIRE(!(relu && d_residual && !y && !relu_mask), "bn_train_bwd: with a residual the ReLU mask must come from the forward (mask or saved output y)");
     CCST_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_train_bwd: need M>0 and C %% 4 == 0");
     if (ws_bytes < ccst_bn_workspace_bytes(M, C)) {
         ccst_set_error("bn_train_bwd: workspace too small");
@@ -569,13 +597,14 @@ extern "C" int ccst_bn_train_bwd_f32(const float* dy, const float* x, const floa
     const Split sp = pick_split(M, C);
     float* part = (float*)ws;
     float* sums = part + (int64_t)MAXS * C * 2;
-    const int mask = !relu ? 0 : (y ? 1 : 2);
+    const int mask = !relu ? 0 : (relu_mask ? 3 : (y ? 1 : 2));
 #define CCST_PARTIALS1(MK)                                                                                                          \
     hipLaunchKernelGGL((chan_partials_kernel<1, MK>), dim3(sp.S, sp.gy), dim3(TPB), 0, st, x, dy, y, save_mean, save_invstd, gamma, beta, \
-                       relu, part, (long long)M, C, sp.S, sp.cgb, sp.PL)
+                       relu, part, (long long)M, C, sp.S, sp.cgb, sp.PL, relu_mask)
     if (mask == 0) CCST_PARTIALS1(0);
     else if (mask == 1) CCST_PARTIALS1(1);
-    else CCST_PARTIALS1(2);
+    else if (mask == 2) CCST_PARTIALS1(2);
+    else CCST_PARTIALS1(3);
 #undef CCST_PARTIALS1
     if (sp.S > 512)
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3((C + 3) / 4), dim3(256), 0, st, part, dgamma, dbeta, sums, C, sp.S, accumulate);
@@ -584,12 +613,21 @@ extern "C" int ccst_bn_train_bwd_f32(const float* dy, const float* x, const floa
     const long long total4 = (long long)M * (C / 4);
 #define CCST_BWD_APPLY(MK)                                                                                                          \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<MK>), dim3(grid_for(total4)), dim3(TPB), 0, st, dy, x, y, gamma, beta, save_mean, save_invstd, \
-                       sums, relu, dx, d_residual, total4, C, 1.f / (float)M)
+                       sums, relu, dx, d_residual, total4, C, 1.f / (float)M, relu_mask)
     if (mask == 0) CCST_BWD_APPLY(0);
     else if (mask == 1) CCST_BWD_APPLY(1);
-    else CCST_BWD_APPLY(2);
+    else if (mask == 2) CCST_BWD_APPLY(2);
+    else CCST_BWD_APPLY(3);
 #undef CCST_BWD_APPLY
     return ccst_launch_status("bn_train_bwd");
+}
+
+extern "C" int ccst_bn_train_bwd_f32(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
+                                     const float* save_mean, const float* save_invstd, int relu, float* dx, float* d_residual,
+                                     float* dgamma, float* dbeta, int accumulate, int64_t M, int C, void* ws, int64_t ws_bytes,
+                                     void* stream) {
+    return ccst_bn_train_bwd_mask_f32(dy, x, y, nullptr, gamma, beta, save_mean, save_invstd, relu, dx, d_residual, dgamma, dbeta, accumulate,
+                                      M, C, ws, ws_bytes, stream);
 }
 
 extern "C" int ccst_maxpool3s2_fwd_f32(const float* x, float* y, uint32_t* idx, int N, int H, int W, int C, int Ho, int Wo,

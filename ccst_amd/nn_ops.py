@@ -17,6 +17,7 @@ _WS = {}
 # ReLU mask of BN backward: from the saved output (1) or recomputed from x when no residual was added (0)
 import os as _os
 BN_MASK_FROM_Y = _os.environ.get("CCST_BN_MASK_FROM_Y", "0") != "0"
+BN_BYTE_MASK = _os.environ.get("CCST_BN_BYTE_MASK", "1") != "0"      # ReLU mask of the residual BNs as bytes (0: read the saved output)
 
 
 def _workspace(nbytes, device):
@@ -390,16 +391,19 @@ class BNFn(torch.autograd.Function):
             nb = int(lib.ccst_bn_workspace_bytes(M, C))
             ws = _workspace(nb, x.device)
             track = mod.track_running_stats and mod.running_mean is not None
-            check(lib.ccst_bn_train_fwd_f32(ptr(x), ptr(gamma), ptr(beta), ptr(mod.running_mean if track else None),
-                                            ptr(mod.running_var if track else None), float(mod.momentum), float(mod.eps),
-                                            ptr(residual), int(relu), ptr(y), ptr(save[0]), ptr(save[1]), M, C, ptr(stats),
-                                            0 if stats is None else int(stats.shape[0]), ptr(ws), ws.numel(), stream_ptr()),
-                  "bn_train_fwd")
             ctx.relu, ctx.has_res = bool(relu), residual is not None
-            # ReLU mask for the backward: with a residual it must come from the saved output; without one it is
-            # recomputed from x in the kernels (y == NULL), which measured 2373 vs 2360 img/s and keeps one tensor
-            # less alive per BN
-            ctx.save_for_backward(x, y if (ctx.relu and (ctx.has_res or BN_MASK_FROM_Y)) else None, gamma, beta, save)
+            # ReLU mask for the backward.  With a residual it cannot be recomputed from x: the forward leaves a byte mask (4 elements
+            # per byte), so both backward passes read 1/16 of a tensor instead of the whole saved output (the block outputs are the
+            # 4P-channel tensors: 2 x 1.4 GB per ResNet50 step).  Without a residual it is recomputed from x in the kernels
+            # (y == NULL), which measured 2373 vs 2360 img/s and keeps one tensor less alive per BN.
+            mask = torch.empty((M * C // 4,), device=x.device, dtype=torch.uint8) if (ctx.relu and ctx.has_res and BN_BYTE_MASK) else None
+            check(lib.ccst_bn_train_fwd_mask_f32(ptr(x), ptr(gamma), ptr(beta), ptr(mod.running_mean if track else None),
+                                                 ptr(mod.running_var if track else None), float(mod.momentum), float(mod.eps),
+                                                 ptr(residual), int(relu), ptr(y), ptr(mask), ptr(save[0]), ptr(save[1]), M, C, ptr(stats),
+                                                 0 if stats is None else int(stats.shape[0]), ptr(ws), ws.numel(), stream_ptr()),
+                  "bn_train_fwd")
+            keep_y = ctx.relu and mask is None and (ctx.has_res or BN_MASK_FROM_Y)
+            ctx.save_for_backward(x, y if keep_y else None, mask, gamma, beta, save)
         else:
             check(lib.ccst_bn_eval_fwd_f32(ptr(x), ptr(gamma), ptr(beta), ptr(mod.running_mean), ptr(mod.running_var),
                                            float(mod.eps), ptr(residual), int(relu), ptr(y), M, C, stream_ptr()), "bn_eval_fwd")
@@ -411,7 +415,7 @@ class BNFn(torch.autograd.Function):
     def backward(ctx, dy):
         if getattr(ctx, "eval_mode", False):
             raise RuntimeError("ccst_amd: backward through eval-mode BatchNorm is not on the reference path")
-        x, y, gamma, beta, save = ctx.saved_tensors
+        x, y, mask, gamma, beta, save = ctx.saved_tensors
         lib = _lib.load()
         N, H, W, C = x.shape
         M = N * H * W
@@ -419,9 +423,9 @@ class BNFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         dres = torch.empty_like(x) if ctx.has_res else None
         ws = _workspace(int(lib.ccst_bn_workspace_bytes(M, C)), x.device)
-        check(lib.ccst_bn_train_bwd_f32(ptr(dy), ptr(x), ptr(y), ptr(gamma), ptr(beta), ptr(save[0]), ptr(save[1]), int(ctx.relu), ptr(dx),
-                                        ptr(dres), ptr(_grad_slot(gamma)), ptr(_grad_slot(beta)), 1, M, C, ptr(ws), ws.numel(),
-                                        stream_ptr()), "bn_train_bwd")
+        check(lib.ccst_bn_train_bwd_mask_f32(ptr(dy), ptr(x), ptr(y), ptr(mask), ptr(gamma), ptr(beta), ptr(save[0]), ptr(save[1]),
+                                             int(ctx.relu), ptr(dx), ptr(dres), ptr(_grad_slot(gamma)), ptr(_grad_slot(beta)), 1, M, C,
+                                             ptr(ws), ws.numel(), stream_ptr()), "bn_train_bwd")
         if ctx.sink is not None and dres is not None:
             ctx.sink.grad, dres = dres, None        # handed to the block's first conv (GradSink), not to autograd
         return dx, None, None, dres, None, None, None, None

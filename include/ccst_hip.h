@@ -252,6 +252,17 @@ int ccst_bn_train_bwd_f32(const float* dy, const float* x, const float* y, const
                           const float* save_mean, const float* save_invstd, int relu, float* dx,
                           float* d_residual, float* dgamma, float* dbeta, int accumulate, int64_t M, int C,
                           void* ws, int64_t ws_bytes, void* stream);
+/* The same two with a compact ReLU mask between them: the forward writes relu_mask[M*C/4] (bit j of byte i <-> element 4 i + j is
+ * positive before the ReLU), the backward reads it instead of the whole saved output y (y may then be NULL even with a residual):
+ * 1/16 of a tensor per pass instead of one.  relu_mask == NULL gives the functions above. */
+int ccst_bn_train_fwd_mask_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, float momentum, float eps, const float* residual, int relu,
+                               float* y, uint8_t* relu_mask, float* save_mean, float* save_invstd, int64_t M, int C,
+                               const float* stats_in, int stats_groups, void* ws, int64_t ws_bytes, void* stream);
+int ccst_bn_train_bwd_mask_f32(const float* dy, const float* x, const float* y, const uint8_t* relu_mask,
+                               const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                               int relu, float* dx, float* d_residual, float* dgamma, float* dbeta, int accumulate,
+                               int64_t M, int C, void* ws, int64_t ws_bytes, void* stream);
 int64_t ccst_bn_workspace_bytes(int64_t M, int C);
 
 /* MaxPool2d(kernel 3, stride 2, padding 1) nets/resnet.py:140, NHWC, C % 4 == 0.  idx[N,Ho,Wo,C/4]

@@ -112,9 +112,11 @@ def test_stem_conv_fwd_bwd(dev):
     assert relerr(y, yr) < 1e-4 and relerr(conv.weight.grad, wr.grad) < 1e-4
 
 
-@pytest.mark.parametrize("relu,res", [(False, False), (True, False), (True, True)])
-def test_batchnorm_fwd_bwd(dev, relu, res):
+@pytest.mark.parametrize("relu,res,bytemask", [(False, False, True), (True, False, True), (True, True, True), (True, True, False)])
+def test_batchnorm_fwd_bwd(dev, relu, res, bytemask, monkeypatch):
+    from ccst_amd import nn_ops
     from ccst_amd.nets import resnet
+    monkeypatch.setattr(nn_ops, "BN_BYTE_MASK", bytemask)       # ReLU mask of a residual BN: the forward's byte mask / the saved output
     N, C, H, W = 4, 64, 9, 11
     x = rnd((N, C, H, W), 7, 2.0) + 0.5
     r = rnd((N, C, H, W), 8)
