@@ -115,41 +115,51 @@ __global__ __launch_bounds__(TPB) void chan_partials_kernel(const float* __restr
     }
 }
 
-// Sum the S split partials of NCH channels with 256/NCH split-lanes each (fp64), then combine the lanes in
-// fixed order through LDS.  Returns the two totals for channel c (valid on lanes with sl == 0).
-// NCH = 16 for the BN kernels' own <= 256 splits, 4 when the conv epilogue supplies thousands of row groups.
+// Sum the S split partials of NCH channels with 256/NCH split-lanes each (fp64): every lane adds its partials (k = sl, sl + NL, ...)
+// in order, the lanes of a channel are folded with a fixed xor tree inside the wave and the four waves through LDS -- a fixed
+// summation order, so the result is bitwise reproducible.  Returns the two totals for channel c (valid on lanes with sl == 0).
+// NCH = 16 for up to 512 splits, 4 above (the conv epilogue supplies thousands of row groups).
+// These kernels are pure latency (one small workgroup per 4-16 channels on the critical path of every BatchNorm, ~100 per ResNet50
+// step): all loads of a lane are issued eight at a time INCLUDING the tail (clamped index, the value dropped), and no lane walks
+// an LDS column serially.
 template <int NCH>
 __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int C, int S, int c, int sl, double& s, double& q) {
-    constexpr int NL = 256 / NCH;
-    __shared__ double red[2][NL][NCH + 1];
+    constexpr int NL = 256 / NCH;            // split-lanes per channel
+    constexpr int LW = 64 / NCH;             // of which in one wave
+    __shared__ double red[2][4][NCH];
     double a = 0.0, b = 0.0;
     if (c < C) {
-        // eight loads in flight per lane (the loop is a chain of ~L2-latency loads otherwise: 23 us for 6272 row groups); the adds
-        // keep their order, so the result is bit-identical to the one-at-a-time loop
-        int k = sl;
-        for (; k + 7 * NL < S; k += 8 * NL) {
+        for (int k = sl; k < S; k += 8 * NL) {
             float2 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2*>(part + ((long long)(k + u * NL) * C + c) * 2);
+            for (int u = 0; u < 8; ++u) {
+                const int ku = k + u * NL;
+                v[u] = *reinterpret_cast<const float2*>(part + ((long long)(ku < S ? ku : S - 1) * C + c) * 2);
+                if (ku >= S) v[u] = float2{0.f, 0.f};
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 a += (double)v[u].x;
                 b += (double)v[u].y;
             }
         }
-        for (; k < S; k += NL) {
-            const float2 v = *reinterpret_cast<const float2*>(part + ((long long)k * C + c) * 2);
-            a += (double)v.x;
-            b += (double)v.y;
-        }
     }
-    red[0][sl][c % NCH] = a;
-    red[1][sl][c % NCH] = b;
+#pragma unroll
+    for (int o = NCH; o < 64; o <<= 1) {     // lanes of one channel in this wave: lane = c % NCH + NCH * (sl % LW)
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((sl % LW) == 0) {
+        red[0][wave][c % NCH] = a;
+        red[1][wave][c % NCH] = b;
+    }
     __syncthreads();
     s = 0.0;
     q = 0.0;
     if (sl == 0) {
-        for (int k = 0; k < NL; ++k) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
             s += red[0][k][c % NCH];
             q += red[1][k][c % NCH];
         }
@@ -508,7 +518,8 @@ Split pick_split(long long M, int C) {
     sp.PL = TPB / sp.cgb;
     sp.gy = (cg + sp.cgb - 1) / sp.cgb;
     long long s = 2048 / sp.gy;                        // ~2048 workgroups (8 per CU: these loops are latency chains)
-    const long long smax = (M + 4LL * sp.PL - 1) / (4LL * sp.PL);   // >= 4 rows per row lane
+    const long long rows = 4LL * sp.PL > 16 ? 4LL * sp.PL : 16;     // >= 4 rows per row lane and >= 16 rows per split (the partials stay
+    const long long smax = (M + rows - 1) / rows;                   //    below 1/8 of the tensor they summarise)
     if (s > smax) s = smax;
     if (s > MAXS) s = MAXS;
     if (s < 1) s = 1;
