@@ -8,6 +8,7 @@ Lives next to bench.py, outside the ``ccst_amd`` package: its ``cpu_baseline`` l
 ``ccst_amd/`` may do.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -57,6 +58,8 @@ def build(dev, arch="resnet50", classes=7, batch=64, size=222, lr=0.001, seed=1)
 def make_step(model, opt, loss_fun, x, y, join_side=False):
     from ccst_amd import fed
 
+    window = fed.StepWindow() if (x.is_cuda and not join_side) else None      # as fed.train(): the host stays <= 2 steps ahead
+
     def step():
         opt.zero_grad()
         loss = loss_fun(model(x), y)
@@ -65,6 +68,8 @@ def make_step(model, opt, loss_fun, x, y, join_side=False):
         if join_side:         # graph capture: every forked stream must re-join before the capture ends
             from ccst_amd import nn_ops
             nn_ops.join_prepack(x.device)
+        if window is not None:
+            window.tick()
         return loss
     return step
 
@@ -136,12 +141,44 @@ def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False
         run_step = g.replay
     else:
         run_step = step
+    # a full collection of the interpreter's cyclic GC takes 60-80 ms in a process that has imported torch + the AdaIN bench, and its
+    # allocation-count trigger lands deterministically inside the first timed step (measured: that step's host issue 80 ms instead of
+    # 12, 2830 instead of 3160 images/s over 25 steps); collect now, so that the next full pass is far away
+    gc.collect()
     if distributed:
         dist.barrier()
         sync()
+    if os.environ.get("CCST_BENCH_MEM_TRACE") == "1":
+        st = torch.cuda.memory_stats()
+        print("mem before: reserved %.2f GB, device allocs %d, frees %d" % (st["reserved_bytes.all.current"] / 1e9, st["num_device_alloc"], st["num_device_free"]), file=sys.stderr)
+    trace = os.environ.get("CCST_BENCH_STEP_TRACE") == "1"       # per-step host and device times to stderr (diagnosis only)
+    evs, host_ts = [], []
     t0 = time.perf_counter()
+    htrace = os.environ.get("CCST_BENCH_HOST_TRACE") == "1"
+    hts = []
+    dev_ev = None
+    if sync is torch.cuda.synchronize:
+        dev_ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        dev_ev[0].record()
     for _ in range(steps):
+        if htrace:
+            hts.append(time.perf_counter())
+        if trace:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            evs.append(e)
+            host_ts.append(time.perf_counter())
         run_step()
+    if trace:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        evs.append(e)
+        host_ts.append(time.perf_counter())
+        sync()
+        print("step trace (device ms | host issue ms): " + " ".join("%.1f|%.1f" % (evs[i].elapsed_time(evs[i + 1]), (host_ts[i + 1] - host_ts[i]) * 1e3)
+                                                                    for i in range(steps)), file=sys.stderr)
+    if dev_ev is not None:
+        dev_ev[1].record()
     allreduce_ms = None
     if distributed:
         sync()
@@ -158,6 +195,12 @@ def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False
         tt = torch.tensor([total, allreduce_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         total, allreduce_ms = float(tt[0].item()), float(tt[1].item())
+    if os.environ.get("CCST_BENCH_MEM_TRACE") == "1":
+        st = torch.cuda.memory_stats()
+        print("mem after: reserved %.2f GB, device allocs %d, frees %d, total %.1f ms" % (st["reserved_bytes.all.current"] / 1e9, st["num_device_alloc"], st["num_device_free"], total * 1e3), file=sys.stderr)
+    if htrace:
+        hts.append(t0 + total)
+        print("host trace ms: " + " ".join("%.1f" % ((hts[i + 1] - hts[i]) * 1e3) for i in range(len(hts) - 1)), file=sys.stderr)
     dt = total / steps
     gflop = GFLOP_PER_IMAGE.get(arch, 0.0) * batch
     tf = gflop / dt / 1e3
@@ -165,6 +208,9 @@ def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False
     out = {"metric": "%s train images/sec @222x222 B=%d" % (arch, batch), "value": round(n_ranks_seen * batch / dt, 2), "unit": "images/sec",
            "n_gpus": world, "n_ranks_seen": n_ranks_seen, "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup, "dtype": "f32",
            "hip_graph": bool(graph), "scaling": "weak",
+           # HIP events around the same K steps on the compute stream (the host clock above is the contract's; the two agree unless
+           # the host, not the GPU, is what the loop waits for)
+           "device_ms_per_step": round(dev_ev[0].elapsed_time(dev_ev[1]) / steps, 3) if dev_ev is not None else None,
            "config": {"workload": "fed_run.py train() body, %s classes=7, SGD lr 0.001, one client per GPU%s"
                       % (arch, ", + 1 FedAvg all-reduce (RCCL) per %d steps" % steps if distributed else "")},
            "tflops_per_gpu": round(tf, 2), "frac_of_f32_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4),

@@ -199,6 +199,25 @@ class CrossEntropyLoss(nn.Module):
 # ---------------------------------------------------------------------------
 # train / test  (fed_run.py:31-88, :214-259)
 # ---------------------------------------------------------------------------
+class StepWindow(object):
+    """Bounds how far the host runs ahead of the GPU in a train loop: tick() at the end of every iteration records an event and
+    waits for the one `depth` iterations back.  Nothing in the loop synchronises otherwise (the reference's two .item() per
+    iteration, fed_run.py:69,76, are accumulated on the device), and a host that issues a 12 ms step while the GPU runs it in 20 ms
+    gets arbitrarily far ahead: every block that was last used on the weight-gradient stream stays unusable until its event has
+    completed ON THE GPU, so the caching allocator keeps hipMalloc-ing instead of reusing (measured: 11 -> 40 GB and 440 device
+    allocations in 25 ResNet50 steps).  With a window of 2 the GPU never waits for the host and the working set stays put."""
+
+    def __init__(self, depth=2):
+        self.depth, self.events = depth, []
+
+    def tick(self):
+        e = torch.cuda.Event()
+        e.record()
+        self.events.append(e)
+        if len(self.events) > self.depth:
+            self.events.pop(0).synchronize()
+
+
 def _dg(args):
     return (getattr(args, "dg_method", "") or "").lower()
 
@@ -262,6 +281,7 @@ def train(model, train_loader, optimizer, loss_fun, client_num, device, args, it
     steps = model.__dict__.setdefault("_ccst_graph_steps", {}) if use_graph else None
     used = set()
     eager_iters, stale_keys = 0, False
+    window = StepWindow() if torch.device(device).type == "cuda" else None
     for it, data in enumerate(train_loader):
         img, class_l = data
         img, class_l = img.to(device, non_blocking=True), class_l.to(device, non_blocking=True)
@@ -279,6 +299,8 @@ def train(model, train_loader, optimizer, loss_fun, client_num, device, args, it
                     gs.reset()
                 gs.run(img, class_l)
                 stale_keys = True
+                if window is not None:
+                    window.tick()
                 continue
             if stale_keys:          # an eager step after replays: the host-side packed-weight keys are behind the device
                 ops.bump_weights_epoch()
@@ -299,6 +321,8 @@ def train(model, train_loader, optimizer, loss_fun, client_num, device, args, it
         backward(loss)
         optimizer.step()
         del img, class_l
+        if window is not None:
+            window.tick()
     if use_graph:
         for key in used:
             loss_all += steps[key].loss_all
