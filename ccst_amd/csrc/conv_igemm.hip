@@ -458,6 +458,181 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Pointwise (1x1, stride 1, dense NHWC in and out) convolution as a PERSISTENT streaming GEMM: D[M][N] = A[M][K] W[K][N].
+// Two thirds of the ResNet50 trunk, forward and backward-data, with K = 64..2048: 2..64 k-steps per 64x64 tile.  In the kernel
+// above a tile is a workgroup: its first loads (~2.5 us before the first MFMA) and its epilogue (~1.5 us of statistics and
+// stores) are not covered by anything, because the workgroups that share a CU start together and stay in phase -- measured on the
+// 6.6-GFLOP layers: 72-85 us, of which 42 us MFMA time and 30 us that adds to it instead of hiding behind it.  Here a workgroup
+// walks a sequence of tiles and its loader simply runs on: the k-steps of all its tiles form ONE stream (global -> registers two
+// steps ahead, registers -> LDS one step ahead), so the next tile's first operands are already in LDS / in flight while the
+// current tile's epilogue runs, and workgroups drift out of phase.  Same 64x64x32 step as tile 1222 (one 32x32 MFMA tile per
+// wave, 16 MFMAs per step, 4 workgroups per CU).
+// ------------------------------------------------------------------------------------------------------------------------
+template <bool STATS, bool ACCUM>
+__global__ __launch_bounds__(256, 4) void conv1x1_stream_kernel(const ConvArgs p, int ntiles) {
+    constexpr int BM = 64, BN = 64, CK = 32, A_LD = CK + 4, PPR = CK / 4, AR = BM * PPR / 256, BR = (CK / 4) * BN / 256;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * A_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][CK * BN];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int T = p.Cin / CK;                                                   // k-steps per tile
+    const int mine = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this workgroup (>= 1)
+    const int G = mine * T;                                                     // k-steps of this workgroup
+    // i-th tile of this workgroup: sequence position blockIdx + i * grid (same XCD every time: the grid is a multiple of 8 or
+    // covers every tile once), XCD-contiguous; column tile fastest, so the workgroups of an XCD share A rows through its L2
+    auto tile_of = [&](int i) { return ccst_xcd_remap((int)blockIdx.x + i * (int)gridDim.x, ntiles); };
+
+    // ---- loader state (runs up to two k-steps = possibly one tile ahead of the MFMAs) ----
+    const int part = tid % PPR;
+    unsigned aBase[AR], bBase[BR];
+    int lt = 0, lc = 0;                                                         // loader's tile index / chunk
+    auto loader_tile = [&](int i) {
+        const int t = tile_of(i);
+        const int tn = t % p.tilesN, tm = t / p.tilesN;
+#pragma unroll
+        for (int a = 0; a < AR; ++a) {
+            const int m = min(tm * BM + tid / PPR + (256 / PPR) * a, p.M - 1);
+            aBase[a] = (unsigned)(m * p.xsW + part * 4);
+        }
+#pragma unroll
+        for (int b = 0; b < BR; ++b) {
+            const int u = tid + 256 * b;
+            bBase[b] = (unsigned)(((u / BN) * p.CoutPad + tn * BN + (u % BN)) * 4);
+        }
+    };
+    f32x4 ra[AR], rb[BR];
+    auto load_step = [&]() {
+        const float* xc = p.x + lc * CK;                                                  // uniform
+        const float* wc = p.w + (long long)lc * (CK / 4) * p.CoutPad * 4;                 // uniform
+#pragma unroll
+        for (int a = 0; a < AR; ++a) ra[a] = *reinterpret_cast<const f32x4*>(xc + aBase[a]);
+#pragma unroll
+        for (int b = 0; b < BR; ++b) rb[b] = *reinterpret_cast<const f32x4*>(wc + bBase[b]);
+    };
+    auto advance = [&]() {
+        if (++lc == T) {
+            lc = 0;
+            loader_tile(++lt);
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int a = 0; a < AR; ++a) *reinterpret_cast<f32x4*>(&As[buf][(tid / PPR + (256 / PPR) * a) * A_LD + part * 4]) = ra[a];
+#pragma unroll
+        for (int b = 0; b < BR; ++b) *reinterpret_cast<f32x4*>(&Bs[buf][(tid + 256 * b) * 4]) = rb[b];
+    };
+
+    const float* aRd0 = &As[0][(wm * 32 + li) * A_LD + lh * 4];
+    const float* bRd0 = &Bs[0][(lh * BN + wn * 32 + li) * 4];
+    constexpr int NQ = CK / 8, NG = 4 * NQ;
+    f32x4 af[NQ], bf[NQ];
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    auto read_frags = [&](int buf, int q) {
+        af[q] = *reinterpret_cast<const f32x4*>(aRd0 + buf * (BM * A_LD) + q * 8);
+        bf[q] = *reinterpret_cast<const f32x4*>(bRd0 + buf * (CK * BN) + 2 * q * BN * 4);
+    };
+    auto step = [&](int buf, auto do_store, auto do_load) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g == 0) read_frags(buf, 0);
+            if (g == NG - 2 && decltype(do_store)::value) {
+                __builtin_amdgcn_sched_barrier(0);
+                store_step(buf ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (g == NG - 1 && decltype(do_load)::value) {
+                __builtin_amdgcn_sched_barrier(0);
+                advance();
+                load_step();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if ((g & 3) == 3 && (g >> 2) + 1 < NQ) {
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(buf, (g >> 2) + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g >> 2][g & 3], bf[g >> 2][g & 3], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- epilogue of the tile the MFMAs just finished: statistics, (accumulate,) stores through ONE buffer resource over the whole
+    // output (rows beyond M are beyond its size: the hardware drops those stores and answers those loads with zeros) ----
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y + p.y_off, 0, (int)((unsigned)p.M * (unsigned)p.ysW * 4u), 0x00020000);
+    int ct = 0, ci = 0;                                                         // compute side: chunk in tile, tile index
+    auto finish_tile = [&]() {
+        if (++ct < T) return;
+        ct = 0;
+        const int t = tile_of(ci++);
+        const int tn = t % p.tilesN, tm = t / p.tilesN;
+        const int row0 = tm * BM + wm * 32, col = tn * BN + wn * 32 + li;
+        if (STATS) {
+            float s1 = 0.f, s2 = 0.f;
+            if (tm * BM + BM <= p.M) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s1 += acc[r];
+                    s2 += acc[r] * acc[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = (row0 + (r & 3) + 8 * (r >> 2) + 4 * lh < p.M) ? acc[r] : 0.f;
+                    s1 += v;
+                    s2 += v * v;
+                }
+            }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lh == 0) {
+                float* o = p.stats + ((long long)(tm * 2 + wm) * p.Cout + col) * 2;
+                o[0] = s1;
+                o[1] = s2;
+            }
+        }
+        const unsigned voff = (unsigned)(((row0 + 4 * lh) * p.ysW + col) * 4);
+        if (ACCUM) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[r] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, voff, (unsigned)(((r & 3) + 8 * (r >> 2)) * p.ysW * 4), 0));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), yrs, voff, (unsigned)(((r & 3) + 8 * (r >> 2)) * p.ysW * 4), 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    };
+
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
+    loader_tile(0);
+    load_step();
+    store_step(0);
+    if (G > 1) {
+        advance();
+        load_step();
+    }
+    __syncthreads();
+    for (int g = 0; g < G - 2; ++g) {
+        step(g & 1, Yes{}, Yes{});
+        finish_tile();
+        __syncthreads();
+    }
+    if (G > 1) {
+        step((G - 2) & 1, Yes{}, No{});
+        finish_tile();
+        __syncthreads();
+    }
+    step((G - 1) & 1, No{}, No{});
+    finish_tile();
+}
+
 // OIHW -> packed [tap][K/4][n_pad][4]
 __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin, int ntap,
                                    int transpose, int k_pad, int n_pad) {
@@ -594,11 +769,19 @@ static int choose_tile(int M, int cout, int cin, int taps, bool pool) {
     return tile;
 }
 
+// The persistent pointwise kernel (conv1x1_stream_kernel) takes every 1x1 stride-1 convolution between dense NHWC tensors whose
+// channel counts fit its 64x64x32 step.  CCST_CONV_STREAM=0 keeps them on the per-tile kernel (A/B).
+static bool stream_shape_ok(int M, int cout, int cin, int taps) {
+    static const bool on = [] { const char* e = getenv("CCST_CONV_STREAM"); return !(e && atoi(e) == 0); }();
+    return on && taps == 1 && cin % 32 == 0 && cout % 64 == 0 && M >= 64 && (long long)M * cout * 4 < 0xffffffffLL;
+}
+
 // Tile code (WM WN NT as decimal digits) the dispatcher picks for this problem; bench.py names kernels with it.
 extern "C" int ccst_conv2d_igemm_tile(int M, int cout, int cin, int taps, int pool) { return choose_tile(M, cout, cin, taps, pool != 0); }
 
 // Row groups of 64 output rows that ccst_conv2d_igemm_stats_f32 writes for a problem of M rows and cout columns.
 extern "C" int ccst_conv2d_igemm_stats_groups(int M, int cout, int cin, int taps) {
+    if (stream_shape_ok(M, cout, cin, taps)) return ((M + 63) / 64) * 2;        // one slab per 32 rows (a wave row of a 64-row tile)
     const int tile = choose_tile(M, cout, cin, taps, false);
     const int WM = (tile / 100) % 10, BM = (tile >= 1000 ? 32 : 64) * WM;      // one slab per wave row
     return ((M + BM - 1) / BM) * WM;
@@ -650,7 +833,21 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
     a.fastdiv = a.M < (1 << 22);
     a.stats = stats;
     hipStream_t s = (hipStream_t)stream;
-    const int tile = choose_tile(a.M, d->cout, d->cin, d->nky * d->nkx, pool);
+    if ((a.flags & CONV_DENSE_IN) && (a.flags & CONV_DENSE_OUT) && a.ysC == 1 && a.ysW == d->cout && bias == nullptr &&
+        !(a.flags & CCST_CONV_RELU) && stream_shape_ok(a.M, d->cout, d->cin, 1)) {
+        a.tilesN = d->cout / 64;
+        const int ntiles = ((a.M + 63) / 64) * a.tilesN;
+        const int grid = ntiles < 1024 ? ntiles : 1024;                        // 4 workgroups per CU, a multiple of 8 (XCD remap)
+        const bool acc = (a.flags & CCST_CONV_ACCUM) != 0;
+        if (stats) hipLaunchKernelGGL((conv1x1_stream_kernel<true, false>), dim3(grid), dim3(256), 0, s, a, ntiles);
+        else if (acc) hipLaunchKernelGGL((conv1x1_stream_kernel<false, true>), dim3(grid), dim3(256), 0, s, a, ntiles);
+        else hipLaunchKernelGGL((conv1x1_stream_kernel<false, false>), dim3(grid), dim3(256), 0, s, a, ntiles);
+        return ccst_launch_status("conv1x1_stream");
+    }
+    int tile = choose_tile(a.M, d->cout, d->cin, d->nky * d->nkx, pool);
+    // ccst_conv2d_igemm_stats_groups() does not see strides: a 1x1 problem it counted for the streaming kernel (32-row slabs) but
+    // that is not dense (the stride-2 downsample convs) runs on the tile with the same slabs
+    if (stats && stream_shape_ok(a.M, d->cout, d->cin, d->nky * d->nkx)) tile = 1222;
     if (pool) {
         if (tile == 412) return launch_conv<4, 1, 2, true>(a, s);
         if (tile == 221) return launch_conv<2, 2, 1, true>(a, s);
