@@ -162,8 +162,52 @@ def _compile(mods):
     return steps
 
 
+# The kernels address a tensor with 32-bit element offsets (one VGPR per address, no 64-bit adds per load).  A batch whose widest
+# activation (64 channels at full resolution) would not fit is run in slices of the batch dimension: every layer of this path and
+# the AdaIN statistics are per sample, so the result is the same.  (6 x 512 x 512: 100 M elements; the limit is reached at e.g.
+# 8 x 2048 x 2048.)
+MAX_ELEMS = 2 ** 31 - 1
+
+
+def _peak_elems_per_sample(steps, C, H, W):
+    """Largest NHWC buffer (elements per sample, channel padding included) a plan touches for a C x H x W input."""
+    peak = max(C, 4) * H * W
+    for s in steps:
+        if s.kind in ("stem", "smallco"):
+            C = s.pc.cout if s.kind == "stem" else s.cout
+        elif s.kind == "conv":
+            if s.ups:
+                H, W = 2 * H, 2 * W
+            peak = max(peak, s.pc.k_pad * H * W)
+            H = (H + 2 * s.pad - s.pc.kh) // s.stride + 1
+            W = (W + 2 * s.pad - s.pc.kw) // s.stride + 1
+            if s.pool:                       # (the un-pooled map is never written)
+                H, W = (H + 1) // 2, (W + 1) // 2
+            C = s.pc.cout
+        elif s.kind == "pad":
+            H, W = H + 2 * s.pad, W + 2 * s.pad
+        elif s.kind == "up":
+            H, W = 2 * H, 2 * W
+        elif s.kind == "pool":
+            H, W = (H + 1) // 2, (W + 1) // 2
+        peak = max(peak, ((C + 15) // 16 * 16) * H * W)
+    return peak
+
+
 def _run(steps, x):
     """x: logical NCHW CUDA tensor.  Returns a logical NCHW tensor."""
+    if isinstance(x, torch.Tensor) and x.dim() == 4 and x.shape[0] > 0:
+        per = _peak_elems_per_sample(steps, int(x.shape[1]), int(x.shape[2]), int(x.shape[3]))
+        if per > MAX_ELEMS:
+            raise ValueError("ccst_amd.net: a %dx%d image needs an activation of %d elements; the kernels address < 2^31 per tensor"
+                             % (x.shape[2], x.shape[3], per))
+        if per * int(x.shape[0]) > MAX_ELEMS:
+            n = max(1, MAX_ELEMS // per)
+            return torch.cat([_run_batch(steps, x[i:i + n]) for i in range(0, int(x.shape[0]), n)], dim=0)
+    return _run_batch(steps, x)
+
+
+def _run_batch(steps, x):
     if not (isinstance(x, torch.Tensor) and x.is_cuda):
         raise RuntimeError("ccst_amd.net: input must be a CUDA (ROCm) tensor; the HIP path has no CPU fallback")
     if x.dim() != 4:

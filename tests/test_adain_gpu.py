@@ -581,6 +581,24 @@ def test_style_transfer_bitwise_reproducible(dev, nets, A):
     assert torch.equal(a, b)
 
 
+def test_batch_slices_for_tensors_beyond_32bit_offsets(dev, nets, A, monkeypatch):
+    """A batch whose widest activation would pass 2^31 elements (the kernels' 32-bit offsets) runs in slices of the batch dimension
+    with the same result; an image that does not fit alone is refused.  (The limit is lowered for the test.)"""
+    from ccst_amd import net, style
+    vgg31, dec, _, _ = nets
+    content = A.synth_content(5, 48, 80, seed=43).to(dev)
+    stat = [t.to(dev) for t in A.synth_style_stat(512, seed=9)]
+    with torch.no_grad():
+        whole = style.style_transfer(vgg31, dec, content, stat, 1.0)
+        per = 64 * 48 * 80                                            # the 64-channel full-resolution maps are the widest
+        monkeypatch.setattr(net, "MAX_ELEMS", 2 * per + 5)            # -> slices of 2, 2, 1 samples
+        sliced = style.style_transfer(vgg31, dec, content, stat, 1.0)
+        assert sliced.shape == whole.shape and torch.equal(sliced, whole)
+        monkeypatch.setattr(net, "MAX_ELEMS", per - 1)
+        with pytest.raises(ValueError):
+            vgg31(content[:1])
+
+
 def test_no_cpu_fallback(nets):
     vgg31, _, _, _ = nets
     with pytest.raises(RuntimeError):
