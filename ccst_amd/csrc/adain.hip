@@ -361,7 +361,9 @@ extern "C" int ccst_calc_mean_std_f32(const float* x, float* mean, float* stdv, 
         return CCST_EWORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    const int S = pick_splits(N, C, HW, layout);
+    // per-plane statistics: the split count (= the summation order) is a function of the plane only, so a sample's result does
+    // not depend on how many others share its batch (the batch-sliced AdaIN path, net.py, relies on it)
+    const int S = pick_splits(1, C, HW, layout);
     float* part = (float*)ws;
     rc = run_partials<true>(x, part, N, C, HW, layout, S, st);
     if (rc) return rc;

@@ -599,6 +599,21 @@ def test_batch_slices_for_tensors_beyond_32bit_offsets(dev, nets, A, monkeypatch
             vgg31(content[:1])
 
 
+def test_sample_result_does_not_depend_on_its_batch(dev, nets, A):
+    """Every layer of the path and the AdaIN statistics are per sample: an image stylised alone and inside a batch gives the same
+    bits -- also where the statistics take the split-partials path (feature planes above 4096 pixels), whose split count is a
+    function of the plane, not of the batch."""
+    from ccst_amd import style
+    vgg31, dec, _, _ = nets
+    stat = [t.to(dev) for t in A.synth_style_stat(512, seed=11)]
+    for (n, h, w) in ((3, 96, 160), (3, 768, 640)):
+        content = A.synth_content(n, h, w, seed=47).to(dev)
+        with torch.no_grad():
+            whole = style.style_transfer(vgg31, dec, content, stat, 1.0)
+            alone = style.style_transfer(vgg31, dec, content[1:2], stat, 1.0)
+        assert torch.equal(whole[1:2], alone), (n, h, w)
+
+
 def test_no_cpu_fallback(nets):
     vgg31, _, _, _ = nets
     with pytest.raises(RuntimeError):
