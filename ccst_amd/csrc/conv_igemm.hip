@@ -49,6 +49,7 @@ struct ConvArgs {
     float invHW, invWo;  // reciprocals for the division-free pixel decode (valid while M < 2^22)
     int fastdiv;
     float* stats;        // optional [row groups][Cout][2]: per-64-row (sum, sum of squares) of the output (BN statistics)
+    const unsigned char* rmask;   // pointwise streaming kernel, accumulate form: optional ReLU byte mask applied to the SUM (see the entry point)
 };
 
 // floor(m / d) for 0 <= m < 2^22 via one float multiply + correction (an integer division is ~40 VALU
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
 // current tile's epilogue runs, and workgroups drift out of phase.  Same 64x64x32 step as tile 1222 (one 32x32 MFMA tile per
 // wave, 16 MFMAs per step, 4 workgroups per CU).
 // ------------------------------------------------------------------------------------------------------------------------
-template <bool STATS, bool ACCUM>
+template <bool STATS, bool ACCUM, bool MASKED = false>
 __global__ __launch_bounds__(256, 4) void conv1x1_stream_kernel(const ConvArgs p, int ntiles) {
     constexpr int BM = 64, BN = 64, CK = 32, A_LD = CK + 4, PPR = CK / 4, AR = BM * PPR / 256, BR = (CK / 4) * BN / 256;
     __shared__ __attribute__((aligned(16))) float As[2][BM * A_LD];
@@ -601,6 +602,15 @@ __global__ __launch_bounds__(256, 4) void conv1x1_stream_kernel(const ConvArgs p
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 acc[r] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, voff, (unsigned)(((r & 3) + 8 * (r >> 2)) * p.ysW * 4), 0));
+        }
+        if (MASKED) {       // the sum is the gradient of a ReLU output: zero where the forward's byte mask (bit j of byte i <-> element 4 i + j) says so
+            const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.rmask), 0, (int)((unsigned)p.M * (unsigned)(p.ysW / 4)), 0x00020000);
+            const unsigned moff = voff >> 4;
+            unsigned char mb[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mb[r] = __builtin_amdgcn_raw_buffer_load_b8(mrs, moff, (unsigned)(((r & 3) + 8 * (r >> 2)) * (p.ysW / 4)), 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = ((mb[r] >> (li & 3)) & 1) ? acc[r] : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -788,7 +798,7 @@ extern "C" int ccst_conv2d_igemm_stats_groups(int M, int cout, int cin, int taps
 }
 
 static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w_packed, const float* bias, float* y,
-                           float* stats, void* stream);
+                           float* stats, void* stream, const unsigned char* relu_mask = nullptr);
 
 extern "C" int ccst_conv2d_igemm_f32(const CcstConvDesc* d, const float* x, const float* w_packed, const float* bias,
                                      float* y, void* stream) {
@@ -802,8 +812,24 @@ extern "C" int ccst_conv2d_igemm_stats_f32(const CcstConvDesc* d, const float* x
     return conv_igemm_impl(d, x, w_packed, bias, y, stats, stream);
 }
 
+// 1 when this problem runs on the persistent pointwise kernel (the only one with the masked accumulate form).
+extern "C" int ccst_conv2d_pointwise_ok(const CcstConvDesc* d) {
+    if (!d || (d->flags & (CCST_CONV_POOL2 | CCST_CONV_RELU | CCST_CONV_UPS2 | CCST_CONV_REFLECT))) return 0;
+    const bool dense_out = d->ysC == 1 && d->ysW == d->cout && d->ysH == (long long)d->wo * d->ysW && d->ysN == (long long)d->ho * d->wo * d->ysW;
+    const bool dense_in = d->nky == 1 && d->nkx == 1 && d->ay == 1 && d->ax == 1 && d->cy == 0 && d->cx == 0 && d->hi == d->ho && d->wi == d->wo &&
+                          d->xsH == (long long)d->wi * d->xsW && d->xsN == (long long)d->hi * d->wi * d->xsW;
+    return (dense_in && dense_out && stream_shape_ok(d->n * d->ho * d->wo, d->cout, d->cin, 1)) ? 1 : 0;
+}
+
+extern "C" int ccst_conv2d_igemm_accum_masked_f32(const CcstConvDesc* d, const float* x, const float* w_packed, float* y,
+                                                  const uint8_t* relu_mask, void* stream) {
+    CCST_REQUIRE(d && relu_mask && (d->flags & CCST_CONV_ACCUM), "conv_accum_masked: needs a mask and CCST_CONV_ACCUM");
+    CCST_REQUIRE(ccst_conv2d_pointwise_ok(d), "conv_accum_masked: not a pointwise problem of the streaming kernel (ccst_conv2d_pointwise_ok)");
+    return conv_igemm_impl(d, x, w_packed, nullptr, y, nullptr, stream, relu_mask);
+}
+
 static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w_packed, const float* bias, float* y,
-                           float* stats, void* stream) {
+                           float* stats, void* stream, const unsigned char* relu_mask) {
     CCST_REQUIRE(d && x && w_packed && y, "conv: null pointer");
     CCST_REQUIRE(d->cin > 0 && d->cin % CK_MIN == 0, "conv: cin=%d must be a positive multiple of 16", d->cin);
     CCST_REQUIRE(d->cout > 0 && d->cout_pad >= d->cout && d->cout_pad % 128 == 0, "conv: cout=%d cout_pad=%d (need multiple of 128)",
@@ -832,6 +858,7 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
     a.invWo = 1.0f / (float)d->wo;
     a.fastdiv = a.M < (1 << 22);
     a.stats = stats;
+    a.rmask = relu_mask;
     hipStream_t s = (hipStream_t)stream;
     if ((a.flags & CONV_DENSE_IN) && (a.flags & CONV_DENSE_OUT) && a.ysC == 1 && a.ysW == d->cout && bias == nullptr &&
         !(a.flags & CCST_CONV_RELU) && stream_shape_ok(a.M, d->cout, d->cin, 1)) {
@@ -839,11 +866,14 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
         const int ntiles = ((a.M + 63) / 64) * a.tilesN;
         const int grid = ntiles < 1024 ? ntiles : 1024;                        // 4 workgroups per CU, a multiple of 8 (XCD remap)
         const bool acc = (a.flags & CCST_CONV_ACCUM) != 0;
+        if (relu_mask) CCST_REQUIRE(acc && !stats, "conv: the ReLU mask goes with CCST_CONV_ACCUM (the sum is masked)");
         if (stats) hipLaunchKernelGGL((conv1x1_stream_kernel<true, false>), dim3(grid), dim3(256), 0, s, a, ntiles);
+        else if (acc && relu_mask) hipLaunchKernelGGL((conv1x1_stream_kernel<false, true, true>), dim3(grid), dim3(256), 0, s, a, ntiles);
         else if (acc) hipLaunchKernelGGL((conv1x1_stream_kernel<false, true>), dim3(grid), dim3(256), 0, s, a, ntiles);
         else hipLaunchKernelGGL((conv1x1_stream_kernel<false, false>), dim3(grid), dim3(256), 0, s, a, ntiles);
         return ccst_launch_status("conv1x1_stream");
     }
+    CCST_REQUIRE(relu_mask == nullptr, "conv: masked accumulation is only available where ccst_conv2d_pointwise_ok() says so");
     int tile = choose_tile(a.M, d->cout, d->cin, d->nky * d->nkx, pool);
     // ccst_conv2d_igemm_stats_groups() does not see strides: a 1x1 problem it counted for the streaming kernel (32-row slabs) but
     // that is not dense (the stride-2 downsample convs) runs on the tile with the same slabs

@@ -91,10 +91,13 @@ class Conv2d(nn.Conv2d):
         if self.in_channels <= 4:
             y = ops.to_api(nn_ops.StemConvFn.apply(x, self.weight, self))
             return (y, None) if want_stats else y
+        # x is the ReLU output of the previous block's closing BatchNorm and this conv completes x's gradient (residual sink):
+        # hand its mask to the backward (nn_ops.MaskLink)
+        link = getattr(x, "_ccst_mask_link", None) if (sink is not None and not sink.pair) else None
         if want_stats:
-            y, stats = nn_ops.ConvFn.apply(_to_nhwc(x), self.weight, self, True, sink)
+            y, stats = nn_ops.ConvFn.apply(_to_nhwc(x), self.weight, self, True, sink, link)
             return ops.to_api(y), stats
-        return ops.to_api(nn_ops.ConvFn.apply(_to_nhwc(x), self.weight, self, False, sink))
+        return ops.to_api(nn_ops.ConvFn.apply(_to_nhwc(x), self.weight, self, False, sink, link))
 
 
 class BatchNorm2d(nn.BatchNorm2d):
@@ -106,9 +109,13 @@ class BatchNorm2d(nn.BatchNorm2d):
         if not self.training and not self.track_running_stats:
             raise NotImplementedError("ccst_amd.nets: eval-mode BatchNorm2d needs running statistics")
         res = _to_nhwc(residual) if residual is not None else None
+        self._ccst_mask_link = None
         y = nn_ops.BNFn.apply(_to_nhwc(x), self.weight, self.bias, res, self, bool(relu), stats if self.training else None,
                               sink if self.training else None)
-        return ops.to_api(y)
+        out = ops.to_api(y)
+        if self._ccst_mask_link is not None:        # travels with the block output to the next block's first conv
+            out._ccst_mask_link, self._ccst_mask_link = self._ccst_mask_link, None
+        return out
 
 
 def conv_bn(conv, bn, x, residual=None, relu=False, sink_in=None, sink_out=None):

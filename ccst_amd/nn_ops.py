@@ -175,7 +175,7 @@ def _fwd_desc(N, Hs, Ws, Cx, kh, kw, stride, pad, cin_k, cout, n_pad):
     return d, ho, wo
 
 
-def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None):
+def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None, relu_mask=None):
     """dX of a zero-padded conv: an implicit GEMM over dY with the transposed packed weight.
     Stride 1: one launch (iy = oy + pad - ky).  Stride s: one launch per output parity class.
     accumulate_into (stride 1 only): a tensor of x's shape that already holds another gradient contribution (the
@@ -222,12 +222,18 @@ def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None):
         d.xsN, d.xsH, d.xsW = Ho * Wo * Cout, Wo * Cout, Cout
         d.y_off, d.ysN, d.ysH, d.ysW, d.ysC = (py * W + px) * Cin, H * W * Cin, stride * W * Cin, stride * Cin, 1
         d.flags = _lib.CONV_ACCUM if accumulate_into is not None else 0
+        if relu_mask is not None:       # masked accumulate (see MaskLink); the caller checked masked_accum_ok()
+            assert accumulate_into is not None and stride == 1
+            launch = lambda: check(lib.ccst_conv2d_igemm_accum_masked_f32(ctypes.byref(d), ptr(dy), ptr(pc_t.w), ptr(dx), ptr(relu_mask),
+                                                                          stream_ptr()), "conv bwd-data (masked)")
+        else:
+            launch = lambda: check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(dy), ptr(pc_t.w), None, ptr(dx), stream_ptr()), "conv bwd-data")
         if ops.TIMING is None:
-            check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(dy), ptr(pc_t.w), None, ptr(dx), stream_ptr()), "conv bwd-data")
+            launch()
         else:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(dy), ptr(pc_t.w), None, ptr(dx), stream_ptr()), "conv bwd-data")
+            launch()
             e1.record()
             ops.TIMING.append(("bwd_data:" + ops._conv_kernel_name(Cin, False, N * Hc * Wc, pc_t.k_pad, nky * nkx), 2.0 * N * Hc * Wc * Cin * Cout * nky * nkx,
                                e0, e1, "n%d %dx%d cin%d cout%d taps%dx%d s%d" % (N, Hc, Wc, Cout, Cin, nky, nkx, stride)))
@@ -252,6 +258,40 @@ def conv_bwd_weight(d, x, dy, weight_grad_oihw, accumulate=True):
                            "n%d %dx%d cin%d cout%d taps%dx%d splits%d" % (d.n, d.ho, d.wo, d.cin, d.cout, d.nky, d.nkx, splits)))
 
 
+class MaskLink(object):
+    """Ties the BatchNorm that closes a residual block (y = relu(bn(x) + identity), byte ReLU mask in `mask`) to the first conv of
+    the NEXT block when that block's identity branch is y itself: the gradient of y is (next block's identity share) + (that
+    conv's backward-data), summed in the conv's `y +=` epilogue -- which can apply y's ReLU mask to the sum while it is in
+    registers.  It then sets `premasked`, and the BatchNorm's backward takes its incoming gradient as already masked: no mask
+    reads in its two passes and its skip-connection share IS the incoming tensor (no masked copy: 1.06 GB of writes per ResNet50
+    step)."""
+    __slots__ = ("mask", "premasked")
+
+    def __init__(self, mask):
+        self.mask, self.premasked = mask, False
+
+
+MASK_LINK = _os.environ.get("CCST_MASK_LINK", "1") != "0"
+
+
+def masked_accum_ok(dy, pc_t, x_shape, stride, pad):
+    """True when conv_bwd_data(..., accumulate_into=..., relu_mask=...) exists for this problem (pointwise streaming kernel)."""
+    if stride != 1 or pad != 0 or pc_t.kh != 1 or pc_t.kw != 1:
+        return False
+    N, H, W, Cin = x_shape
+    Cout = dy.shape[3]
+    d = CcstConvDesc()
+    d.n, d.ho, d.wo, d.hi, d.wi = N, H, W, H, W
+    d.cin, d.cout, d.cout_pad = pc_t.k_pad, Cin, pc_t.n_pad
+    d.nky, d.nkx = 1, 1
+    d.ay, d.by, d.cy = 1, -1, 0
+    d.ax, d.bx, d.cx = 1, -1, 0
+    d.xsN, d.xsH, d.xsW = H * W * Cout, W * Cout, Cout
+    d.y_off, d.ysN, d.ysH, d.ysW, d.ysC = 0, H * W * Cin, W * Cin, Cin, 1
+    d.flags = _lib.CONV_ACCUM
+    return bool(_lib.load().ccst_conv2d_pointwise_ok(ctypes.byref(d)))
+
+
 class GradSink(object):
     """Carries the identity-branch gradient of a residual block from the closing BatchNorm's backward to the block's
     first convolution, whose backward-data epilogue adds to it in place -- instead of autograd materialising both
@@ -270,11 +310,12 @@ class ConvFn(torch.autograd.Function):
     """Bias-free zero-padded Conv2d on NHWC (nets/resnet.py:160-161 + torchvision blocks)."""
 
     @staticmethod
-    def forward(ctx, x, weight, mod, want_stats=False, sink=None):
+    def forward(ctx, x, weight, mod, want_stats=False, sink=None, link=None):
         pc = mod.packed()
         ctx.save_for_backward(x, weight)
         ctx.mod = mod
         ctx.sink = sink
+        ctx.link = link          # MaskLink of the ReLU that produced x (residual blocks), or None
         ctx.want_stats = bool(want_stats)
         ctx.set_materialize_grads(False)       # no zero tensor for the non-differentiable stats output
         ctx.wino = mod.wino_ok(x.shape[1], x.shape[2])
@@ -292,7 +333,7 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, *unused):
         if dy is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         x, weight = ctx.saved_tensors
         mod = ctx.mod
         dy = dy.contiguous()
@@ -316,10 +357,18 @@ class ConvFn(torch.autograd.Function):
             if ctx.wino:
                 dx = ops.conv3x3_wino_train(dy, mod.wino_bwd(), accumulate_into=into, tag="bwd_data:")
             else:
-                dx = conv_bwd_data(dy, mod.packed_t(), tuple(x.shape), stride, pad, accumulate_into=into)
+                mask = None
+                link = ctx.link
+                # this launch completes the gradient of x (identity share + this conv): mask it by x's ReLU here (MaskLink)
+                if link is not None and into is not None and not ctx.sink.pair and link.mask is not None and \
+                        masked_accum_ok(dy, mod.packed_t(), tuple(x.shape), stride, pad):
+                    mask = link.mask
+                dx = conv_bwd_data(dy, mod.packed_t(), tuple(x.shape), stride, pad, accumulate_into=into, relu_mask=mask)
+                if mask is not None:
+                    link.premasked = True
             if deposit:
                 ctx.sink.grad, dx = dx, None
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
 class StemConvFn(torch.autograd.Function):
@@ -404,6 +453,7 @@ class BNFn(torch.autograd.Function):
                   "bn_train_fwd")
             keep_y = ctx.relu and mask is None and (ctx.has_res or BN_MASK_FROM_Y)
             ctx.save_for_backward(x, y if keep_y else None, mask, gamma, beta, save)
+            ctx.link = mod._ccst_mask_link = MaskLink(mask) if (mask is not None and MASK_LINK) else None
         else:
             check(lib.ccst_bn_eval_fwd_f32(ptr(x), ptr(gamma), ptr(beta), ptr(mod.running_mean), ptr(mod.running_var),
                                            float(mod.eps), ptr(residual), int(relu), ptr(y), M, C, stream_ptr()), "bn_eval_fwd")
@@ -421,11 +471,21 @@ class BNFn(torch.autograd.Function):
         M = N * H * W
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dres = torch.empty_like(x) if ctx.has_res else None
         ws = _workspace(int(lib.ccst_bn_workspace_bytes(M, C)), x.device)
-        check(lib.ccst_bn_train_bwd_mask_f32(ptr(dy), ptr(x), ptr(y), ptr(mask), ptr(gamma), ptr(beta), ptr(save[0]), ptr(save[1]),
-                                             int(ctx.relu), ptr(dx), ptr(dres), ptr(_grad_slot(gamma)), ptr(_grad_slot(beta)), 1, M, C,
-                                             ptr(ws), ws.numel(), stream_ptr()), "bn_train_bwd")
+        link = getattr(ctx, "link", None)
+        if link is not None and link.premasked:
+            # the producer of dy already applied this BatchNorm's ReLU mask (MaskLink): plain backward, and the skip connection's
+            # share is dy itself
+            link.premasked = False
+            dres = dy if ctx.has_res else None
+            check(lib.ccst_bn_train_bwd_mask_f32(ptr(dy), ptr(x), None, None, ptr(gamma), ptr(beta), ptr(save[0]), ptr(save[1]),
+                                                 0, ptr(dx), None, ptr(_grad_slot(gamma)), ptr(_grad_slot(beta)), 1, M, C,
+                                                 ptr(ws), ws.numel(), stream_ptr()), "bn_train_bwd")
+        else:
+            dres = torch.empty_like(x) if ctx.has_res else None
+            check(lib.ccst_bn_train_bwd_mask_f32(ptr(dy), ptr(x), ptr(y), ptr(mask), ptr(gamma), ptr(beta), ptr(save[0]), ptr(save[1]),
+                                                 int(ctx.relu), ptr(dx), ptr(dres), ptr(_grad_slot(gamma)), ptr(_grad_slot(beta)), 1, M, C,
+                                                 ptr(ws), ws.numel(), stream_ptr()), "bn_train_bwd")
         if ctx.sink is not None and dres is not None:
             ctx.sink.grad, dres = dres, None        # handed to the block's first conv (GradSink), not to autograd
         return dx, None, None, dres, None, None, None, None

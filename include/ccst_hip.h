@@ -135,6 +135,15 @@ int ccst_conv3x3_halo_stats_groups(int N, int H, int W);
  * M = n*ho*wo output pixels, cout channels, cin (padded) input channels and taps = nky*nkx. */
 int ccst_conv2d_igemm_tile(int M, int cout, int cin, int taps, int pool);
 
+/* y = relu_mask ? (y + conv(x)) : 0 for a pointwise (1x1, stride 1, dense NHWC) problem with CCST_CONV_ACCUM: the gradient that
+ * reaches a residual block's input is (identity share, already in y) + (first conv's backward-data), and that input is the previous
+ * block's ReLU output -- masking the SUM here (relu_mask[M*cout/4] as written by ccst_bn_train_fwd_mask_f32: bit j of byte i <->
+ * element 4 i + j) lets that block's BatchNorm backward take it as is: no mask reads there and no separate masked copy for its
+ * skip connection (nets/resnet.py:160-165 inside loss.backward(), fed_run.py:79).  ccst_conv2d_pointwise_ok(d) = 1 where the form exists. */
+int ccst_conv2d_pointwise_ok(const CcstConvDesc* d);
+int ccst_conv2d_igemm_accum_masked_f32(const CcstConvDesc* d, const float* x, const float* w_packed, float* y,
+                                       const uint8_t* relu_mask, void* stream);
+
 /* Direct 3x3 stride-1 conv with 1..4 output channels writing NCHW (the decoder's last layer,
  * net.py:35): x NHWC [N,H,W,Cin] (Cin % 16 == 0), w [3][3][Cout][Cin], y NCHW [N,Cout,H,W].
  * HBM-bound (13 FLOP/B), so it runs on the VALU rather than padding Cout to an MFMA tile. */
