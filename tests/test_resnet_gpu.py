@@ -96,6 +96,31 @@ def test_halo_train_form_vs_gather(dev, shape):
     assert float((acc2 - (base + dx_ref)).abs().max()) < 1e-5 * max(1.0, float(dx_ref.abs().max()))
 
 
+def test_pointwise_backward_data_masked_accumulate(dev):
+    """ccst_conv2d_igemm_accum_masked_f32: y = mask ? y + dX : 0 (the residual-block input gradient, masked by the previous block's
+    ReLU in the conv's own epilogue) against torch; the byte mask has the layout ccst_bn_train_fwd_mask_f32 writes."""
+    from ccst_amd import nn_ops, ops
+    N, H, W, Cin, Cout = 3, 14, 10, 256, 64            # forward conv Cin -> Cout (1x1); backward-data yields Cin channels
+    g = torch.Generator().manual_seed(23)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * 0.1
+    dy = torch.randn(N, H, W, Cout, generator=g)
+    base = torch.randn(N, H, W, Cin, generator=g)
+    keep = torch.rand(N, H, W, Cin, generator=g) > 0.4
+    bits = keep.reshape(-1, 4).to(torch.uint8)
+    mask = (bits[:, 0] | (bits[:, 1] << 1) | (bits[:, 2] << 2) | (bits[:, 3] << 3)).contiguous()
+    pct = ops.pack_conv_weight(w.to(dev), transpose=True)
+    assert nn_ops.masked_accum_ok(dy.to(dev), pct, (N, H, W, Cin), 1, 0)
+    ref = torch.nn.grad.conv2d_input((N, Cin, H, W), w, dy.permute(0, 3, 1, 2)).permute(0, 2, 3, 1) + base
+    ref = torch.where(keep, ref, torch.zeros(()))
+    acc = base.to(dev).contiguous()
+    out = nn_ops.conv_bwd_data(dy.to(dev), pct, (N, H, W, Cin), 1, 0, accumulate_into=acc, relu_mask=mask.to(dev))
+    assert out.data_ptr() == acc.data_ptr()
+    assert float((out.cpu() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
+    assert bool((out.cpu()[~keep] == 0).all())
+    # shapes the streaming kernel does not take are refused by the predicate (3x3, stride 2)
+    assert not nn_ops.masked_accum_ok(dy.to(dev), ops.pack_conv_weight(torch.randn(Cout, Cin, 3, 3).to(dev), transpose=True), (N, H, W, Cin), 1, 1)
+
+
 def test_stem_conv_fwd_bwd(dev):
     from ccst_amd.nets import resnet
     x = rnd((2, 3, 38, 38), 4)
