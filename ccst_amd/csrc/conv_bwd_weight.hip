@@ -86,6 +86,37 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs p) 
 
     f32x4 rx[XR], rd[DR];
     const int HW = p.Ho * p.Wo;
+    // (n, oy, ox) of the first pixel of the step being loaded: carried from step to step in scalar registers (a step advances by PK
+    // pixels = PK / Wo rows + PK % Wo columns, one wrap each) instead of two divisions per thread and unit -- vector instructions are
+    // paid on top of the MFMA time, and this loop had ~170 of them (16 quarter-rate v_mul_lo among them) per 32 MFMAs.
+    int un = 0, uoy = 0, uox = 0;                       // valid when !PW
+    const int stepRows = PK / p.Wo, stepCols = PK - (PK / p.Wo) * p.Wo;
+    // t / d == (t * magic) >> 16 with magic = ceil(2^16 / d) while t * d < 2^16; here t < d + 32, so d <= 224 -- beyond that PK < d and
+    // the quotient is 0 or 1 (a comparison)
+    const unsigned magicW = (65536u + (unsigned)p.Wo - 1u) / (unsigned)p.Wo, magicH = (65536u + (unsigned)p.Ho - 1u) / (unsigned)p.Ho;
+    const bool wideW = p.Wo > 224, wideH = p.Ho > 224;
+    if (!PW) {
+        const int m0 = min(s0 * PK, p.M - 1);
+        un = m0 / HW;
+        const int rem = m0 - un * HW;
+        uoy = rem / p.Wo;
+        uox = rem - uoy * p.Wo;
+        un = __builtin_amdgcn_readfirstlane(un);
+        uoy = __builtin_amdgcn_readfirstlane(uoy);
+        uox = __builtin_amdgcn_readfirstlane(uox);
+    }
+    auto advance_pixels = [&]() {          // to the next step's first pixel (uniform)
+        uox += stepCols;
+        uoy += stepRows;
+        if (uox >= p.Wo) {
+            uox -= p.Wo;
+            ++uoy;
+        }
+        while (uoy >= p.Ho) {               // (more than once only for maps narrower than a step)
+            uoy -= p.Ho;
+            ++un;
+        }
+    };
 
     auto load_step = [&](int st) {
         const int m0 = st * PK;
@@ -111,21 +142,20 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs p) 
                 ok = (m < p.M) & (ci < p.Cin);
                 v = *reinterpret_cast<const f32x4*>(p.x + (long long)mc * p.xsW + cic);
             } else {
-                int n, oy;
-                if (p.fastdiv) {
-                    n = fdiv(mc, HW, p.invHW);
-                    oy = fdiv(mc - n * HW, p.Wo, p.invWo);
-                } else {
-                    n = mc / HW;
-                    oy = (mc - n * HW) / p.Wo;
-                }
-                const int rem = mc - n * HW;
-                const int ox = rem - oy * p.Wo;
-                int iy = oy * p.ay + kyu * p.by + p.cy, ix = ox * p.ax + kxu * p.bx + p.cx;
+                // pixel m0 + px from the step's uniform (n, oy, ox): px < PK <= 32 columns further on, at most PK / Wo + 1 row wraps
+                // and one image wrap (rows beyond M are masked by ok and may decode to anything inside the tensor)
+                const unsigned t = (unsigned)(uox + px);
+                const unsigned q = wideW ? (t >= (unsigned)p.Wo ? 1u : 0u) : (__umul24(t, magicW) >> 16);
+                const int ox = (int)(t - __umul24(q, (unsigned)p.Wo));
+                const unsigned ty = (unsigned)uoy + q;
+                const unsigned r = wideH ? (ty >= (unsigned)p.Ho ? 1u : 0u) : (__umul24(ty, magicH) >> 16);
+                const int oy = (int)(ty - __umul24(r, (unsigned)p.Ho));
+                const int n = min(un + (int)r, p.N - 1);
+                int iy = __mul24(oy, p.ay) + kyu * p.by + p.cy, ix = __mul24(ox, p.ax) + kxu * p.bx + p.cx;
                 ok = (m < p.M) & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi) & (ci < p.Cin) & tap_ok;
                 iy = min(max(iy, 0), p.Hi - 1);
                 ix = min(max(ix, 0), p.Wi - 1);
-                v = *reinterpret_cast<const f32x4*>(p.x + (long long)n * p.xsN + (long long)iy * p.xsH + (long long)ix * p.xsW + cic);
+                v = *reinterpret_cast<const f32x4*>(p.x + (long long)n * p.xsN + (unsigned)(__mul24(iy, p.xsH) + __mul24(ix, p.xsW) + cic));
             }
             if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
             rx[u] = v;
@@ -138,6 +168,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs p) 
             const int co = min(co0 + cp * 4, p.Cout - 4);
             rd[u] = *reinterpret_cast<const f32x4*>(p.dy + (long long)mc * p.Cout + co);
         }
+        if (!PW) advance_pixels();
     };
     auto store_step = [&](int buf) {
 #pragma unroll
@@ -354,6 +385,8 @@ extern "C" int ccst_conv2d_bwd_weight_f32(const CcstConvDesc* d, const float* x,
     CCST_REQUIRE(d->cin > 0 && d->cin % 4 == 0 && d->cout > 0 && d->cout % 4 == 0, "bwd_weight: cin/cout must be multiples of 4");
     CCST_REQUIRE(d->n > 0 && d->ho > 0 && d->wo > 0 && d->nky > 0 && d->nkx > 0 && splits >= 1, "bwd_weight: bad extents");
     CCST_REQUIRE((long long)d->n * d->ho * d->wo < 0x7fffffffLL, "bwd_weight: M too large");
+    CCST_REQUIRE(d->xsH < (1 << 23) && d->xsW < (1 << 23) && d->hi < (1 << 15) && d->wi < (1 << 15) && d->ho < (1 << 15) && d->wo < (1 << 15) &&
+                 (long long)d->hi * d->xsH < 0x7fffffffLL, "bwd_weight: extents beyond the 24-bit index arithmetic of the loader");
     const int ntap = d->nky * d->nkx;
     const long long need = (long long)splits * ntap * d->cin * d->cout * 4;
     if (ws_bytes < need) {
