@@ -50,6 +50,10 @@ struct ConvArgs {
     int fastdiv;
     float* stats;        // optional [row groups][Cout][2]: per-64-row (sum, sum of squares) of the output (BN statistics)
     const unsigned char* rmask;   // pointwise streaming kernel, accumulate form: optional ReLU byte mask applied to the SUM (see the entry point)
+    const float* bn_x;            // ... and, with it, the BatchNorm whose output gradient that sum is: its input, saved mean / invstd,
+    const float* bn_mean;         //     and where to leave the per-32-row partial sums (sum g, sum g * xhat) of its backward
+    const float* bn_invstd;
+    float* bn_part;
 };
 
 // floor(m / d) for 0 <= m < 2^22 via one float multiply + correction (an integer division is ~40 VALU
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
 // current tile's epilogue runs, and workgroups drift out of phase.  Same 64x64x32 step as tile 1222 (one 32x32 MFMA tile per
 // wave, 16 MFMAs per step, 4 workgroups per CU).
 // ------------------------------------------------------------------------------------------------------------------------
-template <bool STATS, bool ACCUM, bool MASKED = false>
+template <bool STATS, bool ACCUM, bool MASKED = false, bool BSTATS = false>
 __global__ __launch_bounds__(256, 4) void conv1x1_stream_kernel(const ConvArgs p, int ntiles) {
     constexpr int BM = 64, BN = 64, CK = 32, A_LD = CK + 4, PPR = CK / 4, AR = BM * PPR / 256, BR = (CK / 4) * BN / 256;
     __shared__ __attribute__((aligned(16))) float As[2][BM * A_LD];
@@ -611,6 +615,28 @@ __global__ __launch_bounds__(256, 4) void conv1x1_stream_kernel(const ConvArgs p
             for (int r = 0; r < 16; ++r) mb[r] = __builtin_amdgcn_raw_buffer_load_b8(mrs, moff, (unsigned)(((r & 3) + 8 * (r >> 2)) * (p.ysW / 4)), 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = ((mb[r] >> (li & 3)) & 1) ? acc[r] : 0.f;
+        }
+        if (BSTATS) {       // the masked sum g is the output gradient of a BatchNorm: its backward's per-channel partial sums, from here
+            const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bn_x), 0, (int)((unsigned)p.M * (unsigned)p.ysW * 4u), 0x00020000);
+            const float mu = p.bn_mean[col], is = p.bn_invstd[col];
+            float xv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, voff, (unsigned)(((r & 3) + 8 * (r >> 2)) * p.ysW * 4), 0));
+            float s1 = 0.f, s2 = 0.f;
+            const bool full = tm * BM + BM <= p.M;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float gq = (full || row0 + (r & 3) + 8 * (r >> 2) + 4 * lh < p.M) ? acc[r] : 0.f;
+                s1 += gq;
+                s2 += gq * ((xv[r] - mu) * is);
+            }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lh == 0) {
+                float* o = p.bn_part + ((long long)(tm * 2 + wm) * p.Cout + col) * 2;
+                o[0] = s1;
+                o[1] = s2;
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -821,15 +847,33 @@ extern "C" int ccst_conv2d_pointwise_ok(const CcstConvDesc* d) {
     return (dense_in && dense_out && stream_shape_ok(d->n * d->ho * d->wo, d->cout, d->cin, 1)) ? 1 : 0;
 }
 
+namespace {
+struct BnLink {
+    const float *x, *mean, *invstd;
+    float* part;
+};
+}  // namespace
+static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w_packed, const float* bias, float* y, float* stats,
+                           void* stream, const unsigned char* relu_mask, const BnLink* bn);
+
 extern "C" int ccst_conv2d_igemm_accum_masked_f32(const CcstConvDesc* d, const float* x, const float* w_packed, float* y,
-                                                  const uint8_t* relu_mask, void* stream) {
+                                                  const uint8_t* relu_mask, const float* bn_x, const float* bn_mean,
+                                                  const float* bn_invstd, float* bn_partials, void* stream) {
     CCST_REQUIRE(d && relu_mask && (d->flags & CCST_CONV_ACCUM), "conv_accum_masked: needs a mask and CCST_CONV_ACCUM");
     CCST_REQUIRE(ccst_conv2d_pointwise_ok(d), "conv_accum_masked: not a pointwise problem of the streaming kernel (ccst_conv2d_pointwise_ok)");
-    return conv_igemm_impl(d, x, w_packed, nullptr, y, nullptr, stream, relu_mask);
+    CCST_REQUIRE((bn_x != nullptr) == (bn_partials != nullptr) && (bn_x == nullptr || (bn_mean && bn_invstd)),
+                 "conv_accum_masked: the BatchNorm link needs its input, mean, invstd and the partials buffer together");
+    const BnLink bn = {bn_x, bn_mean, bn_invstd, bn_partials};
+    return conv_igemm_impl(d, x, w_packed, nullptr, y, nullptr, stream, relu_mask, bn_x ? &bn : nullptr);
 }
 
-static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w_packed, const float* bias, float* y,
-                           float* stats, void* stream, const unsigned char* relu_mask) {
+static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w_packed, const float* bias, float* y, float* stats,
+                           void* stream, const unsigned char* relu_mask) {
+    return conv_igemm_impl(d, x, w_packed, bias, y, stats, stream, relu_mask, nullptr);
+}
+
+static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w_packed, const float* bias, float* y, float* stats,
+                           void* stream, const unsigned char* relu_mask, const BnLink* bn) {
     CCST_REQUIRE(d && x && w_packed && y, "conv: null pointer");
     CCST_REQUIRE(d->cin > 0 && d->cin % CK_MIN == 0, "conv: cin=%d must be a positive multiple of 16", d->cin);
     CCST_REQUIRE(d->cout > 0 && d->cout_pad >= d->cout && d->cout_pad % 128 == 0, "conv: cout=%d cout_pad=%d (need multiple of 128)",
@@ -859,6 +903,7 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
     a.fastdiv = a.M < (1 << 22);
     a.stats = stats;
     a.rmask = relu_mask;
+    a.bn_x = bn ? bn->x : nullptr; a.bn_mean = bn ? bn->mean : nullptr; a.bn_invstd = bn ? bn->invstd : nullptr; a.bn_part = bn ? bn->part : nullptr;
     hipStream_t s = (hipStream_t)stream;
     if ((a.flags & CONV_DENSE_IN) && (a.flags & CONV_DENSE_OUT) && a.ysC == 1 && a.ysW == d->cout && bias == nullptr &&
         !(a.flags & CCST_CONV_RELU) && stream_shape_ok(a.M, d->cout, d->cin, 1)) {
@@ -868,6 +913,7 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
         const bool acc = (a.flags & CCST_CONV_ACCUM) != 0;
         if (relu_mask) CCST_REQUIRE(acc && !stats, "conv: the ReLU mask goes with CCST_CONV_ACCUM (the sum is masked)");
         if (stats) hipLaunchKernelGGL((conv1x1_stream_kernel<true, false>), dim3(grid), dim3(256), 0, s, a, ntiles);
+        else if (acc && relu_mask && bn) hipLaunchKernelGGL((conv1x1_stream_kernel<false, true, true, true>), dim3(grid), dim3(256), 0, s, a, ntiles);
         else if (acc && relu_mask) hipLaunchKernelGGL((conv1x1_stream_kernel<false, true, true>), dim3(grid), dim3(256), 0, s, a, ntiles);
         else if (acc) hipLaunchKernelGGL((conv1x1_stream_kernel<false, true>), dim3(grid), dim3(256), 0, s, a, ntiles);
         else hipLaunchKernelGGL((conv1x1_stream_kernel<false, false>), dim3(grid), dim3(256), 0, s, a, ntiles);

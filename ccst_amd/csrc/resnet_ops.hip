@@ -633,6 +633,27 @@ extern "C" int ccst_bn_train_bwd_mask_f32(const float* dy, const float* x, const
     return ccst_launch_status("bn_train_bwd");
 }
 
+extern "C" int ccst_bn_train_bwd_partials_f32(const float* dy, const float* x, const float* gamma, const float* save_mean,
+                                              const float* save_invstd, const float* partials, int groups, float* dx, float* dgamma,
+                                              float* dbeta, int accumulate, int64_t M, int C, void* ws, int64_t ws_bytes, void* stream) {
+    CCST_REQUIRE(dy && x && gamma && save_mean && save_invstd && partials && dx && dgamma && dbeta && ws, "bn_train_bwd_partials: null pointer");
+    CCST_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && groups > 0, "bn_train_bwd_partials: need M>0, groups>0 and C %% 4 == 0");
+    if (ws_bytes < ccst_bn_workspace_bytes(M, C)) {
+        ccst_set_error("bn_train_bwd_partials: workspace too small");
+        return CCST_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* sums = (float*)ws + (int64_t)MAXS * C * 2;
+    if (groups > 512)
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3((C + 3) / 4), dim3(256), 0, st, partials, dgamma, dbeta, sums, C, groups, accumulate);
+    else
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<16>, dim3((C + 15) / 16), dim3(256), 0, st, partials, dgamma, dbeta, sums, C, groups, accumulate);
+    const long long total4 = (long long)M * (C / 4);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), dim3(grid_for(total4)), dim3(TPB), 0, st, dy, x, nullptr, gamma, nullptr, save_mean, save_invstd,
+                       sums, 0, dx, nullptr, total4, C, 1.f / (float)M, nullptr);
+    return ccst_launch_status("bn_train_bwd_partials");
+}
+
 extern "C" int ccst_bn_train_bwd_f32(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
                                      const float* save_mean, const float* save_invstd, int relu, float* dx, float* d_residual,
                                      float* dgamma, float* dbeta, int accumulate, int64_t M, int C, void* ws, int64_t ws_bytes,

@@ -175,7 +175,7 @@ def _fwd_desc(N, Hs, Ws, Cx, kh, kw, stride, pad, cin_k, cout, n_pad):
     return d, ho, wo
 
 
-def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None, relu_mask=None):
+def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None, relu_mask=None, bn_link=None):
     """dX of a zero-padded conv: an implicit GEMM over dY with the transposed packed weight.
     Stride 1: one launch (iy = oy + pad - ky).  Stride s: one launch per output parity class.
     accumulate_into (stride 1 only): a tensor of x's shape that already holds another gradient contribution (the
@@ -224,8 +224,10 @@ def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None, relu_mas
         d.flags = _lib.CONV_ACCUM if accumulate_into is not None else 0
         if relu_mask is not None:       # masked accumulate (see MaskLink); the caller checked masked_accum_ok()
             assert accumulate_into is not None and stride == 1
+            bx, bm, bi, bp = bn_link if bn_link is not None else (None, None, None, None)     # (bn input, mean, invstd, partials out)
             launch = lambda: check(lib.ccst_conv2d_igemm_accum_masked_f32(ctypes.byref(d), ptr(dy), ptr(pc_t.w), ptr(dx), ptr(relu_mask),
-                                                                          stream_ptr()), "conv bwd-data (masked)")
+                                                                          ptr(bx), ptr(bm), ptr(bi), ptr(bp), stream_ptr()),
+                                   "conv bwd-data (masked)")
         else:
             launch = lambda: check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(dy), ptr(pc_t.w), None, ptr(dx), stream_ptr()), "conv bwd-data")
         if ops.TIMING is None:
@@ -265,13 +267,17 @@ class MaskLink(object):
     registers.  It then sets `premasked`, and the BatchNorm's backward takes its incoming gradient as already masked: no mask
     reads in its two passes and its skip-connection share IS the incoming tensor (no masked copy: 1.06 GB of writes per ResNet50
     step)."""
-    __slots__ = ("mask", "premasked")
+    __slots__ = ("mask", "premasked", "bn_x", "bn_save", "partials")
 
-    def __init__(self, mask):
+    def __init__(self, mask, bn_x=None, bn_save=None):
         self.mask, self.premasked = mask, False
+        # the BatchNorm's input and saved (mean, invstd): with them that epilogue also leaves the BatchNorm backward's per-channel
+        # partial sums (it has the masked gradient in registers and reads x at the same addresses), in `partials`
+        self.bn_x, self.bn_save, self.partials = bn_x, bn_save, None
 
 
 MASK_LINK = _os.environ.get("CCST_MASK_LINK", "1") != "0"
+MASK_LINK_STATS = _os.environ.get("CCST_MASK_LINK_STATS", "1") != "0"      # BN-backward partial sums from that epilogue too
 
 
 def masked_accum_ok(dy, pc_t, x_shape, stride, pad):
@@ -363,7 +369,12 @@ class ConvFn(torch.autograd.Function):
                 if link is not None and into is not None and not ctx.sink.pair and link.mask is not None and \
                         masked_accum_ok(dy, mod.packed_t(), tuple(x.shape), stride, pad):
                     mask = link.mask
-                dx = conv_bwd_data(dy, mod.packed_t(), tuple(x.shape), stride, pad, accumulate_into=into, relu_mask=mask)
+                bn_link = None
+                if mask is not None and MASK_LINK_STATS and link.bn_x is not None:
+                    M = N * H * W
+                    link.partials = torch.empty((2 * ((M + 63) // 64), Cin, 2), device=x.device, dtype=torch.float32)
+                    bn_link = (link.bn_x, link.bn_save[0], link.bn_save[1], link.partials)
+                dx = conv_bwd_data(dy, mod.packed_t(), tuple(x.shape), stride, pad, accumulate_into=into, relu_mask=mask, bn_link=bn_link)
                 if mask is not None:
                     link.premasked = True
             if deposit:
@@ -453,7 +464,7 @@ class BNFn(torch.autograd.Function):
                   "bn_train_fwd")
             keep_y = ctx.relu and mask is None and (ctx.has_res or BN_MASK_FROM_Y)
             ctx.save_for_backward(x, y if keep_y else None, mask, gamma, beta, save)
-            ctx.link = mod._ccst_mask_link = MaskLink(mask) if (mask is not None and MASK_LINK) else None
+            ctx.link = mod._ccst_mask_link = MaskLink(mask, x, save) if (mask is not None and MASK_LINK) else None
         else:
             check(lib.ccst_bn_eval_fwd_f32(ptr(x), ptr(gamma), ptr(beta), ptr(mod.running_mean), ptr(mod.running_var),
                                            float(mod.eps), ptr(residual), int(relu), ptr(y), M, C, stream_ptr()), "bn_eval_fwd")
@@ -478,9 +489,15 @@ class BNFn(torch.autograd.Function):
             # share is dy itself
             link.premasked = False
             dres = dy if ctx.has_res else None
-            check(lib.ccst_bn_train_bwd_mask_f32(ptr(dy), ptr(x), None, None, ptr(gamma), ptr(beta), ptr(save[0]), ptr(save[1]),
-                                                 0, ptr(dx), None, ptr(_grad_slot(gamma)), ptr(_grad_slot(beta)), 1, M, C,
-                                                 ptr(ws), ws.numel(), stream_ptr()), "bn_train_bwd")
+            part, link.partials = link.partials, None
+            if part is not None:        # ... and left this backward's partial sums: finalize + apply only
+                check(lib.ccst_bn_train_bwd_partials_f32(ptr(dy), ptr(x), ptr(gamma), ptr(save[0]), ptr(save[1]), ptr(part), int(part.shape[0]),
+                                                         ptr(dx), ptr(_grad_slot(gamma)), ptr(_grad_slot(beta)), 1, M, C, ptr(ws), ws.numel(),
+                                                         stream_ptr()), "bn_train_bwd")
+            else:
+                check(lib.ccst_bn_train_bwd_mask_f32(ptr(dy), ptr(x), None, None, ptr(gamma), ptr(beta), ptr(save[0]), ptr(save[1]),
+                                                     0, ptr(dx), None, ptr(_grad_slot(gamma)), ptr(_grad_slot(beta)), 1, M, C,
+                                                     ptr(ws), ws.numel(), stream_ptr()), "bn_train_bwd")
         else:
             dres = torch.empty_like(x) if ctx.has_res else None
             check(lib.ccst_bn_train_bwd_mask_f32(ptr(dy), ptr(x), ptr(y), ptr(mask), ptr(gamma), ptr(beta), ptr(save[0]), ptr(save[1]),

@@ -142,7 +142,11 @@ int ccst_conv2d_igemm_tile(int M, int cout, int cin, int taps, int pool);
  * skip connection (nets/resnet.py:160-165 inside loss.backward(), fed_run.py:79).  ccst_conv2d_pointwise_ok(d) = 1 where the form exists. */
 int ccst_conv2d_pointwise_ok(const CcstConvDesc* d);
 int ccst_conv2d_igemm_accum_masked_f32(const CcstConvDesc* d, const float* x, const float* w_packed, float* y,
-                                       const uint8_t* relu_mask, void* stream);
+                                       const uint8_t* relu_mask, const float* bn_x, const float* bn_mean,
+                                       const float* bn_invstd, float* bn_partials, void* stream);
+/* bn_x .. bn_partials (all or none): the masked sum is the output gradient of a BatchNorm with input bn_x [M][cout] and saved
+ * mean / invstd; the epilogue also leaves that BatchNorm's backward partial sums (sum g, sum g*xhat) per 32 rows in
+ * bn_partials[2*ceil(M/64)][cout][2], for ccst_bn_train_bwd_partials_f32 -- one pass over (x, g) less. */
 
 /* Direct 3x3 stride-1 conv with 1..4 output channels writing NCHW (the decoder's last layer,
  * net.py:35): x NHWC [N,H,W,Cin] (Cin % 16 == 0), w [3][3][Cout][Cin], y NCHW [N,Cout,H,W].
@@ -272,6 +276,11 @@ int ccst_bn_train_bwd_mask_f32(const float* dy, const float* x, const float* y, 
                                const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                                int relu, float* dx, float* d_residual, float* dgamma, float* dbeta, int accumulate,
                                int64_t M, int C, void* ws, int64_t ws_bytes, void* stream);
+/* BatchNorm2d backward WITHOUT its reduction pass: the per-channel partial sums [groups][C][2] of (dy, dy*xhat) come from the kernel
+ * that produced dy (ccst_conv2d_igemm_accum_masked_f32); dy carries no ReLU to undo and the skip connection's share is dy itself. */
+int ccst_bn_train_bwd_partials_f32(const float* dy, const float* x, const float* gamma, const float* save_mean,
+                                   const float* save_invstd, const float* partials, int groups, float* dx, float* dgamma,
+                                   float* dbeta, int accumulate, int64_t M, int C, void* ws, int64_t ws_bytes, void* stream);
 int64_t ccst_bn_workspace_bytes(int64_t M, int C);
 
 /* MaxPool2d(kernel 3, stride 2, padding 1) nets/resnet.py:140, NHWC, C % 4 == 0.  idx[N,Ho,Wo,C/4]

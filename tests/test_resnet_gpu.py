@@ -113,10 +113,34 @@ def test_pointwise_backward_data_masked_accumulate(dev):
     ref = torch.nn.grad.conv2d_input((N, Cin, H, W), w, dy.permute(0, 3, 1, 2)).permute(0, 2, 3, 1) + base
     ref = torch.where(keep, ref, torch.zeros(()))
     acc = base.to(dev).contiguous()
-    out = nn_ops.conv_bwd_data(dy.to(dev), pct, (N, H, W, Cin), 1, 0, accumulate_into=acc, relu_mask=mask.to(dev))
+    out = nn_ops.conv_bwd_data(dy.to(dev), pct, (N, H, W, Cin), 1, 0, accumulate_into=acc, relu_mask=mask.to(dev))       # (without the BatchNorm link)
     assert out.data_ptr() == acc.data_ptr()
     assert float((out.cpu() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max()))
     assert bool((out.cpu()[~keep] == 0).all())
+    # with the BatchNorm link the same launch also leaves that BatchNorm's backward partial sums: finalize + apply from them must
+    # give the gradients of the plain backward on the masked sum
+    import ctypes
+    from ccst_amd import _lib
+    from ccst_amd._lib import check, ptr, stream_ptr
+    lib = _lib.load()
+    M, C = N * H * W, Cin
+    bx = torch.randn(N, H, W, Cin, generator=g).to(dev)
+    gam = (torch.rand(C, generator=g) + 0.5).to(dev)
+    bet = torch.zeros(C, device=dev)
+    mean, invstd = bx.reshape(-1, C).mean(0).contiguous(), (1.0 / torch.sqrt(bx.reshape(-1, C).var(0, unbiased=False) + 1e-5)).contiguous()
+    acc2 = base.to(dev).contiguous()
+    part = torch.empty((2 * ((M + 63) // 64), C, 2), device=dev)
+    out2 = nn_ops.conv_bwd_data(dy.to(dev), pct, (N, H, W, Cin), 1, 0, accumulate_into=acc2, relu_mask=mask.to(dev), bn_link=(bx, mean, invstd, part))
+    assert torch.equal(out2, out)
+    ws = torch.empty(int(lib.ccst_bn_workspace_bytes(M, C)) // 4, device=dev)
+    dx_a, dg_a, db_a = torch.empty_like(bx), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    check(lib.ccst_bn_train_bwd_partials_f32(ptr(out2), ptr(bx), ptr(gam), ptr(mean), ptr(invstd), ptr(part), int(part.shape[0]), ptr(dx_a),
+                                             ptr(dg_a), ptr(db_a), 0, M, C, ptr(ws), ws.numel() * 4, stream_ptr()), "bn bwd partials")
+    dx_b, dg_b, db_b = torch.empty_like(bx), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    check(lib.ccst_bn_train_bwd_mask_f32(ptr(out2), ptr(bx), None, None, ptr(gam), ptr(bet), ptr(mean), ptr(invstd), 0, ptr(dx_b), None,
+                                         ptr(dg_b), ptr(db_b), 0, M, C, ptr(ws), ws.numel() * 4, stream_ptr()), "bn bwd")
+    for a, b in ((dx_a, dx_b), (dg_a, dg_b), (db_a, db_b)):
+        assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
     # shapes the streaming kernel does not take are refused by the predicate (3x3, stride 2)
     assert not nn_ops.masked_accum_ok(dy.to(dev), ops.pack_conv_weight(torch.randn(Cout, Cin, 3, 3).to(dev), transpose=True), (N, H, W, Cin), 1, 1)
 
