@@ -42,6 +42,7 @@ _SIGNATURES = {
     "ccst_conv2d_igemm_stats_groups": [c_int, c_int, c_int, c_int],
     "ccst_conv2d_pointwise_ok": [POINTER(CcstConvDesc)],
     "ccst_conv2d_igemm_accum_masked_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ccst_conv2d_igemm_bn_relu_bwd_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ccst_bn_train_bwd_partials_f32": [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int64, c_int, _P, c_int64, _P],
     "ccst_conv3x3_halo_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_conv3x3_halo_narrow": [c_int, c_int, c_int, c_int],

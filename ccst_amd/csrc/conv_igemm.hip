@@ -53,6 +53,8 @@ struct ConvArgs {
     const float* bn_x;            // ... and, with it, the BatchNorm whose output gradient that sum is: its input, saved mean / invstd,
     const float* bn_mean;         //     and where to leave the per-32-row partial sums (sum g, sum g * xhat) of its backward
     const float* bn_invstd;
+    const float* bn_gamma;        //     (gamma, beta: only where the ReLU mask is recomputed from bn_x)
+    const float* bn_beta;
     float* bn_part;
 };
 
@@ -474,7 +476,8 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
 // current tile's epilogue runs, and workgroups drift out of phase.  Same 64x64x32 step as tile 1222 (one 32x32 MFMA tile per
 // wave, 16 MFMAs per step, 4 workgroups per CU).
 // ------------------------------------------------------------------------------------------------------------------------
-template <bool STATS, bool ACCUM, bool MASKED = false, bool BSTATS = false>
+// MASKED: 0 none, 1 the forward's byte mask (ACCUM), 2 recomputed from the BatchNorm's own input (bn(x) > 0; needs BSTATS)
+template <bool STATS, bool ACCUM, int MASKED = 0, bool BSTATS = false>
 __global__ __launch_bounds__(256, 4) void conv1x1_stream_kernel(const ConvArgs p, int ntiles) {
     constexpr int BM = 64, BN = 64, CK = 32, A_LD = CK + 4, PPR = CK / 4, AR = BM * PPR / 256, BR = (CK / 4) * BN / 256;
     __shared__ __attribute__((aligned(16))) float As[2][BM * A_LD];
@@ -607,7 +610,7 @@ __global__ __launch_bounds__(256, 4) void conv1x1_stream_kernel(const ConvArgs p
             for (int r = 0; r < 16; ++r)
                 acc[r] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(yrs, voff, (unsigned)(((r & 3) + 8 * (r >> 2)) * p.ysW * 4), 0));
         }
-        if (MASKED) {       // the sum is the gradient of a ReLU output: zero where the forward's byte mask (bit j of byte i <-> element 4 i + j) says so
+        if (MASKED == 1) {  // the sum is the gradient of a ReLU output: zero where the forward's byte mask (bit j of byte i <-> element 4 i + j) says so
             const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.rmask), 0, (int)((unsigned)p.M * (unsigned)(p.ysW / 4)), 0x00020000);
             const unsigned moff = voff >> 4;
             unsigned char mb[16];
@@ -616,19 +619,26 @@ __global__ __launch_bounds__(256, 4) void conv1x1_stream_kernel(const ConvArgs p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = ((mb[r] >> (li & 3)) & 1) ? acc[r] : 0.f;
         }
-        if (BSTATS) {       // the masked sum g is the output gradient of a BatchNorm: its backward's per-channel partial sums, from here
+        if (BSTATS) {       // the (masked) result g is the output gradient of a BatchNorm: its backward's per-channel partial sums, from here
             const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bn_x), 0, (int)((unsigned)p.M * (unsigned)p.ysW * 4u), 0x00020000);
             const float mu = p.bn_mean[col], is = p.bn_invstd[col];
             float xv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) xv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, voff, (unsigned)(((r & 3) + 8 * (r >> 2)) * p.ysW * 4), 0));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xv[r] = (xv[r] - mu) * is;                     // xhat
+            if (MASKED == 2) {  // that BatchNorm ends in a ReLU without a residual: its mask is bn(x) > 0, and what is stored is the masked gradient
+                const float ga = p.bn_gamma[col], be = p.bn_beta[col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = (xv[r] * ga + be > 0.f) ? acc[r] : 0.f;
+            }
             float s1 = 0.f, s2 = 0.f;
             const bool full = tm * BM + BM <= p.M;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float gq = (full || row0 + (r & 3) + 8 * (r >> 2) + 4 * lh < p.M) ? acc[r] : 0.f;
                 s1 += gq;
-                s2 += gq * ((xv[r] - mu) * is);
+                s2 += gq * xv[r];
             }
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
@@ -849,7 +859,7 @@ extern "C" int ccst_conv2d_pointwise_ok(const CcstConvDesc* d) {
 
 namespace {
 struct BnLink {
-    const float *x, *mean, *invstd;
+    const float *x, *mean, *invstd, *gamma, *beta;
     float* part;
 };
 }  // namespace
@@ -863,8 +873,18 @@ extern "C" int ccst_conv2d_igemm_accum_masked_f32(const CcstConvDesc* d, const f
     CCST_REQUIRE(ccst_conv2d_pointwise_ok(d), "conv_accum_masked: not a pointwise problem of the streaming kernel (ccst_conv2d_pointwise_ok)");
     CCST_REQUIRE((bn_x != nullptr) == (bn_partials != nullptr) && (bn_x == nullptr || (bn_mean && bn_invstd)),
                  "conv_accum_masked: the BatchNorm link needs its input, mean, invstd and the partials buffer together");
-    const BnLink bn = {bn_x, bn_mean, bn_invstd, bn_partials};
+    const BnLink bn = {bn_x, bn_mean, bn_invstd, nullptr, nullptr, bn_partials};
     return conv_igemm_impl(d, x, w_packed, nullptr, y, nullptr, stream, relu_mask, bn_x ? &bn : nullptr);
+}
+
+extern "C" int ccst_conv2d_igemm_bn_relu_bwd_f32(const CcstConvDesc* d, const float* x, const float* w_packed, float* y, const float* bn_x,
+                                                 const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                                                 float* bn_partials, void* stream) {
+    CCST_REQUIRE(d && !(d->flags & CCST_CONV_ACCUM), "conv_bn_relu_bwd: plain (non-accumulating) form");
+    CCST_REQUIRE(ccst_conv2d_pointwise_ok(d), "conv_bn_relu_bwd: not a pointwise problem of the streaming kernel (ccst_conv2d_pointwise_ok)");
+    CCST_REQUIRE(bn_x && bn_mean && bn_invstd && bn_gamma && bn_beta && bn_partials, "conv_bn_relu_bwd: null BatchNorm link");
+    const BnLink bn = {bn_x, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_partials};
+    return conv_igemm_impl(d, x, w_packed, nullptr, y, nullptr, stream, nullptr, &bn);
 }
 
 static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w_packed, const float* bias, float* y, float* stats,
@@ -904,6 +924,7 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
     a.stats = stats;
     a.rmask = relu_mask;
     a.bn_x = bn ? bn->x : nullptr; a.bn_mean = bn ? bn->mean : nullptr; a.bn_invstd = bn ? bn->invstd : nullptr; a.bn_part = bn ? bn->part : nullptr;
+    a.bn_gamma = bn ? bn->gamma : nullptr; a.bn_beta = bn ? bn->beta : nullptr;
     hipStream_t s = (hipStream_t)stream;
     if ((a.flags & CONV_DENSE_IN) && (a.flags & CONV_DENSE_OUT) && a.ysC == 1 && a.ysW == d->cout && bias == nullptr &&
         !(a.flags & CCST_CONV_RELU) && stream_shape_ok(a.M, d->cout, d->cin, 1)) {
@@ -912,14 +933,16 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
         const int grid = ntiles < 1024 ? ntiles : 1024;                        // 4 workgroups per CU, a multiple of 8 (XCD remap)
         const bool acc = (a.flags & CCST_CONV_ACCUM) != 0;
         if (relu_mask) CCST_REQUIRE(acc && !stats, "conv: the ReLU mask goes with CCST_CONV_ACCUM (the sum is masked)");
+        if (bn) CCST_REQUIRE(!stats && ((acc && relu_mask) || (!acc && bn->gamma)), "conv: BatchNorm link without its masked form");
         if (stats) hipLaunchKernelGGL((conv1x1_stream_kernel<true, false>), dim3(grid), dim3(256), 0, s, a, ntiles);
-        else if (acc && relu_mask && bn) hipLaunchKernelGGL((conv1x1_stream_kernel<false, true, true, true>), dim3(grid), dim3(256), 0, s, a, ntiles);
-        else if (acc && relu_mask) hipLaunchKernelGGL((conv1x1_stream_kernel<false, true, true>), dim3(grid), dim3(256), 0, s, a, ntiles);
+        else if (acc && relu_mask && bn) hipLaunchKernelGGL((conv1x1_stream_kernel<false, true, 1, true>), dim3(grid), dim3(256), 0, s, a, ntiles);
+        else if (acc && relu_mask) hipLaunchKernelGGL((conv1x1_stream_kernel<false, true, 1>), dim3(grid), dim3(256), 0, s, a, ntiles);
+        else if (bn) hipLaunchKernelGGL((conv1x1_stream_kernel<false, false, 2, true>), dim3(grid), dim3(256), 0, s, a, ntiles);
         else if (acc) hipLaunchKernelGGL((conv1x1_stream_kernel<false, true>), dim3(grid), dim3(256), 0, s, a, ntiles);
         else hipLaunchKernelGGL((conv1x1_stream_kernel<false, false>), dim3(grid), dim3(256), 0, s, a, ntiles);
         return ccst_launch_status("conv1x1_stream");
     }
-    CCST_REQUIRE(relu_mask == nullptr, "conv: masked accumulation is only available where ccst_conv2d_pointwise_ok() says so");
+    CCST_REQUIRE(relu_mask == nullptr && bn == nullptr, "conv: the masked / BatchNorm-linked forms exist only where ccst_conv2d_pointwise_ok() says so");
     int tile = choose_tile(a.M, d->cout, d->cin, d->nky * d->nkx, pool);
     // ccst_conv2d_igemm_stats_groups() does not see strides: a 1x1 problem it counted for the streaming kernel (32-row slabs) but
     // that is not dense (the stride-2 downsample convs) runs on the tile with the same slabs

@@ -81,7 +81,7 @@ class Conv2d(nn.Conv2d):
             return ops.pack_conv_weight(wv), kwp
         return self._cached("pks", build)
 
-    def forward(self, x, want_stats=False, sink=None):
+    def forward(self, x, want_stats=False, sink=None, sole_reader=False):
         """want_stats=True (training only): returns (y, stats) with the BatchNorm batch-statistic partials of y
         produced in the conv epilogue; pass them to the following BatchNorm2d(..., stats=stats).
         sink: nn_ops.GradSink whose content this conv's backward-data adds to (residual blocks)."""
@@ -93,7 +93,12 @@ class Conv2d(nn.Conv2d):
             return (y, None) if want_stats else y
         # x is the ReLU output of the previous block's closing BatchNorm and this conv completes x's gradient (residual sink):
         # hand its mask to the backward (nn_ops.MaskLink)
-        link = getattr(x, "_ccst_mask_link", None) if (sink is not None and not sink.pair) else None
+        link = getattr(x, "_ccst_mask_link", None)
+        if link is not None:
+            # the residual form goes with a (non-pair) sink, the BatchNorm + ReLU form with a conv that is x's only reader (no sink)
+            # (sole_reader: the caller -- a block's forward -- vouches that nothing else reads x, so x's gradient is this conv's alone)
+            ok = (link.mask is not None and sink is not None and not sink.pair) or (link.mask is None and sink is None and sole_reader)
+            link = link if ok else None
         if want_stats:
             y, stats = nn_ops.ConvFn.apply(_to_nhwc(x), self.weight, self, True, sink, link)
             return ops.to_api(y), stats
@@ -118,12 +123,12 @@ class BatchNorm2d(nn.BatchNorm2d):
         return out
 
 
-def conv_bn(conv, bn, x, residual=None, relu=False, sink_in=None, sink_out=None):
+def conv_bn(conv, bn, x, residual=None, relu=False, sink_in=None, sink_out=None, sole_reader=False):
     """bn(conv(x)) [+ residual] [ReLU]; in training the batch statistics come out of the conv epilogue.
     sink_out / sink_in: the GradSink that this BatchNorm's backward fills with the residual gradient / that this
     conv's backward-data adds to (a residual block whose identity branch is its input, see _residual_sink)."""
     if bn.training:
-        y, stats = conv(x, want_stats=True, sink=sink_in)
+        y, stats = conv(x, want_stats=True, sink=sink_in, sole_reader=sole_reader)
         return bn(y, residual=residual, relu=relu, stats=stats, sink=sink_out)
     return bn(conv(x), residual=residual, relu=relu)
 
@@ -238,7 +243,7 @@ class Bottleneck(nn.Module):
             identity = conv_bn(self.downsample[0], self.downsample[1], x, sink_in=pair)
         out = conv_bn(self.conv1, self.bn1, x, relu=True, sink_in=sink if sink is not None else pair)
         out = conv_bn(self.conv2, self.bn2, out, relu=True)
-        return conv_bn(self.conv3, self.bn3, out, residual=identity, relu=True, sink_out=sink)
+        return conv_bn(self.conv3, self.bn3, out, residual=identity, relu=True, sink_out=sink, sole_reader=True)     # out = relu(bn2(..)): read here only
 
 
 class ResNet(nn.Module):

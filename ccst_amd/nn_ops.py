@@ -175,7 +175,7 @@ def _fwd_desc(N, Hs, Ws, Cx, kh, kw, stride, pad, cin_k, cout, n_pad):
     return d, ho, wo
 
 
-def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None, relu_mask=None, bn_link=None):
+def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None, relu_mask=None, bn_link=None, bn_relu=None):
     """dX of a zero-padded conv: an implicit GEMM over dY with the transposed packed weight.
     Stride 1: one launch (iy = oy + pad - ky).  Stride s: one launch per output parity class.
     accumulate_into (stride 1 only): a tensor of x's shape that already holds another gradient contribution (the
@@ -228,6 +228,10 @@ def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None, relu_mas
             launch = lambda: check(lib.ccst_conv2d_igemm_accum_masked_f32(ctypes.byref(d), ptr(dy), ptr(pc_t.w), ptr(dx), ptr(relu_mask),
                                                                           ptr(bx), ptr(bm), ptr(bi), ptr(bp), stream_ptr()),
                                    "conv bwd-data (masked)")
+        elif bn_relu is not None:       # (bn input, mean, invstd, gamma, beta, partials out): masked by that BatchNorm's recomputed ReLU
+            assert accumulate_into is None and stride == 1
+            launch = lambda: check(lib.ccst_conv2d_igemm_bn_relu_bwd_f32(ctypes.byref(d), ptr(dy), ptr(pc_t.w), ptr(dx), *[ptr(t) for t in bn_relu],
+                                                                         stream_ptr()), "conv bwd-data (bn+relu)")
         else:
             launch = lambda: check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(dy), ptr(pc_t.w), None, ptr(dx), stream_ptr()), "conv bwd-data")
         if ops.TIMING is None:
@@ -267,10 +271,13 @@ class MaskLink(object):
     registers.  It then sets `premasked`, and the BatchNorm's backward takes its incoming gradient as already masked: no mask
     reads in its two passes and its skip-connection share IS the incoming tensor (no masked copy: 1.06 GB of writes per ResNet50
     step)."""
-    __slots__ = ("mask", "premasked", "bn_x", "bn_save", "partials")
+    __slots__ = ("mask", "premasked", "bn_x", "bn_save", "partials", "gamma", "beta")
 
-    def __init__(self, mask, bn_x=None, bn_save=None):
+    def __init__(self, mask, bn_x=None, bn_save=None, gamma=None, beta=None):
         self.mask, self.premasked = mask, False
+        # mask is None + (gamma, beta): the BatchNorm + ReLU WITHOUT a residual in front of a pointwise conv (bn2 -> conv3): that conv's
+        # backward-data epilogue recomputes the mask from the BatchNorm's own input, stores the masked gradient and the partial sums
+        self.gamma, self.beta = gamma, beta
         # the BatchNorm's input and saved (mean, invstd): with them that epilogue also leaves the BatchNorm backward's per-channel
         # partial sums (it has the masked gradient in registers and reads x at the same addresses), in `partials`
         self.bn_x, self.bn_save, self.partials = bn_x, bn_save, None
@@ -369,13 +376,19 @@ class ConvFn(torch.autograd.Function):
                 if link is not None and into is not None and not ctx.sink.pair and link.mask is not None and \
                         masked_accum_ok(dy, mod.packed_t(), tuple(x.shape), stride, pad):
                     mask = link.mask
-                bn_link = None
+                bn_link = bn_relu = None
+                M = N * H * W
                 if mask is not None and MASK_LINK_STATS and link.bn_x is not None:
-                    M = N * H * W
                     link.partials = torch.empty((2 * ((M + 63) // 64), Cin, 2), device=x.device, dtype=torch.float32)
                     bn_link = (link.bn_x, link.bn_save[0], link.bn_save[1], link.partials)
-                dx = conv_bwd_data(dy, mod.packed_t(), tuple(x.shape), stride, pad, accumulate_into=into, relu_mask=mask, bn_link=bn_link)
-                if mask is not None:
+                # x is the output of a BatchNorm + ReLU that only this conv reads (bn2 -> conv3): mask and partial sums from here
+                if link is not None and link.mask is None and link.gamma is not None and into is None and ctx.sink is None and \
+                        MASK_LINK_STATS and masked_accum_ok(dy, mod.packed_t(), tuple(x.shape), stride, pad):
+                    link.partials = torch.empty((2 * ((M + 63) // 64), Cin, 2), device=x.device, dtype=torch.float32)
+                    bn_relu = (link.bn_x, link.bn_save[0], link.bn_save[1], link.gamma, link.beta, link.partials)
+                dx = conv_bwd_data(dy, mod.packed_t(), tuple(x.shape), stride, pad, accumulate_into=into, relu_mask=mask, bn_link=bn_link,
+                                   bn_relu=bn_relu)
+                if mask is not None or bn_relu is not None:
                     link.premasked = True
             if deposit:
                 ctx.sink.grad, dx = dx, None
@@ -464,7 +477,12 @@ class BNFn(torch.autograd.Function):
                   "bn_train_fwd")
             keep_y = ctx.relu and mask is None and (ctx.has_res or BN_MASK_FROM_Y)
             ctx.save_for_backward(x, y if keep_y else None, mask, gamma, beta, save)
-            ctx.link = mod._ccst_mask_link = MaskLink(mask, x, save) if (mask is not None and MASK_LINK) else None
+            if mask is not None and MASK_LINK:
+                ctx.link = mod._ccst_mask_link = MaskLink(mask, x, save)
+            elif ctx.relu and not ctx.has_res and MASK_LINK and not BN_MASK_FROM_Y:
+                ctx.link = mod._ccst_mask_link = MaskLink(None, x, save, gamma, beta)
+            else:
+                ctx.link = mod._ccst_mask_link = None
         else:
             check(lib.ccst_bn_eval_fwd_f32(ptr(x), ptr(gamma), ptr(beta), ptr(mod.running_mean), ptr(mod.running_var),
                                            float(mod.eps), ptr(residual), int(relu), ptr(y), M, C, stream_ptr()), "bn_eval_fwd")

@@ -144,6 +144,12 @@ int ccst_conv2d_pointwise_ok(const CcstConvDesc* d);
 int ccst_conv2d_igemm_accum_masked_f32(const CcstConvDesc* d, const float* x, const float* w_packed, float* y,
                                        const uint8_t* relu_mask, const float* bn_x, const float* bn_mean,
                                        const float* bn_invstd, float* bn_partials, void* stream);
+/* The same idea for a BatchNorm + ReLU WITHOUT a residual (bn2 -> conv3 of a bottleneck): y = (bn(bn_x) > 0) ? conv(x) : 0, i.e. the
+ * backward-data result masked by the ReLU of the BatchNorm whose output gradient it is (mask recomputed from that BatchNorm's own
+ * input), plus the partial sums for ccst_bn_train_bwd_partials_f32. */
+int ccst_conv2d_igemm_bn_relu_bwd_f32(const CcstConvDesc* d, const float* x, const float* w_packed, float* y, const float* bn_x,
+                                      const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                                      float* bn_partials, void* stream);
 /* bn_x .. bn_partials (all or none): the masked sum is the output gradient of a BatchNorm with input bn_x [M][cout] and saved
  * mean / invstd; the epilogue also leaves that BatchNorm's backward partial sums (sum g, sum g*xhat) per 32 rows in
  * bn_partials[2*ceil(M/64)][cout][2], for ccst_bn_train_bwd_partials_f32 -- one pass over (x, g) less. */
