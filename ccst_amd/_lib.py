@@ -43,6 +43,9 @@ _SIGNATURES = {
     "ccst_conv2d_pointwise_ok": [POINTER(CcstConvDesc)],
     "ccst_conv2d_igemm_accum_masked_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ccst_conv2d_igemm_bn_relu_bwd_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ccst_bn_relu_maxpool_train_fwd_f32": [_P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P,
+                                           c_int64, _P],
+    "ccst_bn_relu_maxpool_train_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P],
     "ccst_bn_train_bwd_partials_f32": [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int64, c_int, _P, c_int64, _P],
     "ccst_conv3x3_halo_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_conv3x3_halo_narrow": [c_int, c_int, c_int, c_int],

@@ -283,6 +283,153 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------
+// The stem's BatchNorm -> ReLU -> MaxPool2d(3, 2, 1) (nets/resnet.py:138-140) without the full-resolution tensors in between (64 x 111 x
+// 111 x 64 floats = 201 MB each at B = 64): the forward pools relu(x * scale + shift) straight from the conv output (no normalised
+// tensor is written or read back), the backward's two passes gather the pooled gradient through the saved window positions on the
+// fly (no full-resolution gradient is written by a pooling backward and read twice).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void bn_relu_maxpool_fwd_kernel(const f32x4* __restrict__ x, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, f32x4* __restrict__ y,
+                                                                  unsigned* __restrict__ idx, int N, int H, int W, int C4, int Ho, int Wo) {
+    const long long total = (long long)N * Ho * Wo * C4;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+        const int c = (int)(i % C4);
+        long long j = i / C4;
+        const int ox = (int)(j % Wo);
+        j /= Wo;
+        const int oy = (int)(j % Ho);
+        const int n = (int)(j / Ho);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c * 4), sh = *reinterpret_cast<const f32x4*>(shift + c * 4);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        unsigned bi[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy - 1 + ky;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox - 1 + kx;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                    f32x4 v = x[(((long long)n * H + iy) * W + ix) * C4 + c];
+                    v = v * sc + sh;                                  // as bn_apply_kernel
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        v[k] = fmaxf(v[k], 0.f);
+                        if (v[k] > best[k] || (v[k] != v[k])) {       // first maximum wins; NaN propagates like torch
+                            best[k] = v[k];
+                            bi[k] = ky * 3 + kx;
+                        }
+                    }
+                }
+            }
+        }
+        y[i] = best;
+        idx[i] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+    }
+}
+
+// gradient of the pooling INPUT pixel (n, iy, ix), channel group c, gathered from the pooled gradient (as maxpool3s2_bwd_kernel)
+__device__ __forceinline__ f32x4 pool_grad_at(const f32x4* __restrict__ dy, const unsigned* __restrict__ idx, int n, int iy, int ix, int c,
+                                              int C4, int Ho, int Wo) {
+    f32x4 g = {0, 0, 0, 0};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int ty = iy + 1 - ky;
+        if (ty < 0 || (ty & 1)) continue;
+        const int oy = ty >> 1;
+        if (oy >= Ho) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int tx = ix + 1 - kx;
+            if (tx < 0 || (tx & 1)) continue;
+            const int ox = tx >> 1;
+            if (ox >= Wo) continue;
+            const long long o = (((long long)n * Ho + oy) * Wo + ox) * C4 + c;
+            const unsigned id = idx[o];
+            const f32x4 d = dy[o];
+            const unsigned me = ky * 3 + kx;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (((id >> (8 * k)) & 0xffu) == me) g[k] += d[k];
+        }
+    }
+    return g;
+}
+
+// BN-backward partial sums with dy = ReLU-masked pooled gradient gathered on the fly; layout / reduction as chan_partials_kernel
+__global__ __launch_bounds__(TPB) void stem_bwd_partials_kernel(const float* __restrict__ x, const f32x4* __restrict__ dyp,
+                                                                const unsigned* __restrict__ idx, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ part, long long M, int C,
+                                                                int S, int cgb, int PL, int H, int W, int Ho, int Wo) {
+    __shared__ f32x4 red[2][TPB];
+    const int split = blockIdx.x, t = threadIdx.x;
+    const int cgl = t % cgb, pl = t / cgb;
+    const int cg = blockIdx.y * cgb + cgl;
+    const long long per = (M + S - 1) / S;
+    const long long r0 = split * per;
+    const long long r1 = (r0 + per < M) ? r0 + per : M;
+    f32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+    if (pl < PL && cg * 4 < C) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cg * 4), is = *reinterpret_cast<const f32x4*>(invstd + cg * 4);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + cg * 4), be = *reinterpret_cast<const f32x4*>(beta + cg * 4);
+        for (long long r = r0 + pl; r < r1; r += PL) {
+            const int ix = (int)(r % W);
+            const long long q = r / W;
+            const int iy = (int)(q % H), n = (int)(q / H);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + cg * 4);
+            f32x4 g = pool_grad_at(dyp, idx, n, iy, ix, cg, C / 4, Ho, Wo);
+            const f32x4 xh = (v - mu) * is;
+            const f32x4 o = xh * ga + be;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
+            a += g;
+            b += g * xh;
+        }
+    }
+    red[0][t] = a;
+    red[1][t] = b;
+    __syncthreads();
+    if (pl == 0 && cg * 4 < C) {
+        for (int k = 1; k < PL; ++k) {
+            a += red[0][t + k * cgb];
+            b += red[1][t + k * cgb];
+        }
+        float* o = part + ((long long)split * C + cg * 4) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[2 * j] = a[j];
+            o[2 * j + 1] = b[j];
+        }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void stem_bwd_apply_kernel(const float* __restrict__ x, const f32x4* __restrict__ dyp,
+                                                             const unsigned* __restrict__ idx, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, const float* __restrict__ sums,
+                                                             float* __restrict__ dx, long long total4, int C, float invM, int H, int W, int Ho,
+                                                             int Wo) {
+    const int cg = C / 4;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total4; i += (long long)gridDim.x * TPB) {
+        const int cq = (int)(i % cg), c = cq * 4;
+        const long long r = i / cg;
+        const int ix = (int)(r % W);
+        const long long q = r / W;
+        const int iy = (int)(q % H), n = (int)(q / H);
+        f32x4 g = pool_grad_at(dyp, idx, n, iy, ix, cq, cg, Ho, Wo);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 xh = (v - mu) * is;
+        const f32x4 o = xh * ga + *reinterpret_cast<const f32x4*>(beta + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + c), s2 = *reinterpret_cast<const f32x4*>(sums + C + c);
+        *reinterpret_cast<f32x4*>(dx + i * 4) = ga * is * (g - s1 * invM - xh * (s2 * invM));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // MaxPool2d(3, stride 2, padding 1), NHWC.  idx = position (0..8) of the first maximum in the window.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void maxpool3s2_fwd_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y,
@@ -660,6 +807,73 @@ extern "C" int ccst_bn_train_bwd_f32(const float* dy, const float* x, const floa
                                      void* stream) {
     return ccst_bn_train_bwd_mask_f32(dy, x, y, nullptr, gamma, beta, save_mean, save_invstd, relu, dx, d_residual, dgamma, dbeta, accumulate,
                                       M, C, ws, ws_bytes, stream);
+}
+
+extern "C" int ccst_bn_relu_maxpool_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
+                                                  float* running_var, float momentum, float eps, float* y_pooled, uint32_t* idx,
+                                                  float* save_mean, float* save_invstd, int N, int H, int W, int C, int Ho, int Wo,
+                                                  const float* stats_in, int stats_groups, void* ws, int64_t ws_bytes, void* stream) {
+    CCST_REQUIRE(x && gamma && beta && y_pooled && idx && save_mean && save_invstd && ws, "bn_relu_maxpool_fwd: null pointer");
+    CCST_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "bn_relu_maxpool_fwd: bad extents");
+    CCST_REQUIRE(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, "bn_relu_maxpool_fwd: Ho/Wo must be floor((H+2-3)/2)+1");
+    CCST_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_relu_maxpool_fwd: running stats must come together");
+    const int64_t M = (int64_t)N * H * W;
+    if (ws_bytes < ccst_bn_workspace_bytes(M, C)) {
+        ccst_set_error("bn_relu_maxpool_fwd: workspace too small");
+        return CCST_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const Split sp = pick_split(M, C);
+    float* part = (float*)ws;
+    float* scale = part + (int64_t)MAXS * C * 2;
+    float* shift = scale + C;
+    const float* fin = part;
+    int S = sp.S;
+    if (stats_in != nullptr) {
+        CCST_REQUIRE(stats_groups > 0, "bn_relu_maxpool_fwd: stats_groups must be positive");
+        fin = stats_in;
+        S = stats_groups;
+    } else {
+        hipLaunchKernelGGL(chan_partials_kernel<0>, dim3(sp.S, sp.gy), dim3(TPB), 0, st, x, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, 0, part, (long long)M, C, sp.S, sp.cgb, sp.PL, nullptr);
+    }
+    if (S > 512)
+        hipLaunchKernelGGL(bn_fwd_finalize_kernel<4>, dim3((C + 3) / 4), dim3(256), 0, st, fin, gamma, beta, running_mean, running_var,
+                           momentum, eps, save_mean, save_invstd, scale, shift, (long long)M, C, S);
+    else
+        hipLaunchKernelGGL(bn_fwd_finalize_kernel<16>, dim3((C + 15) / 16), dim3(256), 0, st, fin, gamma, beta, running_mean,
+                           running_var, momentum, eps, save_mean, save_invstd, scale, shift, (long long)M, C, S);
+    const long long total = (long long)N * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, (const f32x4*)x, scale, shift, (f32x4*)y_pooled, idx,
+                       N, H, W, C / 4, Ho, Wo);
+    return ccst_launch_status("bn_relu_maxpool_fwd");
+}
+
+extern "C" int ccst_bn_relu_maxpool_train_bwd_f32(const float* dy_pooled, const uint32_t* idx, const float* x, const float* gamma,
+                                                  const float* beta, const float* save_mean, const float* save_invstd, float* dx,
+                                                  float* dgamma, float* dbeta, int accumulate, int N, int H, int W, int C, int Ho, int Wo,
+                                                  void* ws, int64_t ws_bytes, void* stream) {
+    CCST_REQUIRE(dy_pooled && idx && x && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta && ws, "bn_relu_maxpool_bwd: null pointer");
+    CCST_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, "bn_relu_maxpool_bwd: bad extents");
+    const int64_t M = (int64_t)N * H * W;
+    if (ws_bytes < ccst_bn_workspace_bytes(M, C)) {
+        ccst_set_error("bn_relu_maxpool_bwd: workspace too small");
+        return CCST_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const Split sp = pick_split(M, C);
+    float* part = (float*)ws;
+    float* sums = part + (int64_t)MAXS * C * 2;
+    hipLaunchKernelGGL(stem_bwd_partials_kernel, dim3(sp.S, sp.gy), dim3(TPB), 0, st, x, (const f32x4*)dy_pooled, idx, save_mean, save_invstd,
+                       gamma, beta, part, (long long)M, C, sp.S, sp.cgb, sp.PL, H, W, Ho, Wo);
+    if (sp.S > 512)
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3((C + 3) / 4), dim3(256), 0, st, part, dgamma, dbeta, sums, C, sp.S, accumulate);
+    else
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<16>, dim3((C + 15) / 16), dim3(256), 0, st, part, dgamma, dbeta, sums, C, sp.S, accumulate);
+    const long long total4 = (long long)M * (C / 4);
+    hipLaunchKernelGGL(stem_bwd_apply_kernel, dim3(grid_for(total4)), dim3(TPB), 0, st, x, (const f32x4*)dy_pooled, idx, gamma, beta, save_mean,
+                       save_invstd, sums, dx, total4, C, 1.f / (float)M, H, W, Ho, Wo);
+    return ccst_launch_status("bn_relu_maxpool_bwd");
 }
 
 extern "C" int ccst_maxpool3s2_fwd_f32(const float* x, float* y, uint32_t* idx, int N, int H, int W, int C, int Ho, int Wo,

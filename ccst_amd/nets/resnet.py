@@ -134,6 +134,7 @@ def conv_bn(conv, bn, x, residual=None, relu=False, sink_in=None, sink_out=None,
 
 
 USE_GRAD_SINK = os.environ.get("CCST_GRAD_SINK", "1") != "0"
+FUSED_STEM = os.environ.get("CCST_FUSED_STEM", "1") != "0"      # bn1 + relu + maxpool of the stem as one op in training
 
 
 def _pair_sink(block, x):
@@ -304,8 +305,7 @@ class ResNet(nn.Module):
     def forward(self, x, **kwargs):
         if self.training:
             self._bump_counters()
-        x = conv_bn(self.conv1, self.bn1, x, relu=True)
-        x = self.maxpool(x)
+        x = self._stem(x)
         x = self.layer1(x)
         x = self.layer2(x)
         x = self.layer3(x)
@@ -313,6 +313,16 @@ class ResNet(nn.Module):
         x = self.avgpool(x)
         x = x.view(x.size(0), -1)
         return self.class_classifier(x)
+
+    def _stem(self, x):
+        """conv1 -> bn1 -> relu -> maxpool (nets/resnet.py:136-140).  In training the last three are one op that never stores the
+        normalised 111 x 111 map or its gradient (nn_ops.StemBnReluPoolFn)."""
+        bn, mp = self.bn1, self.maxpool
+        if FUSED_STEM and bn.training and torch.is_grad_enabled() and isinstance(bn, BatchNorm2d) and isinstance(mp, MaxPool2d) and bn.affine \
+                and (mp.kernel_size, mp.stride, mp.padding, mp.ceil_mode) == (3, 2, 1, False):
+            y, stats = self.conv1(x, want_stats=True)
+            return ops.to_api(nn_ops.StemBnReluPoolFn.apply(_to_nhwc(y), bn.weight, bn.bias, bn, stats))
+        return mp(conv_bn(self.conv1, bn, x, relu=True))
 
     def _apply(self, fn, *a, **k):
         self.__dict__.pop("_ccst_nbt", None)

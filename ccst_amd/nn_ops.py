@@ -526,6 +526,43 @@ class BNFn(torch.autograd.Function):
         return dx, None, None, dres, None, None, None, None
 
 
+class StemBnReluPoolFn(torch.autograd.Function):
+    """BatchNorm2d (training) -> ReLU -> MaxPool2d(3, 2, 1) of the ResNet stem (nets/resnet.py:138-140) as one op: neither the
+    normalised full-resolution map nor its gradient is ever stored (see ccst_bn_relu_maxpool_train_fwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mod, stats=None):
+        lib = _lib.load()
+        N, H, W, C = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        M = N * H * W
+        y = torch.empty((N, Ho, Wo, C), device=x.device, dtype=torch.float32)
+        idx = torch.empty((N, Ho, Wo, C // 4), device=x.device, dtype=torch.int32)
+        save = torch.empty((2, C), device=x.device, dtype=torch.float32)
+        ws = _workspace(int(lib.ccst_bn_workspace_bytes(M, C)), x.device)
+        track = mod.track_running_stats and mod.running_mean is not None
+        check(lib.ccst_bn_relu_maxpool_train_fwd_f32(ptr(x), ptr(gamma), ptr(beta), ptr(mod.running_mean if track else None),
+                                                     ptr(mod.running_var if track else None), float(mod.momentum), float(mod.eps), ptr(y), ptr(idx),
+                                                     ptr(save[0]), ptr(save[1]), N, H, W, C, Ho, Wo, ptr(stats),
+                                                     0 if stats is None else int(stats.shape[0]), ptr(ws), ws.numel(), stream_ptr()),
+              "bn_relu_maxpool_fwd")
+        ctx.save_for_backward(x, idx, gamma, beta, save)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, idx, gamma, beta, save = ctx.saved_tensors
+        lib = _lib.load()
+        N, H, W, C = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        dx = torch.empty_like(x)
+        ws = _workspace(int(lib.ccst_bn_workspace_bytes(N * H * W, C)), x.device)
+        check(lib.ccst_bn_relu_maxpool_train_bwd_f32(ptr(dy.contiguous()), ptr(idx), ptr(x), ptr(gamma), ptr(beta), ptr(save[0]), ptr(save[1]),
+                                                     ptr(dx), ptr(_grad_slot(gamma)), ptr(_grad_slot(beta)), 1, N, H, W, C, Ho, Wo, ptr(ws),
+                                                     ws.numel(), stream_ptr()), "bn_relu_maxpool_bwd")
+        return dx, None, None, None, None
+
+
 # ---------------------------------------------------------------------------
 # pools, linear, loss
 # ---------------------------------------------------------------------------

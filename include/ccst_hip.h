@@ -289,6 +289,19 @@ int ccst_bn_train_bwd_partials_f32(const float* dy, const float* x, const float*
                                    float* dbeta, int accumulate, int64_t M, int C, void* ws, int64_t ws_bytes, void* stream);
 int64_t ccst_bn_workspace_bytes(int64_t M, int C);
 
+/* BatchNorm2d (training) -> ReLU -> MaxPool2d(3, 2, 1), the ResNet stem (nets/resnet.py:138-140), without the full-resolution tensors in
+ * between: the forward pools relu(bn(x)) straight from the conv output x [N,H,W,C] into y_pooled [N,Ho,Wo,C] + idx (as
+ * ccst_maxpool3s2_fwd_f32); the backward takes the pooled gradient and gathers it through idx inside both BatchNorm-backward passes
+ * (ReLU mask recomputed from x).  Same statistics / running-stat semantics as ccst_bn_train_fwd_f32. */
+int ccst_bn_relu_maxpool_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
+                                       float* running_var, float momentum, float eps, float* y_pooled, uint32_t* idx,
+                                       float* save_mean, float* save_invstd, int N, int H, int W, int C, int Ho, int Wo,
+                                       const float* stats_in, int stats_groups, void* ws, int64_t ws_bytes, void* stream);
+int ccst_bn_relu_maxpool_train_bwd_f32(const float* dy_pooled, const uint32_t* idx, const float* x, const float* gamma,
+                                       const float* beta, const float* save_mean, const float* save_invstd, float* dx,
+                                       float* dgamma, float* dbeta, int accumulate, int N, int H, int W, int C, int Ho, int Wo,
+                                       void* ws, int64_t ws_bytes, void* stream);
+
 /* MaxPool2d(kernel 3, stride 2, padding 1) nets/resnet.py:140, NHWC, C % 4 == 0.  idx[N,Ho,Wo,C/4]
  * packs, per channel, the window position (0..8) of the first maximum (one byte each); backward
  * gathers through it (deterministic, no atomics). */

@@ -218,6 +218,25 @@ def test_batchnorm_fwd_bwd(dev, relu, res, bytemask, monkeypatch):
         assert relerr(bn(x.to(dev), relu=relu), F.relu(ref(x)) if relu else ref(x)) < 1e-5
 
 
+def test_fused_stem_bn_relu_maxpool(dev, monkeypatch):
+    """The stem's bn1 -> relu -> maxpool as one op (no full-resolution normalised map, pooled gradient gathered inside both
+    BatchNorm-backward passes) against the three separate ops: same output, same gradients, same running statistics."""
+    from ccst_amd.nets import resnet
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(resnet, "FUSED_STEM", fused)
+        torch.manual_seed(3)
+        m = resnet.resnet18(types.SimpleNamespace(), pretrained=False, classes=7).to(dev).train()
+        x = rnd((3, 3, 45, 39), 21).to(dev)
+        y = m._stem(x)
+        g = rnd(tuple(y.shape), 22).to(dev)
+        y.backward(g)
+        res[fused] = (y.detach().clone(), m.conv1.weight.grad.clone(), m.bn1.weight.grad.clone(), m.bn1.bias.grad.clone(),
+                      m.bn1.running_mean.clone(), m.bn1.running_var.clone())
+    for a, b in zip(res[True], res[False]):
+        assert relerr(a, b) < 1e-6
+
+
 def test_pools_linear_ce(dev):
     from ccst_amd import fed
     from ccst_amd.nets import resnet
