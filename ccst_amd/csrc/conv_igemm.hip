@@ -488,23 +488,42 @@ __global__ __launch_bounds__(256, 4) void conv1x1_stream_kernel(const ConvArgs p
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
     const int T = p.Cin / CK;                                                   // k-steps per tile
-    const int mine = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // tiles of this workgroup (>= 1)
+    // Tiles of this workgroup: ONE column tile tn (the grid is a multiple of the column-tile count) and every strideM-th row tile
+    // from tm0 on.  The workgroups an XCD runs side by side (consecutive ids after the remap) are the column tiles of the same few
+    // row tiles, so they share A rows through its L2; and because tn never changes, the per-channel statistics of all of a
+    // workgroup's tiles add up in registers: 2 * grid / tilesN partial slabs for the BatchNorm finalize instead of one per 32 rows
+    // (6272 for the 56x56 layers at B = 64 -- the finalize kernels read 12.8 MB of partials there).
+    // (Row classes are dealt to the XCDs in turn -- hardware XCD = blockIdx % 8 -- so that the classes that own one tile more than
+    //  the others do not pile up on the first XCDs; the column tiles of a class stay on one XCD.)
+    int wg;
+    if ((int)gridDim.x % (8 * p.tilesN) == 0) {
+        const int xcd = (int)blockIdx.x & 7, k = (int)blockIdx.x >> 3;
+        wg = ((k / p.tilesN) * 8 + xcd) * p.tilesN + k % p.tilesN;
+    } else {
+        wg = ccst_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    }
+    const int tnW = wg % p.tilesN, tm0 = wg / p.tilesN, strideM = (int)gridDim.x / p.tilesN, tilesM = ntiles / p.tilesN;
+    const int mine = (tilesM - tm0 + strideM - 1) / strideM;                    // >= 1: the grid never exceeds the tile count
     const int G = mine * T;                                                     // k-steps of this workgroup
-    // i-th tile of this workgroup: sequence position blockIdx + i * grid (same XCD every time: the grid is a multiple of 8 or
-    // covers every tile once), XCD-contiguous; column tile fastest, so the workgroups of an XCD share A rows through its L2
-    auto tile_of = [&](int i) { return ccst_xcd_remap((int)blockIdx.x + i * (int)gridDim.x, ntiles); };
 
     // ---- loader state (runs up to two k-steps = possibly one tile ahead of the MFMAs) ----
     const int part = tid % PPR;
     unsigned aBase[AR], bBase[BR];
     int lt = 0, lc = 0;                                                         // loader's tile index / chunk
     auto loader_tile = [&](int i) {
-        const int t = tile_of(i);
-        const int tn = t % p.tilesN, tm = t / p.tilesN;
+        const int tn = tnW, tm = tm0 + i * strideM;
 #pragma unroll
         for (int a = 0; a < AR; ++a) {
             const int m = min(tm * BM + tid / PPR + (256 / PPR) * a, p.M - 1);
-            aBase[a] = (unsigned)(m * p.xsW + part * 4);
+            if (p.flags & CONV_DENSE_IN) {
+                aBase[a] = (unsigned)(m * p.xsW + part * 4);
+            } else {            // strided pointwise conv (the downsample branches): pixel (n, oy * ay, ox * ax), always inside the input
+                const int n = fdiv(m, p.Ho * p.Wo, p.invHW, p.fastdiv);
+                const int rem = m - n * (p.Ho * p.Wo);
+                const int oy = fdiv(rem, p.Wo, p.invWo, p.fastdiv);
+                const int ox = rem - oy * p.Wo;
+                aBase[a] = (unsigned)(n * (int)p.xsN + oy * p.ay * p.xsH + ox * p.ax * p.xsW + part * 4);
+            }
         }
 #pragma unroll
         for (int b = 0; b < BR; ++b) {
@@ -574,12 +593,13 @@ __global__ __launch_bounds__(256, 4) void conv1x1_stream_kernel(const ConvArgs p
     // output (rows beyond M are beyond its size: the hardware drops those stores and answers those loads with zeros) ----
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y + p.y_off, 0, (int)((unsigned)p.M * (unsigned)p.ysW * 4u), 0x00020000);
     int ct = 0, ci = 0;                                                         // compute side: chunk in tile, tile index
+    float rs1 = 0.f, rs2 = 0.f;                                                 // running per-channel sums over this workgroup's tiles
+    const int col = tnW * BN + wn * 32 + li;
     auto finish_tile = [&]() {
         if (++ct < T) return;
         ct = 0;
-        const int t = tile_of(ci++);
-        const int tn = t % p.tilesN, tm = t / p.tilesN;
-        const int row0 = tm * BM + wm * 32, col = tn * BN + wn * 32 + li;
+        const int tm = tm0 + (ci++) * strideM;
+        const int row0 = tm * BM + wm * 32;
         if (STATS) {
             float s1 = 0.f, s2 = 0.f;
             if (tm * BM + BM <= p.M) {
@@ -596,13 +616,8 @@ __global__ __launch_bounds__(256, 4) void conv1x1_stream_kernel(const ConvArgs p
                     s2 += v * v;
                 }
             }
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (lh == 0) {
-                float* o = p.stats + ((long long)(tm * 2 + wm) * p.Cout + col) * 2;
-                o[0] = s1;
-                o[1] = s2;
-            }
+            rs1 += s1;
+            rs2 += s2;
         }
         const unsigned voff = (unsigned)(((row0 + 4 * lh) * p.ysW + col) * 4);
         if (ACCUM) {
@@ -640,13 +655,8 @@ __global__ __launch_bounds__(256, 4) void conv1x1_stream_kernel(const ConvArgs p
                 s1 += gq;
                 s2 += gq * xv[r];
             }
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (lh == 0) {
-                float* o = p.bn_part + ((long long)(tm * 2 + wm) * p.Cout + col) * 2;
-                o[0] = s1;
-                o[1] = s2;
-            }
+            rs1 += s1;
+            rs2 += s2;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -677,6 +687,15 @@ __global__ __launch_bounds__(256, 4) void conv1x1_stream_kernel(const ConvArgs p
     }
     step((G - 1) & 1, No{}, No{});
     finish_tile();
+    if (STATS || BSTATS) {      // one slab per (row-tile class, wave row): [2 * strideM][Cout][2]
+        rs1 += __shfl_xor(rs1, 32, 64);
+        rs2 += __shfl_xor(rs2, 32, 64);
+        if (lh == 0) {
+            float* o = (STATS ? p.stats : p.bn_part) + ((long long)(tm0 * 2 + wm) * p.Cout + col) * 2;
+            o[0] = rs1;
+            o[1] = rs2;
+        }
+    }
 }
 
 // OIHW -> packed [tap][K/4][n_pad][4]
@@ -817,6 +836,12 @@ static int choose_tile(int M, int cout, int cin, int taps, bool pool) {
 
 // The persistent pointwise kernel (conv1x1_stream_kernel) takes every 1x1 stride-1 convolution between dense NHWC tensors whose
 // channel counts fit its 64x64x32 step.  CCST_CONV_STREAM=0 keeps them on the per-tile kernel (A/B).
+// Workgroups of the streaming kernel for a problem: at most 4 per CU, a multiple of the column-tile count, never more than tiles.
+static int stream_grid(int M, int cout) {
+    const int tilesN = cout / 64, ntiles = ((M + 63) / 64) * tilesN;
+    const int cap = (1024 / tilesN) * tilesN;
+    return ntiles < cap ? ntiles : (cap > 0 ? cap : tilesN);
+}
 static bool stream_shape_ok(int M, int cout, int cin, int taps) {
     static const bool on = [] { const char* e = getenv("CCST_CONV_STREAM"); return !(e && atoi(e) == 0); }();
     return on && taps == 1 && cin % 32 == 0 && cout % 64 == 0 && M >= 64 && (long long)M * cout * 4 < 0xffffffffLL;
@@ -827,7 +852,7 @@ extern "C" int ccst_conv2d_igemm_tile(int M, int cout, int cin, int taps, int po
 
 // Row groups of 64 output rows that ccst_conv2d_igemm_stats_f32 writes for a problem of M rows and cout columns.
 extern "C" int ccst_conv2d_igemm_stats_groups(int M, int cout, int cin, int taps) {
-    if (stream_shape_ok(M, cout, cin, taps)) return ((M + 63) / 64) * 2;        // one slab per 32 rows (a wave row of a 64-row tile)
+    if (stream_shape_ok(M, cout, cin, taps)) return 2 * stream_grid(M, cout) / (cout / 64);      // see conv1x1_stream_kernel: per (row-tile class, wave row)
     const int tile = choose_tile(M, cout, cin, taps, false);
     const int WM = (tile / 100) % 10, BM = (tile >= 1000 ? 32 : 64) * WM;      // one slab per wave row
     return ((M + BM - 1) / BM) * WM;
@@ -926,11 +951,15 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
     a.bn_x = bn ? bn->x : nullptr; a.bn_mean = bn ? bn->mean : nullptr; a.bn_invstd = bn ? bn->invstd : nullptr; a.bn_part = bn ? bn->part : nullptr;
     a.bn_gamma = bn ? bn->gamma : nullptr; a.bn_beta = bn ? bn->beta : nullptr;
     hipStream_t s = (hipStream_t)stream;
-    if ((a.flags & CONV_DENSE_IN) && (a.flags & CONV_DENSE_OUT) && a.ysC == 1 && a.ysW == d->cout && bias == nullptr &&
-        !(a.flags & CCST_CONV_RELU) && stream_shape_ok(a.M, d->cout, d->cin, 1)) {
+    // pointwise input: dense, or a strided 1x1 without padding (the downsample branches: pixel (oy*ay, ox*ax) is always inside)
+    const bool pw_in = (a.flags & CONV_DENSE_IN) ||
+                       (d->nky == 1 && d->nkx == 1 && d->cy == 0 && d->cx == 0 && d->ay >= 1 && d->ax >= 1 && !(d->flags & (CCST_CONV_UPS2 | CCST_CONV_REFLECT)) &&
+                        (long long)(d->ho - 1) * d->ay < d->hi && (long long)(d->wo - 1) * d->ax < d->wi);
+    if (pw_in && (a.flags & CONV_DENSE_OUT) && a.ysC == 1 && a.ysW == d->cout && bias == nullptr && !pool &&
+        !(a.flags & CCST_CONV_RELU) && stream_shape_ok(a.M, d->cout, d->cin, d->nky * d->nkx)) {
         a.tilesN = d->cout / 64;
         const int ntiles = ((a.M + 63) / 64) * a.tilesN;
-        const int grid = ntiles < 1024 ? ntiles : 1024;                        // 4 workgroups per CU, a multiple of 8 (XCD remap)
+        const int grid = stream_grid(a.M, d->cout);                            // <= 4 workgroups per CU, a multiple of the column-tile count
         const bool acc = (a.flags & CCST_CONV_ACCUM) != 0;
         if (relu_mask) CCST_REQUIRE(acc && !stats, "conv: the ReLU mask goes with CCST_CONV_ACCUM (the sum is masked)");
         if (bn) CCST_REQUIRE(!stats && ((acc && relu_mask) || (!acc && bn->gamma)), "conv: BatchNorm link without its masked form");
@@ -943,10 +972,10 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
         return ccst_launch_status("conv1x1_stream");
     }
     CCST_REQUIRE(relu_mask == nullptr && bn == nullptr, "conv: the masked / BatchNorm-linked forms exist only where ccst_conv2d_pointwise_ok() says so");
-    int tile = choose_tile(a.M, d->cout, d->cin, d->nky * d->nkx, pool);
-    // ccst_conv2d_igemm_stats_groups() does not see strides: a 1x1 problem it counted for the streaming kernel (32-row slabs) but
-    // that is not dense (the stride-2 downsample convs) runs on the tile with the same slabs
-    if (stats && stream_shape_ok(a.M, d->cout, d->cin, d->nky * d->nkx)) tile = 1222;
+    const int tile = choose_tile(a.M, d->cout, d->cin, d->nky * d->nkx, pool);
+    // ccst_conv2d_igemm_stats_groups() counted the streaming kernel's slabs for every 1x1 problem of its shape class
+    CCST_REQUIRE(!(stats && stream_shape_ok(a.M, d->cout, d->cin, d->nky * d->nkx)),
+                 "conv_stats: a 1x1 problem with padding / a non-dense output has no statistics epilogue");
     if (pool) {
         if (tile == 412) return launch_conv<4, 1, 2, true>(a, s);
         if (tile == 221) return launch_conv<2, 2, 1, true>(a, s);

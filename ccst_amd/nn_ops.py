@@ -287,6 +287,11 @@ MASK_LINK = _os.environ.get("CCST_MASK_LINK", "1") != "0"
 MASK_LINK_STATS = _os.environ.get("CCST_MASK_LINK_STATS", "1") != "0"      # BN-backward partial sums from that epilogue too
 
 
+def lib_groups(M, cout, cin):
+    """Partial-sum slabs the pointwise streaming kernel leaves for an M x cout result (see ccst_conv2d_igemm_stats_groups)."""
+    return int(_lib.load().ccst_conv2d_igemm_stats_groups(int(M), int(cout), int(cin), 1))
+
+
 def masked_accum_ok(dy, pc_t, x_shape, stride, pad):
     """True when conv_bwd_data(..., accumulate_into=..., relu_mask=...) exists for this problem (pointwise streaming kernel)."""
     if stride != 1 or pad != 0 or pc_t.kh != 1 or pc_t.kw != 1:
@@ -379,12 +384,12 @@ class ConvFn(torch.autograd.Function):
                 bn_link = bn_relu = None
                 M = N * H * W
                 if mask is not None and MASK_LINK_STATS and link.bn_x is not None:
-                    link.partials = torch.empty((2 * ((M + 63) // 64), Cin, 2), device=x.device, dtype=torch.float32)
+                    link.partials = torch.empty((lib_groups(M, Cin, dy.shape[3]), Cin, 2), device=x.device, dtype=torch.float32)
                     bn_link = (link.bn_x, link.bn_save[0], link.bn_save[1], link.partials)
                 # x is the output of a BatchNorm + ReLU that only this conv reads (bn2 -> conv3): mask and partial sums from here
                 if link is not None and link.mask is None and link.gamma is not None and into is None and ctx.sink is None and \
                         MASK_LINK_STATS and masked_accum_ok(dy, mod.packed_t(), tuple(x.shape), stride, pad):
-                    link.partials = torch.empty((2 * ((M + 63) // 64), Cin, 2), device=x.device, dtype=torch.float32)
+                    link.partials = torch.empty((lib_groups(M, Cin, dy.shape[3]), Cin, 2), device=x.device, dtype=torch.float32)
                     bn_relu = (link.bn_x, link.bn_save[0], link.bn_save[1], link.gamma, link.beta, link.partials)
                 dx = conv_bwd_data(dy, mod.packed_t(), tuple(x.shape), stride, pad, accumulate_into=into, relu_mask=mask, bn_link=bn_link,
                                    bn_relu=bn_relu)

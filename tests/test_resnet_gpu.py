@@ -129,7 +129,7 @@ def test_pointwise_backward_data_masked_accumulate(dev):
     bet = torch.zeros(C, device=dev)
     mean, invstd = bx.reshape(-1, C).mean(0).contiguous(), (1.0 / torch.sqrt(bx.reshape(-1, C).var(0, unbiased=False) + 1e-5)).contiguous()
     acc2 = base.to(dev).contiguous()
-    part = torch.empty((2 * ((M + 63) // 64), C, 2), device=dev)
+    part = torch.empty((nn_ops.lib_groups(M, C, Cout), C, 2), device=dev)
     out2 = nn_ops.conv_bwd_data(dy.to(dev), pct, (N, H, W, Cin), 1, 0, accumulate_into=acc2, relu_mask=mask.to(dev), bn_link=(bx, mean, invstd, part))
     assert torch.equal(out2, out)
     ws = torch.empty(int(lib.ccst_bn_workspace_bytes(M, C)) // 4, device=dev)
