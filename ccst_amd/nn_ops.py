@@ -270,7 +270,9 @@ class MaskLink(object):
     conv's backward-data), summed in the conv's `y +=` epilogue -- which can apply y's ReLU mask to the sum while it is in
     registers.  It then sets `premasked`, and the BatchNorm's backward takes its incoming gradient as already masked: no mask
     reads in its two passes and its skip-connection share IS the incoming tensor (no masked copy: 1.06 GB of writes per ResNet50
-    step)."""
+    step).
+    Contract (kept by nets/resnet.py's blocks, which create the links): every reader of y is such a conv or the identity add it
+    completes -- a reader whose gradient reaches y unmasked (none exists in the reference's ResNets) would not be masked any more."""
     __slots__ = ("mask", "premasked", "bn_x", "bn_save", "partials", "gamma", "beta")
 
     def __init__(self, mask, bn_x=None, bn_save=None, gamma=None, beta=None):
