@@ -126,6 +126,7 @@ def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False
     step = make_step(model, opt, loss_fun, x, y, join_side=graph)
     args = types.SimpleNamespace(mode="fedavg")
     comm_kw = {"scale_fn": scale_fn} if scale_fn is not None else {}
+    gc.collect()        # before the warm-up, see below
     for _ in range(warmup):
         loss = step()
     if distributed:
@@ -141,10 +142,10 @@ def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False
         run_step = g.replay
     else:
         run_step = step
-    # a full collection of the interpreter's cyclic GC takes 60-80 ms in a process that has imported torch + the AdaIN bench, and its
-    # allocation-count trigger lands deterministically inside the first timed step (measured: that step's host issue 80 ms instead of
-    # 12, 2830 instead of 3160 images/s over 25 steps); collect now, so that the next full pass is far away
-    gc.collect()
+    # (a full collection of the interpreter's cyclic GC takes 60-80 ms in a process that has imported torch + the AdaIN bench, and its
+    # allocation-count trigger landed deterministically inside the first timed step: that step's host issue 80 ms instead of 12, 2830
+    # instead of 3160 images/s over 25 steps.  It runs BEFORE the warm-up: between warm-up and timed steps it would leave the GPU idle
+    # long enough to drop its clocks.)
     if distributed:
         dist.barrier()
         sync()
