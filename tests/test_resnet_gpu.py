@@ -67,6 +67,34 @@ def test_conv_fwd_bwd(dev, cfg):
     assert relerr(conv.weight.grad, 2 * wr.grad) < 1e-4
 
 
+@pytest.mark.parametrize("cfg", [
+    # N, Cin, H, W, Cout, stride: the pointwise streaming kernel's corner cases
+    (5, 32, 9, 7, 192, 1),        # partial last row tile (M = 315), three column tiles (not a power of two)
+    (3, 64, 13, 13, 128, 2),      # strided (downsample branch), M = 147
+    (8, 96, 48, 48, 256, 1),      # more tiles (1152) than workgroups (1024): several tiles per workgroup, unequal counts
+    (2, 2048, 7, 7, 64, 1),       # long K (64 k-steps), one column tile
+])
+def test_pointwise_conv_statistics(dev, cfg):
+    """Forward 1x1 conv with the BatchNorm-statistics epilogue (ccst_conv2d_igemm_stats_f32 on conv1x1_stream_kernel): output against
+    torch, and the partial slabs -- as many as ccst_conv2d_igemm_stats_groups promises -- must add up to the output's per-channel
+    sum and sum of squares."""
+    from ccst_amd import _lib, ops
+    N, Cin, H, W, Cout, stride = cfg
+    g = torch.Generator().manual_seed(29)
+    x = torch.randn(N, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * (1.0 / Cin) ** 0.5
+    ref = F.conv2d(x.permute(0, 3, 1, 2), w, stride=stride).permute(0, 2, 3, 1)
+    pc = ops.pack_conv_weight(w.to(dev))
+    y, st = ops.conv2d_nhwc(x.to(dev), pc, stride=stride, pad=0, want_stats=True)
+    M = ref.shape[0] * ref.shape[1] * ref.shape[2]
+    assert st.shape[0] == _lib.load().ccst_conv2d_igemm_stats_groups(M, Cout, Cin, 1) and st.shape[1:] == (Cout, 2)
+    assert float((y.cpu() - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max())) * (Cin / 64) ** 0.5 * 4
+    tot = st.double().sum(0).cpu()
+    r2 = ref.reshape(-1, Cout).double()
+    assert float((tot[:, 0] - r2.sum(0)).abs().max()) < 1e-4 * max(1.0, float(r2.sum(0).abs().max()))
+    assert float((tot[:, 1] - (r2 * r2).sum(0)).abs().max()) < 1e-4 * float((r2 * r2).sum(0).abs().max())
+
+
 @pytest.mark.parametrize("shape", [(3, 28, 28, 128, 128), (2, 56, 56, 64, 64), (2, 14, 14, 256, 192), (1, 13, 19, 32, 48)])
 def test_halo_train_form_vs_gather(dev, shape):
     """ccst_conv3x3_halo_train_f32 (ResNet-trunk form of the halo kernel): forward + BN statistics, backward-data by
