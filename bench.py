@@ -92,6 +92,7 @@ def main():
     # timed steps run 2-25 % slow while they ramp back (6.46 5.90 5.66 5.48 5.33 5.28 ms against 5.19 steady).  So: collect first,
     # then warm up straight into the timed region.
     gc.collect()
+    step_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
@@ -99,7 +100,6 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     ops.TIMING = []                       # per-launch HIP events for the conv kernels and the AdaIN step
-    step_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
         step_ev[i][0].record()
