@@ -39,7 +39,13 @@ WINO_GFLOP_PER_IMAGE_512 = 1.812  # the two layers that do not run on the Winogr
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks of ONE node, one per GPU; when > 1 and not already inside a torch.distributed.run job, bench.py starts that "
+                         "job itself as a child process (python -m torch.distributed.run --nproc-per-node N bench.py ...)")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"), help="nccl = RCCL over xGMI; gloo only with --dry-run")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="protocol check without a GPU: the launch / rendezvous / barrier / max-over-ranks / one-JSON-line path with a "
+                         "stand-in step (CPU tests); measures nothing")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=6)
@@ -50,19 +56,93 @@ def parse():
     return ap.parse_args()
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` from a plain shell: start the N-rank job (one process per GPU, as the reference is run -- one
+    process per GPU from the shell, README.md:27-37) as a CHILD process, relay its output and return its exit code.  Runs before
+    anything has touched the GPU in this process (no torch.cuda call, ccst_amd not imported): a process that has initialised
+    HIP must not be replaced, and this one never is -- it only waits."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, rank, world):
+    """The contract's protocol with a stand-in step on the CPU (gloo): rendezvous, W warm-up steps, barrier, K timed steps, barrier,
+    MAX over ranks, ONE JSON line from rank 0.  `value` is meaningless and flagged as such."""
+    import torch.distributed as dist
+    distributed = world > 1
+    if distributed:
+        dist.init_process_group(backend="gloo")
+    x = torch.full((64, 64), 1.0 + rank)
+
+    def step():
+        return (x @ x).sum()
+    for _ in range(args.warmup):
+        step()
+    if distributed:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if distributed:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    n_ranks_seen = 1
+    if distributed:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        n_ranks_seen = dist.get_world_size()
+        seen = torch.zeros(world, dtype=torch.int64)
+        seen[rank] = 1
+        dist.all_reduce(seen)                                    # every rank really took part
+        assert int(seen.sum()) == world
+    if rank == 0:
+        print(json.dumps({"metric": "AdaIN stylised images/sec @512x512 B=6", "dry_run": True, "value": None, "unit": "images/sec",
+                          "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "none (stand-in step, gloo)", "backend": args.backend,
+                          "config": {"workload": "dry run of the launch protocol, nothing measured"}}), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    in_job = "WORLD_SIZE" in os.environ
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if in_job and world != args.gpus:
+        raise SystemExit("bench.py: launched with WORLD_SIZE=%d but --gpus %d: they must agree" % (world, args.gpus))
+    if args.gpus > 1 and not in_job:
+        sys.exit(spawn_ranks(args))
+    if args.backend == "gloo" and not args.dry_run:
+        raise SystemExit("bench.py: --backend gloo is the CPU protocol check and needs --dry-run (the measured path has no CPU fallback)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        dist.init_process_group(backend=args.backend, device_id=dev)
 
     from ccst_amd import net, ops, style
     from oracle import adain_ref as A          # synthetic inputs + the cpu_baseline leg only
