@@ -278,7 +278,7 @@ def main():
         dom = max(per_kernel, key=lambda n: per_kernel[n][2])
         cnt, fl, sec = per_kernel[dom]
         alg = fl / sec / 1e12
-        wfac = 4.0 if dom.startswith("conv3x3_wino4_kernel") else 2.25 if dom.startswith("conv3x3_wino_kernel") else 1.0
+        wfac = 4.0 if dom.startswith("conv3x3_wino4") else 2.25 if dom.startswith("conv3x3_wino_kernel") else 1.0
         wino = wfac != 1.0
         bound_wino = bound_w4 if wfac == 4.0 else bound_w2
         executed = alg / wfac
@@ -289,7 +289,7 @@ def main():
             base, targs = dom[:-1].split("<")
             targs = targs.split(",")
             nums, pooled = ", ".join(a for a in targs if a not in ("pool", "nopool")), ("true" if "pool" in targs else "false")
-            if base in ("conv3x3_wino_kernel", "conv3x3_wino4_kernel"):
+            if base in ("conv3x3_wino_kernel", "conv3x3_wino4_kernel", "conv3x3_wino4w_kernel"):
                 keys = [k for k in tj if k.startswith("void %s<" % base) and k.rstrip(">").split("<")[1].split(",")[0].strip() == pooled]
             elif base == "conv_igemm_kernel":
                 keys = ["void conv_igemm_kernel<%s, %s, 2, 16>" % (nums, pooled)]

@@ -581,15 +581,13 @@ extern "C" int ccst_conv3x3_wino4_f32(const float* x, const float* u_packed, con
     }
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)2 * HIMG4 * sizeof(float);                      // 104.8 KB: above the 64 KB default, one workgroup per CU
-    static bool attr_set = false;                                              // immutable after the first call (idempotent)
-    if (!attr_set) {
+    {   // the opt-in above the 64 KB default is per device: set it for the current one on every launch (cheap, idempotent, no shared flag)
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e1 != hipSuccess || e2 != hipSuccess) {
             ccst_set_error("conv3x3_wino4: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e1 != hipSuccess ? e1 : e2));
             return (int)(e1 != hipSuccess ? e1 : e2);
         }
-        attr_set = true;
     }
     if (pool) hipLaunchKernelGGL(conv3x3_wino4_kernel<true>, dim3((unsigned)grid), dim3(NT4), lds, s, a);
     else hipLaunchKernelGGL(conv3x3_wino4_kernel<false>, dim3((unsigned)grid), dim3(NT4), lds, s, a);

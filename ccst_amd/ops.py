@@ -202,13 +202,14 @@ def from_api(x, cpad=1):
 class PackedConv(object):
     """Device-resident packed weight [kh*kw][K/4][n_pad][4] (+ optional bias).  `u` / `u_pad`: the Winograd-transformed
     copy (ccst_pack_conv_weight_wino_f32) of a 3x3 weight, built by pack_conv_weight(..., wino=True)."""
-    __slots__ = ("w", "bias", "cin", "cout", "kh", "kw", "k_pad", "n_pad", "transpose", "u", "u_pad", "u4")
+    __slots__ = ("w", "bias", "cin", "cout", "kh", "kw", "k_pad", "n_pad", "transpose", "u", "u_pad", "u4", "u4_pad", "u4n")
 
     def __init__(self, w, bias, cin, cout, kh, kw, k_pad, n_pad, transpose):
         self.w, self.bias, self.cin, self.cout, self.kh, self.kw = w, bias, cin, cout, kh, kw
         self.k_pad, self.n_pad, self.transpose = k_pad, n_pad, transpose
         self.u, self.u_pad = None, 0
-        self.u4 = None              # F(4x4,3x3) transform (ccst_pack_conv_weight_wino4_f32), same u_pad
+        self.u4, self.u4_pad = None, 0   # F(4x4,3x3) transform for the 64-channel workgroups (ccst_pack_conv_weight_wino4w_f32)
+        self.u4n = None                  # ... for the 32-channel workgroups (ccst_pack_conv_weight_wino4_f32), same padding; on demand
 
 
 # Fused Winograd for the 3x3 stride-1 layers of the AdaIN encoder / decoder.  CCST_CONV_WINO = 4 (default): F(4x4,3x3)
@@ -218,6 +219,9 @@ _WINO_MODE = os.environ.get("CCST_CONV_WINO", "4")
 USE_WINO = _WINO_MODE != "0"
 WINO_F4 = _WINO_MODE == "4"
 WINO_F4_MIN_CIN = int(os.environ.get("CCST_WINO4_MIN_CIN", "16"))
+# the F(4x4) kernel runs 64 output channels per workgroup (conv3x3_wino4w.hip); CCST_WINO4_NARROW=1 keeps the 32-channel workgroups
+# of conv3x3_wino4.hip (A/B runs).  The two kernels read differently ordered transformed weights.
+WINO_F4_NARROW = os.environ.get("CCST_WINO4_NARROW", "0") == "1"
 
 
 def wino4_ok(cin, cout, H, W):
@@ -246,28 +250,35 @@ def pack_conv_weight(w_oihw, bias=None, transpose=False, out=None, wino=False):
         pc.u_pad = round_up(cout, 32)
         pc.u = torch.empty(int(lib.ccst_wino_weight_floats(cin, pc.u_pad)), device=w.device, dtype=torch.float32)
         check(lib.ccst_pack_conv_weight_wino_f32(ptr(w), ptr(pc.u), cout, cin, pc.u_pad, stream_ptr()), "pack_conv_weight_wino")
-        if wino == 4 or (WINO_F4 and cin >= WINO_F4_MIN_CIN):
-            pc.u4 = torch.empty(int(lib.ccst_wino4_weight_floats(cin, pc.u_pad)), device=w.device, dtype=torch.float32)
-            check(lib.ccst_pack_conv_weight_wino4_f32(ptr(w), ptr(pc.u4), cout, cin, pc.u_pad, stream_ptr()), "pack_conv_weight_wino4")
+        if wino in (4, "4n") or (WINO_F4 and cin >= WINO_F4_MIN_CIN):
+            pc.u4_pad = round_up(cout, 64)
+            pc.u4 = torch.empty(int(lib.ccst_wino4_weight_floats(cin, pc.u4_pad)), device=w.device, dtype=torch.float32)
+            check(lib.ccst_pack_conv_weight_wino4w_f32(ptr(w), ptr(pc.u4), cout, cin, pc.u4_pad, stream_ptr()), "pack_conv_weight_wino4w")
+            if WINO_F4_NARROW or wino == "4n":
+                pc.u4n = torch.empty_like(pc.u4)
+                check(lib.ccst_pack_conv_weight_wino4_f32(ptr(w), ptr(pc.u4n), cout, cin, pc.u4_pad, stream_ptr()), "pack_conv_weight_wino4")
     return pc
 
 
-def conv3x3_wino4(x, pc, flags=0):
-    """3x3 stride-1 pad-1 conv on the F(4x4,3x3) kernel; x NHWC [N,Hs,Ws,Cin], pc packed with wino=4.  flags: CONV_* bits."""
+def conv3x3_wino4(x, pc, flags=0, narrow=None):
+    """3x3 stride-1 pad-1 conv on the F(4x4,3x3) kernels; x NHWC [N,Hs,Ws,Cin], pc packed with wino=4.  flags: CONV_* bits.
+    narrow: the 32-output-channel workgroups of conv3x3_wino4.hip (pc packed with wino="4n") instead of the 64-channel ones."""
     N, Hs, Ws, Cx = x.shape
     ups, pool = bool(flags & CONV_UPS2), bool(flags & CONV_POOL2)
     Hi, Wi = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
     oh, ow = ((Hi + 1) // 2, (Wi + 1) // 2) if pool else (Hi, Wi)
     out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
-    args = (ptr(x), ptr(pc.u4), ptr(pc.bias), ptr(out), N, Hi, Wi, Cx, pc.cout, pc.u_pad, flags, stream_ptr())
+    narrow = (WINO_F4_NARROW and pc.u4n is not None) if narrow is None else narrow
+    fn = _lib.load().ccst_conv3x3_wino4_f32 if narrow else _lib.load().ccst_conv3x3_wino4w_f32
+    args = (ptr(x), ptr(pc.u4n if narrow else pc.u4), ptr(pc.bias), ptr(out), N, Hi, Wi, Cx, pc.cout, pc.u4_pad, flags, stream_ptr())
     if TIMING is None:
-        check(_lib.load().ccst_conv3x3_wino4_f32(*args), "conv3x3_wino4")
+        check(fn(*args), "conv3x3_wino4")
     else:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(_lib.load().ccst_conv3x3_wino4_f32(*args), "conv3x3_wino4")
+        check(fn(*args), "conv3x3_wino4")
         e1.record()
-        TIMING.append(("conv3x3_wino4_kernel<%s>" % ("pool" if pool else "nopool"), 2.0 * N * Hi * Wi * pc.cout * pc.cin * 9, e0, e1,
+        TIMING.append(("conv3x3_wino4%s_kernel<%s>" % ("" if narrow else "w", "pool" if pool else "nopool"), 2.0 * N * Hi * Wi * pc.cout * pc.cin * 9, e0, e1,
                        "n%d %dx%d cin%d cout%d taps3x3 flags%d" % (N, Hi, Wi, pc.cin, pc.cout, flags)))
     return out
 

@@ -167,10 +167,12 @@ def test_conv3x3_winograd_vs_direct(dev, case, reflect):
                                   (1, 22, 38, 64, 64, False, True), (1, 16, 32, 256, 256, False, False), (1, 9, 7, 16, 33, True, False),
                                   (1, 33, 65, 48, 64, True, False), (3, 50, 84, 64, 128, False, False), (1, 64, 64, 512, 64, False, True)])
 @pytest.mark.parametrize("reflect", [True, False])
-def test_conv3x3_winograd4_vs_direct(dev, case, reflect):
+@pytest.mark.parametrize("narrow", [False, True])
+def test_conv3x3_winograd4_vs_direct(dev, case, reflect, narrow):
     """ccst_conv3x3_wino4_f32 (fused Winograd F(4x4,3x3), 16x32-pixel workgroup tiles) against the direct halo kernel: same flags,
-    sizes that are not multiples of the 4x4 tile or the workgroup tile, Cout not a multiple of 32, pool, upsample.  F(4x4) in fp32
-    carries ~1e-5 relative error per layer (its transform constants reach 8 and 1/24)."""
+    sizes that are not multiples of the 4x4 tile or the workgroup tile, Cout not a multiple of 32 / 64, pool, upsample.  F(4x4) in
+    fp32 carries ~1e-5 relative error per layer (its transform constants reach 8 and 1/24).  narrow: the 32-output-channel
+    workgroups of conv3x3_wino4.hip instead of the 64-channel ones of conv3x3_wino4w.hip."""
     from ccst_amd import ops
     N, H, W, Cin, Cout, pool, ups = case
     g = torch.Generator().manual_seed(9)
@@ -178,14 +180,14 @@ def test_conv3x3_winograd4_vs_direct(dev, case, reflect):
     x = torch.randn(N, Hs, Ws, Cin, generator=g).to(dev)
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(dev)
     b = (torch.randn(Cout, generator=g) * 0.1).to(dev)
-    pc = ops.pack_conv_weight(w, b, wino=4)
-    assert pc.u4 is not None
+    pc = ops.pack_conv_weight(w, b, wino="4n")
+    assert pc.u4 is not None and pc.u4n is not None
     ref = ops.conv2d_nhwc(x, ops.pack_conv_weight(w, b), stride=1, pad=1, reflect=reflect, relu=True, pool=pool, ups=ups)   # direct kernels
     flags = 1 | (2 if pool else 0) | (4 if ups else 0) | (8 if reflect else 0)
-    out = ops.conv3x3_wino4(x, pc, flags)
+    out = ops.conv3x3_wino4(x, pc, flags, narrow=narrow)
     assert out.shape == ref.shape
     assert float((out - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max())), float((out - ref).abs().max())
-    out2 = ops.conv3x3_wino4(x, pc, flags)
+    out2 = ops.conv3x3_wino4(x, pc, flags, narrow=narrow)
     assert torch.equal(out, out2)
 
 
