@@ -213,9 +213,10 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& p, float* __restrict_
         hdstx = hy * ROWPW + (hx & 3) * PLANEW + (hx >> 2) * PITW + part * 4;
     }
     // staging groups: G0 = rows 0..3, G1 = rows 4..7, G2 = row 8 + the extra unit
-    f32x4 rh[4];
-    auto load_g = [&](int g, int c) {
-#ifdef ABLW_NO_HALO
+    // two register sets: a group is stored two pair-steps (~2 us) after its loads were issued -- they come from HBM
+    f32x4 rh[2][4];
+    auto load_g = [&](int g, int c, int rs) {
+#if defined(ABLW_NO_HALO) || defined(ABLW_NO_HALO_LOAD)
         if (c > 1 || nchunks_ > 2) return;
 #endif
         const unsigned cs = (unsigned)c * (CKW * 4);
@@ -223,23 +224,23 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& p, float* __restrict_
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int i = 4 * g + k;
-                rh[k] = bufw_load4(xrs, ((rowbad >> i) & 1) ? OOBW : voff, srow[i] + cs);
+                rh[rs][k] = bufw_load4(xrs, ((rowbad >> i) & 1) ? OOBW : voff, srow[i] + cs);
             }
         } else {
-            rh[0] = bufw_load4(xrs, ((rowbad >> 8) & 1) ? OOBW : voff, srow[8] + cs);
-            if (has_x) rh[1] = bufw_load4(xrs, voffx, cs);
+            rh[rs][0] = bufw_load4(xrs, ((rowbad >> 8) & 1) ? OOBW : voff, srow[8] + cs);
+            if (has_x) rh[rs][1] = bufw_load4(xrs, voffx, cs);
         }
     };
-    auto store_g = [&](int g, float* __restrict__ dst) {
-#ifdef ABLW_NO_HALO
-        return;
+    auto store_g = [&](int g, float* __restrict__ dst, int rs) {
+#if defined(ABLW_NO_HALO) || defined(ABLW_NO_HALO_STORE)
+        if (dst != nullptr) return;
 #endif
         if (g < 2) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(dst + hdst + (4 * g + k) * 2 * ROWPW) = rh[k];
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(dst + hdst + (4 * g + k) * 2 * ROWPW) = rh[rs][k];
         } else {
-            *reinterpret_cast<f32x4*>(dst + hdst + 16 * ROWPW) = rh[0];
-            if (has_x) *reinterpret_cast<f32x4*>(dst + hdstx) = rh[1];
+            *reinterpret_cast<f32x4*>(dst + hdst + 16 * ROWPW) = rh[rs][0];
+            if (has_x) *reinterpret_cast<f32x4*>(dst + hdstx) = rh[rs][1];
         }
     };
 
@@ -262,15 +263,18 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& p, float* __restrict_
     f32x16 acc[9][2];              // written first by the C = 0 MFMAs of the very first pair-step (no 288-register clear)
 
     f32x2 v[9];                    // A operands of the current pair: [position][channel of the pair]
-    f32x4 bq[9];                   // weight operands: [position][2 * channel group + channel of the pair]
+    f32x4 bq[2][9];                // weight operands: [pair-step parity][position][2 * channel group + channel of the pair]
     f32x2 w[3][5];                 // row pass of the next pair: [row of the block][patch column]
     f32x2 d[2][5];                 // raw patch column in flight: [slot][patch row]
 
+    // (chunk c, pair pr) -> set pr & 1: refilled right after position j's MFMAs of the pair-step that used it, for the pair-step
+    // AFTER the next one -- two pair-steps (~2 us) of lead.  Vector memory loads return in order: a weight load (L2) younger than a
+    // halo load (HBM) cannot return before it, and with one pair-step of lead every halo load stalled the MFMAs behind it.
     auto load_b = [&](int j, int c, int pr) {
 #ifdef ABLW_NO_B
-        if (c != 0 || pr != 0 || nchunks > 1) return;
+        if (c != 0 || pr > 1 || nchunks > 1) return;
 #endif
-        bq[j] = bufw_load4(urs, uvoff, (unsigned)c * 144u * up_bytes + upos(j) + (unsigned)pr * up_bytes);
+        bq[pr & 1][j] = bufw_load4(urs, uvoff, (unsigned)c * 144u * up_bytes + upos(j) + (unsigned)pr * up_bytes);
     };
     auto read_col = [&](const float* __restrict__ hs, int pr, int cc, int slot) {
 #ifdef ABLW_NO_LDS_READ
@@ -298,21 +302,21 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& p, float* __restrict_
     // ordinary VGPRs.  Written as assembly because the register class is not expressible through the builtin: left to itself the
     // allocator puts all 18 into AGPRs and then shuttles blocks between the two files inside the loop (496 v_accvgpr_* per chunk).
 #ifdef ABLW_NO_MFMA
-#define WW_M1(j, nb, k) asm volatile("" : "+v"(acc[j][nb][(k) + 2 * (nb)]) : "v"(v[j][k]), "v"(bq[j][2 * (nb) + (k)]))
+#define WW_M1(j, nb, k) asm volatile("" : "+v"(acc[j][nb][(k) + 2 * (nb)]) : "v"(v[j][k]), "v"(bq[ps][j][2 * (nb) + (k)]))
 #else
 #define WW_M1(j, nb, k)                                                                                                              \
     do {                                                                                                                             \
-        if ((j) < 8) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[j][nb]) : "v"(bq[j][2 * (nb) + (k)]), "v"(v[j][k])); \
-        else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[j][nb]) : "v"(bq[j][2 * (nb) + (k)]), "v"(v[j][k]));      \
+        if ((j) < 8) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[j][nb]) : "v"(bq[ps][j][2 * (nb) + (k)]), "v"(v[j][k])); \
+        else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[j][nb]) : "v"(bq[ps][j][2 * (nb) + (k)]), "v"(v[j][k]));      \
     } while (0)
 #endif
 #ifdef ABLW_NO_MFMA
-#define WW_M1I(j, nb, k) acc[j][nb] = f32x16{} + v[j][k] * bq[j][2 * (nb) + (k)]
+#define WW_M1I(j, nb, k) acc[j][nb] = f32x16{} + v[j][k] * bq[ps][j][2 * (nb) + (k)]
 #else
 #define WW_M1I(j, nb, k)                                                                                                             \
     do {                                                                                                                             \
-        if ((j) < 8) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(acc[j][nb]) : "v"(bq[j][2 * (nb) + (k)]), "v"(v[j][k])); \
-        else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(acc[j][nb]) : "v"(bq[j][2 * (nb) + (k)]), "v"(v[j][k]));     \
+        if ((j) < 8) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(acc[j][nb]) : "v"(bq[ps][j][2 * (nb) + (k)]), "v"(v[j][k])); \
+        else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(acc[j][nb]) : "v"(bq[ps][j][2 * (nb) + (k)]), "v"(v[j][k]));     \
     } while (0)
 #endif
 #define WW_MFMA4(j)                                                                                                                  \
@@ -321,49 +325,52 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& p, float* __restrict_
         WW_M1(j, 0, 1); WW_M1(j, 1, 1);                                                                                              \
     } while (0)
 
-    // One pair-step: the 36 MFMAs of the current pair (operands v[], bq[]), position by position; between the groups the LDS
-    // reads (one patch column ahead) + the transform of the NEXT pair (buffer hs, pair pn) and the refill of the weight registers
-    // just used (chunk cn, pair pn).  The staging work of this step (sg_store / sg_load: group or -1) sits in groups 2..4.
-    auto pair_step = [&](const float* __restrict__ hs, int cn, int pn, int sg_store, float* __restrict__ sdst, int sg_load, int sc, auto init) {
+    // One pair-step (pair ps of its chunk): the 36 MFMAs of the current pair (operands v[], bq[ps & 1][]), position by position;
+    // between the groups the LDS reads (one patch column ahead) + the transform of the NEXT pair (buffer hs, pair pn) and the
+    // refill of the weight registers just used, for the pair-step after the next (chunk cb, pair pb).  The staging work of this
+    // step (sg_store / sg_load: group or -1) sits in groups 2..4.
+    auto pair_step = [&](auto ps_t, const float* __restrict__ hs, int pn, int cb, int pb, int sg_store, float* __restrict__ sdst, int sg_load, int sc,
+                         auto init) {
+        constexpr int ps = decltype(ps_t)::value & 1;
         read_col(hs, pn, 0, 0);
         WW_SB;
         WW_MFMA4(0);
-        load_b(0, cn, pn);
+        load_b(0, cb, pb);
         read_col(hs, pn, 1, 1);
         WW_SB;
         WW_MFMA4(1);
-        load_b(1, cn, pn);
+        load_b(1, cb, pb);
         row_pass(0, 0);
         read_col(hs, pn, 2, 0);
         WW_SB;
         WW_MFMA4(2);
-        load_b(2, cn, pn);
+        load_b(2, cb, pb);
         row_pass(1, 1);
         read_col(hs, pn, 3, 1);
-        if (sg_store >= 0) store_g(sg_store, sdst);
+        if (sg_store >= 0) store_g(sg_store, sdst, sg_store == 1);
         WW_SB;
         WW_MFMA4(3);
-        load_b(3, cn, pn);
+        load_b(3, cb, pb);
         row_pass(2, 0);
         read_col(hs, pn, 4, 0);
-        if (sg_load >= 0) load_g(sg_load, sc);
+        if (sg_load >= 0) load_g(sg_load, sc, sg_load == 1);
         WW_SB;
         WW_MFMA4(4);
-        load_b(4, cn, pn);
+        load_b(4, cb, pb);
         row_pass(3, 1);
         WW_SB;
         WW_MFMA4(5);
-        load_b(5, cn, pn);
+        load_b(5, cb, pb);
         row_pass(4, 0);
         WW_SB;
         WW_MFMA4(6);
-        load_b(6, cn, pn);
+        load_b(6, cb, pb);
         WW_SB;
         WW_MFMA4(7);
-        load_b(7, cn, pn);
+        load_b(7, cb, pb);
         WW_SB;
         WW_MFMA4(8);
-        load_b(8, cn, pn);
+        load_b(8, cb, pb);
         WW_SB;
         col_pass(0);
         col_pass(1);
@@ -374,12 +381,15 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& p, float* __restrict_
     // ---- prologue: chunk 0 -> LDS, weights of (chunk 0, pair 0), the transform of pair 0, group 0 of chunk 1 in flight ---------
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
-        load_g(g, 0);
-        store_g(g, Hs0);
+        load_g(g, 0, 0);
+        store_g(g, Hs0, 0);
     }
 #pragma unroll
     for (int j = 0; j < 9; ++j) load_b(j, 0, 0);
-    load_g(0, min(1, last));
+#pragma unroll
+    for (int j = 0; j < 9; ++j) load_b(j, 0, 1);
+    load_g(0, min(1, last), 0);
+    load_g(1, min(1, last), 1);
     __syncthreads();
 #pragma unroll
     for (int cc = 0; cc < 5; ++cc) {
@@ -396,14 +406,16 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& p, float* __restrict_
         const float* cur = (c & 1) ? Hs1 : Hs0;
         float* nxt = (c & 1) ? Hs0 : Hs1;
         const int c1 = min(c + 1, last), c2 = min(c + 2, last);
-        pair_step(cur, c, 1, 0, nxt, 1, c1, first);
-        pair_step(cur, c, 2, 1, nxt, 2, c1, std::false_type{});
-        pair_step(cur, c, 3, 2, nxt, -1, 0, std::false_type{});
+        // halo of chunk c+1 -> the other buffer (its last readers left through the previous barrier): groups 0, 1 were requested two
+        // pair-steps ago (sets 0, 1), group 2 is requested now (set 0, behind group 0's stores); groups 0, 1 of chunk c+2 in steps 2, 3
+        pair_step(std::integral_constant<int, 0>{}, cur, 1, c, 2, 0, nxt, 2, c1, first);
+        pair_step(std::integral_constant<int, 1>{}, cur, 2, c, 3, 1, nxt, -1, 0, std::false_type{});
+        pair_step(std::integral_constant<int, 2>{}, cur, 3, c1, 0, 2, nxt, 0, c2, std::false_type{});
 #ifndef ABLW_NO_BARRIER
         __syncthreads();
 #endif
         WW_SB;
-        pair_step(nxt, c1, 0, -1, nullptr, 0, c2, std::false_type{});
+        pair_step(std::integral_constant<int, 3>{}, nxt, 0, c1, 1, -1, nullptr, 1, c2, std::false_type{});
     };
     chunk(0, std::true_type{});     // its first pair-step starts the accumulators (C = 0)
     for (int c = 1; c < nchunks; ++c) chunk(c, std::false_type{});

@@ -10,6 +10,8 @@ declare -A V=(
   [noxform]="-DABLW_NO_XFORM"
   [nob]="-DABLW_NO_B"
   [nohalo]="-DABLW_NO_HALO"
+  [nohload]="-DABLW_NO_HALO_LOAD"
+  [nohstore]="-DABLW_NO_HALO_STORE"
   [nolds]="-DABLW_NO_LDS_READ -DABLW_NO_XFORM"
   [nobar]="-DABLW_NO_BARRIER"
   [noepi]="-DABLW_NO_EPILOGUE"
@@ -22,7 +24,7 @@ if [ "$1" = build ]; then
   ls build/variants/lib_w4w_*.so
 else
   L=${2:-4}
-  for k in full nomfma noxform nob nohalo nolds nobar noepi mfmaonly loopmfma; do
+  for k in full nomfma noxform nob nohalo nohload nohstore nolds nobar noepi mfmaonly loopmfma; do
     echo "== $k"
     CCST_HIP_LIB=$PWD/build/variants/lib_w4w_$k.so WINO_LAYER=$L python tools/wino_layers.py 20 2>&1 | grep -v amdgpu.ids | cut -c1-28,58-100
   done
