@@ -40,7 +40,7 @@ struct W4wArgs {
     int reflect, ups, relu;
     long long ysN;
     int ysH, ysW;                                  // output strides (of the pooled tensor when POOL)
-    int tilesX, tilesY, tilesN;
+    int tilesX, tilesY, tilesN, ntiles;
 };
 
 constexpr int NTW = 256;                           // threads per workgroup: four waves, one per SIMD
@@ -135,14 +135,39 @@ __device__ __forceinline__ void at4(const KO& K, f32x2 m0, f32x2 m1, f32x2 m2, f
 #define WW_SB __builtin_amdgcn_sched_barrier(0)
 
 template <bool POOL, int RB, int CB>
-__device__ __forceinline__ void wino4w_body(const W4wArgs& p, float* __restrict__ lds) {
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);                    // wave 0..3 = (RB, CB)
-    const int li = lane & 31, lh = lane >> 5;
+__device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict__ lds) {
     float* const Hs0 = lds;
     float* const Hs1 = lds + HIMGW;
 
-    int bid = ccst_xcd_remap(blockIdx.x, gridDim.x);
+    // Persistent workgroups: the grid is one workgroup per CU (a multiple of 8, so that tile ids t and t + 8 still share an XCD) and
+    // each walks tiles blockIdx.x, + gridDim.x, ...  The output stores of a tile then drain while the next tile's loop runs; as one
+    // tile per workgroup every CU finished at the same moment and the whole layer's output went to HBM in one burst that nothing
+    // overlapped (removing the epilogue was worth 7-26 % per layer).
+#pragma unroll 1
+    for (int tile = blockIdx.x; tile < pk.ntiles; tile += gridDim.x) {
+    // Everything below is per tile ON PURPOSE: the arguments and the thread id pass through an opaque zero each iteration, otherwise
+    // the compiler hoists every tile-invariant address, descriptor and constant out of this loop and keeps ~400 scalar registers'
+    // worth of them alive across the whole body (spilled to vector lanes, then the vector registers spill too).
+    int zi = 0;
+    float zf = 0.f;
+    asm volatile("" : "+s"(zi), "+s"(zf));
+    W4wArgs p = pk;
+    p.H += zi; p.W += zi; p.Hs += zi; p.Ws += zi; p.Cin += zi; p.Cout += zi; p.CoutPad += zi; p.ysH += zi; p.ysW += zi; p.ysN += zi;
+    p.tilesX += zi; p.tilesY += zi; p.tilesN += zi; p.reflect += zi; p.ups += zi; p.relu += zi;
+    p.x += zi; p.u += zi; p.y += zi;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);                    // wave 0..3 = (RB, CB)
+    const int li = lane & 31, lh = lane >> 5;
+#ifdef ABLW_STAMPS
+    unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(pk.y) + (long long)tile * 8;
+#define WW_STAMP(k) do { if (tid == 0) stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WW_STAMP(k) do { } while (0)
+#endif
+    WW_STAMP(0);
+    int bid = ccst_xcd_remap(tile, pk.ntiles);
     const int tn = bid % p.tilesN;
     bid /= p.tilesN;
     const int tx = bid % p.tilesX;
@@ -245,7 +270,7 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& p, float* __restrict_
     };
 
     // ---- A side: the lane's tile (li) and channel half (lh); 5x5 patch rows RB.., columns CB.. -------------------------------
-    const KW K{splatw(4.f), splatw(-5.f), splatw(-4.f), splatw(2.f), splatw(-2.f)};
+    const KW K{splatw(4.f + zf), splatw(-5.f + zf), splatw(-4.f + zf), splatw(2.f + zf), splatw(-2.f + zf)};
     const int tyy = li >> 3, txx = li & 7;
     const int abase = (4 * tyy + RB) * ROWPW + txx * PITW + lh * 8;              // + a*ROWPW + (c&3)*PLANEW + (c>>2)*PITW + 2*pair
     auto col_off = [](int cc) { const int c = cc + CB; return (c & 3) * PLANEW + (c >> 2) * PITW; };
@@ -417,8 +442,10 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& p, float* __restrict_
         WW_SB;
         pair_step(std::integral_constant<int, 3>{}, nxt, 0, c1, 1, -1, nullptr, 1, c2, std::false_type{});
     };
+    WW_STAMP(1);
     chunk(0, std::true_type{});     // its first pair-step starts the accumulators (C = 0)
     for (int c = 1; c < nchunks; ++c) chunk(c, std::false_type{});
+    WW_STAMP(2);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (asm MFMAs: no automatic wait states between the last one and the first read of its result)
     __syncthreads();                // every wave is done with the halo buffers: the exchange area overlays them
 
@@ -441,14 +468,14 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& p, float* __restrict_
     // reader: thread = (tile tid >> 3, channel quad tid & 7): consecutive lanes store consecutive 16 bytes of one pixel
     const int rt = tid >> 3, rquad = tid & 7;
     const int rbase = rt * 128 + ((rquad ^ ((rt >> 1) & 7)) << 4);
-    const KO KOut{splatw(2.f), splatw(4.f), splatw(8.f)};
+    const KO KOut{splatw(2.f + zf), splatw(4.f + zf), splatw(8.f + zf)};
     const bool interior = (oy0 + THW <= p.H) && (ox0 + TWW <= p.W);
     const bool relu = p.relu != 0;
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y + (long long)n * p.ysN, 0, (int)(p.ysN * 4), 0x00020000);
     const int oyb = oy0 + 4 * (rt >> 3), oxb = ox0 + 4 * (rt & 7);               // the reader's tile
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-        if (nb == 1) __syncthreads();
+        if (nb == 1) { WW_STAMP(3); __syncthreads(); }
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const f32x16 a = acc[j][nb];
@@ -548,6 +575,10 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& p, float* __restrict_
             else emit(std::false_type{}, std::true_type{});
         }
     }
+    WW_STAMP(4);
+    __syncthreads();                // the next tile's halo overwrites the exchange area
+    WW_STAMP(5);
+    }
 }
 
 template <bool POOL>
@@ -632,7 +663,15 @@ extern "C" int ccst_conv3x3_wino4w_f32(const float* x, const float* u_packed, co
         ccst_set_error("conv3x3_wino4w: bad grid %lld", grid);
         return CCST_EINVAL;
     }
+    a.ntiles = (int)grid;
     hipStream_t s = (hipStream_t)stream;
+    static int n_cu = 0;                                                       // (same for every device of a node)
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n_cu = v / 8 * 8 > 0 ? v / 8 * 8 : 8;
+    }
+    const long long wgs = grid < n_cu ? grid : n_cu;
     const size_t lds = (size_t)EXW_BYTES;                                      // 144 KB of the CU's 160: one workgroup per CU
     // the opt-in above the 64 KB default is per device and idempotent: set it for the current device on every launch
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4w_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -641,7 +680,7 @@ extern "C" int ccst_conv3x3_wino4w_f32(const float* x, const float* u_packed, co
         ccst_set_error("conv3x3_wino4w: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e1 != hipSuccess ? e1 : e2));
         return (int)(e1 != hipSuccess ? e1 : e2);
     }
-    if (pool) hipLaunchKernelGGL(conv3x3_wino4w_kernel<true>, dim3((unsigned)grid), dim3(NTW), lds, s, a);
-    else hipLaunchKernelGGL(conv3x3_wino4w_kernel<false>, dim3((unsigned)grid), dim3(NTW), lds, s, a);
+    if (pool) hipLaunchKernelGGL(conv3x3_wino4w_kernel<true>, dim3((unsigned)wgs), dim3(NTW), lds, s, a);
+    else hipLaunchKernelGGL(conv3x3_wino4w_kernel<false>, dim3((unsigned)wgs), dim3(NTW), lds, s, a);
     return ccst_launch_status("conv3x3_wino4w");
 }
