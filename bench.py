@@ -16,7 +16,9 @@ Prints ONE JSON line on rank 0 (see the bench contract) including
   adain_step   : the statistics + normalise step against its HBM roofline (100.66 MB algorithmic per B=6 batch)
   end_to_end   : images/sec including the H2D of the content batch and the D2H of the result (never ``value``)
   cpu_baseline : the CPU oracle (a port of the reference path) timed on the host cores, rank 0, N=1
-  secondary    : ResNet50 train-step images/sec @222x222 B=64 (second half of the metric) with its MFMA / HBM rooflines
+  secondary    : a list -- [0] ResNet50 train-step images/sec @222x222 B=64 (second half of the metric) with its MFMA / HBM rooflines;
+                 then the other BASELINE configs: stage-1 statistics at B=32 512^2 with the HBM roofline of calc_sum (configs 0/1),
+                 Single-mode style transfer at B=32 (config 3), ResNet18 B=32 classes=2 @222 (config 5)
 """
 import argparse
 import gc
@@ -52,6 +54,7 @@ def parse():
     ap.add_argument("--image_size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="secondary = the ResNet50 line only (skip configs 0/1, 3 and 5)")
     ap.add_argument("--layers", action="store_true", help="print a per-launch conv table (last step) to stderr")
     return ap.parse_args()
 
@@ -282,10 +285,15 @@ def main():
         wino = wfac != 1.0
         bound_wino = bound_w4 if wfac == 4.0 else bound_w2
         executed = alg / wfac
-        traffic, tsrc = None, os.path.join(ROOT, "profiles", "traffic.json")
+        traffic, traffic_src, tsrc = None, None, os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tsrc):      # HBM bytes/launch from the separate rocprofv3 --pmc passes (tools/profile_bench.sh)
             with open(tsrc) as fh:
                 tj = json.load(fh)
+            from bench_resnet import build_stamp
+            meta = tj.get("_source", {})
+            traffic_src = {"file": "profiles/traffic.json", "build_stamp": meta.get("build_stamp"), "date": meta.get("date"),
+                           "profile": meta.get("profile"),
+                           "current_build": meta.get("build_stamp") is not None and meta.get("build_stamp") == build_stamp()}
             base, targs = dom[:-1].split("<")
             targs = targs.split(",")
             nums, pooled = ", ".join(a for a in targs if a not in ("pool", "nopool")), ("true" if "pool" in targs else "false")
@@ -296,11 +304,13 @@ def main():
             else:       # rocprofv3 prints every template argument: <WM, WN, NT, POOL, TRAIN>
                 keys = ["void %s<%s, %s, false>" % (base, nums, pooled), "void %s<%s, %s>" % (base, nums, pooled)]
             for key in keys:
-                if key in tj:
+                if key in tj and traffic_src["current_build"]:      # a committed profile of THIS build, else not reported
                     traffic = round(tj[key]["total_bytes_per_launch"])
                     break
+            if traffic is None:
+                traffic_src["note"] = "no profile of the running build: bytes not reported"
         roofline = {"bound": "mfma", "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "kernel": dom,
+                    "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": dom,
                     "launches_per_step": cnt / max(1, sampled_steps), "avg_launch_us": round(sec / cnt * 1e6, 2),
                     "event_timed_steps": "%d of the %d timed steps (every %d-th)" % (sampled_steps, args.steps, EVENTS_EVERY),
                     "gflop_per_launch": round(fl / cnt / 1e9, 3), "algorithmic_tflops": round(alg, 2),
@@ -349,13 +359,19 @@ def main():
                                   "sample": "%d batches of %d images %dx%d (oracle/adain_ref.py, torch CPU fp32)" % (reps, B, S, S)}
         result["max_abs_diff_vs_cpu"] = float((out.cpu() - ref).abs().max())
 
-    if not args.no_secondary:           # second half of the BASELINE metric; every rank takes part
+    if not args.no_secondary:           # second half of the BASELINE metric, then the other configs; every rank takes part
+        import bench_extra
         import bench_resnet
         del out, content
+        cpu_legs = world == 1 and not args.no_cpu_baseline
         # (no empty_cache(): the freed AdaIN blocks stay in the caching allocator -- returning them makes the first train steps
         #  re-hipMalloc their workspaces inside the timed region: 2870 instead of 3190 images/s over 25 steps)
-        sec = bench_resnet.run(dev, world, steps=max(3, args.steps // 2), warmup=5,
-                               cpu_baseline=(world == 1 and not args.no_cpu_baseline))
+        sec = [bench_resnet.run(dev, world, steps=max(3, args.steps // 2), warmup=5, cpu_baseline=cpu_legs)]      # config 4 (metric, 2nd half)
+        if not args.no_extra:
+            sec.append(bench_extra.stage1(dev, vgg31, A, world, rank, cpu=cpu_legs, vgg_w=vgg_w))                  # configs 0 / 1
+            sec.append(bench_extra.single_mode(dev, vgg31, dec, A, world, rank))                                   # config 3
+            sec.append(bench_resnet.run(dev, world, steps=max(6, args.steps // 2), warmup=5, batch=32, arch="resnet18", classes=2,
+                                        graph="auto", cpu_baseline=cpu_legs))                                     # config 5
         result["secondary"] = sec
 
     if rank == 0:

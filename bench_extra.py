@@ -1,0 +1,107 @@
+"""Throughput lines for the BASELINE configs that are not the headline one (bench.py's ``secondary`` list):
+
+  config 0/1  mean_std_computation_effcientMem.py --image_size 512 --batch 32: stage-1 style statistics, images/sec through
+              vgg[:31] + calc_sum (mean_std_computation_effcientMem.py:117-132), with the HBM roofline of the statistics kernel
+              (268.4 MB read per batch)
+  config 3    CCST_SingleStyleTransfer.py 512x512 batch=32: one style image per batch, its mu / sigma from calc_sum
+              (CCST_SingleStyleTransfer.py:178-212), then style_transfer over the content batch
+  config 5    fed_run.py Camelyon17 ResNet18 B=32 classes=2 @222: train-step images/sec (bench_resnet.run, HIP graph chosen by
+              measurement)
+
+Lives next to bench.py, outside the package: the ``cpu_baseline`` legs import the oracle.
+"""
+import gc
+import time
+
+import torch
+
+PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md, HBM3E
+
+
+def _timed(fn, steps, warmup, dist_barrier):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    dist_barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    dist_barrier()
+    return time.perf_counter() - t0
+
+
+def _max_over_ranks(elapsed, dev, world):
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+    return elapsed
+
+
+def stage1(dev, vgg31, A, world, rank, steps=6, warmup=2, batch=32, size=512, cpu=False, vgg_w=None):
+    """One step = one batch of a domain through vgg[:31] and calc_sum, sums accumulated on the device (the stage-1 loop body)."""
+    from ccst_amd import ops, style
+    import torch.distributed as dist
+    barrier = (lambda: (dist.barrier(), torch.cuda.synchronize())) if world > 1 else (lambda: None)
+    x = A.synth_content(batch, size, size, seed=31 + rank).to(dev)
+    acc = style.StyleStatAccumulator()
+
+    def step():
+        with torch.no_grad():
+            acc.update(vgg31(x))
+    gc.collect()
+    ops.TIMING = None
+    elapsed = _timed(step, steps, warmup, barrier)
+    ops.TIMING = ev = []
+    step()
+    torch.cuda.synchronize()
+    ops.TIMING = None
+    us = [a.elapsed_time(b) * 1e3 for name, _f, a, b, _i in ev if name == "chan_sums"]
+    elapsed = _max_over_ranks(elapsed, dev, world)
+    nbytes = 4 * batch * 512 * (size // 8) * (size // 8)          # the relu4_1 tensor read once (268.4 MB at B=32, 512^2)
+    out = {"metric": "stage-1 style statistics images/sec @%dx%d B=%d (vgg[:31] + calc_sum)" % (size, size, batch),
+           "value": round(world * batch * steps / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(elapsed / steps * 1e3, 3), "dtype": "f32", "scaling": "weak",
+           "config": {"workload": "mean_std_computation_effcientMem PACS %dx%d batch=%d, one domain's batches per rank + one all-reduce of "
+                                  "(sum, sqsum, n) at the end" % (size, size, batch)},
+           "roofline": {"bound": "hbm", "kernel": "ccst_chan_sums_f32 (per-channel sum and sum of squares of relu4_1)", "bytes": nbytes,
+                        "avg_launch_us": round(us[0], 2) if us else None, "achieved": round(nbytes / us[0] / 1e3, 1) if us else None,
+                        "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(nbytes / us[0] / 1e3 / PEAK_HBM_GBPS, 4) if us else None,
+                        "traffic": None}}
+    if cpu and rank == 0 and world == 1:
+        n = 4
+        xc = A.synth_content(n, size, size, seed=31)
+        with torch.no_grad():
+            A.calc_sum(A.encoder(xc[:1], vgg_w))
+            c0 = time.perf_counter()
+            A.calc_sum(A.encoder(xc, vgg_w))
+            c1 = time.perf_counter()
+        out["cpu_baseline"] = {"value": round(n / (c1 - c0), 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": "%d images %dx%d through the oracle's encoder + calc_sum (oracle/adain_ref.py, torch CPU fp32)" % (n, size, size)}
+    return out
+
+
+def single_mode(dev, vgg31, dec, A, world, rank, steps=4, warmup=1, batch=32, size=512):
+    """One step = one style image encoded -> calc_sum -> mu / sigma, then style_transfer over a content batch of 32
+    (CCST_SingleStyleTransfer.py:178-212)."""
+    from ccst_amd import style
+    import torch.distributed as dist
+    barrier = (lambda: (dist.barrier(), torch.cuda.synchronize())) if world > 1 else (lambda: None)
+    content = A.synth_content(batch, size, size, seed=41 + rank).to(dev)
+    style_img = A.synth_content(1, size, size, seed=43 + rank).to(dev)
+
+    def step():
+        with torch.no_grad():
+            s, q, n = style.calc_sum(vgg31(style_img))
+            stat = list(style.finalise_style_stats(s, q, n))
+            return style.style_transfer(vgg31, dec, content, stat, 1.0)
+    gc.collect()
+    elapsed = _max_over_ranks(_timed(step, steps, warmup, barrier), dev, world)
+    return {"metric": "AdaIN single-style stylised images/sec @%dx%d B=%d" % (size, size, batch),
+            "value": round(world * batch * steps / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 3), "dtype": "f32", "scaling": "weak",
+            "config": {"workload": "CCST_SingleStyleTransfer PACS %dx%d batch=%d: one style image per batch (encode + calc_sum), then "
+                                   "encoder -> AdaIN -> decoder over the content batch; source domains shard one per rank" % (size, size, batch)},
+            "note": "same kernels as the headline line (its roofline applies); 33 encoder passes + 32 decoder passes per step"}

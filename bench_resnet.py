@@ -93,21 +93,38 @@ def layer_table(step):
         print("TOTAL %-12s %9.1f us  %7.1f GFLOP  %6.1f TF" % (k, us, fl / 1e9, fl / us / 1e6), file=sys.stderr)
 
 
+def build_stamp():
+    """Digest of the kernel sources the loaded library was built from (ccst_amd/build.py writes it next to the .so)."""
+    try:
+        with open(os.path.join(ROOT, "ccst_amd", "csrc", ".build_stamp")) as f:
+            return f.read().strip()[:16]
+    except OSError:
+        return None
+
+
 def hbm_traffic_per_step(arch, batch):
-    """HBM bytes one train step moves, from the separate rocprofv3 --pmc passes over this same script (FETCH_SIZE x2 per the
-    gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, summed over every kernel of a step; tools/profile_resnet.sh writes
-    profiles/traffic_resnet.json).  None when no profile for this arch/batch is committed."""
+    """(HBM bytes one train step moves, provenance) from the separate rocprofv3 --pmc passes over this same script (FETCH_SIZE x2
+    per the gfx950 correction of MI355X_MICROARCH.md + WRITE_SIZE, summed over the kernels of the steady-state steps;
+    tools/profile_resnet.sh writes profiles/traffic_resnet.json with the build stamp and date of the profiled build).  The number
+    is a committed profile, not a measurement of this run: it is reported only when the profiled build IS the running build."""
     f = os.path.join(ROOT, "profiles", "traffic_resnet.json")
     if not os.path.exists(f):
-        return None
+        return None, None
     with open(f) as fh:
         tj = json.load(fh)
     key = "%s_b%d" % (arch, batch)
-    return tj.get(key)
+    src = {"file": "profiles/traffic_resnet.json", "build_stamp": tj.get("build_stamp"), "date": tj.get("date"),
+           "profile": tj.get("profile"), "current_build": tj.get("build_stamp") is not None and tj.get("build_stamp") == build_stamp()}
+    if key not in tj:
+        return None, None
+    if not src["current_build"]:
+        src["note"] = "profiled build differs from the running one: bytes not reported"
+        return None, src
+    return tj.get(key), src
 
 
 def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False, cpu_baseline=False, layers=False,
-        build_fn=None, scale_fn=None, sync=None):
+        build_fn=None, scale_fn=None, sync=None, classes=7):
     """One client per rank (weak scaling).  With world > 1 (torch.distributed already initialised by the
     caller) the timed region is K local train steps followed by ONE FedAvg all-reduce of the flat state
     (fed_run.py's round: local epoch(s) then communication()), barrier-bracketed, max over ranks.
@@ -116,13 +133,16 @@ def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False
     import torch.distributed as dist
     from ccst_amd import fed
     sync = sync or torch.cuda.synchronize
+    auto_graph = graph == "auto"
+    graph = False if auto_graph else bool(graph)
     if graph and os.environ.get("CCST_GRAPH_SIDE", "1") == "0":       # single-stream capture
         from ccst_amd import nn_ops
         nn_ops.SIDE_STREAM = False
     distributed = world > 1 and dist.is_available() and dist.is_initialized()
     rank = dist.get_rank() if distributed else 0
     n_ranks_seen = dist.get_world_size() if distributed else 1
-    model, opt, loss_fun, x, y = (build_fn or build)(dev, arch=arch, batch=batch, seed=1 + rank)
+    bkw = {"classes": classes} if build_fn is None else {}
+    model, opt, loss_fun, x, y = (build_fn or build)(dev, arch=arch, batch=batch, seed=1 + rank, **bkw)
     step = make_step(model, opt, loss_fun, x, y, join_side=graph)
     args = types.SimpleNamespace(mode="fedavg")
     comm_kw = {"scale_fn": scale_fn} if scale_fn is not None else {}
@@ -134,6 +154,30 @@ def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False
     sync()
     if layers:
         layer_table(step)
+    graph_choice = None
+    if auto_graph:
+        # launch-bound or GPU-bound?  Issue a few eager steps without waiting: if the host needs longer to issue a step than the GPU to
+        # run it, the HIP-graph replay is the faster loop (fed.train(..., args.hip_graph) makes the same choice available to the CLI)
+        probe = 6
+        sync()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        h0 = time.perf_counter()
+        e0.record()
+        for _ in range(probe):
+            step()
+        e1.record()
+        issue_ms = (time.perf_counter() - h0) * 1e3 / probe
+        sync()
+        device_ms = e0.elapsed_time(e1) / probe
+        graph = issue_ms > 0.9 * device_ms
+        graph_choice = {"host_issue_ms_per_step": round(issue_ms, 3), "device_ms_per_step_eager": round(device_ms, 3),
+                        "rule": "HIP graph when the host needs > 0.9 x the device time to issue a step", "hip_graph": bool(graph)}
+        if graph:
+            # (capture needs every forked stream re-joined inside the step)
+            step = make_step(model, opt, loss_fun, x, y, join_side=True)
+            for _ in range(2):
+                step()
+            sync()
     if graph:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
@@ -205,33 +249,35 @@ def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False
     dt = total / steps
     gflop = GFLOP_PER_IMAGE.get(arch, 0.0) * batch
     tf = gflop / dt / 1e3
-    traffic = hbm_traffic_per_step(arch, batch)
+    traffic, traffic_src = hbm_traffic_per_step(arch, batch)
     out = {"metric": "%s train images/sec @222x222 B=%d" % (arch, batch), "value": round(n_ranks_seen * batch / dt, 2), "unit": "images/sec",
            "n_gpus": world, "n_ranks_seen": n_ranks_seen, "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup, "dtype": "f32",
            "hip_graph": bool(graph), "scaling": "weak",
            # HIP events around the same K steps on the compute stream (the host clock above is the contract's; the two agree unless
            # the host, not the GPU, is what the loop waits for)
            "device_ms_per_step": round(dev_ev[0].elapsed_time(dev_ev[1]) / steps, 3) if dev_ev is not None else None,
-           "config": {"workload": "fed_run.py train() body, %s classes=7, SGD lr 0.001, one client per GPU%s"
-                      % (arch, ", + 1 FedAvg all-reduce (RCCL) per %d steps" % steps if distributed else "")},
+           "config": {"workload": "fed_run.py train() body, %s classes=%d, SGD lr 0.001, one client per GPU%s"
+                      % (arch, classes, ", + 1 FedAvg all-reduce (RCCL) per %d steps" % steps if distributed else "")},
            "tflops_per_gpu": round(tf, 2), "frac_of_f32_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
            # the step is bounded by the fp32 MFMA time of its 3 GEMMs per conv (SURVEY 8d "Roofline 2"); the BN / element-wise
            # kernels are HBM work on top: traffic = measured HBM bytes per step (PMC), hbm_frac = traffic / step time / 8 TB/s
            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "bound_images_per_s": round(PEAK_F32_MFMA_TFLOPS * 1e3 / GFLOP_PER_IMAGE.get(arch, 1.0), 1),
-                        "traffic": traffic,
+                        "traffic": traffic, "traffic_source": traffic_src,
                         "achieved_GBps": round(traffic / dt / 1e9, 1) if traffic else None,
                         "hbm_frac": round(traffic / dt / 1e9 / PEAK_HBM_GBPS, 4) if traffic else None},
            "final_loss": round(float(loss.detach()), 5)}
+    if graph_choice is not None:
+        out["graph_choice"] = graph_choice
     if distributed:
         out["fedavg_allreduce_ms"] = round(allreduce_ms, 3)
         out["fedavg_bytes"] = int(fed.FlatParams.of(model).n_total * 4)
     if cpu_baseline and rank == 0 and world == 1:
         from oracle import resnet_ref as R
         torch.set_num_threads(host_cores())
-        ref = R.resnet50(7) if arch == "resnet50" else R.resnet18(7)
+        ref = R.resnet50(classes) if arch == "resnet50" else R.resnet18(classes)
         nb, reps = batch, 4            # the metric's own batch; ~10 s of host work on 16 cores
-        xc, yc = R.synth_batch(nb, 222, 7, seed=2)
+        xc, yc = R.synth_batch(nb, 222, classes, seed=2)
         R.train_step(ref, xc[:2], yc[:2], 0.001)
         c0 = time.perf_counter()
         for _ in range(reps):

@@ -278,6 +278,12 @@ def train(model, train_loader, optimizer, loss_fun, client_num, device, args, it
     it = -1
     fused_acc = isinstance(loss_fun, CrossEntropyLoss)
     use_graph = _graph_wanted(args) and fused_acc and logger is None and isinstance(optimizer, SGD)
+    if use_graph:
+        # Captured steps hold raw addresses of the parameter arena.  model.to() above (args.offload_models moves the model to the
+        # CPU and back every epoch), a load-by-assignment or any model.cpu() by the caller re-homes the tensors: re-resolve the
+        # arena FIRST -- FlatParams.of() rebuilds it when the tensors moved and drops the captured steps with it -- instead of
+        # replaying a graph that reads and writes freed memory and silently stops training the live tensors.
+        FlatParams.of(model)
     steps = model.__dict__.setdefault("_ccst_graph_steps", {}) if use_graph else None
     used = set()
     eager_iters, stale_keys = 0, False

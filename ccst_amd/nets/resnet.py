@@ -94,6 +94,8 @@ class Conv2d(nn.Conv2d):
         # x is the ReLU output of the previous block's closing BatchNorm and this conv completes x's gradient (residual sink):
         # hand its mask to the backward (nn_ops.MaskLink)
         link = getattr(x, "_ccst_mask_link", None)
+        if link is not None and not _plain_reader(x):
+            link = None             # someone watches x's gradient (hook / retain_grad): it must be complete and unmasked there
         if link is not None:
             # the residual form goes with a (non-pair) sink, the BatchNorm + ReLU form with a conv that is x's only reader (no sink)
             # (sole_reader: the caller -- a block's forward -- vouches that nothing else reads x, so x's gradient is this conv's alone)
@@ -137,9 +139,18 @@ USE_GRAD_SINK = os.environ.get("CCST_GRAD_SINK", "1") != "0"
 FUSED_STEM = os.environ.get("CCST_FUSED_STEM", "1") != "0"      # bn1 + relu + maxpool of the stem as one op in training
 
 
+def _plain_reader(x):
+    """The gradient short-cuts between blocks (GradSink, MaskLink) hand x's gradient from one backward node straight to another:
+    what autograd itself sees for x is then partial (one branch's share) or already masked.  That is only sound while nothing
+    else looks at it, so a tensor hook or retain_grad() on x -- a feature tap registered on a block output, e.g. from a module
+    forward hook -- switches the short-cuts off for the block that reads x."""
+    return not (x.retains_grad or x._backward_hooks)
+
+
 def _pair_sink(block, x):
     """The GradSink shared by the two convolutions that read x in a block with a downsample branch (see nn_ops.GradSink)."""
-    if USE_GRAD_SINK and block.downsample is not None and block.training and torch.is_grad_enabled() and x.requires_grad:
+    if USE_GRAD_SINK and block.downsample is not None and block.training and torch.is_grad_enabled() and x.requires_grad \
+            and _plain_reader(x):
         return nn_ops.GradSink(pair=True)
     return None
 
@@ -148,7 +159,7 @@ def _residual_sink(block, x, first_conv):
     """A GradSink when the block's identity branch is x itself, x needs a gradient and the first conv has stride 1
     (then d(identity) and the first conv's dX have the same shape and the conv can add to it in place)."""
     if USE_GRAD_SINK and block.downsample is None and block.training and torch.is_grad_enabled() and x.requires_grad \
-            and first_conv.stride[0] == 1:
+            and first_conv.stride[0] == 1 and _plain_reader(x):
         return nn_ops.GradSink()
     return None
 
@@ -326,6 +337,7 @@ class ResNet(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self.__dict__.pop("_ccst_nbt", None)
+        self.__dict__.pop("_ccst_graph_steps", None)      # captured train steps (fed.train) hold addresses of the tensors being moved
         return super()._apply(fn, *a, **k)
 
 

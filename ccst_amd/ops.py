@@ -559,5 +559,12 @@ def chan_sums(feat):
     s = torch.empty((1, C, 1, 1), device=feat.device, dtype=torch.float32)
     q = torch.empty((1, C, 1, 1), device=feat.device, dtype=torch.float32)
     ws, nb = _stats_ws(N, C, H * W, feat.device)
-    check(_lib.load().ccst_chan_sums_f32(ptr(buf), ptr(s), ptr(q), N, C, H * W, layout, ptr(ws), nb, stream_ptr()), "chan_sums")
+    if TIMING is None:
+        check(_lib.load().ccst_chan_sums_f32(ptr(buf), ptr(s), ptr(q), N, C, H * W, layout, ptr(ws), nb, stream_ptr()), "chan_sums")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().ccst_chan_sums_f32(ptr(buf), ptr(s), ptr(q), N, C, H * W, layout, ptr(ws), nb, stream_ptr()), "chan_sums")
+        e1.record()
+        TIMING.append(("chan_sums", 0.0, e0, e1, "n%d c%d hw%d bytes%d" % (N, C, H * W, 4 * N * C * H * W)))
     return s, q, N * H * W

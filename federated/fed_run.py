@@ -195,16 +195,23 @@ def main():
                 dist.all_reduce(t)
                 val_acc_sum = float(t)
             val_class_acc_average = val_acc_sum / client_num
+            # does this round write a checkpoint?  val_class_acc_average is all-reduced, so every rank takes the same decision
+            # without another collective (best_val_class_acc is tracked on every rank for that)
+            will_save = (a_iter % args.save_freq == 0 and a_iter > 0) or val_class_acc_average > best_val_class_acc
             client_states = None
-            if fedbn and world > 1:     # one client per rank: rank 0 collects every client's state for the checkpoint (:735-739)
+            if fedbn and world > 1 and will_save:
+                # one client per rank: rank 0 collects every client's state for the checkpoint (:735-739) -- K x 94 MB over RCCL plus K
+                # device-to-host copies, so only on the rounds that use it
                 client_states = fed.gather_client_states(models[rank])
+            if rank != 0 and val_class_acc_average > best_val_class_acc:
+                best_val_class_acc = val_class_acc_average
             if rank == 0:
                 print("-------------Test server model on target domain testset----------------")
                 test_loss, test_acc = fed.test(srv, target_test_loader, loss_fun, device, args)
                 log(' {:<11s}| Global Test Loss: {:.4f}'.format(args.target, test_loss))
                 log(' {:<11s}| Global Test Class Acc: {:.4f}'.format(args.target, test_acc))
-                ckpt = {'server_model': {k: v.detach().cpu() for k, v in srv.state_dict().items()}, 'a_iter': a_iter}
-                if fedbn:       # :735-739
+                ckpt = {'server_model': {k: v.detach().cpu() for k, v in srv.state_dict().items()}, 'a_iter': a_iter} if will_save else None
+                if fedbn and will_save:       # :735-739
                     if client_states is not None:
                         for ci, sd in enumerate(client_states):
                             ckpt['model_{}'.format(ci)] = sd

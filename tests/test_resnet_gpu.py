@@ -378,8 +378,8 @@ def test_resnet50_step_golden(dev, golden):
 def test_resnet50_full_size_step_vs_oracle(dev):
     """BASELINE config 4 at its own size -- ResNet50, B=64, 222x222, SGD lr 0.001 (SURVEY 8d "Synthetic inputs 2") -- one
     whole train step against ONE step of the CPU oracle (pinned bit-for-bit to the reference's ResNet / train(), see
-    tests/test_oracle_golden.py): train-mode logits, loss, accuracy count, every BN's running statistics and the post-step
-    eval-mode logits, all at 1e-3."""
+    tests/test_oracle_golden.py): train-mode logits, loss, accuracy count, ALL 161 gradient tensors, every BN's running
+    statistics, every updated weight and the post-step eval-mode logits, all at 1e-3."""
     from ccst_amd import fed
     from ccst_amd.nets import models
     from oracle import resnet_ref as R
@@ -390,6 +390,10 @@ def test_resnet50_full_size_step_vs_oracle(dev):
     oracle.load_state_dict(sd)
     x, y = R.synth_batch(nb, 222, classes, seed=78)
     loss_ref, logit_ref = R.train_step(oracle, x, y, lr)
+    grads_ref = {k: p.grad.clone() for k, p in oracle.named_parameters()}          # (train_step leaves .grad in place)
+    # what fp32 rounding alone costs on each gradient tensor: the oracle's own fp32 step against its fp64 step on these weights
+    # and this batch (tools/make_resnet_grad_noise.py; ~10 minutes of CPU, hence a fixture)
+    noise = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "resnet50_fullsize_grad_noise.npz"))
     oracle.eval()
     with torch.no_grad():
         after_ref = oracle(x[:16])
@@ -401,6 +405,23 @@ def test_resnet50_full_size_step_vs_oracle(dev):
     logit = model(x.to(dev))
     loss = ce(logit, y.to(dev))
     loss.backward()
+    # every one of the 161 gradient tensors, element by element and in the 2-norm, against the oracle's: within 1e-3 of the
+    # tensor's largest gradient (norm) plus 8x what the reference's OWN fp32 run loses against fp64 on that tensor -- two fp32
+    # evaluations differ by the sum of their rounding errors, and single elements sit behind ~50 ReLU / max-pool masks.  (The
+    # step's lr = 1e-3 would hide a gradient error of 1.0 in the weight comparison further down.)
+    n_checked, worst = 0, (0.0, "")
+    for k, prm in model.named_parameters():
+        g32 = grads_ref[k]
+        dg = prm.grad.detach().cpu() - g32
+        d_max, d_l2 = float(dg.abs().max()), float(dg.double().norm())
+        gmax, gl2 = float(noise["gmax/" + k]), float(noise["g_l2/" + k])
+        assert abs(float(g32.abs().max()) - gmax) <= 1e-3 * gmax + float(noise["noise_max/" + k]), k    # the fixture is of THIS step
+        assert d_max <= 1e-3 * gmax + 8.0 * float(noise["noise_max/" + k]), (k, d_max, float(noise["noise_max/" + k]), gmax)
+        assert d_l2 <= 1e-3 * gl2 + 8.0 * float(noise["noise_l2/" + k]), (k, d_l2, float(noise["noise_l2/" + k]), gl2)
+        worst = max(worst, (d_l2 / gl2, k))
+        n_checked += 1
+    print("worst relative 2-norm gradient difference: %.3g (%s)" % worst)
+    assert n_checked == len(grads_ref) == 161
     opt.step()
     assert float(logit_ref.abs().max()) > 0.5                                      # the 1e-3 below is not vacuous
     assert float((logit.detach().cpu() - logit_ref).abs().max()) < 1e-3
@@ -556,6 +577,81 @@ def test_offload_models_round_trip_keeps_training(dev):
     assert out[True][0][2][0] != out[True][0][0][0]                    # the second epoch saw updated weights
     for k, v in out[False][1].items():
         assert torch.equal(v, out[True][1][k]), k
+
+
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_gradient_shortcuts_on_vs_off(dev, arch):
+    """The gradient short-cuts between blocks -- GradSink (the first conv's backward-data adds to the identity branch's gradient in
+    place), MaskLink (the closing BatchNorm's ReLU mask applied by the next block's conv epilogue) and its partial-sum variant --
+    against the same step with all of them off (autograd's own add, masks in the BatchNorm backward): every parameter gradient
+    within 2e-5 of the tensor's largest entry (the two orders of summation differ by fp32 rounding only).  And the reader
+    contract: a tensor hook on a block output switches the short-cuts off for the block that reads it, so the hook
+    sees the complete gradient."""
+    from ccst_amd import fed, nn_ops
+    from ccst_amd.nets import models, resnet
+    from oracle import resnet_ref as R
+    classes, nb = 7, 4
+    sd = R.seeded_state_dict(R.resnet18(classes) if arch == "resnet18" else R.resnet50(classes), 55, residual_gamma=0.25, fc_gain=8.0)
+    x, y = R.synth_batch(nb, 222, classes, seed=56)
+    x, y = x.to(dev), y.to(dev)
+    saved = (nn_ops.MASK_LINK, nn_ops.MASK_LINK_STATS, resnet.USE_GRAD_SINK)
+
+    def run(on, tap=False):
+        nn_ops.MASK_LINK, nn_ops.MASK_LINK_STATS, resnet.USE_GRAD_SINK = on, on, on
+        model = models.get_network(arch)(ARGS, pretrained=False, classes=classes)
+        model.load_state_dict(sd)
+        model.to(dev).train()
+        seen = {}
+        if tap:     # a feature tap on layer1's output, registered the way DG methods do it: from a module forward hook
+            def tap_hook(_m, _i, o):
+                o.register_hook(lambda g: seen.__setitem__("g", g.detach().clone()))       # (returns None: the output stays the output)
+            model.layer1.register_forward_hook(tap_hook)
+        ce = fed.CrossEntropyLoss()
+        model.zero_grad()
+        loss = ce(model(x), y)
+        loss.backward()
+        return {k: p.grad.detach().clone() for k, p in model.named_parameters()}, seen.get("g")
+    try:
+        g_on, _ = run(True)
+        g_off, _ = run(False)
+        g_tap, seen_on = run(True, tap=True)
+        _, seen_off = run(False, tap=True)
+    finally:
+        nn_ops.MASK_LINK, nn_ops.MASK_LINK_STATS, resnet.USE_GRAD_SINK = saved
+    for k in g_off:
+        tol = 2e-5 * float(g_off[k].abs().max()) + 1e-9
+        assert float((g_on[k] - g_off[k]).abs().max()) <= tol, k
+        assert float((g_tap[k] - g_off[k]).abs().max()) <= tol, k
+    assert seen_on is not None and seen_off is not None
+    assert float((seen_on - seen_off).abs().max()) <= 2e-5 * float(seen_off.abs().max())      # complete and unmasked, as autograd defines it
+
+
+def test_offload_models_with_hip_graph_recaptures(dev):
+    """with --hip_graph the captured train steps hold raw addresses of the parameter arena.  args.offload_models moves
+    the model to the CPU and back between train() calls, so the second call must NOT replay the first call's graphs (they would
+    read and write freed memory and leave the live tensors untrained): the arena is re-resolved before the cache is read, the
+    cache dropped with it, and the result stays bit-identical to the resident eager run."""
+    from ccst_amd import fed
+    from ccst_amd.nets import resnet
+    from oracle import resnet_ref as R
+    loader = [R.synth_batch(4, 222, 3, seed=600 + i) for i in range(5)]       # 2 eager iterations, then capture + replays
+    out = {}
+    for offload, graph in ((False, False), (True, True), (False, True)):
+        args = types.SimpleNamespace(dg_method="", mode="fedavg", offload_models=offload, hip_graph=graph)
+        m = resnet.ResNet(resnet.BasicBlock, [1, 1, 1, 1], classes=3)
+        m.load_state_dict(R.seeded_state_dict(R.ResNet(R.BasicBlock, [1, 1, 1, 1], classes=3), 93))
+        opt = fed.SGD(m, lr=0.01)
+        ce = fed.CrossEntropyLoss()
+        r = [fed.train(m, loader, opt, ce, 1, dev, args, 0, None), fed.train(m, loader, opt, ce, 1, dev, args, 1, None)]
+        if graph and not offload:
+            assert m.__dict__.get("_ccst_graph_steps"), "the resident model keeps its captured steps across train() calls"
+        out[(offload, graph)] = (r, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    ref = out[(False, False)]
+    assert ref[0][1][0] != ref[0][0][0]                                        # the second epoch saw updated weights
+    for key in ((True, True), (False, True)):
+        assert out[key][0] == ref[0], key
+        for k, v in ref[1].items():
+            assert torch.equal(v, out[key][1][k]), (key, k)
 
 
 def test_test_fedbn_merge_and_eval(dev):

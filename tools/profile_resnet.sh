@@ -15,23 +15,40 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/bench_write.log 2>&1
 cd $ROOT
 python3 tools/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
-python3 - "$OUT" "$ARCH" "$BATCH" "$((STEPS + WARM))" <<'PY'
-import csv, glob, json, os, sys
-out, arch, batch, nsteps = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+python3 - "$OUT" "$ARCH" "$BATCH" "$((STEPS + WARM))" "$ROOT" <<'PY'
+import csv, datetime, glob, json, os, sys
+from collections import defaultdict
+out, arch, batch, nsteps, root = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+# Per kernel: dispatches of the steady-state steps only.  A kernel that runs k times per step shows k * nsteps dispatches (+ extras in
+# step 0: the one-off weight packs, first-touch fills); keep the LAST k * (nsteps - 1) of them, k = count // nsteps, and drop kernels
+# that do not run every step (count < nsteps).  FETCH_SIZE x2 per the gfx950 correction of MI355X_MICROARCH.md.
 tot = {}
-for sub, ctr, mult in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SIZE", 1.0)):     # gfx950: FETCH_SIZE x2 (MI355X_MICROARCH.md)
+for sub, ctr, mult in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SIZE", 1.0)):
     fs = glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True)
     if not fs:
         continue
-    s = 0.0
+    per = defaultdict(list)
     with open(fs[0]) as fh:
         for r in csv.DictReader(fh):
             if r.get("Counter_Name") == ctr:
-                s += float(r["Counter_Value"])
-    tot[ctr] = s * mult * 1024.0 / nsteps          # counters are in KB; every launch of the run / (warm-up + timed) steps
+                per[r["Kernel_Name"]].append((int(r.get("Dispatch_Id", 0)), float(r["Counter_Value"])))
+    s = 0.0
+    for name, rows in per.items():
+        k = len(rows) // nsteps
+        if k == 0 or "pack_weight" in name:
+            continue
+        rows.sort()
+        s += sum(v for _, v in rows[-k * (nsteps - 1):])
+    tot[ctr] = s * mult * 1024.0 / (nsteps - 1)          # counters are in KB
 if tot:
+    try:
+        stamp = open(os.path.join(root, "ccst_amd", "csrc", ".build_stamp")).read().strip()[:16]
+    except OSError:
+        stamp = None
     res = {"%s_b%d" % (arch, batch): round(sum(tot.values())), "detail_bytes_per_step": {k: round(v) for k, v in tot.items()},
-           "steps_in_run": nsteps, "note": "FETCH_SIZE x2 + WRITE_SIZE over every kernel of the run / steps (includes the one-off weight packs of step 0)"}
+           "steps_in_run": nsteps, "build_stamp": stamp, "date": datetime.date.today().isoformat(),
+           "profile": os.path.basename(out.rstrip("/")) + "/summary.txt",
+           "note": "FETCH_SIZE x2 + WRITE_SIZE over the kernels of the steady-state steps (step 0 and the one-off weight packs excluded) / (steps - 1)"}
     json.dump(res, open(os.path.join(out, "traffic_resnet.json"), "w"), indent=1)
     print(json.dumps(res))
 PY

@@ -69,5 +69,16 @@ for sub, ctr, mult in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SI
     for k, v in acc.items():
         traffic.setdefault(k, {})[ctr] = v[1] / v[0] * mult * 1024.0
 if traffic:
+    import datetime
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        with open(os.path.join(root, "ccst_amd", "csrc", ".build_stamp")) as fh:
+            stamp = fh.read().strip()[:16]
+    except OSError:
+        stamp = None
+    res = {k: dict(v, total_bytes_per_launch=sum(v.values())) for k, v in traffic.items() if "conv" in k or "adain" in k or "partials" in k or "chan_sums" in k}
+    # provenance: bench.py reports these bytes only while the running build is the profiled one
+    res["_source"] = {"build_stamp": stamp, "date": datetime.date.today().isoformat(), "profile": os.path.basename(out.rstrip("/")) + "/summary.txt",
+                      "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950), per-launch average"}
     with open(os.path.join(out, "traffic.json"), "w") as fh:
-        json.dump({k: dict(v, total_bytes_per_launch=sum(v.values())) for k, v in traffic.items() if "conv" in k or "adain" in k or "partials" in k}, fh, indent=1)
+        json.dump(res, fh, indent=1)
