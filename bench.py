@@ -245,7 +245,24 @@ def main():
             for _ in range(reps):
                 fn()
             rates.append(reps * B / (time.perf_counter() - c0))
+        # the same loop with its edges overlapped (style.StylePipeline, what the stage-2 CLI runs): H2D of batch k+1 and the quantise +
+        # D2H of batch k-1 on their own streams under the compute of batch k
+        pipe = style.StylePipeline(vgg31, dec, dev)
+        nb = 4 * reps
+
+        def feed(n):
+            for _ in range(n):
+                yield host_in, None
+        for _u8, _m in pipe.run(feed(3), stat, 1.0):
+            pass
+        c0 = time.perf_counter()
+        for _u8, _m in pipe.run(feed(nb), stat, 1.0):
+            pass
+        rate_pipe = nb * B / (time.perf_counter() - c0)
         e2e = {"images_per_s": round(rates[0], 2), "images_per_s_u8_output": round(rates[1], 2), "batches": reps,
+               "images_per_s_overlapped_u8": round(rate_pipe, 2), "overlapped_batches": nb,
+               "overlapped_note": "style.StylePipeline: pinned H2D of batch k+1 and quantise + D2H of batch k-1 on their own HIP streams under "
+                                  "the compute of batch k (3 slots); every batch's bytes reach the host",
                "h2d_bytes_per_batch": int(host_in.numel() * 4), "d2h_bytes_per_batch": int(host_out.numel() * 4),
                "note": "serial per batch: pinned H2D -> style_transfer -> D2H -> sync; u8 variant = save_image quantisation on the GPU"}
 

@@ -34,7 +34,18 @@ __global__ __launch_bounds__(TPB) void partials_nhwc_kernel(const float* __restr
         const float* base = x + ((long long)n * HW) * C + cg * 4;
         f32x4 pv = {0, 0, 0, 0};
         if (SHIFT) pv = *reinterpret_cast<const f32x4*>(base + (long long)p0 * C);
-        for (int p = p0 + pl; p < p1; p += PL) {
+        // four pixels in flight per thread: one load per iteration is a chain of HBM latencies (0.85 TB/s on the 268 MB relu4_1 batch
+        // of stage 1); the partial sums stay in pixel order (s0 + s1) + (s2 + s3) per iteration -- fixed, so reproducible
+        int p = p0 + pl;
+        for (; p + 3 * PL < p1; p += 4 * PL) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(base + (long long)p * C) - pv;
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(base + (long long)(p + PL) * C) - pv;
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(base + (long long)(p + 2 * PL) * C) - pv;
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(base + (long long)(p + 3 * PL) * C) - pv;
+            s += (v0 + v1) + (v2 + v3);
+            q += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+        }
+        for (; p < p1; p += PL) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)p * C) - pv;
             s += v;
             q += v * v;
@@ -151,19 +162,46 @@ __global__ __launch_bounds__(256) void finalize_mean_std_kernel(const float* __r
     }
 }
 
-// per-channel totals over n and splits (calc_sum)
-__global__ void finalize_chan_sums_kernel(const float* __restrict__ part, float* __restrict__ sum, float* __restrict__ sq, int N,
-                                          int C, int S) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// per-channel totals over n and splits (calc_sum): a workgroup owns 16 channels, 16 slice-lanes per channel each fold every 16th
+// (n, split) partial in fp64 (consecutive threads read consecutive channels of one partial), then the lanes in fixed order
+__global__ __launch_bounds__(256) void finalize_chan_sums_kernel(const float* __restrict__ part, float* __restrict__ sum, float* __restrict__ sq,
+                                                                 int N, int C, int S) {
+    __shared__ double red[2][16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s = 0.0, q = 0.0;
-    for (int k = 0; k < N * S; ++k) {
-        const float* o = part + ((long long)k * C + c) * 2;
-        s += (double)o[0];
-        q += (double)o[1];
+    if (c < C) {
+        const int K = N * S;
+        int k = sl;
+        for (; k + 48 < K; k += 64) {            // four loads in flight (L2 latency), folded in index order
+            const float2 o0 = *reinterpret_cast<const float2*>(part + ((long long)k * C + c) * 2);
+            const float2 o1 = *reinterpret_cast<const float2*>(part + ((long long)(k + 16) * C + c) * 2);
+            const float2 o2 = *reinterpret_cast<const float2*>(part + ((long long)(k + 32) * C + c) * 2);
+            const float2 o3 = *reinterpret_cast<const float2*>(part + ((long long)(k + 48) * C + c) * 2);
+            s += (double)o0.x; q += (double)o0.y;
+            s += (double)o1.x; q += (double)o1.y;
+            s += (double)o2.x; q += (double)o2.y;
+            s += (double)o3.x; q += (double)o3.y;
+        }
+        for (; k < K; k += 16) {
+            const float2 o = *reinterpret_cast<const float2*>(part + ((long long)k * C + c) * 2);
+            s += (double)o.x;
+            q += (double)o.y;
+        }
     }
-    sum[c] = (float)s;
-    sq[c] = (float)q;
+    red[0][sl][cl] = s;
+    red[1][sl][cl] = q;
+    __syncthreads();
+    if (sl == 0 && c < C) {
+        double ts = 0.0, tq = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            ts += red[0][k][cl];
+            tq += red[1][k][cl];
+        }
+        sum[c] = (float)ts;
+        sq[c] = (float)tq;
+    }
 }
 
 __device__ __forceinline__ float adain_one(float x, float mu, float sd, float sm, float ss, float alpha, bool blend) {
@@ -307,9 +345,9 @@ __global__ __launch_bounds__(FP_T) void adain_fused_nhwc_kernel(const float* __r
 }
 
 int pick_splits(int N, int C, int HW, int layout) {
-    // aim for ~1024 workgroups, at least ~8 pixels (NHWC) / 1024 elements (NCHW) per split
+    // aim for ~2048 workgroups (8 per CU, four 16-byte loads in flight per thread), at least ~8 pixels (NHWC) / 1024 elements (NCHW) per split
     long long units = (layout == 1) ? (long long)N * ((C / 4 + 255) / 256) : (long long)N * C;
-    long long s = 1024 / (units > 0 ? units : 1);
+    long long s = 2048 / (units > 0 ? units : 1);
     const int minper = (layout == 1) ? 8 : 1024;
     const long long smax = (HW + minper - 1) / minper;
     if (s > smax) s = smax;
@@ -419,6 +457,6 @@ extern "C" int ccst_chan_sums_f32(const float* x, float* sum, float* sqsum, int 
     float* part = (float*)ws;
     rc = run_partials<false>(x, part, N, C, HW, layout, S, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(finalize_chan_sums_kernel, dim3((C + 63) / 64), dim3(64), 0, st, part, sum, sqsum, N, C, S);
+    hipLaunchKernelGGL(finalize_chan_sums_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, sum, sqsum, N, C, S);
     return ccst_launch_status("finalize_chan_sums");
 }

@@ -126,3 +126,87 @@ def save_style_stat(path, mean, std):
 def load_style_stat(path, device):
     stat = np.load(path)
     return [torch.from_numpy(np.ascontiguousarray(s)).float().to(device) for s in stat]
+
+
+class StylePipeline(object):
+    """The stage-2 batch loop with its edges overlapped (CCST_OverallStyleTransfer.py:149-167 runs load -> transfer -> .cpu() ->
+    save strictly in turn): the H2D copy of batch k+1 and the quantise + D2H of batch k-1 run on their own HIP streams under the
+    compute of batch k, from / into pinned host buffers; finished batches are handed to `sink` (e.g. the image writers of
+    data.ImageWriterPool) in order.  Results are the bytes of the serial path (same kernels, same order per batch).
+
+        pipe = StylePipeline(vgg, decoder, device, output_size=-1)
+        for u8, meta in pipe.run(((batch, fpaths) for ...), style_stat, alpha): ...      # u8: [N,H,W,3] uint8 numpy, valid until the next item
+    """
+
+    def __init__(self, vgg, decoder, device, output_size=-1, depth=3, u8=True):
+        # depth 3: before batch k+1 can be staged its slot's previous result (batch k-2) is handed out -- finished long ago -- so the
+        # host queues batch k's kernels while the GPU still runs batch k-1 (with 2 slots it would first wait for batch k-1 itself)
+        self.vgg, self.decoder, self.device = vgg, decoder, torch.device(device)
+        self.output_size, self.depth, self.u8 = output_size, max(2, int(depth)), u8
+        self.h2d = torch.cuda.Stream(device=self.device)
+        self.d2h = torch.cuda.Stream(device=self.device)
+        self.slots = [dict(pin_in=None, dev_in=None, pin_out=None, ev_in=torch.cuda.Event(), ev_c=torch.cuda.Event(),
+                           ev_out=torch.cuda.Event(), meta=None, busy=False) for _ in range(self.depth)]
+
+    def _stage_in(self, slot, batch):
+        if slot["pin_in"] is None or slot["pin_in"].shape != batch.shape:
+            slot["pin_in"] = torch.empty(batch.shape, dtype=batch.dtype).pin_memory()
+            slot["dev_in"] = torch.empty(batch.shape, dtype=batch.dtype, device=self.device)
+        src = batch
+        if not batch.is_pinned():
+            slot["pin_in"].copy_(batch)
+            src = slot["pin_in"]
+        with torch.cuda.stream(self.h2d):
+            self.h2d.wait_event(slot["ev_c"])      # the slot's previous batch has been consumed by its kernels
+            slot["dev_in"].copy_(src, non_blocking=True)
+            slot["ev_in"].record(self.h2d)
+        slot["keep"] = src                     # the pinned source stays alive until the copy has run
+
+    def _compute(self, slot, style_stat, alpha):
+        from . import data as cdata
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(slot["ev_in"])
+        with torch.no_grad():
+            out = style_transfer(self.vgg, self.decoder, slot["dev_in"], style_stat, alpha)
+            if self.output_size and self.output_size > 0:
+                out = cdata.resize_tensor(out, self.output_size)
+            res = cdata.quantize_u8(out) if self.u8 else out
+        slot["ev_c"].record(cur)
+        if slot["pin_out"] is None or slot["pin_out"].shape != res.shape or slot["pin_out"].dtype != res.dtype:
+            slot["pin_out"] = torch.empty(res.shape, dtype=res.dtype).pin_memory()
+        with torch.cuda.stream(self.d2h):
+            self.d2h.wait_event(slot["ev_c"])
+            slot["pin_out"].copy_(res, non_blocking=True)
+            slot["ev_out"].record(self.d2h)
+        res.record_stream(self.d2h)            # the allocator must not hand `res` out again before the copy has read it
+
+    def run(self, batches, style_stat, alpha=1.0):
+        """batches: iterable of (CPU tensor [N,3,H,W], meta).  Yields (numpy view of the pinned result, meta) in order; a view is
+        valid until the generator is advanced again (its pinned buffer is reused)."""
+        it = iter(batches)
+        pending = []                               # slots with a batch in flight, oldest first
+        i = 0
+        nxt = next(it, None)
+        if nxt is not None:
+            self._stage_in(self.slots[0], nxt[0])
+            self.slots[0]["meta"] = nxt[1]
+        while nxt is not None:
+            slot = self.slots[i % self.depth]
+            nxt = next(it, None)
+            if nxt is not None:                    # batch k+1 goes up while batch k computes
+                s2 = self.slots[(i + 1) % self.depth]
+                if s2["busy"]:                     # its previous result has not been handed out yet
+                    done = pending.pop(0)
+                    done["ev_out"].synchronize()
+                    done["busy"] = False
+                    yield done["pin_out"].numpy(), done["meta_out"]
+                self._stage_in(s2, nxt[0])
+                s2["meta"] = nxt[1]
+            self._compute(slot, style_stat, alpha)
+            slot["busy"], slot["meta_out"] = True, slot["meta"]
+            pending.append(slot)
+            i += 1
+        for done in pending:
+            done["ev_out"].synchronize()
+            done["busy"] = False
+            yield done["pin_out"].numpy(), done["meta_out"]

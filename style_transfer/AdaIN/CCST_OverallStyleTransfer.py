@@ -22,6 +22,7 @@ from ccst_amd import data, style
 parser = base_parser(image_size_default=512)
 parser.add_argument('--output_size', type=int, default=-1, help='transform images into final size')
 parser.add_argument('--no_save', action='store_true', help='skip PIL encoding (throughput runs)')
+parser.add_argument('--serial', action='store_true', help="the reference's serial batch loop instead of the overlapped pipeline (same images)")
 parser.add_argument('--fuse_stats', action='store_true', help='compute missing style statistics in-process (stage 1 + 2 fused)')
 parser.add_argument('--refresh_stats', action='store_true', help='with --fuse_stats: recompute even if the .npy cache exists')
 args = parser.parse_args()
@@ -38,6 +39,8 @@ if world > 1 and args.fuse_stats:
     dist.init_process_group(backend="nccl", device_id=device)       # only the fused statistics need a collective
 
 vgg, decoder = load_networks(args, device)
+pipeline = None if args.serial else style.StylePipeline(vgg, decoder, device, output_size=args.output_size)
+writers = None if (args.serial or args.no_save) else data.ImageWriterPool()
 data_loader = data.get_train_dataloader(args, args.txt_root, rank, world)      # this rank's shard of the content list
 
 
@@ -60,14 +63,23 @@ for style_name in style_domains:
     style_stat = style_stat_of(style_name)
     start_time = datetime.now()
     img_count = 0
-    for it, (batch, fpaths) in enumerate(data_loader):
-        img_count += len(batch)
-        with torch.no_grad():
-            output = style.style_transfer(vgg, decoder, batch.to(device), style_stat, args.alpha)
-        print(f"    Target: {args.target}, Style: {style_name}, Iteration: {it}/{len(data_loader)}")
-        if not args.no_save:
-            names = [data.stylised_name(f, args.target, style_name, 'all_style_transferred_Overall') for f in fpaths]
-            data.save_images(output, names, args.output_size)
+    if args.serial:          # the reference's loop shape: load -> transfer -> .cpu() -> save, strictly in turn
+        for it, (batch, fpaths) in enumerate(data_loader):
+            img_count += len(batch)
+            with torch.no_grad():
+                output = style.style_transfer(vgg, decoder, batch.to(device), style_stat, args.alpha)
+            print(f"    Target: {args.target}, Style: {style_name}, Iteration: {it}/{len(data_loader)}")
+            if not args.no_save:
+                names = [data.stylised_name(f, args.target, style_name, 'all_style_transferred_Overall') for f in fpaths]
+                data.save_images(output, names, args.output_size)
+    else:                    # same images, edges overlapped: H2D / quantise + D2H on their own streams, encoding in worker processes
+        for it, (u8, fpaths) in enumerate(pipeline.run(data_loader, style_stat, args.alpha)):
+            img_count += len(u8)
+            print(f"    Target: {args.target}, Style: {style_name}, Iteration: {it}/{len(data_loader)}")
+            if writers is not None:
+                writers.submit(u8, [data.stylised_name(f, args.target, style_name, 'all_style_transferred_Overall') for f in fpaths])
+        if writers is not None:
+            writers.drain()
     torch.cuda.synchronize()
     end_time = datetime.now()
     if rank == 0:
@@ -76,6 +88,8 @@ for style_name in style_domains:
             f.write(f"Images number: {img_count}\n")
             f.write(f"Image resolution: {args.image_size}\n")
             f.write(f"Batch_size: {args.batch}\n")
+if writers is not None:
+    writers.close()
 print(f"Target {args.target}: Finished in {(end_time - start_time).seconds} seconds")
 if world > 1 and args.fuse_stats:
     dist.barrier()

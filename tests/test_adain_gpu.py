@@ -706,3 +706,24 @@ def test_wide_dynamic_range_path(dev, A):
         fmax, float(f_gpu.abs().max()), float(ref64.abs().max()), e_gpu, e_cpu))
     assert e_gpu < 1e-3, e_gpu
     assert float((f_gpu.cpu().double() - A.encoder(content.double(), {k: v.double() for k, v in vgg_w.items()})).abs().max()) < 1e-3 * fmax
+
+
+def test_style_pipeline_matches_serial_loop(dev, nets, A):
+    """style.StylePipeline (H2D, compute, quantise + D2H overlapped over three slots) hands out, in order, exactly the bytes of the
+    serial loop: batches of different sizes (the last batch of a list is short), more batches than slots, --output_size resize."""
+    from ccst_amd import data as cdata, style
+    vgg31, dec, _, _ = nets
+    stat = [t.to(dev) for t in A.synth_style_stat(512, seed=13)]
+    batches = [(A.synth_content(n, 64, 96, seed=70 + i), "b%d" % i) for i, n in enumerate((3, 3, 3, 3, 3, 2, 1))]
+    for osz in (-1, 48):
+        pipe = style.StylePipeline(vgg31, dec, dev, output_size=osz)
+        got = [(u8.copy(), meta) for u8, meta in pipe.run(iter(batches), stat, 0.7)]
+        assert [m for _, m in got] == [m for _, m in batches]
+        for (u8, _), (x, _) in zip(got, batches):
+            with torch.no_grad():
+                out = style.style_transfer(vgg31, dec, x.to(dev), stat, 0.7)
+                if osz > 0:
+                    out = cdata.resize_tensor(out, osz)
+                ref = cdata.quantize_u8(out).cpu().numpy()
+            assert u8.shape == ref.shape and (u8 == ref).all()
+    assert list(pipe.run(iter([]), stat, 1.0)) == []
