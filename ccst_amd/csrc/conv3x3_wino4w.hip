@@ -41,6 +41,7 @@ struct W4wArgs {
     long long ysN;
     int ysH, ysW;                                  // output strides (of the pooled tensor when POOL)
     int tilesX, tilesY, tilesN, ntiles;
+    unsigned long long mN, mX, mY;                 // ceil(2^36 / tiles*): exact quotients for tile ids < 2^24 without a division
 };
 
 constexpr int NTW = 256;                           // threads per workgroup: four waves, one per SIMD
@@ -52,6 +53,7 @@ constexpr int ROWPW = 4 * PLANEW + 8;              // 728 floats per halo row
 constexpr int HIMGW = HHW * ROWPW;                 // 13104 floats = 52.4 KB per buffer
 constexpr int EXW_BYTES = 36 * 32 * 32 * 4;        // epilogue exchange: [position][channel][32 tiles] = 147456 B
 static_assert(2 * HIMGW * 4 <= EXW_BYTES, "the halo buffers live inside the exchange area");
+constexpr int MBW_BYTES = 4096 + 4 * 128;          // mailbox behind the exchange area: the NEXT tile's staging set-up (see wino4w_body)
 constexpr unsigned OOBW = 0x40000000u;             // a byte offset beyond any image (images are < 2^30 bytes): the buffer load returns 0
 
 __device__ __forceinline__ int reflectw(int i, int n) {
@@ -138,6 +140,103 @@ template <bool POOL, int RB, int CB>
 __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict__ lds) {
     float* const Hs0 = lds;
     float* const Hs1 = lds + HIMGW;
+    constexpr int rq = RB;                                                       // row parity of this wave's halo rows (wave = 2 RB + CB)
+
+    // tile id -> TileW (threads 0..127 walk the even halo rows, 128..255 the odd ones, nine each: thread = (pixel column hx = 0..31,
+    // 4-channel part); pixel columns 32, 33 (8 units x 18 rows) are one extra unit on threads 0..143)
+    // (plain locals, not a struct: an aggregate with an array and a buffer resource that is copied at the end of an iteration stays
+    //  in scratch memory, its loads count as divergent, and every buffer load with a row offset becomes a waterfall loop)
+    auto setup = [&](int tile, const W4wArgs& p, int tid, int& t_tn, int& t_n, int& t_co0, int& t_oy0, int& t_ox0, __amdgpu_buffer_rsrc_t& t_xrs,
+                     unsigned (&t_srow)[9], unsigned& t_rowbad, unsigned& t_voff, unsigned& t_voffx, int& t_hdst, int& t_hdstx) {
+        // (three runtime integer divisions cost ~1500 cycles of the tile's set-up: multiply by ceil(2^36 / d) instead, exact for
+        //  ids < 2^24 and d <= 4096, both checked by the launcher)
+        auto divmod = [](int a, int d, unsigned long long m, int& r) {
+            const int q = (int)(((unsigned long long)(unsigned)a * m) >> 36);
+            r = a - q * d;
+            return q;
+        };
+        int bid = ccst_xcd_remap(tile, pk.ntiles), tx, ty;
+        bid = divmod(bid, p.tilesN, p.mN, t_tn);
+        bid = divmod(bid, p.tilesX, p.mX, tx);
+        t_n = divmod(bid, p.tilesY, p.mY, ty);
+        t_co0 = t_tn * 64;
+        t_oy0 = ty * THW;
+        t_ox0 = tx * TWW;
+        const int oy0_ = t_oy0, ox0_ = t_ox0;
+        t_xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + (long long)t_n * p.Hs * p.Ws * p.Cin, 0,
+                                                  (int)((unsigned)p.Hs * p.Ws * p.Cin * 4u), 0x00020000);
+        auto src_x = [&](int hx, bool& ok) {
+            int gx = ox0_ + hx - 1;
+            ok = true;
+            if (p.reflect) {
+                gx = reflectw(gx, p.W);
+            } else {
+                ok = (gx >= 0) & (gx < p.W);
+                gx = min(max(gx, 0), p.W - 1);
+            }
+            return gx >> p.ups;
+        };
+        auto src_y = [&](int hy, bool& ok) {
+            int gy = oy0_ + hy - 1;
+            ok = true;
+            if (p.reflect) {
+                gy = reflectw(gy, p.H);
+            } else {
+                ok = (gy >= 0) & (gy < p.H);
+                gy = min(max(gy, 0), p.H - 1);
+            }
+            return gy >> p.ups;
+        };
+        unsigned bad = 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            bool ok;
+            const int gy = src_y(rq + 2 * i, ok);
+            t_srow[i] = (unsigned)__builtin_amdgcn_readfirstlane((gy * p.Ws * p.Cin) * 4);
+            bad |= ok ? 0u : (1u << i);
+        }
+        t_rowbad = (unsigned)__builtin_amdgcn_readfirstlane((int)bad);
+        {
+            const int idx = tid & 127, hx = idx >> 2, part = idx & 3;
+            bool ok;
+            const int gx = src_x(hx, ok);
+            t_voff = ok ? (unsigned)((gx * p.Cin + part * 4) * 4) : OOBW;
+            t_hdst = rq * ROWPW + (hx & 3) * PLANEW + (hx >> 2) * PITW + part * 4;
+        }
+        t_voffx = OOBW;
+        t_hdstx = 0;
+        if (tid < 8 * HHW) {
+            const int hy = tid >> 3, hx = 32 + ((tid >> 2) & 1), part = tid & 3;
+            bool okx, oky;
+            const int gx = src_x(hx, okx), gy = src_y(hy, oky);
+            t_voffx = (okx & oky) ? (unsigned)(((gy * p.Ws + gx) * p.Cin + part * 4) * 4) : OOBW;
+            t_hdstx = hy * ROWPW + (hx & 3) * PLANEW + (hx >> 2) * PITW + part * 4;
+        }
+    };
+    // A tile's FIRST halo chunk is requested one tile early -- before the previous tile's epilogue, whose output stores would
+    // otherwise sit in front of these loads in the memory pipeline (stamps: 3.6k cycles to issue 28 loads behind the store burst
+    // + 3.6k waiting for them, of a 72k-cycle 64 -> 64 tile) -- into ten registers that live through that epilogue.
+    f32x4 rp[10];
+    auto prefetch = [&](__amdgpu_buffer_rsrc_t xr, const unsigned (&sr)[9], unsigned bad, unsigned vo, unsigned vox, bool has_x) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) rp[i] = bufw_load4(xr, ((bad >> i) & 1) ? OOBW : vo, (unsigned)__builtin_amdgcn_readfirstlane((int)sr[i]));
+        rp[9] = bufw_load4(xr, vox, 0);       // every thread: without an extra unit the offset is out of range and nothing is fetched
+        (void)has_x;                          // (a conditional load leaves a phi that is resolved by copies behind an s_waitcnt vmcnt(0),
+                                              //  and the differing load counts of the two paths make every later wait a full drain)
+    };
+    int c_tn = 0, c_n = 0, c_co0 = 0, c_oy0 = 0, c_ox0 = 0, c_hdst = 0, c_hdstx = 0;
+    unsigned c_srow[9], c_rowbad = 0, c_voff = OOBW, c_voffx = OOBW;
+    __amdgpu_buffer_rsrc_t c_xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pk.x), 0, 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c_srow[i] = 0;
+    {
+        int tid0 = threadIdx.x;
+        asm volatile("" : "+v"(tid0));
+        if ((int)blockIdx.x < pk.ntiles) {
+            setup(blockIdx.x, pk, tid0, c_tn, c_n, c_co0, c_oy0, c_ox0, c_xrs, c_srow, c_rowbad, c_voff, c_voffx, c_hdst, c_hdstx);
+            prefetch(c_xrs, c_srow, c_rowbad, c_voff, c_voffx, tid0 < 8 * HHW);
+        }
+    }
 
     // Persistent workgroups: the grid is one workgroup per CU (a multiple of 8, so that tile ids t and t + 8 still share an XCD) and
     // each walks tiles blockIdx.x, + gridDim.x, ...  The output stores of a tile then drain while the next tile's loop runs; as one
@@ -158,85 +257,18 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);                    // wave 0..3 = (RB, CB)
     const int li = lane & 31, lh = lane >> 5;
 #ifdef ABLW_STAMPS
-    unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(pk.y) + (long long)tile * 8;
+    unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(pk.y) + (long long)tile * 16;
 #define WW_STAMP(k) do { if (tid == 0) stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define WW_STAMP(k) do { } while (0)
 #endif
     WW_STAMP(0);
-    int bid = ccst_xcd_remap(tile, pk.ntiles);
-    const int tn = bid % p.tilesN;
-    bid /= p.tilesN;
-    const int tx = bid % p.tilesX;
-    bid /= p.tilesX;
-    const int ty = bid % p.tilesY;
-    const int n = bid / p.tilesY;
-    const int co0 = tn * 64;
-    const int oy0 = ty * THW, ox0 = tx * TWW;
-
-    // ---- halo staging.  Threads 0..127 walk the even halo rows, 128..255 the odd ones (nine each): thread = (pixel column
-    // hx = 0..31, 4-channel part); the row's byte offset is wave-uniform (scalar registers).  Pixel columns 32, 33 (8 units x 18 rows)
-    // are one extra unit on threads 0..143. -----------------------------------------------------------------------------------------
-    const unsigned img_bytes = (unsigned)p.Hs * p.Ws * p.Cin * 4u;
+    const int tn = c_tn, n = c_n, co0 = c_co0, oy0 = c_oy0, ox0 = c_ox0;
     const int nchunks_ = p.Cin / CKW;
     (void)nchunks_;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) + (long long)n * p.Hs * p.Ws * p.Cin, 0,
-                                                                         (int)img_bytes, 0x00020000);
-    const int rq = wv >> 1;                                                      // row parity of this wave's rows
-    auto src_x = [&](int hx, bool& ok) {
-        int gx = ox0 + hx - 1;
-        ok = true;
-        if (p.reflect) {
-            gx = reflectw(gx, p.W);
-        } else {
-            ok = (gx >= 0) & (gx < p.W);
-            gx = min(max(gx, 0), p.W - 1);
-        }
-        return gx >> p.ups;
-    };
-    auto src_y = [&](int hy, bool& ok) {
-        int gy = oy0 + hy - 1;
-        ok = true;
-        if (p.reflect) {
-            gy = reflectw(gy, p.H);
-        } else {
-            ok = (gy >= 0) & (gy < p.H);
-            gy = min(max(gy, 0), p.H - 1);
-        }
-        return gy >> p.ups;
-    };
-    unsigned srow[9];                                                           // scalar: byte offset of halo row rq + 2 i, or 0 + !ok
-    unsigned rowbad = 0;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        bool ok;
-        const int gy = src_y(rq + 2 * i, ok);
-        srow[i] = (unsigned)(gy * p.Ws * p.Cin) * 4u;
-        rowbad |= ok ? 0u : (1u << i);
-    }
-    const int idx = tid & 127;
-    unsigned voff;
-    int hdst;
-    {
-        const int hx = idx >> 2, part = idx & 3;
-        bool ok;
-        const int gx = src_x(hx, ok);
-        voff = ok ? (unsigned)((gx * p.Cin + part * 4) * 4) : OOBW;
-        hdst = rq * ROWPW + (hx & 3) * PLANEW + (hx >> 2) * PITW + part * 4;
-    }
-    unsigned voffx = OOBW;
-    int hdstx = 0;
     const bool has_x = tid < 8 * HHW;
-    if (has_x) {
-        const int hy = tid >> 3, hx = 32 + ((tid >> 2) & 1), part = tid & 3;
-        bool okx, oky;
-        const int gx = src_x(hx, okx), gy = src_y(hy, oky);
-        voffx = (okx & oky) ? (unsigned)(((gy * p.Ws + gx) * p.Cin + part * 4) * 4) : OOBW;
-        hdstx = hy * ROWPW + (hx & 3) * PLANEW + (hx >> 2) * PITW + part * 4;
-    }
     // staging groups: G0 = rows 0..3, G1 = rows 4..7, G2 = row 8 + the extra unit
     // two register sets: a group is stored two pair-steps (~2 us) after its loads were issued -- they come from HBM
     f32x4 rh[2][4];
@@ -249,11 +281,11 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int i = 4 * g + k;
-                rh[rs][k] = bufw_load4(xrs, ((rowbad >> i) & 1) ? OOBW : voff, srow[i] + cs);
+                rh[rs][k] = bufw_load4(c_xrs, ((c_rowbad >> i) & 1) ? OOBW : c_voff, (unsigned)__builtin_amdgcn_readfirstlane((int)c_srow[i]) + cs);
             }
         } else {
-            rh[rs][0] = bufw_load4(xrs, ((rowbad >> 8) & 1) ? OOBW : voff, srow[8] + cs);
-            if (has_x) rh[rs][1] = bufw_load4(xrs, voffx, cs);
+            rh[rs][0] = bufw_load4(c_xrs, ((c_rowbad >> 8) & 1) ? OOBW : c_voff, (unsigned)__builtin_amdgcn_readfirstlane((int)c_srow[8]) + cs);
+            rh[rs][1] = bufw_load4(c_xrs, c_voffx, cs);      // (unconditional, see prefetch)
         }
     };
     auto store_g = [&](int g, float* __restrict__ dst, int rs) {
@@ -262,10 +294,10 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
 #endif
         if (g < 2) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(dst + hdst + (4 * g + k) * 2 * ROWPW) = rh[rs][k];
+            for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(dst + c_hdst + (4 * g + k) * 2 * ROWPW) = rh[rs][k];
         } else {
-            *reinterpret_cast<f32x4*>(dst + hdst + 16 * ROWPW) = rh[rs][0];
-            if (has_x) *reinterpret_cast<f32x4*>(dst + hdstx) = rh[rs][1];
+            *reinterpret_cast<f32x4*>(dst + c_hdst + 16 * ROWPW) = rh[rs][0];
+            if (has_x) *reinterpret_cast<f32x4*>(dst + c_hdstx) = rh[rs][1];
         }
     };
 
@@ -354,68 +386,113 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
     // between the groups the LDS reads (one patch column ahead) + the transform of the NEXT pair (buffer hs, pair pn) and the
     // refill of the weight registers just used, for the pair-step after the next (chunk cb, pair pb).  The staging work of this
     // step (sg_store / sg_load: group or -1) sits in groups 2..4.
+    // opts: bit 0 = refill the weight registers, bit 1 = read + transform the next pair (the tail of a tile's last chunk does neither:
+    // loads still in flight when the epilogue starts are waited for there -- its first ds_reads reuse their destination registers)
     auto pair_step = [&](auto ps_t, const float* __restrict__ hs, int pn, int cb, int pb, int sg_store, float* __restrict__ sdst, int sg_load, int sc,
-                         auto init) {
+                         auto init, auto opts) {
         constexpr int ps = decltype(ps_t)::value & 1;
-        read_col(hs, pn, 0, 0);
+        constexpr bool LB = (decltype(opts)::value & 1) != 0, XF = (decltype(opts)::value & 2) != 0;
+        if (XF) read_col(hs, pn, 0, 0);
         WW_SB;
         WW_MFMA4(0);
-        load_b(0, cb, pb);
-        read_col(hs, pn, 1, 1);
+        if (LB) load_b(0, cb, pb);
+        if (XF) read_col(hs, pn, 1, 1);
         WW_SB;
         WW_MFMA4(1);
-        load_b(1, cb, pb);
-        row_pass(0, 0);
-        read_col(hs, pn, 2, 0);
+        if (LB) load_b(1, cb, pb);
+        if (XF) row_pass(0, 0);
+        if (XF) read_col(hs, pn, 2, 0);
         WW_SB;
         WW_MFMA4(2);
-        load_b(2, cb, pb);
-        row_pass(1, 1);
-        read_col(hs, pn, 3, 1);
+        if (LB) load_b(2, cb, pb);
+        if (XF) row_pass(1, 1);
+        if (XF) read_col(hs, pn, 3, 1);
         if (sg_store >= 0) store_g(sg_store, sdst, sg_store == 1);
         WW_SB;
         WW_MFMA4(3);
-        load_b(3, cb, pb);
-        row_pass(2, 0);
-        read_col(hs, pn, 4, 0);
+        if (LB) load_b(3, cb, pb);
+        if (XF) row_pass(2, 0);
+        if (XF) read_col(hs, pn, 4, 0);
         if (sg_load >= 0) load_g(sg_load, sc, sg_load == 1);
         WW_SB;
         WW_MFMA4(4);
-        load_b(4, cb, pb);
-        row_pass(3, 1);
+        if (LB) load_b(4, cb, pb);
+        if (XF) row_pass(3, 1);
         WW_SB;
         WW_MFMA4(5);
-        load_b(5, cb, pb);
-        row_pass(4, 0);
+        if (LB) load_b(5, cb, pb);
+        if (XF) row_pass(4, 0);
         WW_SB;
         WW_MFMA4(6);
-        load_b(6, cb, pb);
+        if (LB) load_b(6, cb, pb);
         WW_SB;
         WW_MFMA4(7);
-        load_b(7, cb, pb);
+        if (LB) load_b(7, cb, pb);
         WW_SB;
         WW_MFMA4(8);
-        load_b(8, cb, pb);
+        if (LB) load_b(8, cb, pb);
         WW_SB;
-        col_pass(0);
-        col_pass(1);
-        col_pass(2);
+        if (XF) {
+            col_pass(0);
+            col_pass(1);
+            col_pass(2);
+        }
         WW_SB;
     };
 
     // ---- prologue: chunk 0 -> LDS, weights of (chunk 0, pair 0), the transform of pair 0, group 0 of chunk 1 in flight ---------
+    WW_STAMP(8);
+    // the bias of both epilogue passes, loaded HERE: vector memory loads return in order, so inside the epilogue a load issued behind
+    // the next tile's halo requests would wait for HBM, and one issued just before them stalls the epilogue for its own latency
+    const int rquad_ = tid & 7;
+    f32x4 biasv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (p.bias != nullptr) {
 #pragma unroll
-    for (int g = 0; g < 3; ++g) {
-        load_g(g, 0, 0);
-        store_g(g, Hs0, 0);
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = co0 + nb * 32 + 4 * rquad_ + k;
+                biasv[nb][k] = (c < p.Cout) ? p.bias[c] : 0.f;
+            }
     }
 #pragma unroll
     for (int j = 0; j < 9; ++j) load_b(j, 0, 0);
 #pragma unroll
     for (int j = 0; j < 9; ++j) load_b(j, 0, 1);
+    WW_STAMP(9);
+    // chunk 0 was requested a tile ago (rp[]); every wave is past the closing barrier, the exchange area is free
+#if !(defined(ABLW_NO_HALO) || defined(ABLW_NO_HALO_STORE))
+#pragma unroll
+    for (int i = 0; i < 9; ++i) *reinterpret_cast<f32x4*>(Hs0 + c_hdst + i * 2 * ROWPW) = rp[i];
+    if (has_x) *reinterpret_cast<f32x4*>(Hs0 + c_hdstx) = rp[9];
+#endif
+    WW_STAMP(10);
     load_g(0, min(1, last), 0);
     load_g(1, min(1, last), 1);
+    // The NEXT tile's staging set-up, computed here -- where the wave waits for the barrier anyway and the kernel arguments are at
+    // hand -- and parked in LDS behind the exchange area: in the epilogue, where the next tile's first halo chunk is requested, the
+    // same set-up cost 3-4k cycles of serialised scalar-load latencies (the arguments do not survive the loop in registers).
+    const int tile_next = tile + gridDim.x;
+    const bool more = tile_next < pk.ntiles;                                    // (uniform)
+    char* const mbox = reinterpret_cast<char*>(lds) + EXW_BYTES;
+    constexpr int WVB = 4096 + (2 * RB + CB) * 128;
+    if (more) {
+        int t_tn, t_n, t_co0, t_oy0, t_ox0, t_hdst, t_hdstx;
+        unsigned t_srow[9], t_rowbad, t_voff, t_voffx;
+        __amdgpu_buffer_rsrc_t t_xrs;
+        setup(tile_next, p, tid, t_tn, t_n, t_co0, t_oy0, t_ox0, t_xrs, t_srow, t_rowbad, t_voff, t_voffx, t_hdst, t_hdstx);
+        *reinterpret_cast<u32x4*>(mbox + tid * 16) = u32x4{t_voff, t_voffx, (unsigned)t_hdst, (unsigned)t_hdstx};
+        if (lane == 0) {
+            const unsigned long long xb = (unsigned long long)(const_cast<float*>(p.x) + (long long)t_n * p.Hs * p.Ws * p.Cin);
+            *reinterpret_cast<u32x4*>(mbox + WVB) = u32x4{t_srow[0], t_srow[1], t_srow[2], t_srow[3]};
+            *reinterpret_cast<u32x4*>(mbox + WVB + 16) = u32x4{t_srow[4], t_srow[5], t_srow[6], t_srow[7]};
+            *reinterpret_cast<u32x4*>(mbox + WVB + 32) = u32x4{t_srow[8], t_rowbad, (unsigned)xb, (unsigned)(xb >> 32)};
+            *reinterpret_cast<u32x4*>(mbox + WVB + 48) = u32x4{(unsigned)t_tn, (unsigned)t_n, (unsigned)t_co0, (unsigned)t_oy0};
+            *reinterpret_cast<u32x4*>(mbox + WVB + 64) = u32x4{(unsigned)t_ox0, (unsigned)p.Hs * p.Ws * p.Cin * 4u, 0u, 0u};
+        }
+    }
     __syncthreads();
+    WW_STAMP(11);
 #pragma unroll
     for (int cc = 0; cc < 5; ++cc) {
         read_col(Hs0, 0, cc, 0);
@@ -427,25 +504,39 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
 
     // ---- main loop: four pair-steps per 16-channel chunk.  The halo of chunk c+1 goes to the other buffer during steps 0..2 (its
     // last readers left through the previous barrier), the barrier sits before step 3, whose transform already reads chunk c+1. ----
+    typedef std::integral_constant<int, 3> FULL;
     auto chunk = [&](int c, auto first) {
         const float* cur = (c & 1) ? Hs1 : Hs0;
         float* nxt = (c & 1) ? Hs0 : Hs1;
         const int c1 = min(c + 1, last), c2 = min(c + 2, last);
         // halo of chunk c+1 -> the other buffer (its last readers left through the previous barrier): groups 0, 1 were requested two
         // pair-steps ago (sets 0, 1), group 2 is requested now (set 0, behind group 0's stores); groups 0, 1 of chunk c+2 in steps 2, 3
-        pair_step(std::integral_constant<int, 0>{}, cur, 1, c, 2, 0, nxt, 2, c1, first);
-        pair_step(std::integral_constant<int, 1>{}, cur, 2, c, 3, 1, nxt, -1, 0, std::false_type{});
-        pair_step(std::integral_constant<int, 2>{}, cur, 3, c1, 0, 2, nxt, 0, c2, std::false_type{});
+        pair_step(std::integral_constant<int, 0>{}, cur, 1, c, 2, 0, nxt, 2, c1, first, FULL{});
+        pair_step(std::integral_constant<int, 1>{}, cur, 2, c, 3, 1, nxt, -1, 0, std::false_type{}, FULL{});
+        pair_step(std::integral_constant<int, 2>{}, cur, 3, c1, 0, 2, nxt, 0, c2, std::false_type{}, FULL{});
 #ifndef ABLW_NO_BARRIER
         __syncthreads();
 #endif
         WW_SB;
-        pair_step(std::integral_constant<int, 3>{}, nxt, 0, c1, 1, -1, nullptr, 1, c2, std::false_type{});
+        pair_step(std::integral_constant<int, 3>{}, nxt, 0, c1, 1, -1, nullptr, 1, c2, std::false_type{}, FULL{});
+    };
+    // a tile's LAST chunk: no next chunk to stage, no weights beyond pair 3, nothing to transform in its last pair-step, no barrier
+    // (the epilogue brings its own) -- and nothing left in flight when the epilogue starts
+    auto chunk_last = [&](int c, auto first) {
+        const float* cur = (c & 1) ? Hs1 : Hs0;
+        pair_step(std::integral_constant<int, 0>{}, cur, 1, c, 2, -1, nullptr, -1, 0, first, FULL{});
+        pair_step(std::integral_constant<int, 1>{}, cur, 2, c, 3, -1, nullptr, -1, 0, std::false_type{}, FULL{});
+        pair_step(std::integral_constant<int, 2>{}, cur, 3, c, 0, -1, nullptr, -1, 0, std::false_type{}, std::integral_constant<int, 2>{});
+        pair_step(std::integral_constant<int, 3>{}, cur, 0, c, 0, -1, nullptr, -1, 0, std::false_type{}, std::integral_constant<int, 0>{});
     };
     WW_STAMP(1);
-    chunk(0, std::true_type{});     // its first pair-step starts the accumulators (C = 0)
-    for (int c = 1; c < nchunks; ++c) chunk(c, std::false_type{});
+    chunk(0, std::true_type{});         // its first pair-step starts the accumulators (C = 0); Cin >= 32: never the last chunk
+    for (int c = 1; c < last; ++c) chunk(c, std::false_type{});
+    chunk_last(last, std::false_type{});
     WW_STAMP(2);
+    int n_tn = 0, n_n = 0, n_co0 = 0, n_oy0 = 0, n_ox0 = 0, n_hdst = 0, n_hdstx = 0;
+    unsigned n_srow[9], n_rowbad = 0, n_voff = OOBW, n_voffx = OOBW;
+    __amdgpu_buffer_rsrc_t n_xrs = c_xrs;
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (asm MFMAs: no automatic wait states between the last one and the first read of its result)
     __syncthreads();                // every wave is done with the halo buffers: the exchange area overlays them
 
@@ -459,15 +550,15 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
     }
 #endif
     // ---- epilogue ---------------------------------------------------------------------------------------------------------------
-    // exchange area ex[pos][tile 0..31][channel quad ^ ((tile >> 1) & 7)][4 channels]: a lane's accumulator registers 4g..4g+3 are
+    // exchange area ex[pos][tile 0..31][channel quad ^ (tile & 7)][4 channels]: a lane's accumulator registers 4g..4g+3 are
     // channels 8g + 4 lh .. +3 (of the group) of tile li = one 16-byte slot; the XOR spreads the 8 (16) lanes of a b128 access over
     // the banks.
     char* const ex = reinterpret_cast<char*>(lds);
     const int wbase = ((3 * RB) * 6 + 3 * CB) * 4096 + li * 128;                 // + (rr*6 + qq) * 4096 + ((2g + lh) ^ sw) * 16
-    const int sw = (li >> 1) & 7;
+    const int sw = li & 7;            // (LDS stores bank over 128 B = one 32-channel row: eight consecutive tiles need eight different slots)
     // reader: thread = (tile tid >> 3, channel quad tid & 7): consecutive lanes store consecutive 16 bytes of one pixel
     const int rt = tid >> 3, rquad = tid & 7;
-    const int rbase = rt * 128 + ((rquad ^ ((rt >> 1) & 7)) << 4);
+    const int rbase = rt * 128 + ((rquad ^ (rt & 7)) << 4);
     const KO KOut{splatw(2.f + zf), splatw(4.f + zf), splatw(8.f + zf)};
     const bool interior = (oy0 + THW <= p.H) && (ox0 + TWW <= p.W);
     const bool relu = p.relu != 0;
@@ -485,13 +576,36 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
                 *reinterpret_cast<f32x4*>(ex + wbase + ((j / 3) * 6 + (j % 3)) * 4096 + (((2 * g + lh) ^ sw) << 4)) = q4;
             }
         }
-        __syncthreads();
-        const int co = co0 + nb * 32 + 4 * rquad;                              // first of this thread's four channels
-        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias != nullptr) {
+        if (nb == 0) {              // the next tile's first halo chunk: ahead of this tile's output stores, half the accumulators retired
+            WW_STAMP(12);
+            if (more) {
+                const u32x4 ml = *reinterpret_cast<const u32x4*>(mbox + tid * 16);
+                const u32x4 m0 = *reinterpret_cast<const u32x4*>(mbox + WVB), m1 = *reinterpret_cast<const u32x4*>(mbox + WVB + 16);
+                const u32x4 m2 = *reinterpret_cast<const u32x4*>(mbox + WVB + 32), m3 = *reinterpret_cast<const u32x4*>(mbox + WVB + 48);
+                const u32x4 m4 = *reinterpret_cast<const u32x4*>(mbox + WVB + 64);
+                auto uni = [](unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); };
+                n_voff = ml[0]; n_voffx = ml[1]; n_hdst = (int)ml[2]; n_hdstx = (int)ml[3];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) bias4[k] = (co + k < p.Cout) ? p.bias[co + k] : 0.f;
+                for (int i = 0; i < 4; ++i) { n_srow[i] = uni(m0[i]); n_srow[4 + i] = uni(m1[i]); }
+                n_srow[8] = uni(m2[0]);
+                n_rowbad = uni(m2[1]);
+                n_tn = (int)uni(m3[0]); n_n = (int)uni(m3[1]); n_co0 = (int)uni(m3[2]); n_oy0 = (int)uni(m3[3]);
+                n_ox0 = (int)uni(m4[0]);
+                n_xrs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<float*>(((unsigned long long)uni(m2[3]) << 32) | uni(m2[2])), 0,
+                                                          (int)uni(m4[1]), 0x00020000);
+                prefetch(n_xrs, n_srow, n_rowbad, n_voff, n_voffx, has_x);
+            } else {                // (nothing carried over: otherwise the old registers would have to live through the loop)
+#pragma unroll
+                for (int i = 0; i < 10; ++i) rp[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 9; ++i) n_srow[i] = 0;
+            }
+            WW_STAMP(13);
         }
+        __syncthreads();
+        if (nb == 0) WW_STAMP(14);
+        const int co = co0 + nb * 32 + 4 * rquad;                              // first of this thread's four channels
+        const f32x4 bias4 = biasv[nb];
         f32x2 yo[2][4][4];                                                     // [channel pair][out row][out col]
 #pragma unroll
         for (int hp = 0; hp < 2; ++hp) {
@@ -511,6 +625,7 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
             for (int i = 0; i < 4; ++i)
                 at4(KOut, cq[0][i], cq[1][i], cq[2][i], cq[3][i], cq[4][i], cq[5][i], yo[hp][i][0], yo[hp][i][1], yo[hp][i][2], yo[hp][i][3]);
         }
+        if (nb == 0) WW_STAMP(15);
         if (co >= p.Cout) continue;
         // 16 bytes per lane and pixel through a buffer resource on image n: the per-lane byte offset carries (tile, channel quad), the
         // scalar offset the pixel (i, j) of the tile; a row below the image falls beyond the resource and is dropped by the hardware,
@@ -578,6 +693,10 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
     WW_STAMP(4);
     __syncthreads();                // the next tile's halo overwrites the exchange area
     WW_STAMP(5);
+    c_tn = n_tn; c_n = n_n; c_co0 = n_co0; c_oy0 = n_oy0; c_ox0 = n_ox0; c_hdst = n_hdst; c_hdstx = n_hdstx;
+    c_rowbad = n_rowbad; c_voff = n_voff; c_voffx = n_voffx; c_xrs = n_xrs;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) c_srow[i] = n_srow[i];
     }
 }
 
@@ -641,7 +760,7 @@ extern "C" int ccst_pack_conv_weight_wino4w_f32(const float* w_oihw, float* u, i
 extern "C" int ccst_conv3x3_wino4w_f32(const float* x, const float* u_packed, const float* bias, float* y, int N, int H, int W, int Cin,
                                        int Cout, int cout_pad, uint32_t flags, void* stream) {
     CCST_REQUIRE(x && u_packed && y, "conv3x3_wino4w: null pointer");
-    CCST_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0, "conv3x3_wino4w: bad shape");
+    CCST_REQUIRE(N > 0 && H > 0 && W > 0 && Cin >= 32 && Cin % 16 == 0 && Cout > 0, "conv3x3_wino4w: bad shape (Cin a multiple of 16, >= 32)");
     CCST_REQUIRE(cout_pad >= Cout && cout_pad % 64 == 0, "conv3x3_wino4w: cout_pad must be a multiple of 64 >= cout");
     CCST_REQUIRE(!(flags & ~(CCST_CONV_RELU | CCST_CONV_POOL2 | CCST_CONV_UPS2 | CCST_CONV_REFLECT)), "conv3x3_wino4w: unsupported flag");
     const bool pool = (flags & CCST_CONV_POOL2) != 0, ups = (flags & CCST_CONV_UPS2) != 0;
@@ -664,6 +783,10 @@ extern "C" int ccst_conv3x3_wino4w_f32(const float* x, const float* u_packed, co
         return CCST_EINVAL;
     }
     a.ntiles = (int)grid;
+    CCST_REQUIRE(grid < (1 << 24) && a.tilesN <= 4096 && a.tilesX <= 4096 && a.tilesY <= 4096, "conv3x3_wino4w: tile grid too large");
+    a.mN = ((1ULL << 36) + a.tilesN - 1) / a.tilesN;
+    a.mX = ((1ULL << 36) + a.tilesX - 1) / a.tilesX;
+    a.mY = ((1ULL << 36) + a.tilesY - 1) / a.tilesY;
     hipStream_t s = (hipStream_t)stream;
     static int n_cu = 0;                                                       // (same for every device of a node)
     if (n_cu == 0) {
@@ -672,7 +795,7 @@ extern "C" int ccst_conv3x3_wino4w_f32(const float* x, const float* u_packed, co
         n_cu = v / 8 * 8 > 0 ? v / 8 * 8 : 8;
     }
     const long long wgs = grid < n_cu ? grid : n_cu;
-    const size_t lds = (size_t)EXW_BYTES;                                      // 144 KB of the CU's 160: one workgroup per CU
+    const size_t lds = (size_t)EXW_BYTES + MBW_BYTES;                          // 148.5 KB of the CU's 160: one workgroup per CU
     // the opt-in above the 64 KB default is per device and idempotent: set it for the current device on every launch
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4w_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4w_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -370,16 +370,23 @@ def _encode_one(arr, name):
 
 
 class ImageWriterPool(object):
-    """PNG / JPEG encoding of finished batches in worker processes: at > 1000 images/s of stylised output one Python thread
+    """PNG / JPEG encoding of finished batches off the main thread: at > 1000 images/s of stylised output one Python thread
     encoding ~50 images/s is what the stage-2 loop waits for (the reference encodes inline, CCST_OverallStyleTransfer.py:158-167).
-    submit() copies the uint8 HWC arrays out of the (reused) pinned buffer; close() waits for every file."""
+    Worker PROCESSES when the pool is created before this process has touched the GPU (they are forked at once, idle, and never
+    see a HIP context -- the CLIs create the pool first thing); otherwise worker threads (zlib releases the GIL while it
+    compresses).  submit() copies the uint8 HWC arrays out of the (reused) pinned buffer; close() waits for every file."""
 
     def __init__(self, workers=None):
         import concurrent.futures as cf
-        import multiprocessing as mp
         n = workers or max(1, min(16, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4) - 1))
-        self.pool = cf.ProcessPoolExecutor(max_workers=n, mp_context=mp.get_context("spawn"))      # (never fork a process that holds a GPU context)
         self.futures = []
+        if torch.cuda.is_initialized():
+            self.kind, self.pool = "threads", cf.ThreadPoolExecutor(max_workers=n)
+        else:
+            import multiprocessing as mp
+            self.kind, self.pool = "processes", cf.ProcessPoolExecutor(max_workers=n, mp_context=mp.get_context("fork"))
+            for f in [self.pool.submit(os.getpid) for _ in range(4 * n)]:      # start the workers NOW, before any GPU work
+                f.result()
 
     def submit(self, u8_batch, paths):
         for arr, name in zip(u8_batch, paths):

@@ -252,10 +252,12 @@ def pack_conv_weight(w_oihw, bias=None, transpose=False, out=None, wino=False):
         check(lib.ccst_pack_conv_weight_wino_f32(ptr(w), ptr(pc.u), cout, cin, pc.u_pad, stream_ptr()), "pack_conv_weight_wino")
         if wino in (4, "4n") or (WINO_F4 and cin >= WINO_F4_MIN_CIN):
             pc.u4_pad = round_up(cout, 64)
-            pc.u4 = torch.empty(int(lib.ccst_wino4_weight_floats(cin, pc.u4_pad)), device=w.device, dtype=torch.float32)
-            check(lib.ccst_pack_conv_weight_wino4w_f32(ptr(w), ptr(pc.u4), cout, cin, pc.u4_pad, stream_ptr()), "pack_conv_weight_wino4w")
-            if WINO_F4_NARROW or wino == "4n":
-                pc.u4n = torch.empty_like(pc.u4)
+            nfl = int(lib.ccst_wino4_weight_floats(cin, pc.u4_pad))
+            if cin >= 32:           # the 64-channel kernel peels a first and a last 16-channel chunk
+                pc.u4 = torch.empty(nfl, device=w.device, dtype=torch.float32)
+                check(lib.ccst_pack_conv_weight_wino4w_f32(ptr(w), ptr(pc.u4), cout, cin, pc.u4_pad, stream_ptr()), "pack_conv_weight_wino4w")
+            if WINO_F4_NARROW or wino == "4n" or cin < 32:
+                pc.u4n = torch.empty(nfl, device=w.device, dtype=torch.float32)
                 check(lib.ccst_pack_conv_weight_wino4_f32(ptr(w), ptr(pc.u4n), cout, cin, pc.u4_pad, stream_ptr()), "pack_conv_weight_wino4")
     return pc
 
@@ -268,7 +270,7 @@ def conv3x3_wino4(x, pc, flags=0, narrow=None):
     Hi, Wi = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
     oh, ow = ((Hi + 1) // 2, (Wi + 1) // 2) if pool else (Hi, Wi)
     out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
-    narrow = (WINO_F4_NARROW and pc.u4n is not None) if narrow is None else narrow
+    narrow = (pc.u4 is None or (WINO_F4_NARROW and pc.u4n is not None)) if narrow is None else (narrow or pc.u4 is None)
     fn = _lib.load().ccst_conv3x3_wino4_f32 if narrow else _lib.load().ccst_conv3x3_wino4w_f32
     args = (ptr(x), ptr(pc.u4n if narrow else pc.u4), ptr(pc.bias), ptr(out), N, Hi, Wi, Cx, pc.cout, pc.u4_pad, flags, stream_ptr())
     if TIMING is None:
@@ -316,7 +318,7 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
     if not reflect and pc.kh == 3 and pc.kw == 3 and stride == 1 and pad == 1 and not (relu or pool or ups or out_nchw) \
             and out is None and pc.bias is None and halo_train_ok(Hi, Wi, Cx, pc.cout):
         return conv3x3_halo_train(x, pc, want_stats=want_stats)
-    if pc.u4 is not None and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats \
+    if (pc.u4 is not None or pc.u4n is not None) and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats \
             and wino4_ok(pc.cin, pc.cout, Hi, Wi):
         return conv3x3_wino4(x, pc, flags)
     if USE_WINO and pc.u is not None and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats:

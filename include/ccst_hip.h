@@ -112,7 +112,7 @@ int ccst_pack_conv_weight_wino4_f32(const float* w_oihw, float* u, int cout, int
 int ccst_conv3x3_wino4_f32(const float* x, const float* u_packed, const float* bias, float* y, int N, int H, int W, int Cin,
                            int Cout, int cout_pad, uint32_t flags, void* stream);
 /* F(4x4,3x3) with 64 output channels per workgroup (conv3x3_wino4w.hip): the same convolution and flags as ccst_conv3x3_wino4_f32;
- * every transformed input value feeds two MFMAs and the halo is fetched once per 64 output channels.  cout_pad a multiple of 64;
+ * every transformed input value feeds two MFMAs and the halo is fetched once per 64 output channels.  cout_pad a multiple of 64, Cin >= 32;
  * u_packed from ccst_pack_conv_weight_wino4w_f32 ([Cin/16][36][4 channel pairs][2][cout_pad/64][32][2][2] floats: a lane's weights
  * of one position and channel pair for both 32-channel groups are one 16-byte load, a wave's load 2 x 512 contiguous bytes;
  * ccst_wino4_weight_floats(cin, cout_pad) floats). */

@@ -27,6 +27,8 @@ parser.add_argument('--fuse_stats', action='store_true', help='compute missing s
 parser.add_argument('--refresh_stats', action='store_true', help='with --fuse_stats: recompute even if the .npy cache exists')
 args = parser.parse_args()
 
+# the image writers first: worker processes are forked before this process creates its HIP context (data.ImageWriterPool)
+writers = None if (args.serial or args.no_save) else data.ImageWriterPool()
 all_clients = ALL_CLIENTS[args.dataset.lower()]
 style_domains = sorted(set(all_clients) - set([args.target]))    # :107 (sorted: the reference's set order is hash-dependent)
 device = device_or_die()
@@ -40,7 +42,6 @@ if world > 1 and args.fuse_stats:
 
 vgg, decoder = load_networks(args, device)
 pipeline = None if args.serial else style.StylePipeline(vgg, decoder, device, output_size=args.output_size)
-writers = None if (args.serial or args.no_save) else data.ImageWriterPool()
 data_loader = data.get_train_dataloader(args, args.txt_root, rank, world)      # this rank's shard of the content list
 
 

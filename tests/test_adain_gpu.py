@@ -181,7 +181,7 @@ def test_conv3x3_winograd4_vs_direct(dev, case, reflect, narrow):
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(dev)
     b = (torch.randn(Cout, generator=g) * 0.1).to(dev)
     pc = ops.pack_conv_weight(w, b, wino="4n")
-    assert pc.u4 is not None and pc.u4n is not None
+    assert pc.u4n is not None and (pc.u4 is not None or Cin < 32)          # (the 64-channel kernel needs two 16-channel chunks)
     ref = ops.conv2d_nhwc(x, ops.pack_conv_weight(w, b), stride=1, pad=1, reflect=reflect, relu=True, pool=pool, ups=ups)   # direct kernels
     flags = 1 | (2 if pool else 0) | (4 if ups else 0) | (8 if reflect else 0)
     out = ops.conv3x3_wino4(x, pc, flags, narrow=narrow)
