@@ -258,9 +258,13 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int li = lane & 31, lh = lane >> 5;
-#ifdef ABLW_STAMPS
+#if defined(ABLW_STAMPS) || defined(ABLW_GSTAMPS)
     unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(pk.y) + (long long)tile * 16;
+#ifdef ABLW_GSTAMPS
+#define WW_STAMP(k) do { } while (0)
+#else
 #define WW_STAMP(k) do { if (tid == 0) stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
 #else
 #define WW_STAMP(k) do { } while (0)
 #endif
@@ -392,52 +396,76 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
                          auto init, auto opts) {
         constexpr int ps = decltype(ps_t)::value & 1;
         constexpr bool LB = (decltype(opts)::value & 1) != 0, XF = (decltype(opts)::value & 2) != 0;
+#ifdef ABLW_GSTAMPS
+        unsigned long long gst[11];
+        const bool gs_on = (decltype(ps_t)::value == 1) && (cb == 2);
+#define WW_GS(k) do { if (gs_on) gst[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WW_GS(k) do { } while (0)
+#endif
+        WW_GS(0);
         if (XF) read_col(hs, pn, 0, 0);
         WW_SB;
         WW_MFMA4(0);
         if (LB) load_b(0, cb, pb);
         if (XF) read_col(hs, pn, 1, 1);
         WW_SB;
+        WW_GS(1);
         WW_MFMA4(1);
         if (LB) load_b(1, cb, pb);
         if (XF) row_pass(0, 0);
         if (XF) read_col(hs, pn, 2, 0);
         WW_SB;
+        WW_GS(2);
         WW_MFMA4(2);
         if (LB) load_b(2, cb, pb);
         if (XF) row_pass(1, 1);
         if (XF) read_col(hs, pn, 3, 1);
         if (sg_store >= 0) store_g(sg_store, sdst, sg_store == 1);
         WW_SB;
+        WW_GS(3);
         WW_MFMA4(3);
         if (LB) load_b(3, cb, pb);
         if (XF) row_pass(2, 0);
         if (XF) read_col(hs, pn, 4, 0);
         if (sg_load >= 0) load_g(sg_load, sc, sg_load == 1);
         WW_SB;
+        WW_GS(4);
         WW_MFMA4(4);
         if (LB) load_b(4, cb, pb);
         if (XF) row_pass(3, 1);
         WW_SB;
+        WW_GS(5);
         WW_MFMA4(5);
         if (LB) load_b(5, cb, pb);
         if (XF) row_pass(4, 0);
         WW_SB;
+        WW_GS(6);
         WW_MFMA4(6);
         if (LB) load_b(6, cb, pb);
         WW_SB;
+        WW_GS(7);
         WW_MFMA4(7);
         if (LB) load_b(7, cb, pb);
         WW_SB;
+        WW_GS(8);
         WW_MFMA4(8);
         if (LB) load_b(8, cb, pb);
         WW_SB;
+        WW_GS(9);
         if (XF) {
             col_pass(0);
             col_pass(1);
             col_pass(2);
         }
         WW_SB;
+        WW_GS(10);
+#ifdef ABLW_GSTAMPS
+        if (gs_on && tid == 0) {
+#pragma unroll
+            for (int k = 0; k < 11; ++k) stamps[k] = gst[k];
+        }
+#endif
     };
 
     // ---- prologue: chunk 0 -> LDS, weights of (chunk 0, pair 0), the transform of pair 0, group 0 of chunk 1 in flight ---------

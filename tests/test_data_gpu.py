@@ -266,3 +266,72 @@ def test_output_size_resizes_the_tensor_like_the_reference(dev, tmp_path):
         got = np.asarray(Image.open(p)).astype(np.int32)
         want = I.save_image_bytes(ref[i]).astype(np.int32)
         assert got.shape == want.shape and np.abs(got - want).max() <= 1 and (got != want).mean() < 0.01
+
+
+def test_config5_camelyon17_k4_end_to_end(dev, tmp_path):
+    """BASELINE config 5 end to end on generated files (README.md:109; SURVEY App. C-10 for the 222 size): a miniature Camelyon17
+    (five hospitals, two classes, 96x96 patches), hospital1's training patches stylised with the other hospitals' overall style by the
+    drop-in stage-2 CLI (--fuse_stats computes the statistics in-process, the overlapped pipeline + writer processes save the
+    files), the expanded adain-overall-K4 lists (originals + stylised variants, data/data_list_generator.py), then
+    fed_run.py --dataset camelyon17 --network resnet18 --n_classes 2 --fusion_mode adain-overall-K4 with four clients."""
+    import os
+    import subprocess
+    import sys
+    from PIL import Image
+    from ccst_amd import data
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rs = np.random.RandomState(17)
+    hospitals, classes = ["hospital%d" % k for k in range(1, 6)], ["normal", "tumor"]
+    rows = {h: [] for h in hospitals}
+    for h in hospitals:
+        for ci, c in enumerate(classes):
+            os.makedirs(str(tmp_path / "Camelyon17" / "kfold" / h / c), exist_ok=True)
+            for k in range(3):
+                p = str(tmp_path / "Camelyon17" / "kfold" / h / c / ("patch_%03d.png" % k))
+                Image.fromarray(_img(rs, 96, 96, smooth=(k != 1))).save(p)
+                rows[h].append((p, ci))
+    os.makedirs(str(tmp_path / "adain_lists" / "camelyon17"))
+    os.makedirs(str(tmp_path / "fed_lists" / "camelyon17"))
+    os.makedirs(str(tmp_path / "fed_lists" / "camelyon17_adain-overall-K4" / "hospital5"))
+    for h in hospitals:
+        text = "".join("%s %d\n" % r for r in rows[h])
+        (tmp_path / "adain_lists" / "camelyon17" / ("%s_train.txt" % h)).write_text(text)
+        (tmp_path / "fed_lists" / "camelyon17" / ("%s_test.txt" % h)).write_text(text)
+    env = dict(os.environ, PYTHONPATH=root)
+    # stage 2 for hospital1 (statistics of the four style hospitals computed in the same process)
+    out = subprocess.check_output([sys.executable, os.path.join(root, "style_transfer", "AdaIN", "CCST_OverallStyleTransfer.py"),
+                                   "--dataset", "camelyon17", "--target", "hospital1", "--random_weights", "--batch", "4", "--image_size", "96",
+                                   "--fuse_stats", "--txt_root", str(tmp_path / "adain_lists"), "--output", str(tmp_path / "out")],
+                                  cwd=str(tmp_path), env=env, text=True)
+    assert out.count("computed style statistics of") == 4
+    sources = hospitals[:4]
+    for h in sources:
+        names, labels = [], []
+        for p, ci in rows[h]:
+            names.append(p)
+            labels.append(ci)
+            for s in sources:
+                if s == h:
+                    continue
+                q = data.stylised_name(p, h, s, "all_style_transferred_Overall")
+                if h == "hospital1":
+                    assert os.path.exists(q), q                       # written by the stage-2 CLI above
+                    assert Image.open(q).size == (96, 96)
+                else:                                                  # (the other clients: stand-in files under the same naming rule)
+                    os.makedirs(os.path.dirname(q), exist_ok=True)
+                    Image.fromarray(_img(rs, 96, 96, smooth=True)).save(q)
+                names.append(q)
+                labels.append(ci)
+        (tmp_path / "fed_lists" / "camelyon17_adain-overall-K4" / "hospital5" / ("%s_train.txt" % h)).write_text(
+            "".join("%s %d\n" % r for r in zip(names, labels)))
+    cmd = [sys.executable, os.path.join(root, "federated", "fed_run.py"), "--dataset", "camelyon17", "--mode", "fedavg",
+           "--fusion_mode", "adain-overall-K4", "--source"] + sources + ["--target", "hospital5", "--n_classes", "2", "--network", "resnet18",
+           "--lr", "0.001", "--image_size", "222", "--batch", "8", "--val_size", "0.25", "--txt_root", str(tmp_path / "fed_lists"),
+           "--save_path", str(tmp_path / "ckpt"), "--iters", "2"]
+    out = subprocess.check_output(cmd, cwd=str(tmp_path), env=env, text=True)
+    assert out.count("| Train Loss:") == 8 and out.count("| Global Val Class Acc:") == 8 and out.count("| Global Test Class Acc:") == 2
+    losses = [float(l.split(":")[1]) for l in out.splitlines() if "| Train Loss:" in l]
+    assert all(np.isfinite(losses)) and all(0.0 < x < 5.0 for x in losses)
+    d = tmp_path / "ckpt" / "camelyon17" / "fedavg_adain-overall-K4_no_DG_resnet18_locIter1" / "Target_hospital5_seed_1"
+    ck = torch.load(str(d / "fedavg_latest"), map_location="cpu")
+    assert set(ck.keys()) == {"server_model", "a_iter"} and tuple(ck["server_model"]["class_classifier.weight"].shape) == (2, 512)
