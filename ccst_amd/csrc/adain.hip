@@ -443,6 +443,13 @@ extern "C" int ccst_adain_f32(const float* x, const float* style_mean, const flo
     return ccst_launch_status("adain_apply");
 }
 
+// Fold K per-tile (sum, sum of squares) pairs [K][C][2] (the statistics epilogue of ccst_conv3x3_wino4w_f32) into the per-channel totals.
+extern "C" int ccst_chan_sums_finalize_f32(const float* partials, int K, int C, float* sum, float* sqsum, void* stream) {
+    CCST_REQUIRE(partials && sum && sqsum && K > 0 && C > 0, "chan_sums_finalize: bad args");
+    hipLaunchKernelGGL(finalize_chan_sums_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, sum, sqsum, 1, C, K);
+    return ccst_launch_status("finalize_chan_sums");
+}
+
 extern "C" int ccst_chan_sums_f32(const float* x, float* sum, float* sqsum, int N, int C, int HW, int layout, void* ws,
                                   int64_t ws_bytes, void* stream) {
     int rc = check_common(x, N, C, HW, layout);

@@ -36,6 +36,7 @@ struct W4wArgs {
     const float* u;
     const float* bias;
     float* y;
+    float* sums;                                   // STATS: [N * tilesY * tilesX][Cout][2] per-tile (sum, sum of squares) of the output
     int N, H, W, Hs, Ws, Cin, Cout, CoutPad;      // H,W: conv (= output) extent; Hs,Ws: source extent (H/2,W/2 if ups)
     int reflect, ups, relu;
     long long ysN;
@@ -54,6 +55,7 @@ constexpr int HIMGW = HHW * ROWPW;                 // 13104 floats = 52.4 KB per
 constexpr int EXW_BYTES = 36 * 32 * 32 * 4;        // epilogue exchange: [position][channel][32 tiles] = 147456 B
 static_assert(2 * HIMGW * 4 <= EXW_BYTES, "the halo buffers live inside the exchange area");
 constexpr int MBW_BYTES = 4096 + 4 * 128;          // mailbox behind the exchange area: the NEXT tile's staging set-up (see wino4w_body)
+constexpr int SRW_BYTES = 256 * 32;                // STATS: per-thread (sum[4], sq[4]) before the cross-tile reduction
 constexpr unsigned OOBW = 0x40000000u;             // a byte offset beyond any image (images are < 2^30 bytes): the buffer load returns 0
 
 __device__ __forceinline__ int reflectw(int i, int n) {
@@ -136,7 +138,7 @@ __device__ __forceinline__ void at4(const KO& K, f32x2 m0, f32x2 m1, f32x2 m2, f
 
 #define WW_SB __builtin_amdgcn_sched_barrier(0)
 
-template <bool POOL, int RB, int CB>
+template <bool POOL, bool STATS, int RB, int CB>
 __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict__ lds) {
     float* const Hs0 = lds;
     float* const Hs1 = lds + HIMGW;
@@ -270,6 +272,8 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
 #endif
     WW_STAMP(0);
     const int tn = c_tn, n = c_n, co0 = c_co0, oy0 = c_oy0, ox0 = c_ox0;
+    const int tile_spatial = STATS ? (n * p.tilesY + oy0 / THW) * p.tilesX + ox0 / TWW : 0;
+    (void)tile_spatial;
     const int nchunks_ = p.Cin / CKW;
     (void)nchunks_;
     const bool has_x = tid < 8 * HHW;
@@ -654,6 +658,39 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
                 at4(KOut, cq[0][i], cq[1][i], cq[2][i], cq[3][i], cq[4][i], cq[5][i], yo[hp][i][0], yo[hp][i][1], yo[hp][i][2], yo[hp][i][3]);
         }
         if (nb == 0) WW_STAMP(15);
+        if (STATS) {
+            // Per-channel sum and sum of squares of this tile's OUTPUT (bias and ReLU applied, pixels outside the image excluded), the
+            // stage-1 statistic (calc_sum, mean_std_computation_effcientMem.py:103-115) straight from the accumulators: per thread over
+            // its 16 pixels, over the 32 tiles of the workgroup through LDS in fixed order (bitwise reproducible), one (sum, sq) pair
+            // per (spatial tile, channel) to global; ccst_chan_sums_finalize_f32 folds the tiles in fp64.
+            f32x4 ts = {0.f, 0.f, 0.f, 0.f}, tq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool in = interior || ((oyb + i < p.H) && (oxb + j < p.W));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float o = yo[k >> 1][i][j][k & 1];
+                        o = relu ? fmaxf(o, 0.f) : o;
+                        o = in ? o : 0.f;
+                        ts[k] += o;
+                        tq[k] = __builtin_fmaf(o, o, tq[k]);
+                    }
+                }
+            char* const sred = reinterpret_cast<char*>(lds) + EXW_BYTES + MBW_BYTES;
+            *reinterpret_cast<f32x4*>(sred + tid * 32) = ts;
+            *reinterpret_cast<f32x4*>(sred + tid * 32 + 16) = tq;
+            __syncthreads();
+            if (tid < 64) {
+                const int c = tid & 31, which = tid >> 5;
+                float tot = 0.f;
+#pragma unroll 8
+                for (int t = 0; t < 32; ++t) tot += *reinterpret_cast<const float*>(sred + (t * 8 + (c >> 2)) * 32 + which * 16 + (c & 3) * 4);
+                const int cg = co0 + nb * 32 + c;
+                if (cg < p.Cout) p.sums[((long long)(tile_spatial) * p.Cout + cg) * 2 + which] = tot;
+            }
+        }
         if (co >= p.Cout) continue;
         // 16 bytes per lane and pixel through a buffer resource on image n: the per-lane byte offset carries (tile, channel quad), the
         // scalar offset the pixel (i, j) of the tile; a row below the image falls beyond the resource and is dropped by the hardware,
@@ -728,14 +765,14 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
     }
 }
 
-template <bool POOL>
+template <bool POOL, bool STATS>
 __global__ __launch_bounds__(NTW) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3x3_wino4w_kernel(const W4wArgs p) {
-    extern __shared__ __attribute__((aligned(16))) float wino4w_lds[];         // 147456 B: 2 halo buffers, then the epilogue exchange
+    extern __shared__ __attribute__((aligned(16))) float wino4w_lds[];         // 2 halo buffers / the epilogue exchange, mailbox, sums
     const int wv = threadIdx.x >> 6;                                           // wave-uniform dispatch on the position block
-    if (wv == 0) wino4w_body<POOL, 0, 0>(p, wino4w_lds);
-    else if (wv == 1) wino4w_body<POOL, 0, 1>(p, wino4w_lds);
-    else if (wv == 2) wino4w_body<POOL, 1, 0>(p, wino4w_lds);
-    else wino4w_body<POOL, 1, 1>(p, wino4w_lds);
+    if (wv == 0) wino4w_body<POOL, STATS, 0, 0>(p, wino4w_lds);
+    else if (wv == 1) wino4w_body<POOL, STATS, 0, 1>(p, wino4w_lds);
+    else if (wv == 2) wino4w_body<POOL, STATS, 1, 0>(p, wino4w_lds);
+    else wino4w_body<POOL, STATS, 1, 1>(p, wino4w_lds);
 }
 
 // OIHW 3x3 -> U[chunk][pos = r*6+q][pair][k half][cout/64][32][group][2], U = G g G^T (accumulated in double);
@@ -785,8 +822,10 @@ extern "C" int ccst_pack_conv_weight_wino4w_f32(const float* w_oihw, float* u, i
 
 // x: NHWC source [N,Hs,Ws,Cin] (Hs = H/2 if CCST_CONV_UPS2), u: ccst_pack_conv_weight_wino4w_f32 output, y: NHWC [N,H,W,Cout] or
 // its 2x2 ceil-pooled form.  flags: CCST_CONV_RELU | POOL2 | UPS2 | REFLECT.
+extern "C" int ccst_wino4w_spatial_tiles(int N, int H, int W) { return N * ((H + THW - 1) / THW) * ((W + TWW - 1) / TWW); }
+
 extern "C" int ccst_conv3x3_wino4w_f32(const float* x, const float* u_packed, const float* bias, float* y, int N, int H, int W, int Cin,
-                                       int Cout, int cout_pad, uint32_t flags, void* stream) {
+                                       int Cout, int cout_pad, uint32_t flags, float* chan_sum_partials, void* stream) {
     CCST_REQUIRE(x && u_packed && y, "conv3x3_wino4w: null pointer");
     CCST_REQUIRE(N > 0 && H > 0 && W > 0 && Cin >= 32 && Cin % 16 == 0 && Cout > 0, "conv3x3_wino4w: bad shape (Cin a multiple of 16, >= 32)");
     CCST_REQUIRE(cout_pad >= Cout && cout_pad % 64 == 0, "conv3x3_wino4w: cout_pad must be a multiple of 64 >= cout");
@@ -795,9 +834,10 @@ extern "C" int ccst_conv3x3_wino4w_f32(const float* x, const float* u_packed, co
     if (ups) CCST_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv3x3_wino4w: upsampled extent must be even");
     if (flags & CCST_CONV_REFLECT) CCST_REQUIRE(H >= 2 && W >= 2, "conv3x3_wino4w: reflection needs extent >= 2");
     W4wArgs a;
-    a.x = x; a.u = u_packed; a.bias = bias; a.y = y;
+    a.x = x; a.u = u_packed; a.bias = bias; a.y = y; a.sums = chan_sum_partials;
     a.N = N; a.H = H; a.W = W; a.Hs = ups ? H / 2 : H; a.Ws = ups ? W / 2 : W; a.Cin = Cin; a.Cout = Cout; a.CoutPad = cout_pad;
     a.reflect = (flags & CCST_CONV_REFLECT) ? 1 : 0; a.ups = ups ? 1 : 0; a.relu = (flags & CCST_CONV_RELU) ? 1 : 0;
+    CCST_REQUIRE(!(chan_sum_partials && pool), "conv3x3_wino4w: channel sums are of the un-pooled output");
     CCST_REQUIRE((long long)a.Hs * a.Ws * Cin * 4 < (long long)OOBW, "conv3x3_wino4w: one image must be < 2^30 bytes");
     const int oh = pool ? (H + 1) / 2 : H, ow = pool ? (W + 1) / 2 : W;
     a.ysW = Cout; a.ysH = ow * Cout; a.ysN = (long long)oh * ow * Cout;
@@ -823,15 +863,19 @@ extern "C" int ccst_conv3x3_wino4w_f32(const float* x, const float* u_packed, co
         n_cu = v / 8 * 8 > 0 ? v / 8 * 8 : 8;
     }
     const long long wgs = grid < n_cu ? grid : n_cu;
-    const size_t lds = (size_t)EXW_BYTES + MBW_BYTES;                          // 148.5 KB of the CU's 160: one workgroup per CU
+    const bool stats = chan_sum_partials != nullptr;
+    const size_t lds = (size_t)EXW_BYTES + MBW_BYTES + (stats ? SRW_BYTES : 0);   // 148.5 (156.5) KB of the CU's 160: one workgroup per CU
     // the opt-in above the 64 KB default is per device and idempotent: set it for the current device on every launch
-    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4w_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino4w_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e1 != hipSuccess || e2 != hipSuccess) {
-        ccst_set_error("conv3x3_wino4w: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e1 != hipSuccess ? e1 : e2));
-        return (int)(e1 != hipSuccess ? e1 : e2);
+    const void* kfn = pool ? reinterpret_cast<const void*>(&conv3x3_wino4w_kernel<true, false>)
+                           : stats ? reinterpret_cast<const void*>(&conv3x3_wino4w_kernel<false, true>)
+                                   : reinterpret_cast<const void*>(&conv3x3_wino4w_kernel<false, false>);
+    hipError_t e1 = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e1 != hipSuccess) {
+        ccst_set_error("conv3x3_wino4w: cannot reserve %zu bytes of LDS: %s", lds, hipGetErrorString(e1));
+        return (int)e1;
     }
-    if (pool) hipLaunchKernelGGL(conv3x3_wino4w_kernel<true>, dim3((unsigned)wgs), dim3(NTW), lds, s, a);
-    else hipLaunchKernelGGL(conv3x3_wino4w_kernel<false>, dim3((unsigned)wgs), dim3(NTW), lds, s, a);
+    if (pool) hipLaunchKernelGGL((conv3x3_wino4w_kernel<true, false>), dim3((unsigned)wgs), dim3(NTW), lds, s, a);
+    else if (stats) hipLaunchKernelGGL((conv3x3_wino4w_kernel<false, true>), dim3((unsigned)wgs), dim3(NTW), lds, s, a);
+    else hipLaunchKernelGGL((conv3x3_wino4w_kernel<false, false>), dim3((unsigned)wgs), dim3(NTW), lds, s, a);
     return ccst_launch_status("conv3x3_wino4w");
 }

@@ -194,8 +194,10 @@ def _peak_elems_per_sample(steps, C, H, W):
     return peak
 
 
-def _run(steps, x):
-    """x: logical NCHW CUDA tensor.  Returns a logical NCHW tensor."""
+def _run(steps, x, want_sums=False):
+    """x: logical NCHW CUDA tensor.  Returns a logical NCHW tensor; with want_sums also the per-channel (sum, sum of squares, count)
+    of the result (calc_sum, mean_std_computation_effcientMem.py:103-115) -- from the last conv's epilogue where that conv runs on
+    the 64-channel F(4x4) kernel, else from the streaming-sums kernel."""
     if isinstance(x, torch.Tensor) and x.dim() == 4 and x.shape[0] > 0:
         per = _peak_elems_per_sample(steps, int(x.shape[1]), int(x.shape[2]), int(x.shape[3]))
         if per > MAX_ELEMS:
@@ -203,11 +205,27 @@ def _run(steps, x):
                              % (x.shape[2], x.shape[3], per))
         if per * int(x.shape[0]) > MAX_ELEMS:
             n = max(1, MAX_ELEMS // per)
-            return torch.cat([_run_batch(steps, x[i:i + n]) for i in range(0, int(x.shape[0]), n)], dim=0)
-    return _run_batch(steps, x)
+            parts = [_run_batch(steps, x[i:i + n], want_sums) for i in range(0, int(x.shape[0]), n)]
+            if not want_sums:
+                return torch.cat(parts, dim=0)
+            y = torch.cat([p[0] for p in parts], dim=0)
+            return y, (sum(p[1][0] for p in parts), sum(p[1][1] for p in parts), sum(p[1][2] for p in parts))
+    return _run_batch(steps, x, want_sums)
 
 
-def _run_batch(steps, x):
+def _run_batch(steps, x, want_sums=False):
+    if not want_sums:
+        return _run_steps(steps, x, None)
+    box = []
+    y = _run_steps(steps, x, box)
+    if box:
+        s, q = ops.chan_sums_finalize(box[0])
+        return y, (s, q, int(y.shape[0] * y.shape[2] * y.shape[3]))
+    return y, ops.chan_sums(y)
+
+
+def _run_steps(steps, x, sums_box):
+    """sums_box: None, or a list that receives the last conv's per-tile channel-sum partials when that conv can produce them."""
     if not (isinstance(x, torch.Tensor) and x.is_cuda):
         raise RuntimeError("ccst_amd.net: input must be a CUDA (ROCm) tensor; the HIP path has no CPU fallback")
     if x.dim() != 4:
@@ -236,8 +254,13 @@ def _run_batch(steps, x):
         if s.kind == "conv":
             if cur.shape[-1] != s.pc.k_pad:
                 cur = ops.from_api(ops.to_api(cur[..., :C]), cpad=16)
-            out = ops.conv2d_nhwc(cur, s.pc, stride=s.stride, pad=s.pad, reflect=s.reflect, relu=s.relu, pool=s.pool,
-                                  ups=s.ups, out_nchw=s.out_nchw)
+            if sums_box is not None and s is steps[-1] and ops.wino4w_sums_ok(s.pc, s.stride, s.pad, s.pool, s.out_nchw):
+                out, part = ops.conv2d_nhwc(cur, s.pc, stride=s.stride, pad=s.pad, reflect=s.reflect, relu=s.relu, pool=s.pool,
+                                            ups=s.ups, chan_sums=True)
+                sums_box.append(part)
+            else:
+                out = ops.conv2d_nhwc(cur, s.pc, stride=s.stride, pad=s.pad, reflect=s.reflect, relu=s.relu, pool=s.pool,
+                                      ups=s.ups, out_nchw=s.out_nchw)
             C = s.pc.cout
             if s.out_nchw:
                 return out
@@ -295,6 +318,16 @@ class Sequential(nn.Sequential):
             cache = _PlanCache()
             self.__dict__["_ccst_plan"] = cache
         return _run(cache.get(list(self.children())), input)
+
+    def forward_with_chan_sums(self, input):
+        """(self(input), (sum, sqsum, count)): the features AND their per-channel sums over (N, H, W) -- stage 1's
+        ``feat = vgg(x); calc_sum(feat)`` (mean_std_computation_effcientMem.py:124-126) with the sums taken from the last conv's
+        epilogue instead of a pass over the 268 MB tensor."""
+        cache = self.__dict__.get("_ccst_plan")
+        if cache is None:
+            cache = _PlanCache()
+            self.__dict__["_ccst_plan"] = cache
+        return _run(cache.get(list(self.children())), input, want_sums=True)
 
 
 class _SingleMixin(object):

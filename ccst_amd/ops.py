@@ -262,17 +262,28 @@ def pack_conv_weight(w_oihw, bias=None, transpose=False, out=None, wino=False):
     return pc
 
 
-def conv3x3_wino4(x, pc, flags=0, narrow=None):
+def conv3x3_wino4(x, pc, flags=0, narrow=None, sums=False):
     """3x3 stride-1 pad-1 conv on the F(4x4,3x3) kernels; x NHWC [N,Hs,Ws,Cin], pc packed with wino=4.  flags: CONV_* bits.
-    narrow: the 32-output-channel workgroups of conv3x3_wino4.hip (pc packed with wino="4n") instead of the 64-channel ones."""
+    narrow: the 32-output-channel workgroups of conv3x3_wino4.hip (pc packed with wino="4n") instead of the 64-channel ones.
+    sums=True (64-channel kernel, no pool): also returns the per-tile (sum, sum of squares) partials [tiles, Cout, 2] of the
+    output from the conv epilogue -- fold them with chan_sums_finalize()."""
     N, Hs, Ws, Cx = x.shape
     ups, pool = bool(flags & CONV_UPS2), bool(flags & CONV_POOL2)
     Hi, Wi = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
     oh, ow = ((Hi + 1) // 2, (Wi + 1) // 2) if pool else (Hi, Wi)
     out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
     narrow = (pc.u4 is None or (WINO_F4_NARROW and pc.u4n is not None)) if narrow is None else (narrow or pc.u4 is None)
-    fn = _lib.load().ccst_conv3x3_wino4_f32 if narrow else _lib.load().ccst_conv3x3_wino4w_f32
-    args = (ptr(x), ptr(pc.u4n if narrow else pc.u4), ptr(pc.bias), ptr(out), N, Hi, Wi, Cx, pc.cout, pc.u4_pad, flags, stream_ptr())
+    lib = _lib.load()
+    part = None
+    if sums:
+        if narrow or pool:
+            raise ValueError("ccst_amd.ops: the statistics epilogue belongs to the 64-channel F(4x4) kernel without pooling")
+        part = torch.empty((int(lib.ccst_wino4w_spatial_tiles(N, Hi, Wi)), pc.cout, 2), device=x.device, dtype=torch.float32)
+    if narrow:
+        fn, args = lib.ccst_conv3x3_wino4_f32, (ptr(x), ptr(pc.u4n), ptr(pc.bias), ptr(out), N, Hi, Wi, Cx, pc.cout, pc.u4_pad, flags, stream_ptr())
+    else:
+        fn, args = lib.ccst_conv3x3_wino4w_f32, (ptr(x), ptr(pc.u4), ptr(pc.bias), ptr(out), N, Hi, Wi, Cx, pc.cout, pc.u4_pad, flags, ptr(part),
+                                                 stream_ptr())
     if TIMING is None:
         check(fn(*args), "conv3x3_wino4")
     else:
@@ -282,11 +293,33 @@ def conv3x3_wino4(x, pc, flags=0, narrow=None):
         e1.record()
         TIMING.append(("conv3x3_wino4%s_kernel<%s>" % ("" if narrow else "w", "pool" if pool else "nopool"), 2.0 * N * Hi * Wi * pc.cout * pc.cin * 9, e0, e1,
                        "n%d %dx%d cin%d cout%d taps3x3 flags%d" % (N, Hi, Wi, pc.cin, pc.cout, flags)))
-    return out
+    return (out, part) if sums else out
+
+
+def chan_sums_finalize(partials):
+    """[K, C, 2] per-tile (sum, sum of squares) pairs -> ([1,C,1,1] sum, [1,C,1,1] sqsum), folded in fp64 in a fixed order."""
+    K, C, _ = partials.shape
+    s = torch.empty((1, C, 1, 1), device=partials.device, dtype=torch.float32)
+    q = torch.empty((1, C, 1, 1), device=partials.device, dtype=torch.float32)
+    if TIMING is None:
+        check(_lib.load().ccst_chan_sums_finalize_f32(ptr(partials), K, C, ptr(s), ptr(q), stream_ptr()), "chan_sums_finalize")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().ccst_chan_sums_finalize_f32(ptr(partials), K, C, ptr(s), ptr(q), stream_ptr()), "chan_sums_finalize")
+        e1.record()
+        TIMING.append(("chan_sums_finalize", 0.0, e0, e1, "k%d c%d bytes%d" % (K, C, 8 * K * C)))
+    return s, q
+
+
+def wino4w_sums_ok(pc, stride, pad, pool, out_nchw):
+    """Can this conv leave the per-channel sums of its output in its epilogue (the 64-channel F(4x4) kernel, un-pooled)?"""
+    return pc.u4 is not None and not WINO_F4_NARROW and stride == 1 and pad == 1 and not pool and not out_nchw and pc.kh == 3 and pc.kw == 3 \
+        and wino4_ok(pc.cin, pc.cout, 0, 0)
 
 
 def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, ups=False, out_nchw=False, out=None,
-                want_stats=False):
+                want_stats=False, chan_sums=False):
     """Forward convolution of an NHWC tensor x [N,Hs,Ws,Cin_pad] with PackedConv pc.
 
     ups:  x is read through a nearest x2 upsample (logical input is [2Hs,2Ws]).
@@ -318,6 +351,8 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
     if not reflect and pc.kh == 3 and pc.kw == 3 and stride == 1 and pad == 1 and not (relu or pool or ups or out_nchw) \
             and out is None and pc.bias is None and halo_train_ok(Hi, Wi, Cx, pc.cout):
         return conv3x3_halo_train(x, pc, want_stats=want_stats)
+    if chan_sums:       # (the caller checked wino4w_sums_ok)
+        return conv3x3_wino4(x, pc, flags, sums=True)
     if (pc.u4 is not None or pc.u4n is not None) and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats \
             and wino4_ok(pc.cin, pc.cout, Hi, Wi):
         return conv3x3_wino4(x, pc, flags)

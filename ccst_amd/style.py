@@ -74,11 +74,25 @@ class StyleStatAccumulator(object):
         self.sum, self.sqsum, self.count, self.images = 0, 0, 0, 0
 
     def update(self, feat):
-        s, q, n = calc_sum(feat)
+        self._add(calc_sum(feat), feat.shape[0])
+
+    def update_from_images(self, vgg, images):
+        """Stage 1's loop body on a batch of images: encode and accumulate, the sums coming out of the encoder's last conv
+        (net.Sequential.forward_with_chan_sums) when the encoder is the fused plan; returns the features."""
+        if hasattr(vgg, "forward_with_chan_sums"):
+            feat, triple = vgg.forward_with_chan_sums(images)
+        else:
+            feat = vgg(images)
+            triple = calc_sum(feat)
+        self._add(triple, feat.shape[0])
+        return feat
+
+    def _add(self, triple, images):
+        s, q, n = triple
         self.sum = self.sum + s
         self.sqsum = self.sqsum + q
         self.count += n
-        self.images += feat.shape[0]
+        self.images += images
 
     def all_reduce(self):
         """Intra-domain sharding: one all_reduce(SUM) of 2*C floats + the count."""
@@ -106,7 +120,7 @@ def domain_style_stat(vgg, loader, device, world=1, rank=0, progress=None):
     acc = StyleStatAccumulator()
     with torch.no_grad():
         for it, (batch, _) in enumerate(loader):
-            acc.update(vgg(batch.to(device)))
+            acc.update_from_images(vgg, batch.to(device))
             if progress is not None:
                 progress(it, len(loader))
     if acc.images == 0:         # a rank without batches still takes part in the all-reduce

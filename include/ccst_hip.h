@@ -118,7 +118,13 @@ int ccst_conv3x3_wino4_f32(const float* x, const float* u_packed, const float* b
  * ccst_wino4_weight_floats(cin, cout_pad) floats). */
 int ccst_pack_conv_weight_wino4w_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, void* stream);
 int ccst_conv3x3_wino4w_f32(const float* x, const float* u_packed, const float* bias, float* y, int N, int H, int W, int Cin,
-                            int Cout, int cout_pad, uint32_t flags, void* stream);
+                            int Cout, int cout_pad, uint32_t flags, float* chan_sum_partials, void* stream);
+/* chan_sum_partials (NULL, or [ccst_wino4w_spatial_tiles(N,H,W)][Cout][2] floats; not with CCST_CONV_POOL2): the epilogue also leaves
+ * the per-channel sum and sum of squares of each 16x32-pixel tile of the OUTPUT (bias / ReLU applied) -- calc_sum,
+ * mean_std_computation_effcientMem.py:103-115, without a pass over the tensor; ccst_chan_sums_finalize_f32 folds K such pairs
+ * [K][C][2] into the [C] totals in fp64 (fixed order: bitwise reproducible). */
+int ccst_wino4w_spatial_tiles(int N, int H, int W);
+int ccst_chan_sums_finalize_f32(const float* partials, int K, int C, float* sum, float* sqsum, void* stream);
 /* The Winograd kernel for the ResNet trunk's 3x3 stride-1 zero-padded bias-free convs (forward with the BatchNorm statistics
  * epilogue, backward-data with the weights from ccst_pack_conv_weight_wino_bwd_f32 and x = dY, optional y += with
  * CCST_CONV_ACCUM).  stats: NULL or [ccst_conv3x3_wino_stats_groups(N,H,W)][Cout][2]. */

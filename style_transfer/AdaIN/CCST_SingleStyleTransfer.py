@@ -70,8 +70,8 @@ for style_name in style_domains:
         img_count += len(batch)
         print(f"    Style: {style_name}, Iteration: {it}/{len(data_loader)}")
         with torch.no_grad():
-            style_feat = vgg(load_style_image(style_img_path).to(device).unsqueeze(0))
-            feat_sum, feat_square_sum, count = style.calc_sum(style_feat)
+            # (features and their per-channel sums in one go: the sums come out of the encoder's last conv)
+            style_feat, (feat_sum, feat_square_sum, count) = vgg.forward_with_chan_sums(load_style_image(style_img_path).to(device).unsqueeze(0))
             style_stat = list(style.finalise_style_stats(feat_sum, feat_square_sum, count))
             output = style.style_transfer(vgg, decoder, batch.to(device), style_stat, args.alpha)
         if not args.no_save:

@@ -727,3 +727,39 @@ def test_style_pipeline_matches_serial_loop(dev, nets, A):
                 ref = cdata.quantize_u8(out).cpu().numpy()
             assert u8.shape == ref.shape and (u8 == ref).all()
     assert list(pipe.run(iter([]), stat, 1.0)) == []
+
+
+def test_chan_sums_from_the_conv_epilogue(dev, nets, A):
+    """Stage 1's per-channel (sum, sum of squares) of relu4_1 taken from conv4_1's epilogue (net.Sequential.forward_with_chan_sums:
+    per-tile partials + the fp64 fold) against the oracle's calc_sum and against the stand-alone pass over the tensor: sizes that
+    leave partial 16x32-pixel tiles at the right and bottom edges (their out-of-image pixels must not be counted), a batch, and an
+    encoder slice whose last conv cannot produce the sums (the fallback pass)."""
+    from ccst_amd import net, ops, style
+    vgg31, dec, vgg_w, dec_w = nets
+    for (n, h, w) in ((2, 64, 64), (3, 200, 136), (1, 512, 512)):
+        x = A.synth_content(n, h, w, seed=90 + h)
+        with torch.no_grad():
+            feat, (s, q, cnt) = vgg31.forward_with_chan_sums(x.to(dev))
+            s2, q2, cnt2 = ops.chan_sums(feat)
+            rf = A.encoder(x, vgg_w)
+            rs_, rq, rn = A.calc_sum(rf)
+        assert cnt == cnt2 == rn == n * feat.shape[2] * feat.shape[3]
+        assert maxdiff(feat, rf) < TOL
+        for got, other, ref in ((s, s2, rs_), (q, q2, rq)):
+            scale = float(ref.abs().max())
+            assert float((got.cpu() - ref).abs().max()) < 1e-4 * scale, (h, w)      # fp32 sums of ~1e4 non-negative terms
+            assert float((got - other).abs().max()) < 2e-5 * scale, (h, w)          # the two HIP paths differ by summation order only
+        again = vgg31.forward_with_chan_sums(x.to(dev))[1]
+        assert torch.equal(again[0], s) and torch.equal(again[1], q)               # fixed-order reductions: bitwise reproducible
+    # accumulator API (the stage-1 loop body) and the fallback for a plan that does not end in an eligible conv
+    acc = style.StyleStatAccumulator()
+    xs = [A.synth_content(2, 96, 80, seed=5 + i) for i in range(2)]
+    with torch.no_grad():
+        for xb in xs:
+            acc.update_from_images(vgg31, xb.to(dev))
+        mean, std = acc.finalise()
+        rmean, rstd = A.overall_style_stats(xs, vgg_w)
+        f2, (s3, q3, c3) = net.vgg[:4].to(dev).forward_with_chan_sums(xs[0].to(dev))     # ends in ReLU after conv1_1 (the stem kernel)
+        s4, q4, c4 = ops.chan_sums(f2)
+    assert acc.images == 4 and maxdiff(mean, rmean) < 1e-4 and maxdiff(std, rstd) < 1e-3
+    assert c3 == c4 and torch.equal(s3, s4) and torch.equal(q3, q4)
