@@ -337,8 +337,15 @@ class ResNet(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self.__dict__.pop("_ccst_nbt", None)
-        self.__dict__.pop("_ccst_graph_steps", None)      # captured train steps (fed.train) hold addresses of the tensors being moved
-        return super()._apply(fn, *a, **k)
+        p0 = next(self.parameters(), None)
+        before = None if p0 is None else (p0.device, p0.data_ptr())
+        out = super()._apply(fn, *a, **k)
+        p1 = next(self.parameters(), None)
+        if before != (None if p1 is None else (p1.device, p1.data_ptr())):
+            # captured train steps (fed.train) hold addresses of the tensors that just moved; a model.to(device) that moves nothing
+            # (train() and test() call it every time) keeps them
+            self.__dict__.pop("_ccst_graph_steps", None)
+        return out
 
 
 def _maybe_pretrained(model, name, pretrained):

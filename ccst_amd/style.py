@@ -166,6 +166,9 @@ class StylePipeline(object):
         if slot["pin_in"] is None or slot["pin_in"].shape != batch.shape:
             slot["pin_in"] = torch.empty(batch.shape, dtype=batch.dtype).pin_memory()
             slot["dev_in"] = torch.empty(batch.shape, dtype=batch.dtype, device=self.device)
+            # the caching allocator may hand out a block that kernels already queued on the compute stream still read (it is free in
+            # that stream's order only): the copy stream must not write it before they are done
+            self.h2d.wait_stream(torch.cuda.current_stream(self.device))
         src = batch
         if not batch.is_pinned():
             slot["pin_in"].copy_(batch)

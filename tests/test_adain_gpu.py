@@ -672,7 +672,7 @@ def test_conv3x3_winograd4_conditioning(dev, narrow):
     assert float(err.max()) < 1e-5, float(err.max())
 
 
-def test_wide_dynamic_range_path(dev, A):
+def test_wide_dynamic_range_path(dev, nets, A):
     """The whole encoder -> AdaIN -> decoder path on weights that make the activations large, the way a trained VGG's are (the real
     vgg_normalised.pth / decoder.pth are not available here): every encoder conv scaled by 1.3 (relu4_1 reaches 40-50),
     style statistics of that size, the decoder's first conv scaled back down so that the image is O(1) again.  F(4x4) in fp32
@@ -692,13 +692,17 @@ def test_wide_dynamic_range_path(dev, A):
     dec_w[dkeys[0] + ".weight"] = dec_w[dkeys[0] + ".weight"] / (fmax / 4.0)
     ref64 = A.style_transfer({k: v.double() for k, v in vgg_w.items()}, {k: v.double() for k, v in dec_w.items()}, content.double(),
                              [t.double() for t in stat], 1.0)
-    net.vgg.load_state_dict(vgg_w)
-    net.decoder.load_state_dict(dec_w)
+    net.vgg.load_state_dict(vgg_w)                      # (net.vgg / net.decoder are the module-level networks the `nets` fixture shares:
+    net.decoder.load_state_dict(dec_w)                  #  the fixture's weights go back in below)
     vgg31 = net.vgg[:31].to(dev).eval()
     dec = net.decoder.to(dev).eval()
-    with torch.no_grad():
-        out = style.style_transfer(vgg31, dec, content.to(dev), [t.to(dev) for t in stat], 1.0)
-        f_gpu = vgg31(content.to(dev))
+    try:
+        with torch.no_grad():
+            out = style.style_transfer(vgg31, dec, content.to(dev), [t.to(dev) for t in stat], 1.0)
+            f_gpu = vgg31(content.to(dev))
+    finally:
+        net.vgg.load_state_dict(nets[2])
+        net.decoder.load_state_dict(nets[3])
     ref32 = A.style_transfer(vgg_w, dec_w, content, stat, 1.0)
     e_gpu = float((out.cpu().double() - ref64).abs().max())
     e_cpu = float((ref32.double() - ref64).abs().max())
