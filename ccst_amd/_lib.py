@@ -58,6 +58,8 @@ _SIGNATURES = {
     "ccst_pack_conv_weight_wino4w_f32": [_P, _P, c_int, c_int, c_int, _P],
     "ccst_conv3x3_wino4w_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P, _P],
     "ccst_wino4w_spatial_tiles": [c_int, c_int, c_int],
+    "ccst_pack_stem3_weight_f32": [_P, _P, _P, c_int, _P],
+    "ccst_conv3x3_stem3_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
     "ccst_chan_sums_finalize_f32": [_P, c_int, c_int, _P, _P, _P],
     "ccst_pack_conv_weight_wino_bwd_f32": [_P, _P, c_int, c_int, c_int, _P],
     "ccst_conv3x3_wino_train_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],

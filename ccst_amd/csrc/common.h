@@ -27,6 +27,17 @@ static inline int ccst_launch_status(const char* what) {
     return CCST_OK;
 }
 
+// Compute units of the current device (256 on MI355X; the same for every device of a node, so asked once).
+static inline int ccst_num_cus() {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n_cu = v;
+    }
+    return n_cu;
+}
+
 // Bijective XCD-aware remap of a linear workgroup id: blocks b and b+8 share an XCD
 // (observed round-robin dispatch), so give each XCD a contiguous chunk of the tile
 // space.  Speed only, never correctness (cdna_hip_programming.md T1).

@@ -856,12 +856,7 @@ extern "C" int ccst_conv3x3_wino4w_f32(const float* x, const float* u_packed, co
     a.mX = ((1ULL << 36) + a.tilesX - 1) / a.tilesX;
     a.mY = ((1ULL << 36) + a.tilesY - 1) / a.tilesY;
     hipStream_t s = (hipStream_t)stream;
-    static int n_cu = 0;                                                       // (same for every device of a node)
-    if (n_cu == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        n_cu = v / 8 * 8 > 0 ? v / 8 * 8 : 8;
-    }
+    const int n_cu = ccst_num_cus() / 8 * 8 > 0 ? ccst_num_cus() / 8 * 8 : 8;   // a multiple of the 8 XCDs
     const long long wgs = grid < n_cu ? grid : n_cu;
     const bool stats = chan_sum_partials != nullptr;
     const size_t lds = (size_t)EXW_BYTES + MBW_BYTES + (stats ? SRW_BYTES : 0);   // 148.5 (156.5) KB of the CU's 160: one workgroup per CU

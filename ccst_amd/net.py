@@ -56,11 +56,11 @@ def _is_up2(m):
 class _Step(object):
     """One launch (or launch pair) of the plan."""
     __slots__ = ("kind", "pc", "kw", "kwp", "stride", "pad", "reflect", "relu", "pool", "ups", "out_nchw",
-                 "w_small", "b_small", "cout")
+                 "w_small", "b_small", "cout", "wa")
 
     def __init__(self, kind, **kw):
         self.kind = kind
-        self.pc = self.kw = self.kwp = self.w_small = self.b_small = self.cout = None
+        self.pc = self.kw = self.kwp = self.w_small = self.b_small = self.cout = self.wa = None
         self.stride, self.pad = 1, 0
         self.reflect = self.relu = self.pool = self.ups = self.out_nchw = False
         for k, v in kw.items():
@@ -101,8 +101,11 @@ def _compile(mods):
             j = i + 3
             relu = isinstance(at(j), nn.ReLU)
             j += int(relu)
-            wv, kwp = ops.stem_virtual_weight(wf)
-            steps.append(_Step("stem", pc=ops.pack_conv_weight(wv, bf.contiguous()), kw=3, kwp=kwp, pad=1, reflect=True, relu=relu))
+            if ops.STEM3 and tuple(wf.shape) == (64, 3, 3, 3):      # the encoder's first layer: its own kernel, NCHW image in
+                steps.append(_Step("stem3", wa=ops.pack_stem3(wf, bf), relu=relu))
+            else:
+                wv, kwp = ops.stem_virtual_weight(wf)
+                steps.append(_Step("stem", pc=ops.pack_conv_weight(wv, bf.contiguous()), kw=3, kwp=kwp, pad=1, reflect=True, relu=relu))
             i = j
             continue
         if _is_pad1(m) and at(i + 1) is not None and _is_valid3(at(i + 1)):
@@ -110,7 +113,9 @@ def _compile(mods):
             j = i + 2
             relu = isinstance(at(j), nn.ReLU)
             j += int(relu)
-            if conv.in_channels <= 4:
+            if conv.in_channels <= 4 and ops.STEM3 and tuple(conv.weight.shape) == (64, 3, 3, 3):
+                steps.append(_Step("stem3", wa=ops.pack_stem3(conv.weight.detach(), None if conv.bias is None else conv.bias.detach()), relu=relu))
+            elif conv.in_channels <= 4:
                 wv, kwp = ops.stem_virtual_weight(conv.weight.detach())
                 steps.append(_Step("stem", pc=ops.pack_conv_weight(wv, conv.bias), kw=3, kwp=kwp, pad=1, reflect=True, relu=relu))
             elif conv.out_channels <= 4 and conv.in_channels % 16 == 0 and not pending_up:
@@ -173,7 +178,9 @@ def _peak_elems_per_sample(steps, C, H, W):
     """Largest NHWC buffer (elements per sample, channel padding included) a plan touches for a C x H x W input."""
     peak = max(C, 4) * H * W
     for s in steps:
-        if s.kind in ("stem", "smallco"):
+        if s.kind == "stem3":
+            C = 64
+        elif s.kind in ("stem", "smallco"):
             C = s.pc.cout if s.kind == "stem" else s.cout
         elif s.kind == "conv":
             if s.ups:
@@ -234,6 +241,12 @@ def _run_steps(steps, x, sums_box):
     cur = None          # NHWC buffer
     api = x             # logical NCHW tensor not yet converted
     for s in steps:
+        if s.kind == "stem3":
+            if cur is not None:
+                api = ops.to_api(cur[..., :C]) if cur.shape[-1] != C else ops.to_api(cur)
+            cur = ops.conv3x3_stem3_nchw(ops.as_nchw_contiguous(api), s.wa, relu=s.relu)
+            C, api = 64, None
+            continue
         if s.kind == "stem":
             if cur is not None:
                 api = ops.to_api(cur[..., :C]) if cur.shape[-1] != C else ops.to_api(cur)

@@ -465,6 +465,42 @@ def conv2d_stem_nchw(x_nchw, pc_virtual, kwp, kw, stride=1, pad=0, reflect=False
     return out
 
 
+STEM3 = os.environ.get("CCST_STEM3", "1") != "0"      # the dedicated first-layer kernel (conv_stem3.hip); 0: the generic stem path
+
+
+def pack_stem3(w_oihw, bias=None):
+    """[64,3,3,3] weight (+ bias [64]) -> the A operands of conv_stem3.hip."""
+    w = w_oihw.contiguous()
+    b = None if bias is None else bias.contiguous()
+    wa = torch.empty(18 * 2 * 64, device=w.device, dtype=torch.float32)
+    check(_lib.load().ccst_pack_stem3_weight_f32(ptr(w), ptr(b), ptr(wa), int(w.shape[0]), stream_ptr()), "pack_stem3")
+    return wa
+
+
+def conv3x3_stem3_nchw(x_nchw, wa, relu=True):
+    """ReflectionPad2d(1) + Conv2d(3,64,3x3) (+ReLU) on a contiguous NCHW image -> NHWC [N,H,W,64]."""
+    _require_cuda(x_nchw, "image")
+    x = as_nchw_contiguous(x_nchw)
+    N, C, H, W = x.shape
+    assert C == 3
+    out = torch.empty((N, H, W, 64), device=x.device, dtype=torch.float32)
+    # the kernel addresses its output through one 32-bit buffer resource: slices of < 2^31 bytes along the batch
+    per = max(1, (2 ** 31 - 1) // (H * W * 64 * 4))
+    lib = _lib.load()
+    for n0 in range(0, N, per):
+        n = min(per, N - n0)
+        args = (ptr(x[n0:]), ptr(wa), ptr(out[n0:]), n, H, W, int(relu), stream_ptr())
+        if TIMING is None:
+            check(lib.ccst_conv3x3_stem3_f32(*args), "conv3x3_stem3")
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(lib.ccst_conv3x3_stem3_f32(*args), "conv3x3_stem3")
+            e1.record()
+            TIMING.append(("conv_stem3_kernel", 2.0 * n * H * W * 64 * 27, e0, e1, "n%d %dx%d cin3 cout64 taps3x3" % (n, H, W)))
+    return out
+
+
 # ---------------------------------------------------------------------------
 # stand-alone NHWC layers (un-fused use)
 # ---------------------------------------------------------------------------

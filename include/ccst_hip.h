@@ -111,6 +111,11 @@ int64_t ccst_wino4_weight_floats(int cin, int cout_pad);
 int ccst_pack_conv_weight_wino4_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, void* stream);
 int ccst_conv3x3_wino4_f32(const float* x, const float* u_packed, const float* bias, float* y, int N, int H, int W, int Cin,
                            int Cout, int cout_pad, uint32_t flags, void* stream);
+/* The AdaIN encoder's first layer (net.py:39-42: the 1x1 colour conv folded into ReflectionPad2d(1) + Conv2d(3,64,3x3) + ReLU) from the
+ * contiguous NCHW image [N,3,H,W] to the NHWC map [N,H,W,64]; wa = ccst_pack_stem3_weight_f32(w [64,3,3,3], bias [64] or null)
+ * (18*2*64 floats: the bias is packed with the weights, in the one k slot three channels leave unused). */
+int ccst_pack_stem3_weight_f32(const float* w_oihw, const float* bias, float* wa, int cout, void* stream);
+int ccst_conv3x3_stem3_f32(const float* x_nchw, const float* wa, float* y_nhwc, int N, int H, int W, int relu, void* stream);
 /* F(4x4,3x3) with 64 output channels per workgroup (conv3x3_wino4w.hip): the same convolution and flags as ccst_conv3x3_wino4_f32;
  * every transformed input value feeds two MFMAs and the halo is fetched once per 64 output channels.  cout_pad a multiple of 64, Cin >= 32;
  * u_packed from ccst_pack_conv_weight_wino4w_f32 ([Cin/16][36][4 channel pairs][2][cout_pad/64][32][2][2] floats: a lane's weights

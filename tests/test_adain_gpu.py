@@ -767,3 +767,24 @@ def test_chan_sums_from_the_conv_epilogue(dev, nets, A):
         s4, q4, c4 = ops.chan_sums(f2)
     assert acc.images == 4 and maxdiff(mean, rmean) < 1e-4 and maxdiff(std, rstd) < 1e-3
     assert c3 == c4 and torch.equal(s3, s4) and torch.equal(q3, q4)
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 64), (1, 17, 33), (3, 64, 50), (1, 2, 2)])
+def test_stem3_first_layer_kernel(dev, shape):
+    """conv_stem3.hip (ReflectionPad2d(1) + Conv2d(3,64,3x3) + ReLU from the NCHW image to the NHWC map, the encoder's first layer)
+    against torch in fp64: widths that are not a multiple of the 32-pixel block, the smallest image reflection allows, no bias /
+    no ReLU variants."""
+    from ccst_amd import ops
+    n, h, w = shape
+    g = torch.Generator().manual_seed(3 + h)
+    x = torch.rand(n, 3, h, w, generator=g)
+    wt = torch.randn(64, 3, 3, 3, generator=g) * 0.3
+    b = torch.randn(64, generator=g) * 0.1
+    ref = F.conv2d(F.pad(x.double(), (1, 1, 1, 1), mode="reflect"), wt.double(), b.double())
+    for bias, relu in ((b, True), (None, False)):
+        wa = ops.pack_stem3(wt.to(dev), None if bias is None else bias.to(dev))
+        y = ops.conv3x3_stem3_nchw(x.to(dev), wa, relu=relu)
+        r = ref if bias is not None else ref - b.double().view(1, 64, 1, 1)
+        r = r.clamp_min(0) if relu else r
+        assert tuple(y.shape) == (n, h, w, 64)
+        assert float((y.permute(0, 3, 1, 2).cpu().double() - r).abs().max()) < 1e-5
