@@ -29,6 +29,12 @@
 #include "common.h"
 #include <type_traits>
 
+#ifndef W4W_STORE_AUX
+#define W4W_STORE_AUX 0
+#endif
+#ifndef W4W_LOAD_AUX
+#define W4W_LOAD_AUX 0
+#endif
 namespace {
 
 struct W4wArgs {
@@ -69,7 +75,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x4 bufw_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, W4W_LOAD_AUX));
 }
 __device__ __forceinline__ f32x2 bufw_load2(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0));
@@ -157,8 +163,16 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
             r = a - q * d;
             return q;
         };
+#if defined(W4W_MAP) && W4W_MAP == 1
+        int bid = tile, tx, ty;
+#else
         int bid = ccst_xcd_remap(tile, pk.ntiles), tx, ty;
+#endif
+#if defined(W4W_MAP) && W4W_MAP == 2
+        { const int sp = pk.ntiles / p.tilesN; t_tn = bid / sp; bid -= t_tn * sp; }
+#else
         bid = divmod(bid, p.tilesN, p.mN, t_tn);
+#endif
         bid = divmod(bid, p.tilesX, p.mX, tx);
         t_n = divmod(bid, p.tilesY, p.mY, ty);
         t_co0 = t_tn * 64;
@@ -701,7 +715,7 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
             const bool vec4 = !EDGE || (co + 3 < p.Cout && (p.Cout & 3) == 0);
             auto put = [&](f32x4 o, unsigned vo, unsigned so) {
                 if (vec4) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrs, vo, so, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrs, vo, so, W4W_STORE_AUX);
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; ++k)

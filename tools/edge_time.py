@@ -17,7 +17,7 @@ wa = ops.pack_stem3(w1, b1)
 feat = torch.randn(B, S, S, 64, generator=g).to(dev)
 w2 = (torch.randn(3, 64, 3, 3, generator=g) * 0.05).to(dev)
 b2 = torch.randn(3, generator=g).to(dev)
-pc2 = ops.pack_conv_weight(w2, b2)
+w2t = w2.permute(2, 3, 0, 1).contiguous()       # [3][3][Cout][Cin], as net.py hands it over
 
 
 def timed(fn):
@@ -36,7 +36,7 @@ def timed(fn):
 
 out_bytes = B * S * S * 64 * 4
 for name, fn, nbytes in (("stem3", lambda: ops.conv3x3_stem3_nchw(img, wa, relu=True), out_bytes + B * 3 * S * S * 4),
-                         ("smallco", lambda: ops.conv2d_nhwc(feat, pc2, pad=1, reflect=True, relu=False, out_nchw=True), out_bytes + B * 3 * S * S * 4),
+                         ("smallco", lambda: ops.conv3x3_smallco_nchw(feat, w2t, b2, 3, reflect=True, relu=False), out_bytes + B * 3 * S * S * 4),
                          ("fill", lambda: feat.fill_(1.0), out_bytes),
                          ("copy", lambda: feat.clone(), 2 * out_bytes)):
     try:
