@@ -65,6 +65,8 @@ _SIGNATURES = {
     "ccst_conv3x3_wino_train_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_conv3x3_wino_stats_groups": [c_int, c_int, c_int],
     "ccst_pack_conv_weights_wino_batch_f32": [_P, c_int, _P],
+    "ccst_pack_conv_weight_wino4w_bwd_f32": [_P, _P, c_int, c_int, c_int, _P],
+    "ccst_pack_conv_weights_wino4w_batch_f32": [_P, c_int, _P],
     "ccst_conv3x3_halo_train_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_conv3x3_halo_stats_groups": [c_int, c_int, c_int],
     "ccst_conv2d_igemm_tile": [c_int, c_int, c_int, c_int, c_int],
@@ -82,6 +84,7 @@ _SIGNATURES = {
     "ccst_conv2d_bwd_weight_f32": [POINTER(CcstConvDesc), _P, _P, _P, c_int, c_int, _P, c_int64, _P],
     "ccst_conv2d_bwd_weight_splits": [c_int, c_int, c_int, c_int],
     "ccst_calc_mean_std_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, c_int64, _P],
+    "ccst_interp_blend_f32": [_P, _P, _P, c_int, c_int64, c_float, c_float, _P, _P],
     "ccst_adain_f32": [_P, _P, _P, c_int, c_float, _P, c_int, c_int, c_int, c_int, c_float, _P, c_int64, _P],
     "ccst_chan_sums_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _P],
     "ccst_stats_workspace_bytes": [c_int, c_int, c_int],

@@ -381,6 +381,18 @@ int check_common(const void* x, int N, int C, int HW, int layout) {
     return CCST_OK;
 }
 
+// CCST_OverallStyleTransfer.py:36-45, the interpolation branch: feat = sum_k w_k * base[k] (accumulated in the reference's order, from
+// zero, every product and sum rounded separately), then feat * alpha + content[0] * (1 - alpha).  Elementwise, so any layout.
+__global__ __launch_bounds__(TPB) void interp_blend_kernel(const float* __restrict__ base, const float* __restrict__ content0,
+                                                           const float* __restrict__ w, int K, long long elems, float alpha, float oma,
+                                                           float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < elems; i += (long long)gridDim.x * TPB) {
+        float feat = 0.f;
+        for (int k = 0; k < K; ++k) feat = __fadd_rn(feat, __fmul_rn(w[k], base[(long long)k * elems + i]));
+        out[i] = __fadd_rn(__fmul_rn(feat, alpha), __fmul_rn(content0[i], oma));
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t ccst_stats_workspace_bytes(int N, int C, int HW) {
@@ -441,6 +453,19 @@ extern "C" int ccst_adain_f32(const float* x, const float* style_mean, const flo
                            style_per_n, alpha, HW, C);
     }
     return ccst_launch_status("adain_apply");
+}
+
+// style_transfer's interpolation branch (CCST_OverallStyleTransfer.py:36-45): base [K][elems] = the K stylised feature maps of one
+// content image, content0 [elems] its encoder output, weights [K] (device), out [elems] = (sum_k w_k base[k]) * alpha + content0 *
+// one_minus_alpha (the host's float(1 - alpha), as the reference's Python computes it).
+extern "C" int ccst_interp_blend_f32(const float* base, const float* content0, const float* weights, int K, int64_t elems, float alpha,
+                                     float one_minus_alpha, float* out, void* stream) {
+    CCST_REQUIRE(base && content0 && weights && out && K > 0 && elems > 0, "interp_blend: bad args");
+    CCST_REQUIRE(alpha >= 0.f && alpha <= 1.f, "interp_blend: alpha=%f outside [0,1]", (double)alpha);
+    const long long blocks = (elems + TPB - 1) / TPB;
+    hipLaunchKernelGGL(interp_blend_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(TPB), 0, (hipStream_t)stream, base, content0,
+                       weights, K, (long long)elems, alpha, one_minus_alpha, out);
+    return ccst_launch_status("interp_blend");
 }
 
 // Fold K per-tile (sum, sum of squares) pairs [K][C][2] (the statistics epilogue of ccst_conv3x3_wino4w_f32) into the per-channel totals.

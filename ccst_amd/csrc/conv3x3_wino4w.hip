@@ -790,8 +790,11 @@ __global__ __launch_bounds__(NTW) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 }
 
 // OIHW 3x3 -> U[chunk][pos = r*6+q][pair][k half][cout/64][32][group][2], U = G g G^T (accumulated in double);
-// input channel = chunk*16 + half*8 + 2*pair + e, output channel = block*64 + group*32 + lane
-__global__ void pack_weight_wino4w_kernel(const float* __restrict__ w, float* __restrict__ u, int cout, int cin, int cin_pad, int cout_pad) {
+// input channel = chunk*16 + half*8 + 2*pair + e, output channel = block*64 + group*32 + lane.  (cout, cin) are those of the conv the
+// transform serves; bwd: that conv is the backward-data of a forward conv with weight w [cin][cout][3][3] -- channels swapped, taps
+// reversed.  Grid-stride over blockIdx.x / gridDim.x.
+__device__ __forceinline__ void pack_weight_wino4w_body(const float* __restrict__ w, float* __restrict__ u, int cout, int cin, int cin_pad,
+                                                        int cout_pad, int bwd) {
     const double G[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
                             {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
     const int ncb = cout_pad >> 6;
@@ -812,9 +815,10 @@ __global__ void pack_weight_wino4w_kernel(const float* __restrict__ w, float* __
         const int co = cb * 64 + grp * 32 + lane;
         double val = 0.0;
         if (co < cout && ci < cin) {
-            const float* g = w + ((long long)co * cin + ci) * 9;
+            const float* g = bwd ? w + ((long long)ci * cout + co) * 9 : w + ((long long)co * cin + ci) * 9;
             for (int cc = 0; cc < 3; ++cc) {
-                const double gg = G[r][0] * (double)g[0 * 3 + cc] + G[r][1] * (double)g[1 * 3 + cc] + G[r][2] * (double)g[2 * 3 + cc];
+                const int c0 = bwd ? 8 - cc : cc, st = bwd ? -3 : 3;          // tap (a, cc) of the served conv = tap (2 - a, 2 - cc) of w
+                const double gg = G[r][0] * (double)g[c0] + G[r][1] * (double)g[c0 + st] + G[r][2] * (double)g[c0 + 2 * st];
                 val += gg * G[q][cc];
             }
         }
@@ -822,16 +826,46 @@ __global__ void pack_weight_wino4w_kernel(const float* __restrict__ w, float* __
     }
 }
 
+__global__ void pack_weight_wino4w_kernel(const float* __restrict__ w, float* __restrict__ u, int cout, int cin, int cin_pad, int cout_pad,
+                                          int bwd) {
+    pack_weight_wino4w_body(w, u, cout, cin, cin_pad, cout_pad, bwd);
+}
+
+// the same for many weight tensors in one launch: jobs[j] = {src, dst, n_out, n_in, n_in_pad16, n_out_pad64, bwd, 0} (int64, device)
+__global__ void pack_weight_wino4w_batch_kernel(const long long* __restrict__ jobs) {
+    const long long* jb = jobs + (long long)blockIdx.y * 8;
+    pack_weight_wino4w_body(reinterpret_cast<const float*>(jb[0]), reinterpret_cast<float*>(jb[1]), (int)jb[2], (int)jb[3], (int)jb[4],
+                            (int)jb[5], (int)jb[6]);
+}
+
 }  // namespace
 
-extern "C" int ccst_pack_conv_weight_wino4w_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, void* stream) {
+static int pack_wino4w_impl(const float* w_oihw, float* u, int cout, int cin, int cout_pad, int bwd, void* stream) {
     CCST_REQUIRE(w_oihw && u && cout > 0 && cin > 0, "pack_wino4w: bad args");
     CCST_REQUIRE(cout_pad >= cout && cout_pad % 64 == 0, "pack_wino4w: cout_pad must be a multiple of 64 >= cout");
     const int cin_pad = (cin + 15) / 16 * 16;
     const long long total = (long long)(cin_pad / 16) * 36 * 16 * cout_pad;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(pack_weight_wino4w_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, u, cout, cin, cin_pad, cout_pad);
+    hipLaunchKernelGGL(pack_weight_wino4w_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, u, cout, cin, cin_pad, cout_pad, bwd);
     return ccst_launch_status("pack_weight_wino4w");
+}
+
+extern "C" int ccst_pack_conv_weight_wino4w_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, void* stream) {
+    return pack_wino4w_impl(w_oihw, u, cout, cin, cout_pad, 0, stream);
+}
+
+// The backward-data operand of a stride-1 3x3 conv with forward weight w_oihw [cout][cin][3][3]: the transformed weights of the conv
+// dY -> dX (output channels = cin, input channels = cout; cin_pad a multiple of 64 >= cin).
+extern "C" int ccst_pack_conv_weight_wino4w_bwd_f32(const float* w_oihw, float* u, int cout, int cin, int cin_pad, void* stream) {
+    return pack_wino4w_impl(w_oihw, u, cin, cout, cin_pad, 1, stream);
+}
+
+// Many transforms in one launch (the per-step refresh after ccst_sgd_f32): jobs_device [njobs][8] int64 {src OIHW, dst, n_out, n_in,
+// n_in rounded up to 16, n_out rounded up to 64, bwd, 0}, (n_out, n_in) = channels of the conv the transform serves.
+extern "C" int ccst_pack_conv_weights_wino4w_batch_f32(const int64_t* jobs_device, int njobs, void* stream) {
+    CCST_REQUIRE(jobs_device && njobs > 0 && njobs <= 65535, "pack_wino4w_batch: bad job table");
+    hipLaunchKernelGGL(pack_weight_wino4w_batch_kernel, dim3(64, njobs), dim3(256), 0, (hipStream_t)stream, (const long long*)jobs_device);
+    return ccst_launch_status("pack_weight_wino4w_batch");
 }
 
 // x: NHWC source [N,Hs,Ws,Cin] (Hs = H/2 if CCST_CONV_UPS2), u: ccst_pack_conv_weight_wino4w_f32 output, y: NHWC [N,H,W,Cout] or

@@ -72,7 +72,7 @@ def _prepack_jobs(model, convs):
     """Device tables for the batched re-pack launches covering every packed copy the model's convs hold: the direct
     layouts (ccst_pack_conv_weights_batch_f32) and the Winograd transforms (ccst_pack_conv_weights_wino_batch_f32).  Rebuilt
     only if a weight or a packed buffer moved (the key is the tuple of their addresses)."""
-    slots, wslots = [], []
+    slots, wslots, w4slots = [], [], []
     for m in convs:
         if m.in_channels <= 4:
             continue
@@ -84,14 +84,18 @@ def _prepack_jobs(model, convs):
             slot = m.__dict__.get(name)
             if slot is not None:
                 wslots.append((m, name, slot[1], bwd))
+        for name, bwd in (("_ccst_w4", 0), ("_ccst_w4t", 1)):
+            slot = m.__dict__.get(name)
+            if slot is not None:
+                w4slots.append((m, name, slot[1], bwd))
     sig = tuple((m.weight.data_ptr(), pc.w.data_ptr()) for m, _n, pc, _t in slots) + \
-        tuple((m.weight.data_ptr(), pk[0].data_ptr()) for m, _n, pk, _b in wslots)
+        tuple((m.weight.data_ptr(), pk[0].data_ptr()) for m, _n, pk, _b in wslots + w4slots)
     cached = model.__dict__.get("_ccst_prepack_jobs")
-    if not slots and not wslots:
-        return (sig, None, slots, None, wslots)
+    if not slots and not wslots and not w4slots:
+        return (sig, None, slots, None, wslots, None, w4slots)
     if cached is None or cached[0] != sig:
-        dev = (slots or wslots)[0][0].weight.device
-        table = wtable = None
+        dev = (slots or wslots or w4slots)[0][0].weight.device
+        table = wtable = w4table = None
         if slots:
             rows = [[m.weight.data_ptr(), pc.w.data_ptr(), m.out_channels, m.in_channels, pc.kh * pc.kw, t, pc.k_pad, pc.n_pad]
                     for m, _n, pc, t in slots]
@@ -102,7 +106,13 @@ def _prepack_jobs(model, convs):
                 n_in = m.out_channels if bwd else m.in_channels
                 rows.append([m.weight.data_ptr(), u.data_ptr(), n_out, n_in, (n_in + 15) // 16 * 16, pad, bwd, 0])
             wtable = torch.tensor(rows, dtype=torch.int64).to(dev)
-        cached = (sig, table, slots, wtable, wslots)
+        if w4slots:
+            rows = []
+            for m, _n, (u, pad, n_out), bwd in w4slots:
+                n_in = m.out_channels if bwd else m.in_channels
+                rows.append([m.weight.data_ptr(), u.data_ptr(), n_out, n_in, (n_in + 15) // 16 * 16, pad, bwd, 0])
+            w4table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        cached = (sig, table, slots, wtable, wslots, w4table, w4slots)
         model.__dict__["_ccst_prepack_jobs"] = cached
     return cached
 
@@ -116,8 +126,8 @@ def prepack_on_side(model):
     if not convs:
         return
     device = convs[0].weight.device
-    _sig, table, slots, wtable, wslots = _prepack_jobs(model, convs)
-    if table is None and wtable is None:
+    _sig, table, slots, wtable, wslots, w4table, w4slots = _prepack_jobs(model, convs)
+    if table is None and wtable is None and w4table is None:
         return
 
     def launch():
@@ -126,6 +136,8 @@ def prepack_on_side(model):
             check(lib.ccst_pack_conv_weights_batch_f32(ptr(table), len(slots), stream_ptr()), "pack_weights_batch")
         if wtable is not None:
             check(lib.ccst_pack_conv_weights_wino_batch_f32(ptr(wtable), len(wslots), stream_ptr()), "pack_weights_wino_batch")
+        if w4table is not None:
+            check(lib.ccst_pack_conv_weights_wino4w_batch_f32(ptr(w4table), len(w4slots), stream_ptr()), "pack_weights_wino4w_batch")
     if SIDE_STREAM:
         side = _side_stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
@@ -134,7 +146,7 @@ def prepack_on_side(model):
         _PREPACK_PENDING.add(device.index)
     else:
         launch()
-    for m, name, pk, _t in slots + wslots:           # the packed copies now match the weights of this epoch
+    for m, name, pk, _t in slots + wslots + w4slots:           # the packed copies now match the weights of this epoch
         w = m.weight
         m.__dict__[name] = ((w._version, w.data_ptr(), ops.WEIGHTS_EPOCH), pk)
 
@@ -331,21 +343,26 @@ class ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, mod, want_stats=False, sink=None, link=None):
-        pc = mod.packed()
         ctx.save_for_backward(x, weight)
         ctx.mod = mod
         ctx.sink = sink
         ctx.link = link          # MaskLink of the ReLU that produced x (residual blocks), or None
         ctx.want_stats = bool(want_stats)
         ctx.set_materialize_grads(False)       # no zero tensor for the non-differentiable stats output
+        ctx.wino4 = mod.wino4_ok(x.shape[1], x.shape[2])       # 64-channel F(4x4): the trunk's 56x56 and 28x28 maps
         ctx.wino = mod.wino_ok(x.shape[1], x.shape[2])
+        pc = None if (ctx.wino4 or ctx.wino) else mod.packed()      # (the direct layout is packed only where it is used)
         if want_stats:      # BN batch statistics from the conv epilogue (non-differentiable side output)
-            if ctx.wino:
+            if ctx.wino4:
+                y, stats = ops.conv3x3_wino4w_train(x, mod.wino4_fwd(), want_stats=True)
+            elif ctx.wino:
                 y, stats = ops.conv3x3_wino_train(x, mod.wino_fwd(), want_stats=True)
             else:
                 y, stats = ops.conv2d_nhwc(x, pc, stride=mod.stride[0], pad=mod.padding[0], want_stats=True)
             ctx.mark_non_differentiable(stats)
             return y, stats
+        if ctx.wino4:
+            return ops.conv3x3_wino4w_train(x, mod.wino4_fwd())
         if ctx.wino:
             return ops.conv3x3_wino_train(x, mod.wino_fwd())
         return ops.conv2d_nhwc(x, pc, stride=mod.stride[0], pad=mod.padding[0])
@@ -374,7 +391,9 @@ class ConvFn(torch.autograd.Function):
                     into, ctx.sink.grad = ctx.sink.grad, None
                 elif ctx.sink.pair:
                     deposit = True
-            if ctx.wino:
+            if ctx.wino4 and into is None:          # (y += lives in the F(2x2) kernel only)
+                dx = ops.conv3x3_wino4w_train(dy, mod.wino4_bwd(), tag="bwd_data:")
+            elif ctx.wino:
                 dx = ops.conv3x3_wino_train(dy, mod.wino_bwd(), accumulate_into=into, tag="bwd_data:")
             else:
                 mask = None

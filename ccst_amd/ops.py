@@ -97,6 +97,58 @@ def conv3x3_wino_train(x, packed, want_stats=False, accumulate_into=None, tag=""
     return (y, stats) if want_stats else y
 
 
+# F(4x4) with 64 output channels per workgroup under the ResNet trunk's large maps: OPT-IN.  Alone it beats the F(2x2) kernel on the
+# 56x56 and 28x28 layers (115 -> 90 us, 111 -> 72 us per B=64 layer; from 14x14 down its 16x32-pixel tiles are mostly padding and too
+# few to fill the chip), but in the train step it gains 0.7 % (19.12 vs 19.25 ms on one box): its one workgroup per CU holds 148 KB of LDS,
+# so the weight-gradient stream's kernels cannot share those CUs while it runs; and F(4x4)'s rounding (~20x that of F(2x2)) carried
+# through eight layers puts the ResNet18 fixture's gradient probes at 1.2e-3 of the tensor's largest gradient, outside the 1e-3 gate.
+RESNET_WINO4 = os.environ.get("CCST_RESNET_WINO4", "0") == "1"
+
+
+def wino4w_train_ok(H, W, cin, cout):
+    return RESNET_WINO4 and cin % 16 == 0 and cin >= 32 and cout % 16 == 0 and cout >= 32 and H >= 28 and W >= 28
+
+
+def pack_wino4w(w_oihw, bwd=False, out=None):
+    """F(4x4) transformed copy of a 3x3 OIHW weight for conv3x3_wino4w.hip: (u, cout_pad, cout) of the forward conv, or with bwd=True
+    of the backward-data conv dY -> dX (its `cout` is the forward Cin)."""
+    cout, cin = w_oihw.shape[0], w_oihw.shape[1]
+    lib = _lib.load()
+    n_out, n_in = (cin, cout) if bwd else (cout, cin)
+    pad = round_up(n_out, 64)
+    nfl = int(lib.ccst_wino4_weight_floats(n_in, pad))
+    u = out if out is not None and out.numel() == nfl else torch.empty(nfl, device=w_oihw.device, dtype=torch.float32)
+    w = w_oihw.contiguous()
+    if bwd:
+        check(lib.ccst_pack_conv_weight_wino4w_bwd_f32(ptr(w), ptr(u), cout, cin, pad, stream_ptr()), "pack_wino4w_bwd")
+    else:
+        check(lib.ccst_pack_conv_weight_wino4w_f32(ptr(w), ptr(u), cout, cin, pad, stream_ptr()), "pack_wino4w")
+    return u, pad, n_out
+
+
+def conv3x3_wino4w_train(x, packed, want_stats=False, tag=""):
+    """3x3 stride-1 zero-padded bias-free conv on the 64-channel F(4x4) kernel (ResNet trunk, large maps).  packed = pack_wino4w(...);
+    the statistics are per-tile (sum, sum^2) partials [tiles, cout, 2] like every other producer of BatchNorm statistics."""
+    u, pad, cout = packed
+    N, H, W, Cx = x.shape
+    lib = _lib.load()
+    y = torch.empty((N, H, W, cout), device=x.device, dtype=torch.float32)
+    stats = None
+    if want_stats:
+        stats = torch.empty((int(lib.ccst_wino4w_spatial_tiles(N, H, W)), cout, 2), device=x.device, dtype=torch.float32)
+    args = (ptr(x), ptr(u), None, ptr(y), N, H, W, Cx, cout, pad, 0, ptr(stats), stream_ptr())
+    if TIMING is None:
+        check(lib.ccst_conv3x3_wino4w_f32(*args), "conv3x3_wino4w_train")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.ccst_conv3x3_wino4w_f32(*args), "conv3x3_wino4w_train")
+        e1.record()
+        TIMING.append((tag + "conv3x3_wino4w_kernel<train>", 2.0 * N * H * W * cout * Cx * 9, e0, e1,
+                       "n%d %dx%d cin%d cout%d taps3x3 s1" % (N, H, W, Cx, cout)))
+    return (y, stats) if want_stats else y
+
+
 def conv3x3_halo_train(x, pc, want_stats=False, flip=False, accumulate_into=None):
     """3x3 stride-1 zero-padded bias-free conv on the halo kernel (ResNet trunk).  pc: PackedConv whose K side matches
     x's channels (the transposed pack + flip=True gives the backward-data).  Returns y or (y, stats)."""
@@ -623,6 +675,24 @@ def adain(feat, style_mean, style_std, alpha=1.0, eps=1e-5):
         e1.record()
         TIMING.append(("adain_step", 0.0, e0, e1, "n%d c%d hw%d bytes%d" % (N, C, H * W, 2 * 4 * N * C * H * W)))
     return out if layout == NCHW else to_api(out)
+
+
+def interp_blend(base, content_f, weights, alpha=1.0):
+    """CCST_OverallStyleTransfer.py:36-45: sum_k weights[k] * base[k] blended with content_f[0] -> [1,C,H,W] in base's memory format.
+    base, content_f: [N,C,H,W] (same format), N >= len(weights)."""
+    N, C, H, W = base.shape
+    K = len(weights)
+    if K > N or tuple(content_f.shape) != tuple(base.shape):
+        raise RuntimeError("ccst_amd: %d interpolation weights for a batch of %d" % (K, N))
+    bb, lb = _layout_of(base)
+    cb, lc = _layout_of(content_f)
+    if lb != lc:
+        raise RuntimeError("ccst_amd: interp_blend operands differ in memory format")
+    w = torch.tensor([float(x) for x in weights], dtype=torch.float32).to(base.device)
+    out = torch.empty((1,) + tuple(bb.shape[1:]), device=base.device, dtype=torch.float32)
+    check(_lib.load().ccst_interp_blend_f32(ptr(bb), ptr(cb), ptr(w), K, C * H * W, float(alpha), float(1 - alpha), ptr(out), stream_ptr()),
+          "interp_blend")
+    return out if lb == NCHW else to_api(out)
 
 
 def chan_sums(feat):

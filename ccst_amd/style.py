@@ -41,8 +41,12 @@ def _style_transfer_two_streams(vgg, decoder, content, style_stat, alpha):
 def style_transfer(vgg, decoder, content, style_stat, alpha=1.0, interpolation_weights=None):
     assert (0.0 <= alpha <= 1.0)
     if interpolation_weights:
-        # unreachable from the reference CLIs (do_interpolation is never set, CCST_OverallStyleTransfer.py:109)
-        raise NotImplementedError("ccst_amd: style interpolation is outside the hot path")
+        # CCST_OverallStyleTransfer.py:36-42: the batch holds one content image per style; their stylised features are mixed by the
+        # weights, then blended with the first image's features (unreachable from the reference CLIs: do_interpolation is never set, :109)
+        content_f = vgg(content)
+        style_mean, style_std = style_stat
+        base_feat = ops.adain(content_f, style_mean, style_std, alpha=1.0)
+        return decoder(ops.interp_blend(base_feat, content_f, interpolation_weights, alpha))
     if HALF_BATCH_STREAMS and content.shape[0] >= 2 and content.is_cuda:
         return _style_transfer_two_streams(vgg, decoder, content, style_stat, alpha)
     content_f = vgg(content)

@@ -129,6 +129,14 @@ int ccst_conv3x3_wino4w_f32(const float* x, const float* u_packed, const float* 
  * mean_std_computation_effcientMem.py:103-115, without a pass over the tensor; ccst_chan_sums_finalize_f32 folds K such pairs
  * [K][C][2] into the [C] totals in fp64 (fixed order: bitwise reproducible). */
 int ccst_wino4w_spatial_tiles(int N, int H, int W);
+/* The same kernel under the ResNet trunk's 3x3 stride-1 zero-padded bias-free convs where the feature map is at least 28x28
+ * (nets/resnet.py:160-161 via the torchvision blocks): forward = ccst_conv3x3_wino4w_f32 with flags 0, bias NULL and the partials as
+ * the following BatchNorm2d's statistics; backward-data = the same call on dY with the weights of ccst_pack_conv_weight_wino4w_bwd_f32
+ * (channels swapped, taps reversed; cin_pad a multiple of 64).  ccst_pack_conv_weights_wino4w_batch_f32 refreshes many transforms in
+ * one launch after an optimiser step: jobs_device [njobs][8] int64 {src OIHW, dst, n_out, n_in, n_in rounded up to 16, n_out rounded
+ * up to 64, bwd, 0}. */
+int ccst_pack_conv_weight_wino4w_bwd_f32(const float* w_oihw, float* u, int cout, int cin, int cin_pad, void* stream);
+int ccst_pack_conv_weights_wino4w_batch_f32(const int64_t* jobs_device, int njobs, void* stream);
 int ccst_chan_sums_finalize_f32(const float* partials, int K, int C, float* sum, float* sqsum, void* stream);
 /* The Winograd kernel for the ResNet trunk's 3x3 stride-1 zero-padded bias-free convs (forward with the BatchNorm statistics
  * epilogue, backward-data with the weights from ccst_pack_conv_weight_wino_bwd_f32 and x = dY, optional y += with
@@ -260,6 +268,11 @@ int ccst_calc_mean_std_f32(const float* x, float* mean, float* std, int N, int C
 int ccst_adain_f32(const float* x, const float* style_mean, const float* style_std, int style_per_n,
                    float alpha, float* y, int N, int C, int HW, int layout, float eps,
                    void* ws, int64_t ws_bytes, void* stream);
+/* CCST_OverallStyleTransfer.py:36-45, style_transfer's interpolation branch after the AdaIN of the K copies of one content image
+ * against K styles: out[elems] = (sum_k weights[k] * base[k][elems], from zero in index order, products and sums rounded separately)
+ * * alpha + content0[elems] * one_minus_alpha.  weights: K floats on the device.  Elementwise: any (common) layout. */
+int ccst_interp_blend_f32(const float* base, const float* content0, const float* weights, int K, int64_t elems, float alpha,
+                          float one_minus_alpha, float* out, void* stream);
 /* mean_std_computation_effcientMem.py:103-115 calc_sum: per-channel sum and sum of squares over
  * N*H*W.  sum/sqsum: [C]. */
 int ccst_chan_sums_f32(const float* x, float* sum, float* sqsum, int N, int C, int HW, int layout,

@@ -137,13 +137,22 @@ def adain(content_feat, style_feat):
     return normalized * s_std.expand(size) + s_mean.expand(size)
 
 
-def style_transfer(vgg_w, dec_w, content, style_stat, alpha=1.0):
-    """CCST_OverallStyleTransfer.py:32-46 (non-interpolation branch; the
-    interpolation branch is unreachable from the CLIs: do_interpolation is
-    never set, :109)."""
+def style_transfer(vgg_w, dec_w, content, style_stat, alpha=1.0, interpolation_weights=None):
+    """CCST_OverallStyleTransfer.py:32-46.  The interpolation branch (:36-42;
+    unreachable from the CLIs: do_interpolation is never set, :109) mixes the
+    stylised features of the batch by the weights, from a zero tensor in index
+    order, and blends with the first image's features."""
     assert 0.0 <= alpha <= 1.0
     content_f = encoder(content, vgg_w)
-    feat = adain_style_stat(content_f, style_stat)
+    if interpolation_weights:
+        _, C, H, W = content_f.shape
+        feat = torch.zeros(1, C, H, W, dtype=torch.float32)
+        base_feat = adain_style_stat(content_f, style_stat)
+        for i, w in enumerate(interpolation_weights):
+            feat = feat + w * base_feat[i:i + 1]
+        content_f = content_f[0:1]
+    else:
+        feat = adain_style_stat(content_f, style_stat)
     feat = feat * alpha + content_f * (1 - alpha)
     return decoder(feat, dec_w)
 

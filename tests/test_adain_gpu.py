@@ -388,6 +388,24 @@ def test_style_transfer_golden_64(dev, golden, nets, A):
         style.style_transfer(vgg31, dec, content, stat, 1.5)
 
 
+def test_style_transfer_interpolation_golden(dev, golden, nets, A):
+    """style_transfer's interpolation branch (CCST_OverallStyleTransfer.py:36-42) against the reference's outputs."""
+    from ccst_amd import style
+    vgg31, dec, _, _ = nets
+    g = golden("style_transfer_interp")
+    content3 = A.synth_content(1, 64, 64, seed=int(g["seed"])).repeat(3, 1, 1, 1).to(dev)
+    stats3 = [A.synth_style_stat(512, seed=int(s)) for s in g["style_seeds"]]
+    stat3 = [torch.cat([s[0] for s in stats3]).to(dev), torch.cat([s[1] for s in stats3]).to(dev)]
+    wts = [float(w) for w in g["weights"]]
+    out = style.style_transfer(vgg31, dec, content3, stat3, 1.0, wts)
+    assert tuple(out.shape) == (1, 3, 64, 64)
+    assert maxdiff(out, torch.from_numpy(g["out"])) < TOL
+    out6 = style.style_transfer(vgg31, dec, content3, stat3, 0.6, wts)
+    assert maxdiff(out6, torch.from_numpy(g["out_alpha06"])) < TOL
+    with pytest.raises(RuntimeError):
+        style.style_transfer(vgg31, dec, content3[:2], [s[:2] for s in stat3], 1.0, wts)
+
+
 def test_style_transfer_golden_odd(dev, golden, nets, A):
     from ccst_amd import style
     vgg31, dec, _, _ = nets

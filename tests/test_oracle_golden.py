@@ -55,6 +55,17 @@ def test_style_transfer_64(golden):
     assert torch.equal(A.style_transfer(VGG_W, DEC_W, content, stat, 0.5), t(g["out_alpha05"]))
 
 
+def test_style_transfer_interpolation(golden):
+    """CCST_OverallStyleTransfer.py:36-42 against the reference's own outputs."""
+    g = golden("style_transfer_interp")
+    content3 = A.synth_content(1, 64, 64, seed=int(g["seed"])).repeat(3, 1, 1, 1)
+    stats3 = [A.synth_style_stat(512, seed=int(s)) for s in g["style_seeds"]]
+    stat3 = [torch.cat([s[0] for s in stats3]), torch.cat([s[1] for s in stats3])]
+    wts = [float(w) for w in g["weights"]]
+    assert torch.equal(A.style_transfer(VGG_W, DEC_W, content3, stat3, 1.0, wts), t(g["out"]))
+    assert torch.equal(A.style_transfer(VGG_W, DEC_W, content3, stat3, 0.6, wts), t(g["out_alpha06"]))
+
+
 def test_style_transfer_odd(golden):
     g = golden("style_transfer_odd")
     stat = A.synth_style_stat(512, seed=7)

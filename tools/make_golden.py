@@ -142,6 +142,17 @@ with torch.no_grad():
     out_a = ref_style_transfer(ref_vgg31, ref_dec, content, stat, 0.5)
     save("style_transfer_64", seed=1, relu4_1=enc, out=out, out_alpha05=out_a)
 
+    # 4b. the interpolation branch (CCST_OverallStyleTransfer.py:36-42): one content image three times, three styles, weights
+    one = A.synth_content(1, 64, 64, seed=5)
+    content3 = one.repeat(3, 1, 1, 1)
+    stats3 = [A.synth_style_stat(512, seed=s) for s in (7, 8, 9)]
+    stat3 = [torch.cat([s[0] for s in stats3]), torch.cat([s[1] for s in stats3])]
+    wts = [0.5, 0.3, 0.2]
+    out_i = ref_style_transfer(ref_vgg31, ref_dec, content3, stat3, 1.0, wts)
+    out_ia = ref_style_transfer(ref_vgg31, ref_dec, content3, stat3, 0.6, wts)
+    assert tuple(out_i.shape) == (1, 3, 64, 64)
+    save("style_transfer_interp", seed=5, style_seeds=[7, 8, 9], weights=np.array(wts), out=out_i, out_alpha06=out_ia)
+
     # 5. odd size [1,3,222,222] -> [1,3,224,224]; non-square [1,3,50,84]
     content = A.synth_content(1, 222, 222, seed=2)
     out = ref_style_transfer(ref_vgg31, ref_dec, content, stat, 1.0)
