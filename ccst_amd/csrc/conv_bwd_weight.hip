@@ -296,36 +296,37 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs p) 
         }
 }
 
-// dw[co][ci][tap] (+)= sum_s ws[s][tap][ci][co].  A workgroup owns (8/NL) ci x 32 co output elements and NL
-// split-lanes per element: lane l sums the slabs l, l+NL, ... (8 loads in flight), the lanes are folded in fixed
-// order through LDS, and the tile is transposed so the stores run along ci.  NL = 4 for the small weight tensors
-// (a 64x256 1x1 layer has only 64 tiles of 8x32 but 256-512 slabs to sum: one element per thread was pure latency).
+// dw[co][ci][tap] (+)= sum_s ws[s][tap][ci][co].  The slabs are the bulk of the traffic (splits x the weight tensor: 17-75 MB per
+// ResNet50 layer at B=64) and this kernel is bound by reading them: a thread owns four consecutive co (one 16-byte load per slab) of
+// one ci and sums the slabs l, l + NL, ... of its split-lane l with eight loads in flight; a workgroup = 32 co x (32 / NL) ci x NL
+// lanes, the lanes folded in fixed order through LDS, the tile transposed so that the stores run along ci.  NL is chosen by the
+// launcher so that there are >= 1024 workgroups where the tensor allows it (a 64x256 1x1 layer: 16 K elements, 256 slabs: NL = 32).
 // Fixed summation order for a given (problem, NL) => bitwise reproducible.
 template <int NL>
 __global__ __launch_bounds__(256) void bwd_weight_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int ntap, int Cin,
                                                                 int Cout, int splits, int accumulate) {
-    constexpr int TCI = 8 / NL;                      // ci rows per workgroup
-    __shared__ float part[NL][TCI][33];
+    constexpr int TCI = 32 / NL;                     // ci rows per workgroup
+    __shared__ float part[NL][TCI][36];
     const int tap = blockIdx.z;
     const int ci0 = blockIdx.y * TCI, co0 = blockIdx.x * 32;
-    const int tx = threadIdx.x & 31, ty = (threadIdx.x >> 5) % TCI, sl = (threadIdx.x >> 5) / TCI;
+    const int q = threadIdx.x & 7, ty = (threadIdx.x >> 3) % TCI, sl = (threadIdx.x >> 3) / TCI;
     {
-        const int ci = ci0 + ty, co = co0 + tx;
-        float s = 0.f;
+        const int ci = ci0 + ty, co = co0 + 4 * q;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
         if (ci < Cin && co < Cout) {
             const long long stride = (long long)ntap * Cin * Cout;
             const float* p = ws + ((long long)tap * Cin + ci) * Cout + co;
             int k = sl;
             for (; k + 7 * NL < splits; k += 8 * NL) {
-                float v[8];
+                f32x4 v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = p[(long long)(k + j * NL) * stride];
+                for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const f32x4*>(p + (long long)(k + j * NL) * stride);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s += v[j];
             }
-            for (; k < splits; k += NL) s += p[(long long)k * stride];
+            for (; k < splits; k += NL) s += *reinterpret_cast<const f32x4*>(p + (long long)k * stride);
         }
-        part[sl][ty][tx] = s;
+        *reinterpret_cast<f32x4*>(&part[sl][ty][4 * q]) = s;
     }
     __syncthreads();
     if (threadIdx.x < TCI * 32) {
@@ -413,15 +414,18 @@ extern "C" int ccst_conv2d_bwd_weight_f32(const CcstConvDesc* d, const float* x,
     else if (!pw && ntap > 1 && d->cin <= 32) rc = launch<1, 1, 32, false, true>(a, s);      // two taps per ci tile
     else rc = pw ? launch<1, 1, 32, true>(a, s) : launch<1, 1, 32, false>(a, s);
     if (rc) return rc;
-    const long long tiles8 = (long long)((d->cout + 31) / 32) * ((d->cin + 7) / 8) * ntap;
-    if (tiles8 >= 1024) {
-        dim3 grid((d->cout + 31) / 32, (d->cin + 7) / 8, ntap);
-        hipLaunchKernelGGL(bwd_weight_reduce_kernel<1>, grid, dim3(256), 0, s, (const float*)ws, dw_oihw, ntap, d->cin, d->cout, splits,
-                           accumulate);
-    } else {
-        dim3 grid((d->cout + 31) / 32, (d->cin + 1) / 2, ntap);
-        hipLaunchKernelGGL(bwd_weight_reduce_kernel<4>, grid, dim3(256), 0, s, (const float*)ws, dw_oihw, ntap, d->cin, d->cout, splits,
-                           accumulate);
-    }
+    // split-lanes of the reduce: the fewest (4, 8, 16, 32) that give >= 1024 workgroups, never more than there are slabs to share
+    const long long cols = (long long)((d->cout + 31) / 32) * ntap;
+    int nl = 4;
+    while (nl < 32 && nl < splits && cols * ((d->cin + 32 / nl - 1) / (32 / nl)) < 1024) nl *= 2;
+    dim3 grid((d->cout + 31) / 32, (d->cin + 32 / nl - 1) / (32 / nl), ntap);
+#define CCST_REDUCE(NL_)                                                                                                       \
+    hipLaunchKernelGGL(bwd_weight_reduce_kernel<NL_>, grid, dim3(256), 0, s, (const float*)ws, dw_oihw, ntap, d->cin, d->cout, splits, \
+                       accumulate)
+    if (nl == 4) CCST_REDUCE(4);
+    else if (nl == 8) CCST_REDUCE(8);
+    else if (nl == 16) CCST_REDUCE(16);
+    else CCST_REDUCE(32);
+#undef CCST_REDUCE
     return ccst_launch_status("bwd_weight_reduce");
 }

@@ -165,7 +165,9 @@ def test_conv3x3_winograd_vs_direct(dev, case, reflect):
 
 @pytest.mark.parametrize("case", [(2, 32, 48, 64, 64, False, False), (1, 17, 23, 32, 96, False, False), (2, 24, 24, 128, 40, True, False),
                                   (1, 22, 38, 64, 64, False, True), (1, 16, 32, 256, 256, False, False), (1, 9, 7, 16, 33, True, False),
-                                  (1, 33, 65, 48, 64, True, False), (3, 50, 84, 64, 128, False, False), (1, 64, 64, 512, 64, False, True)])
+                                  (1, 33, 65, 48, 64, True, False), (3, 50, 84, 64, 128, False, False), (1, 64, 64, 512, 64, False, True),
+                                  # 384 and 300 tiles on 256 CUs: persistent workgroups walk a second, partly filled round
+                                  (6, 64, 64, 32, 512, False, False), (5, 50, 70, 32, 320, False, False)])
 @pytest.mark.parametrize("reflect", [True, False])
 @pytest.mark.parametrize("narrow", [False, True])
 def test_conv3x3_winograd4_vs_direct(dev, case, reflect, narrow):
