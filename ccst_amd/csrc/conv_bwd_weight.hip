@@ -418,6 +418,9 @@ extern "C" int ccst_conv2d_bwd_weight_f32(const CcstConvDesc* d, const float* x,
     const long long cols = (long long)((d->cout + 31) / 32) * ntap;
     int nl = 4;
     while (nl < 32 && nl < splits && cols * ((d->cin + 32 / nl - 1) / (32 / nl)) < 1024) nl *= 2;
+#ifdef REDUCE_FORCE_NL          // (diagnostic builds: the split-lane count fixes the summation order)
+    nl = REDUCE_FORCE_NL;
+#endif
     dim3 grid((d->cout + 31) / 32, (d->cin + 32 / nl - 1) / (32 / nl), ntap);
 #define CCST_REDUCE(NL_)                                                                                                       \
     hipLaunchKernelGGL(bwd_weight_reduce_kernel<NL_>, grid, dim3(256), 0, s, (const float*)ws, dw_oihw, ntap, d->cin, d->cout, splits, \

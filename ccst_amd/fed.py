@@ -231,12 +231,13 @@ class _GraphedTrainStep(object):
     vs 25.2 ms), so this is opt-in (args.hip_graph / --hip_graph / CCST_TRAIN_GRAPH=1).  Results are bit-identical
     to the eager loop (tests/test_resnet_gpu.py::test_train_hip_graph_matches_eager)."""
 
-    def __init__(self, model, optimizer, loss_fun, img, class_l):
+    def __init__(self, model, optimizer, loss_fun, img, class_l, loss_all, correct_all):
         self.model, self.shape = model, (tuple(img.shape), tuple(class_l.shape))
         self.x, self.y = img.clone(), class_l.clone()
         dev = img.device
-        self.loss_all = torch.zeros((), device=dev)
-        self.correct_all = torch.zeros((), device=dev, dtype=torch.int64)
+        # the epoch's running sums: the SAME tensors the eager iterations add to, so that the loss is summed in iteration order
+        # whatever mix of eager and replayed iterations an epoch has (separate sums added at the end differ in the last bit)
+        self.loss_all, self.correct_all = loss_all, correct_all
         self.convs = [m for m in model.modules() if hasattr(m, "prepack")]
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
@@ -247,10 +248,6 @@ class _GraphedTrainStep(object):
             backward(loss)
             optimizer.step()
             nn_ops.join_prepack(dev)            # every forked stream re-joins before the capture ends
-
-    def reset(self):
-        self.loss_all.zero_()
-        self.correct_all.zero_()
 
     def run(self, img, class_l):
         self.x.copy_(img, non_blocking=True)
@@ -285,7 +282,13 @@ def train(model, train_loader, optimizer, loss_fun, client_num, device, args, it
         # replaying a graph that reads and writes freed memory and silently stops training the live tensors.
         FlatParams.of(model)
     steps = model.__dict__.setdefault("_ccst_graph_steps", {}) if use_graph else None
-    used = set()
+    if use_graph:           # captured steps add into these (static addresses): one pair per model, zeroed per epoch
+        acc = steps.get("_sums")
+        if acc is None:
+            acc = steps["_sums"] = (loss_all, correct_all)
+        loss_all, correct_all = acc
+        loss_all.zero_()
+        correct_all.zero_()
     eager_iters, stale_keys = 0, False
     window = StepWindow() if torch.device(device).type == "cuda" else None
     for it, data in enumerate(train_loader):
@@ -295,14 +298,11 @@ def train(model, train_loader, optimizer, loss_fun, client_num, device, args, it
         if use_graph:
             key = (tuple(img.shape), tuple(class_l.shape), float(optimizer.lr), id(loss_fun))
             gs = steps.get(key)
-            if gs is None and eager_iters >= 2 and len(steps) < 4:     # capture once caches / workspaces are warm
+            if gs is None and eager_iters >= 2 and len(steps) < 5:     # capture once caches / workspaces are warm (<= 4 shapes)
                 nn_ops.join_prepack(device)
                 torch.cuda.current_stream(device).synchronize()
-                gs = steps[key] = _GraphedTrainStep(model, optimizer, loss_fun, img, class_l)
+                gs = steps[key] = _GraphedTrainStep(model, optimizer, loss_fun, img, class_l, loss_all, correct_all)
             if gs is not None:
-                if key not in used:
-                    used.add(key)
-                    gs.reset()
                 gs.run(img, class_l)
                 stale_keys = True
                 if window is not None:
@@ -329,12 +329,8 @@ def train(model, train_loader, optimizer, loss_fun, client_num, device, args, it
         del img, class_l
         if window is not None:
             window.tick()
-    if use_graph:
-        for key in used:
-            loss_all += steps[key].loss_all
-            correct_all += steps[key].correct_all
-        if stale_keys:
-            ops.bump_weights_epoch()
+    if use_graph and stale_keys:
+        ops.bump_weights_epoch()
     train_loss = float(loss_all) / (it + 1)
     train_acc = float(correct_all) / num_data
     # fed_run.py:85 moves the model back to the CPU after every client epoch; on MI355X the client

@@ -711,7 +711,7 @@ def test_train_hip_graph_matches_eager(dev):
         r3 = fed.test(model, loader, ce, dev, args)
         out[mode] = (r1, r2, r3, {k: v.detach().clone() for k, v in model.state_dict().items()})
         if mode:
-            assert len(model.__dict__["_ccst_graph_steps"]) == 2        # full batch + the ragged last batch
+            assert len([k for k in model.__dict__["_ccst_graph_steps"] if k != "_sums"]) == 2        # full batch + the ragged last batch
     for a, b in zip(out[False][:3], out[True][:3]):
         assert abs(a[0] - b[0]) < 1e-6 * abs(a[0]) and a[1] == b[1], (a, b)      # the running loss is summed per graph, then added
     for k, v in out[False][3].items():
