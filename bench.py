@@ -345,6 +345,27 @@ def main():
                       "kernels": "adain_fused_nhwc_kernel: two-pass statistics on register-resident planes + normalise, one read and one write, "
                                  "ONE launch (HIP events around ccst_adain_f32)"}
 
+    # ---- the same step with the two halves of the batch on two HIP streams (CCST_ADAIN_STREAMS=2, style._style_transfer_two_streams):
+    # one half's tails, partly filled rounds and HBM-bound edge layers run under the other half's MFMA work.  Reported beside `value`,
+    # not as it: with two kernels sharing the chip a launch's duration says nothing about the kernel, and the roofline above is
+    # measured on the plain schedule.
+    two_streams = None
+    if rank == 0 and B >= 2:
+        prev = style.HALF_BATCH_STREAMS
+        style.HALF_BATCH_STREAMS = True
+        try:
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            h0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            two_streams = {"images_per_s": round(B * args.steps / (time.perf_counter() - h0), 2), "steps": args.steps,
+                           "note": "same batch and result; halves of the batch on two streams (opt-in, CCST_ADAIN_STREAMS=2)"}
+        finally:
+            style.HALF_BATCH_STREAMS = prev
+
     result = {
         "metric": "AdaIN stylised images/sec @512x512 B=6", "value": round(value, 3), "unit": "images/sec",
         "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup, "init_passes": INIT_PASSES, "ms_per_step": round(ms_per_step, 3),
@@ -355,6 +376,7 @@ def main():
         "roofline": roofline,
         "adain_step": adain_step,
         "end_to_end": e2e,
+        "two_stream_schedule": two_streams,
         "whole_path_tflops": round(GFLOP_PER_IMAGE_512 * 1e9 * scale * B * n_ranks_seen * args.steps / elapsed / 1e12, 2),
         "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in kernels.items()},
     }
