@@ -342,8 +342,9 @@ def main():
         us = sorted(adain_us)[len(adain_us) // 2]
         adain_step = {"bound": "hbm", "bytes": nbytes, "median_us": round(us, 2), "achieved": round(nbytes / us / 1e3, 1),
                       "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(nbytes / us / 1e3 / PEAK_HBM_GBPS, 4),
-                      "kernels": "adain_fused_nhwc_kernel: two-pass statistics on register-resident planes + normalise, one read and one write, "
-                                 "ONE launch (HIP events around ccst_adain_f32)"}
+                      "kernels": "adain_tile_sums_nhwc_kernel: content statistics folded from the per-tile channel sums that conv4_1's epilogue left "
+                                 "(no statistics pass), normalise + blend streamed once: one read, one write, ONE launch (HIP events around "
+                                 "ccst_adain_tile_sums_f32; CCST_ADAIN_TILE_SUMS=0: the two-pass register-resident kernel of ccst_adain_f32)"}
 
     # ---- the same step with the two halves of the batch on two HIP streams (CCST_ADAIN_STREAMS=2, style._style_transfer_two_streams):
     # one half's tails, partly filled rounds and HBM-bound edge layers run under the other half's MFMA work.  Reported beside `value`,

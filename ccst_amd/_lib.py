@@ -84,6 +84,7 @@ _SIGNATURES = {
     "ccst_conv2d_bwd_weight_f32": [POINTER(CcstConvDesc), _P, _P, _P, c_int, c_int, _P, c_int64, _P],
     "ccst_conv2d_bwd_weight_splits": [c_int, c_int, c_int, c_int],
     "ccst_calc_mean_std_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, c_int64, _P],
+    "ccst_adain_tile_sums_f32": [_P, _P, c_int, _P, _P, c_int, c_float, _P, c_int, c_int, c_int, c_float, _P, _P, _P],
     "ccst_interp_blend_f32": [_P, _P, _P, c_int, c_int64, c_float, c_float, _P, _P],
     "ccst_adain_f32": [_P, _P, _P, c_int, c_float, _P, c_int, c_int, c_int, c_int, c_float, _P, c_int64, _P],
     "ccst_chan_sums_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _P],

@@ -381,6 +381,65 @@ int check_common(const void* x, int N, int C, int HW, int layout) {
     return CCST_OK;
 }
 
+// AdaIN where the producer of x has already left the statistics: per-(spatial tile, channel) sums (S, Q) of x and x^2 from the epilogue of
+// the conv that wrote x (ccst_conv3x3_wino4w_f32 with chan_sum_partials; tiles n * tpi .. (n + 1) * tpi - 1 belong to image n, pixels
+// outside the image excluded).  A workgroup = (64 channels, image, 256 pixels): every thread folds the tpi tile pairs of its four
+// channels in fp64 -- mean = S / HW, unbiased variance = (Q - S * mean) / (HW - 1): 4 KB of partials per workgroup -- and then the
+// tensor is streamed ONCE, every CU busy, no load-everything-then-store phase; function.py:26-33's four separately rounded operations.
+// (Raw moments are fine here and only here: the sums are over 512-pixel tiles in fp32, folded in fp64, of a feature map whose
+//  producer is known -- the general entry ccst_adain_f32 keeps the two-pass / pivot-shifted forms for arbitrary planes.)
+constexpr int TS_CQ = 16, TS_PL = TPB / TS_CQ, TS_PIX = 256;
+__global__ __launch_bounds__(TPB) void adain_tile_sums_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                   const float* __restrict__ part, int tpi,
+                                                                   const float* __restrict__ smean, const float* __restrict__ sstd,
+                                                                   int style_per_n, float alpha, int HW, int C, float eps,
+                                                                   float* __restrict__ mean_out, float* __restrict__ std_out) {
+    const int t = threadIdx.x, cq = t % TS_CQ, pl = t / TS_CQ;
+    const int n = blockIdx.y, c0 = blockIdx.x * (4 * TS_CQ) + cq * 4;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    const float* pp = part + ((long long)n * tpi * C + c0) * 2;
+    for (int k = 0; k < tpi; ++k) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(pp + (long long)k * C * 2);          // S c0, Q c0, S c0+1, Q c0+1
+        const f32x4 b = *reinterpret_cast<const f32x4*>(pp + (long long)k * C * 2 + 4);
+        s[0] += (double)a[0]; q[0] += (double)a[1]; s[1] += (double)a[2]; q[1] += (double)a[3];
+        s[2] += (double)b[0]; q[2] += (double)b[1]; s[3] += (double)b[2]; q[3] += (double)b[3];
+    }
+    f32x4 mu, sd;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double m = s[j] / (double)HW;
+        const double var = fmax(q[j] - s[j] * m, 0.0) / ((double)HW - 1.0);
+        mu[j] = (float)m;
+        sd[j] = sqrtf((float)var + eps);
+    }
+    if (mean_out != nullptr && blockIdx.z == 0 && pl == 0) {
+        *reinterpret_cast<f32x4*>(mean_out + n * C + c0) = mu;
+        *reinterpret_cast<f32x4*>(std_out + n * C + c0) = sd;
+    }
+    const int so = (style_per_n ? n * C : 0) + c0;
+    const f32x4 sm = *reinterpret_cast<const f32x4*>(smean + so), ss = *reinterpret_cast<const f32x4*>(sstd + so);
+    const bool blend = (alpha != 1.f);
+    const float* xb = x + ((long long)n * HW) * C + c0;
+    float* yb = y + ((long long)n * HW) * C + c0;
+    const int p0 = blockIdx.z * TS_PIX;
+    f32x4 v[TS_PIX / TS_PL];
+#pragma unroll
+    for (int i = 0; i < TS_PIX / TS_PL; ++i) {
+        const int p = p0 + pl + i * TS_PL;
+        if (p < HW) v[i] = *reinterpret_cast<const f32x4*>(xb + (long long)p * C);
+    }
+#pragma unroll
+    for (int i = 0; i < TS_PIX / TS_PL; ++i) {
+        const int p = p0 + pl + i * TS_PL;
+        if (p < HW) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = adain_one(v[i][j], mu[j], sd[j], sm[j], ss[j], alpha, blend);
+            *reinterpret_cast<f32x4*>(yb + (long long)p * C) = o;
+        }
+    }
+}
+
 // CCST_OverallStyleTransfer.py:36-45, the interpolation branch: feat = sum_k w_k * base[k] (accumulated in the reference's order, from
 // zero, every product and sum rounded separately), then feat * alpha + content[0] * (1 - alpha).  Elementwise, so any layout.
 __global__ __launch_bounds__(TPB) void interp_blend_kernel(const float* __restrict__ base, const float* __restrict__ content0,
@@ -453,6 +512,23 @@ extern "C" int ccst_adain_f32(const float* x, const float* style_mean, const flo
                            style_per_n, alpha, HW, C);
     }
     return ccst_launch_status("adain_apply");
+}
+
+// function.py:26-33 (+ the alpha blend) on an NHWC tensor x [N][HW][C] whose producer left per-tile channel sums: partials
+// [N * tiles_per_image][C][2] = (sum, sum of squares) of x over the pixels of spatial tile t, tiles of image n contiguous
+// (ccst_conv3x3_wino4w_f32's chan_sum_partials).  C a multiple of 64.  mean_out / std_out: NULL or [N*C] (the content statistics).
+extern "C" int ccst_adain_tile_sums_f32(const float* x, const float* partials, int tiles_per_image, const float* style_mean,
+                                        const float* style_std, int style_per_n, float alpha, float* y, int N, int C, int HW, float eps,
+                                        float* mean_out, float* std_out, void* stream) {
+    CCST_REQUIRE(x && partials && style_mean && style_std && y, "adain_tile_sums: null pointer");
+    CCST_REQUIRE(N > 0 && N <= 65535 && C > 0 && C % (4 * TS_CQ) == 0 && HW >= 2 && tiles_per_image > 0, "adain_tile_sums: bad shape (C %% 64 == 0, HW >= 2)");
+    CCST_REQUIRE(alpha >= 0.f && alpha <= 1.f, "adain_tile_sums: alpha=%f outside [0,1]", (double)alpha);
+    CCST_REQUIRE((mean_out == nullptr) == (std_out == nullptr), "adain_tile_sums: mean_out and std_out come together");
+    const int chunks = (HW + TS_PIX - 1) / TS_PIX;
+    CCST_REQUIRE(chunks <= 65535, "adain_tile_sums: plane too large");
+    hipLaunchKernelGGL(adain_tile_sums_nhwc_kernel, dim3(C / (4 * TS_CQ), N, chunks), dim3(TPB), 0, (hipStream_t)stream, x, y, partials,
+                       tiles_per_image, style_mean, style_std, style_per_n, alpha, HW, C, eps, mean_out, std_out);
+    return ccst_launch_status("adain_tile_sums");
 }
 
 // style_transfer's interpolation branch (CCST_OverallStyleTransfer.py:36-45): base [K][elems] = the K stylised feature maps of one

@@ -343,6 +343,38 @@ class Sequential(nn.Sequential):
         return _run(cache.get(list(self.children())), input, want_sums=True)
 
 
+def _forward_with_tile_sums(self, input):
+    """(self(input), partials): the features and, where the last conv runs on the 64-channel F(4x4) kernel, the per-(spatial tile,
+    channel) (sum, sum of squares) pairs its epilogue leaves ([N * tiles, C, 2], an image's tiles contiguous) -- what
+    ops.adain_from_tile_sums needs instead of a statistics pass over the features; partials is None where that conv cannot
+    produce them (other kernels, or a batch that has to be processed in slices)."""
+    cache = self.__dict__.get("_ccst_plan")
+    if cache is None:
+        cache = _PlanCache()
+        self.__dict__["_ccst_plan"] = cache
+    steps = cache.get(list(self.children()))
+    x = input
+    if isinstance(x, torch.Tensor) and x.dim() == 4 and x.shape[0] > 0:
+        per = _peak_elems_per_sample(steps, int(x.shape[1]), int(x.shape[2]), int(x.shape[3]))
+        if per > MAX_ELEMS:
+            return _run(steps, x), None                   # (raises: one image does not fit)
+        if per * int(x.shape[0]) > MAX_ELEMS:             # slices of the batch: an image's tiles stay contiguous, so the partials concatenate
+            n = max(1, MAX_ELEMS // per)
+            ys, ps = [], []
+            for i in range(0, int(x.shape[0]), n):
+                bx = []
+                ys.append(_run_steps(steps, x[i:i + n], bx))
+                ps.append(bx[0] if bx else None)
+            y = torch.cat([v.permute(0, 2, 3, 1) for v in ys], dim=0).permute(0, 3, 1, 2)        # (stays NHWC in memory)
+            return y, (torch.cat(ps, dim=0) if all(p_ is not None for p_ in ps) else None)
+    box = []
+    y = _run_steps(steps, x, box)
+    return y, (box[0] if box else None)
+
+
+Sequential.forward_with_tile_sums = _forward_with_tile_sums
+
+
 class _SingleMixin(object):
     def _ccst_forward(self, input):
         cache = self.__dict__.get("_ccst_plan")

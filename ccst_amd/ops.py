@@ -677,6 +677,43 @@ def adain(feat, style_mean, style_std, alpha=1.0, eps=1e-5):
     return out if layout == NCHW else to_api(out)
 
 
+def adain_tile_sums_ok(feat, partials):
+    """Can adain_from_tile_sums() take this feature map (NHWC in memory, C % 64 == 0, partials of whole images)?"""
+    if partials is None or feat.dim() != 4 or not feat.is_cuda:
+        return False
+    N, C, H, W = feat.shape
+    return C % 64 == 0 and H * W >= 2 and feat.permute(0, 2, 3, 1).is_contiguous() and partials.shape[0] % N == 0 and \
+        partials.shape[1] == C and N <= 65535
+
+
+def adain_from_tile_sums(feat, partials, style_mean, style_std, alpha=1.0, eps=1e-5):
+    """function.py:26-33 + the alpha blend where the conv that produced feat left per-tile channel sums (conv3x3_wino4 with sums=True:
+    partials [N * tiles, C, 2]): one streaming launch, no statistics pass.  feat: logical NCHW view of an NHWC buffer."""
+    N, C, H, W = feat.shape
+    buf = feat.permute(0, 2, 3, 1)
+    assert buf.is_contiguous() and partials.is_contiguous() and partials.shape[0] % N == 0 and partials.shape[1] == C
+    sm = style_mean.to(device=feat.device, dtype=torch.float32).reshape(-1).contiguous()
+    ss = style_std.to(device=feat.device, dtype=torch.float32).reshape(-1).contiguous()
+    if sm.numel() == C and ss.numel() == C:
+        per_n = 0
+    elif sm.numel() == N * C and ss.numel() == N * C:
+        per_n = 1
+    else:
+        raise RuntimeError("ccst_amd: style statistics must have C or N*C elements")
+    out = torch.empty_like(buf)
+    args = (ptr(buf), ptr(partials), int(partials.shape[0] // N), ptr(sm), ptr(ss), per_n, float(alpha), ptr(out), N, C, H * W, eps, None, None,
+            stream_ptr())
+    if TIMING is None:
+        check(_lib.load().ccst_adain_tile_sums_f32(*args), "adain_tile_sums")
+    else:       # bench.py: the AdaIN step of the path = this one launch; HBM-bound: algorithmic bytes = read x + write y
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().ccst_adain_tile_sums_f32(*args), "adain_tile_sums")
+        e1.record()
+        TIMING.append(("adain_step", 0.0, e0, e1, "n%d c%d hw%d bytes%d" % (N, C, H * W, 2 * 4 * N * C * H * W)))
+    return to_api(out)
+
+
 def interp_blend(base, content_f, weights, alpha=1.0):
     """CCST_OverallStyleTransfer.py:36-45: sum_k weights[k] * base[k] blended with content_f[0] -> [1,C,H,W] in base's memory format.
     base, content_f: [N,C,H,W] (same format), N >= len(weights)."""

@@ -20,6 +20,24 @@ HALF_BATCH_STREAMS = os.environ.get("CCST_ADAIN_STREAMS", "1") == "2"
 _SIDE = {}
 
 
+# The AdaIN statistics of the content features come out of the encoder's last conv (per-tile channel sums in its epilogue,
+# net.Sequential.forward_with_tile_sums) where that conv can produce them: the AdaIN step is then ONE streaming launch over the
+# features (ops.adain_from_tile_sums) instead of load-everything / two-pass / store.  CCST_ADAIN_TILE_SUMS=0: always ops.adain.
+TILE_SUM_ADAIN = os.environ.get("CCST_ADAIN_TILE_SUMS", "1") != "0"
+
+
+def _encode_and_adain(vgg, content, style_stat, alpha):
+    """vgg(content) -> adaIN_StyleStat_ContentFeat -> alpha blend (CCST_OverallStyleTransfer.py:35,43,45)."""
+    style_mean, style_std = style_stat
+    if TILE_SUM_ADAIN and hasattr(vgg, "forward_with_tile_sums"):
+        content_f, part = vgg.forward_with_tile_sums(content)
+        if ops.adain_tile_sums_ok(content_f, part):
+            return ops.adain_from_tile_sums(content_f, part, style_mean, style_std, alpha=alpha)
+    else:
+        content_f = vgg(content)
+    return ops.adain(content_f, style_mean, style_std, alpha=alpha)   # AdaIN + alpha blend in one pass
+
+
 def _style_transfer_two_streams(vgg, decoder, content, style_stat, alpha):
     dev = content.device
     main = torch.cuda.current_stream(dev)
@@ -31,8 +49,7 @@ def _style_transfer_two_streams(vgg, decoder, content, style_stat, alpha):
     side.wait_stream(main)
     for i, st in enumerate((main, side)):
         with torch.cuda.stream(st):
-            f = ops.adain(vgg(parts[i]), style_stat[0], style_stat[1], alpha=alpha)
-            outs[i] = decoder(f)
+            outs[i] = decoder(_encode_and_adain(vgg, parts[i], style_stat, alpha))
     main.wait_stream(side)
     outs[1].record_stream(main)
     return torch.cat(outs, 0)
@@ -50,10 +67,7 @@ def style_transfer(vgg, decoder, content, style_stat, alpha=1.0, interpolation_w
         return decoder(ops.interp_blend(base_feat, content_f, interpolation_weights, alpha))
     if HALF_BATCH_STREAMS and content.shape[0] >= 2 and content.is_cuda:
         return _style_transfer_two_streams(vgg, decoder, content, style_stat, alpha)
-    content_f = vgg(content)
-    style_mean, style_std = style_stat
-    feat = ops.adain(content_f, style_mean, style_std, alpha=alpha)   # AdaIN + alpha blend in one pass
-    return decoder(feat)
+    return decoder(_encode_and_adain(vgg, content, style_stat, alpha))
 
 
 def calc_sum(feat):

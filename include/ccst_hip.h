@@ -268,6 +268,14 @@ int ccst_calc_mean_std_f32(const float* x, float* mean, float* std, int N, int C
 int ccst_adain_f32(const float* x, const float* style_mean, const float* style_std, int style_per_n,
                    float alpha, float* y, int N, int C, int HW, int layout, float eps,
                    void* ws, int64_t ws_bytes, void* stream);
+/* The same AdaIN (+ alpha blend) for an NHWC x [N][HW][C] whose producer already left the statistics: partials
+ * [N * tiles_per_image][C][2] = per-(spatial tile, channel) (sum, sum of squares) of x, the tiles of image n contiguous -- what
+ * ccst_conv3x3_wino4w_f32 writes into chan_sum_partials (tiles_per_image = ccst_wino4w_spatial_tiles(1, H, W)).  One launch, x read
+ * once, no pass for the statistics: mean = S / HW, unbiased variance = (Q - S mean) / (HW - 1) folded in fp64.  C % 64 == 0.
+ * mean_out / std_out: NULL, or [N*C] receiving the content statistics. */
+int ccst_adain_tile_sums_f32(const float* x, const float* partials, int tiles_per_image, const float* style_mean,
+                             const float* style_std, int style_per_n, float alpha, float* y, int N, int C, int HW, float eps,
+                             float* mean_out, float* std_out, void* stream);
 /* CCST_OverallStyleTransfer.py:36-45, style_transfer's interpolation branch after the AdaIN of the K copies of one content image
  * against K styles: out[elems] = (sum_k weights[k] * base[k][elems], from zero in index order, products and sums rounded separately)
  * * alpha + content0[elems] * one_minus_alpha.  weights: K floats on the device.  Elementwise: any (common) layout. */

@@ -808,3 +808,35 @@ def test_stem3_first_layer_kernel(dev, shape):
         r = r.clamp_min(0) if relu else r
         assert tuple(y.shape) == (n, h, w, 64)
         assert float((y.permute(0, 3, 1, 2).cpu().double() - r).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 64, 512), (3, 40, 70, 32, 128), (1, 17, 33, 64, 64)])
+def test_adain_from_the_conv_epilogue_tile_sums(dev, case):
+    """ops.adain_from_tile_sums (one streaming launch, the content statistics folded from the per-tile channel sums that the
+    producing conv's epilogue left) against ops.adain on the same features: images that are not a multiple of the 16x32-pixel tile,
+    alpha blend, per-image style statistics; and against function.py:26-33 restated in fp64 on the conv's own output."""
+    from ccst_amd import ops
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(N, H, W, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(dev)
+    b = (torch.randn(Cout, generator=g) * 0.3).to(dev)
+    pc = ops.pack_conv_weight(w, b, wino=4)
+    y, part = ops.conv3x3_wino4(x, pc, 1 | 8, sums=True)                     # ReLU + reflection: relu4_1's form
+    feat = ops.to_api(y)
+    assert ops.adain_tile_sums_ok(feat, part) and part.shape[0] % N == 0
+    sm = torch.randn(1, Cout, 1, 1, generator=g).to(dev)
+    ss = (torch.rand(1, Cout, 1, 1, generator=g) + 0.5).to(dev)
+    smn = torch.randn(N, Cout, 1, 1, generator=g).to(dev)
+    ssn = (torch.rand(N, Cout, 1, 1, generator=g) + 0.5).to(dev)
+    f64 = feat.double()
+    mu = f64.mean(dim=(2, 3), keepdim=True)
+    sd = (f64.var(dim=(2, 3), keepdim=True) + 1e-5).sqrt()
+    for m_, s_, alpha in ((sm, ss, 1.0), (sm, ss, 0.5), (smn, ssn, 1.0)):
+        ref = ops.adain(feat, m_, s_, alpha=alpha)
+        got = ops.adain_from_tile_sums(feat, part, m_, s_, alpha=alpha)
+        assert got.shape == ref.shape
+        scale = max(1.0, float(ref.abs().max()))
+        assert float((got - ref).abs().max()) < 2e-5 * scale
+        t = (f64 - mu) / sd * s_.double() + m_.double()
+        assert float((got.double() - (t * alpha + f64 * (1 - alpha))).abs().max()) < 2e-5 * scale
