@@ -388,7 +388,10 @@ int check_common(const void* x, int N, int C, int HW, int layout) {
 // tensor is streamed ONCE, every CU busy, no load-everything-then-store phase; function.py:26-33's four separately rounded operations.
 // (Raw moments are fine here and only here: the sums are over 512-pixel tiles in fp32, folded in fp64, of a feature map whose
 //  producer is known -- the general entry ccst_adain_f32 keeps the two-pass / pivot-shifted forms for arbitrary planes.)
-constexpr int TS_CQ = 16, TS_PL = TPB / TS_CQ, TS_PIX = 256;
+#ifndef TS_PIXELS
+#define TS_PIXELS 256
+#endif
+constexpr int TS_CQ = 16, TS_PL = TPB / TS_CQ, TS_PIX = TS_PIXELS;
 __global__ __launch_bounds__(TPB) void adain_tile_sums_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                    const float* __restrict__ part, int tpi,
                                                                    const float* __restrict__ smean, const float* __restrict__ sstd,
@@ -396,6 +399,16 @@ __global__ __launch_bounds__(TPB) void adain_tile_sums_nhwc_kernel(const float* 
                                                                    float* __restrict__ mean_out, float* __restrict__ std_out) {
     const int t = threadIdx.x, cq = t % TS_CQ, pl = t / TS_CQ;
     const int n = blockIdx.y, c0 = blockIdx.x * (4 * TS_CQ) + cq * 4;
+    const float* xb = x + ((long long)n * HW) * C + c0;
+    float* yb = y + ((long long)n * HW) * C + c0;
+    const int p0 = blockIdx.z * TS_PIX;
+    // the tensor first: its loads are in flight while the statistics are folded
+    f32x4 v[TS_PIX / TS_PL];
+#pragma unroll
+    for (int i = 0; i < TS_PIX / TS_PL; ++i) {
+        const int p = p0 + pl + i * TS_PL;
+        if (p < HW) v[i] = *reinterpret_cast<const f32x4*>(xb + (long long)p * C);
+    }
     double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
     const float* pp = part + ((long long)n * tpi * C + c0) * 2;
     for (int k = 0; k < tpi; ++k) {
@@ -419,15 +432,6 @@ __global__ __launch_bounds__(TPB) void adain_tile_sums_nhwc_kernel(const float* 
     const int so = (style_per_n ? n * C : 0) + c0;
     const f32x4 sm = *reinterpret_cast<const f32x4*>(smean + so), ss = *reinterpret_cast<const f32x4*>(sstd + so);
     const bool blend = (alpha != 1.f);
-    const float* xb = x + ((long long)n * HW) * C + c0;
-    float* yb = y + ((long long)n * HW) * C + c0;
-    const int p0 = blockIdx.z * TS_PIX;
-    f32x4 v[TS_PIX / TS_PL];
-#pragma unroll
-    for (int i = 0; i < TS_PIX / TS_PL; ++i) {
-        const int p = p0 + pl + i * TS_PL;
-        if (p < HW) v[i] = *reinterpret_cast<const f32x4*>(xb + (long long)p * C);
-    }
 #pragma unroll
     for (int i = 0; i < TS_PIX / TS_PL; ++i) {
         const int p = p0 + pl + i * TS_PL;
