@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=6)
+    ap.add_argument("--two-stream", action="store_true", help="also time the step with the halves of the batch on two HIP streams "
+                    "(reported as two_stream_schedule, never as value)")
     ap.add_argument("--image_size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
@@ -351,7 +353,7 @@ def main():
     # not as it: with two kernels sharing the chip a launch's duration says nothing about the kernel, and the roofline above is
     # measured on the plain schedule.
     two_streams = None
-    if rank == 0 and B >= 2:
+    if rank == 0 and B >= 2 and args.two_stream:          # (opt-in: its launches would blur a rocprofv3 --stats of the default command)
         prev = style.HALF_BATCH_STREAMS
         style.HALF_BATCH_STREAMS = True
         try:

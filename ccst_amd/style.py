@@ -13,7 +13,7 @@ from . import ops
 
 # CCST_ADAIN_STREAMS=2: run the two halves of a content batch on two HIP streams, so one half's launch ramps, tails and
 # partly filled rounds and HBM-bound edges (first layer, last decoder layer, AdaIN) overlap the other half's MFMA work: 1382 -> 1416
-# images/s at B=6 512x512 (bench.py reports it as `two_stream_schedule`).  Off by default: with kernels of two streams sharing the
+# images/s at B=6 512x512 (`bench.py --two-stream` reports it as `two_stream_schedule`).  Off by default: with kernels of two streams sharing the
 # chip a per-launch duration no longer says anything about the kernel (bench.py's `value` and roofline are measured on the plain
 # single-stream schedule).
 HALF_BATCH_STREAMS = os.environ.get("CCST_ADAIN_STREAMS", "1") == "2"
