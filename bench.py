@@ -322,10 +322,12 @@ def main():
                 keys = ["void conv_igemm_kernel<%s, %s, 2, 16>" % (nums, pooled)]
             else:       # rocprofv3 prints every template argument: <WM, WN, NT, POOL, TRAIN>
                 keys = ["void %s<%s, %s, false>" % (base, nums, pooled), "void %s<%s, %s>" % (base, nums, pooled)]
-            for key in keys:
-                if key in tj and traffic_src["current_build"]:      # a committed profile of THIS build, else not reported
-                    traffic = round(tj[key]["total_bytes_per_launch"])
-                    break
+            hits = [tj[key] for key in keys if key in tj]
+            if hits and traffic_src["current_build"]:               # a committed profile of THIS build, else not reported
+                # (the bucket may hold several instantiations -- with / without the statistics epilogue: launch-weighted average)
+                wsum = sum(max(1, int(h.get("launches", 1))) for h in hits)
+                traffic = round(sum(h["total_bytes_per_launch"] * max(1, int(h.get("launches", 1))) for h in hits) / wsum)
+                traffic_src["kernels"] = [key for key in keys if key in tj]
             if traffic is None:
                 traffic_src["note"] = "no profile of the running build: bytes not reported"
         roofline = {"bound": "mfma", "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

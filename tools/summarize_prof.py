@@ -54,6 +54,7 @@ for sub, ctr, mult in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SI
 # machine-readable HBM traffic per launch (bytes), FETCH_SIZE doubled per the gfx950 correction
 import json
 traffic = {}
+launches = {}
 for sub, ctr, mult in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SIZE", 1.0)):
     f = find(sub, "*counter_collection.csv")
     if not f:
@@ -68,6 +69,7 @@ for sub, ctr, mult in (("pmc_fetch", "FETCH_SIZE", 2.0), ("pmc_write", "WRITE_SI
             k[1] += float(r["Counter_Value"])
     for k, v in acc.items():
         traffic.setdefault(k, {})[ctr] = v[1] / v[0] * mult * 1024.0
+        launches[k] = max(launches.get(k, 0), v[0])
 if traffic:
     import datetime
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -76,7 +78,8 @@ if traffic:
             stamp = fh.read().strip()[:16]
     except OSError:
         stamp = None
-    res = {k: dict(v, total_bytes_per_launch=sum(v.values())) for k, v in traffic.items() if "conv" in k or "adain" in k or "partials" in k or "chan_sums" in k}
+    res = {k: dict(v, total_bytes_per_launch=sum(v.values()), launches=launches.get(k, 0)) for k, v in traffic.items()
+           if "conv" in k or "adain" in k or "partials" in k or "chan_sums" in k}
     # provenance: bench.py reports these bytes only while the running build is the profiled one
     res["_source"] = {"build_stamp": stamp, "date": datetime.date.today().isoformat(), "profile": os.path.basename(out.rstrip("/")) + "/summary.txt",
                       "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950), per-launch average"}
