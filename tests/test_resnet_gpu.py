@@ -877,3 +877,35 @@ def test_wino4w_train_form_vs_gather(dev, shape):
     table = torch.tensor(rows, dtype=torch.int64).to(dev)
     check(_lib.load().ccst_pack_conv_weights_wino4w_batch_f32(ptr(table), 2, stream_ptr()), "batch")
     assert torch.equal(uf, pf[0]) and torch.equal(ub, pb[0])
+
+
+@pytest.mark.parametrize("pieces,tol", [(2, 3e-5), (3, 4e-6)])
+def test_pointwise_conv_on_the_bf16_mfma(dev, pieces, tol):
+    """CCST_CONV_BF=2 / 3 (opt-in): the streaming pointwise kernel with every fp32 product as three / six bf16 MFMA products of
+    bf16 pieces of the operands, fp32 accumulation: against an fp64 convolution, in a child process (the mode is read once per
+    process).  Two pieces carry 16 significant bits (error ~5e-6 of max |y|), three the fp32 MFMA's own accuracy."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import torch
+from ccst_amd import ops
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(5)
+worst = 0.0
+for (N, H, cin, cout, stride) in ((8, 56, 64, 128, 2), (8, 56, 64, 256, 1), (8, 14, 256, 512, 2), (4, 28, 128, 512, 1), (3, 7, 2048, 512, 1)):
+    x = torch.randn(N, H, H, cin, generator=g).to(dev)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5).to(dev)
+    y, st = ops.conv2d_nhwc(x, ops.pack_conv_weight(w, None), stride=stride, pad=0, want_stats=True)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), stride=stride).permute(0, 2, 3, 1)
+    worst = max(worst, float((y - ref).abs().max() / ref.abs().max()))
+    s_ref = torch.stack([ref.sum(dim=(0, 1, 2)), (ref * ref).sum(dim=(0, 1, 2))], dim=1)
+    worst = max(worst, float((st.double().sum(0) - s_ref).abs().max() / s_ref.abs().max()))
+print("WORST %.3e" % worst)
+'''
+    env = dict(os.environ, CCST_CONV_BF=str(pieces))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr[-2000:]
+    worst = float(out.stdout.strip().split("WORST")[-1])
+    assert worst < tol, worst
