@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_F16_MFMA_TFLOPS = 2516.6     # dense fp16 / bf16 matrix peak (16x the fp32 MFMA: measured 2.3-2.47 PFLOP/s, tools/micro/bf16x3.hip)
 PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md, HBM3E
 GFLOP_PER_IMAGE_512 = 253.07      # 19 convs, encoder 126.54 + decoder 126.53
 WINO_GFLOP_PER_IMAGE_512 = 1.812  # the two layers that do not run on the Winograd kernel (conv1_1 stem, last decoder 64->3)
@@ -304,6 +305,12 @@ def main():
         wino = wfac != 1.0
         bound_wino = bound_w4 if wfac == 4.0 else bound_w2
         executed = alg / wfac
+        # the direct kernel's SPLIT form executes three half-precision MFMA products per fp32 product: its pipe is the 16-bit MFMA
+        split = dom.startswith("conv3x3_halo_split")
+        peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+        if split:
+            executed = alg * 3.0
+        bound_split = PEAK_F16_MFMA_TFLOPS / 3.0 * 1e3 / (GFLOP_PER_IMAGE_512 * scale)
         traffic, traffic_src, tsrc = None, None, os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tsrc):      # HBM bytes/launch from the separate rocprofv3 --pmc passes (tools/profile_bench.sh)
             with open(tsrc) as fh:
@@ -318,6 +325,9 @@ def main():
             nums, pooled = ", ".join(a for a in targs if a not in ("pool", "nopool")), ("true" if "pool" in targs else "false")
             if base in ("conv3x3_wino_kernel", "conv3x3_wino4_kernel", "conv3x3_wino4w_kernel"):
                 keys = [k for k in tj if k.startswith("void %s<" % base) and k.rstrip(">").split("<")[1].split(",")[0].strip() == pooled]
+            elif base == "conv3x3_halo_split_kernel":       # rocprofv3: conv3x3_halo_kernel<WM, WN, NT, POOL, TRAIN, SPLIT>
+                keys = [k for k in tj if k.startswith("void conv3x3_halo_kernel<") and k.rstrip(">").split(",")[-1].strip() == "true"
+                        and k.rstrip(">").split(",")[3].strip() == pooled]
             elif base == "conv_igemm_kernel":
                 keys = ["void conv_igemm_kernel<%s, %s, 2, 16>" % (nums, pooled)]
             else:       # rocprofv3 prints every template argument: <WM, WN, NT, POOL, TRAIN>
@@ -330,16 +340,19 @@ def main():
                 traffic_src["kernels"] = [key for key in keys if key in tj]
             if traffic is None:
                 traffic_src["note"] = "no profile of the running build: bytes not reported"
-        roofline = {"bound": "mfma", "achieved": round(executed, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(executed / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": dom,
+        roofline = {"bound": "mfma", "achieved": round(executed, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(executed / peak, 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": dom,
                     "launches_per_step": cnt / max(1, sampled_steps), "avg_launch_us": round(sec / cnt * 1e6, 2),
                     "event_timed_steps": "%d of the %d timed steps (every %d-th)" % (sampled_steps, args.steps, EVENTS_EVERY),
                     "gflop_per_launch": round(fl / cnt / 1e9, 3), "algorithmic_tflops": round(alg, 2),
                     "algorithm": ("winograd F(%s,3x3): the MFMA pipe executes gflop_per_launch / %.4g; achieved and frac are the EXECUTED rate"
-                                  % ("4x4" if wfac == 4.0 else "2x2", wfac) if wino else "direct"),
-                    "executed_gflop_per_launch": round(fl / cnt / 1e9 / wfac, 3),
-                    "bound_images_per_s": {"direct": round(bound_direct, 1), "winograd_f2x2": round(bound_w2, 1), "winograd_f4x4": round(bound_w4, 1)},
-                    "path_frac_of_bound": round(value / n_ranks_seen / (bound_wino if wino else bound_direct), 4)}
+                                  % ("4x4" if wfac == 4.0 else "2x2", wfac) if wino else
+                                  "direct, every fp32 product as three half-precision MFMA products (fp32 accumulate): achieved and frac are the "
+                                  "EXECUTED 16-bit MFMA rate" if split else "direct"),
+                    "executed_gflop_per_launch": round(fl / cnt / 1e9 * (3.0 if split else 1.0 / wfac), 3),
+                    "bound_images_per_s": {"direct": round(bound_direct, 1), "winograd_f2x2": round(bound_w2, 1), "winograd_f4x4": round(bound_w4, 1),
+                                           "direct_split_f16x3": round(bound_split, 1)},
+                    "path_frac_of_bound": round(value / n_ranks_seen / (bound_wino if wino else bound_split if split else bound_direct), 4)}
     adain_step = None
     if adain_us:
         nbytes = 2 * 4 * B * 512 * (S // 8) * (S // 8)       # read x once + write y once (SURVEY 8d "AdaIN-step roofline")

@@ -48,6 +48,9 @@ _SIGNATURES = {
     "ccst_bn_relu_maxpool_train_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P],
     "ccst_bn_train_bwd_partials_f32": [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int64, c_int, _P, c_int64, _P],
     "ccst_conv3x3_halo_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
+    "ccst_conv3x3_halo_split_f32": [_P, _P, c_float, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P, _P],
+    "ccst_conv3x3_halo_split_tiles": [c_int, c_int, c_int],
+    "ccst_pack_conv_weight_halo_split_f32": [_P, _P, c_int, c_int, c_int, c_float, _P],
     "ccst_conv3x3_halo_narrow": [c_int, c_int, c_int, c_int],
     "ccst_wino_weight_floats": [c_int, c_int],
     "ccst_pack_conv_weight_wino_f32": [_P, _P, c_int, c_int, c_int, _P],

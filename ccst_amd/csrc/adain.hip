@@ -409,13 +409,41 @@ __global__ __launch_bounds__(TPB) void adain_tile_sums_nhwc_kernel(const float* 
         const int p = p0 + pl + i * TS_PL;
         if (p < HW) v[i] = *reinterpret_cast<const f32x4*>(xb + (long long)p * C);
     }
+    // the tile pairs of this thread's four channels: the 16 pixel-lanes of a channel quad share them (tiles pl, pl + 16, ...), folded
+    // over the four lanes of a wave by shuffles and over the four waves through LDS, in a fixed order (bitwise reproducible)
+    __shared__ double red[TPB / 64][TS_CQ][8];
     double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
     const float* pp = part + ((long long)n * tpi * C + c0) * 2;
-    for (int k = 0; k < tpi; ++k) {
+    for (int k = pl; k < tpi; k += TS_PL) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(pp + (long long)k * C * 2);          // S c0, Q c0, S c0+1, Q c0+1
         const f32x4 b = *reinterpret_cast<const f32x4*>(pp + (long long)k * C * 2 + 4);
         s[0] += (double)a[0]; q[0] += (double)a[1]; s[1] += (double)a[2]; q[1] += (double)a[3];
         s[2] += (double)b[0]; q[2] += (double)b[1]; s[3] += (double)b[2]; q[3] += (double)b[3];
+    }
+#pragma unroll
+    for (int off = TS_CQ; off < 64; off <<= 1)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[j] += __shfl_xor(s[j], off, 64);
+            q[j] += __shfl_xor(q[j], off, 64);
+        }
+    if ((t & 63) < TS_CQ) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            red[t >> 6][cq][j] = s[j];
+            red[t >> 6][cq][4 + j] = q[j];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s[j] = red[0][cq][j];
+        q[j] = red[0][cq][4 + j];
+#pragma unroll
+        for (int w = 1; w < TPB / 64; ++w) {
+            s[j] += red[w][cq][j];
+            q[j] += red[w][cq][4 + j];
+        }
     }
     f32x4 mu, sd;
 #pragma unroll

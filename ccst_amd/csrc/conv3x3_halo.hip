@@ -39,6 +39,7 @@ struct HaloArgs {
     long long ysN;
     int ysH, ysW;                                 // output strides (of the pooled tensor when POOL)
     int tilesX, tilesY, tilesN;
+    float oscale;        // SPLIT: the weights were packed scaled by 1 / oscale (a power of two): accumulators are scaled back before the epilogue
     float* stats;        // TRAIN: per-(spatial tile, wave row) (sum, sum^2) partials of the output, or nullptr
     int flip, accum;     // TRAIN: taps read in reverse order (backward-data); y += conv
 };
@@ -57,6 +58,21 @@ struct HaloArgs {
 #define PRE_P 5        // first fragment pair of the NEXT step (visible since the previous barrier: 3-deep weight ring)
 #endif
 constexpr int CKH = 16, PITCH = CKH + 4, HW_ = 18;
+constexpr int BPITCH = 20;      // SPLIT: words per output-channel row of the weight image (16 channels hi | lo as half = 16 words, + 4 of pad)
+typedef unsigned u32x2h __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8h __attribute__((ext_vector_type(8)));      // the 16-bit pieces are IEEE half: 11 significant bits each
+
+// four fp32 values -> two half pieces each (hi = half(x), lo = half(x - hi): 22 significant bits while |x| is in half's normal range),
+// two per word
+__device__ __forceinline__ void split4h(f32x4 v, u32x2h& hi, u32x2h& lo) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const _Float16 h0 = (_Float16)v[2 * h], h1 = (_Float16)v[2 * h + 1];
+        const _Float16 l0 = (_Float16)(v[2 * h] - (float)h0), l1 = (_Float16)(v[2 * h + 1] - (float)h1);
+        hi[h] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+        lo[h] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+    }
+}
 
 __device__ __forceinline__ int reflect_h(int i, int n) {
     i = (i < 0) ? -i : i;
@@ -68,8 +84,17 @@ __device__ __forceinline__ int reflect_h(int i, int n) {
 // BatchNorm statistics of the output from the epilogue (as ccst_conv2d_igemm_stats_f32), the taps in reverse
 // order (backward-data of a stride-1 3x3 conv = the same conv with flipped taps and the transposed weight), and
 // y += conv (CCST_CONV_ACCUM).  A separate instantiation so the AdaIN kernels carry none of it.
-template <int WM, int WN, int NT, bool POOL, bool TRAIN = false>
-__global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) {
+// SPLIT = true (the AdaIN path's layers with Cin != Cout): the products on the 16-bit MFMA, each fp32 product as three products of
+// IEEE-half pieces (x = hi + lo, hi = half(x), lo = half(x - hi): 22 significant bits; a_lo b_hi + a_hi b_lo + a_hi b_hi, fp32
+// accumulate): v_mfma_f32_32x32x16_f16 does 16x the multiply-adds per cycle of v_mfma_f32_32x32x2_f32, so three products run at 5.3x the
+// fp32 MFMA's rate (tools/micro/bf16x3.hip measures the bf16 twin), at 1e-6 of max |y| per layer -- bf16 pieces (16 bits) measured
+// 5e-6 and failed the wide-dynamic-range path test at 1.8e-3.  The halo is split where it passes from registers to LDS: a pixel is
+// [16 channels hi | 16 channels lo] as half -- the same 64 bytes (+ pad) as its fp32 form; the weights come pre-split (and scaled by a
+// power of two into half's normal range, the accumulators scaled back) as rows [output channel][16 k hi | lo]; a k-step (tap, 16
+// channels) is then 12 MFMAs of K = 16 per wave instead of 32 of K = 2.  Activations must stay below 65504.
+template <int WM, int WN, int NT, bool POOL, bool TRAIN = false, bool SPLIT = false>
+__global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_kernel(const HaloArgs p) {
+    static_assert(!(SPLIT && TRAIN), "the train form stays on the fp32 MFMA");
     static_assert(!(TRAIN && POOL), "the train form has no pooled epilogue");
     constexpr int MT = 2;
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
@@ -82,7 +107,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
     static_assert(HR <= 9, "halo load rounds must fit the 9 tap steps of a chunk");
 
     __shared__ __attribute__((aligned(16))) float Hs_[2][HPIX * PITCH];
-    __shared__ __attribute__((aligned(16))) float Bs[3][CKH * BN];
+    __shared__ __attribute__((aligned(16))) float Bs[3][SPLIT ? BN * BPITCH : CKH * BN];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -127,14 +152,15 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
     for (int b = 0; b < BR; ++b) {
         const int u = min(tid + 256 * b, BUNITS - 1);
         const int g = u / BN, col = u - g * BN;
-        boff[b] = (unsigned)((g * p.CoutPad + co0 + col) * 4);
+        boff[b] = SPLIT ? (unsigned)((co0 + (u >> 2)) * 16 + (u & 3) * 4)          // pre-split rows [output channel][16 k hi | lo]: 16 words
+                     : (unsigned)((g * p.CoutPad + co0 + col) * 4);
     }
 
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = co0 + wn * (32 * NT) + nt * 32 + li;
-        const float b = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+        const float b = ((p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f) * (SPLIT ? 1.f / p.oscale : 1.f);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -156,7 +182,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
 
     auto load_b = [&](int c_, int tap) {
         const int tw = (TRAIN && p.flip) ? 8 - tap : tap;
-        const float* wc = p.w + ((long long)tw * (p.Cin / 4) + c_ * (CKH / 4)) * p.CoutPad * 4;   // uniform
+        const float* wc = SPLIT ? p.w + ((long long)tw * (p.Cin / CKH) + c_) * p.CoutPad * 16
+                             : p.w + ((long long)tw * (p.Cin / 4) + c_ * (CKH / 4)) * p.CoutPad * 4;   // uniform
 #pragma unroll
         for (int b = 0; b < BR; ++b) rb[b] = *reinterpret_cast<const f32x4*>(wc + boff[b]);
     };
@@ -164,6 +191,10 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
 #pragma unroll
         for (int b = 0; b < BR; ++b) {
             const int u = tid + 256 * b;
+            if (SPLIT) {           // unit u = (output channel u >> 2, 16-byte part u & 3) of a pre-split row
+                if (BUNITS % 256 == 0 || u < BUNITS) *reinterpret_cast<f32x4*>(&Bs[buf][(u >> 2) * BPITCH + (u & 3) * 4]) = rb[b];
+                continue;
+            }
             if (BUNITS % 256 == 0 || u < BUNITS) *reinterpret_cast<f32x4*>(&Bs[buf][u * 4]) = rb[b];
         }
     };
@@ -174,6 +205,13 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
         if (u < HUNITS) {
             f32x4 v = rh;
             if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (SPLIT) {
+                u32x2h hi, lo;
+                split4h(v, hi, lo);
+                float* px_ = &Hs_[buf][(u >> 2) * PITCH + (u & 3) * 2];
+                *reinterpret_cast<u32x2h*>(px_) = hi;
+                *reinterpret_cast<u32x2h*>(px_ + 8) = lo;
+            } else
             *reinterpret_cast<f32x4*>(&Hs_[buf][(u >> 2) * PITCH + (u & 3) * 4]) = v;
         }
     };
@@ -196,6 +234,28 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][mt][s], bf[q][nt][s], acc[mt][nt], 0, 0, 0);
     };
     static_assert(CKH == 16, "the step body below is written for two 8-channel halves");
+    // SPLIT fragments of one step: [piece][tile]; a lane's 8 consecutive channels (lh * 8 ..) = words lh * 4 .. of the piece
+    struct FragsSplit {
+        f16x8h a[2][MT], b[2][NT];
+    };
+    const float* bRdB0 = &Bs[0][(wn * (32 * NT) + li) * BPITCH + lh * 4];
+    auto read_frags_split = [&](FragsSplit& f, int hbuf, int bbuf, int tapoff) {
+        const float* hb = &Hs_[hbuf][tapoff];
+        const float* bRd = bRdB0 + bbuf * (BN * BPITCH);
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) f.a[pc][mt] = __builtin_bit_cast(f16x8h, *reinterpret_cast<const f32x4*>(hb + aBase[mt] + 8 * pc));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) f.b[pc][nt] = __builtin_bit_cast(f16x8h, *reinterpret_cast<const f32x4*>(bRd + nt * 32 * BPITCH + 8 * pc));
+        }
+    };
+    auto mfma_split = [&](const FragsSplit& f, int pa, int pb) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[pa][mt], f.b[pb][nt], acc[mt][nt], 0, 0, 0);
+    };
 
     // ---- prologue: halo of chunk 0, weights of steps 0 and 1 in LDS, weights of step 2 in flight -----------------
 #pragma unroll
@@ -213,6 +273,41 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
     store_b(1);
     load_b(0, 2);
     __syncthreads();
+    if (SPLIT) {
+        FragsSplit cur, nxt;
+        read_frags_split(cur, 0, 0, 0);
+        for (int c = 0; c < nchunks; ++c) {
+            const int cn = min(c + 1, nchunks - 1);
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                mfma_split(cur, 1, 0);                                             // a_lo b_hi
+                __builtin_amdgcn_sched_barrier(0);
+                {   // first fragments of the NEXT step (visible since the previous barrier: 3-deep weight ring, halo of this chunk)
+                    const int tp = (tap + 1) % 9;
+                    read_frags_split(nxt, tap == 8 ? (c + 1) & 1 : c & 1, tp % 3, ((tp / 3) * HW_ + (tp % 3)) * PITCH);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_split(cur, 0, 1);                                             // a_hi b_lo
+                __builtin_amdgcn_sched_barrier(0);
+                store_b((tap + 2) % 3);
+                if (tap >= 1 && tap <= HR) store_h((c + 1) & 1, tap - 1, hok[tap - 1]);
+                if (tap + 3 < 9) load_b(c, tap + 3);
+                else load_b(cn, tap + 3 - 9);
+                if (tap < HR) load_h(cn, tap, hoff[tap]);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_split(cur, 0, 0);                                             // a_hi b_hi
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                cur = nxt;
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= p.oscale;           // (a power of two: exact)
+    } else {
     read_frags(0, 0, 0, 0);
 #ifdef ABLATE_LOOP_REPEAT
     for (int rep_ = 0; rep_ < ABLATE_LOOP_REPEAT; ++rep_)
@@ -254,6 +349,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
             __syncthreads();
         }
     }
+    }
 
     // ---- epilogue ----------------------------------------------------------------------------------------
 #ifdef ABLATE_NO_STORE      // timing experiments only: keep one store so the accumulators stay live
@@ -271,8 +367,9 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
         const unsigned lane_off = (unsigned)(2 * lh * p.ysW + li);
         const bool interior = (oy0 + TH <= p.H) && (ox0 + 16 <= p.W) && (co0 + BN <= p.Cout);
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile, 0, 0x7fffffff, 0x00020000);
-        if (TRAIN && p.stats != nullptr) {
-            // this wave's 64 pixels x 32*NT channels -> per-channel (sum, sum^2); pixels outside the image excluded
+        if ((TRAIN || SPLIT) && p.stats != nullptr) {
+            // this wave's 64 pixels x 32*NT channels -> per-channel (sum, sum^2) of the OUTPUT (after bias / ReLU); pixels outside the
+            // image excluded.  SPLIT: these are the per-tile channel sums the AdaIN step and stage 1 take instead of a pass over the features.
             const int slab = ((n * p.tilesY + ty) * p.tilesX + tx) * WM + wm;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -282,7 +379,8 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int dy = 2 * (wm * MT + mt) + ((r & 3) >> 1), dx = 4 * (r >> 2) + (r & 1) + 2 * lh;
-                        const float v = (interior || (oy0 + dy < p.H && ox0 + dx < p.W)) ? acc[mt][nt][r] : 0.f;
+                        float v = (interior || (oy0 + dy < p.H && ox0 + dx < p.W)) ? acc[mt][nt][r] : 0.f;
+                        if (relu) v = fmaxf(v, 0.f);
                         s1 += v;
                         s2 += v * v;
                     }
@@ -378,7 +476,7 @@ __global__ __launch_bounds__(256, 3) void conv3x3_halo_kernel(const HaloArgs p) 
     }
 }
 
-template <int WM, int WN, int NT, bool POOL, bool TRAIN = false>
+template <int WM, int WN, int NT, bool POOL, bool TRAIN = false, bool SPLIT = false>
 int launch_halo(HaloArgs& a, hipStream_t s) {
     constexpr int BM = 64 * WM, BN = 32 * NT * WN, TH = BM / 16;
     a.tilesN = (a.Cout + BN - 1) / BN;
@@ -389,18 +487,76 @@ int launch_halo(HaloArgs& a, hipStream_t s) {
         ccst_set_error("conv3x3_halo: bad grid %lld", grid);
         return CCST_EINVAL;
     }
-    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, WN, NT, POOL, TRAIN>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<WM, WN, NT, POOL, TRAIN, SPLIT>), dim3((unsigned)grid), dim3(256), 0, s, a);
     return ccst_launch_status("conv3x3_halo");
+}
+
+// OIHW 3x3 -> the pre-split weight image of the SPLIT kernels: [tap][Cin/16][cout_pad][16 words] with words 0..7 = the 16 input
+// channels of the chunk as half(w * scale) (two per word, even channel in the low half), words 8..15 = half(w * scale - hi)
+__global__ void pack_weight_halo_split_kernel(const float* __restrict__ w, unsigned* __restrict__ out, int cout, int cin, int cout_pad, float scale) {
+    const int nch = cin / 16;
+    const long long total = 9LL * nch * cout_pad * 16;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int word = (int)(i & 15);
+        long long j = i >> 4;
+        const int co = (int)(j % cout_pad);
+        j /= cout_pad;
+        const int chunk = (int)(j % nch), tap = (int)(j / nch);
+        const int piece = word >> 3, k0 = chunk * 16 + 2 * (word & 7);
+        unsigned r = 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float v = (co < cout) ? w[((long long)co * cin + k0 + e) * 9 + tap] * scale : 0.f;
+            const _Float16 h = (_Float16)v;
+            const _Float16 q = piece ? (_Float16)(v - (float)h) : h;
+            r |= (unsigned)__builtin_bit_cast(unsigned short, q) << (16 * e);
+        }
+        out[i] = r;
+    }
 }
 
 }  // namespace
 
 extern "C" int ccst_conv3x3_halo_narrow(int N, int H, int W, int Cout);
 
+// Weights of ccst_conv3x3_halo_split_f32: 9 * cin * cout_pad floats (the same size as the fp32 packed form); cin a multiple of 16,
+// cout_pad a multiple of 128.
+extern "C" int ccst_pack_conv_weight_halo_split_f32(const float* w_oihw, float* out, int cout, int cin, int cout_pad, float scale, void* stream) {
+    CCST_REQUIRE(w_oihw && out && cout > 0 && cin > 0 && cin % 16 == 0, "pack_halo_split: bad args (cin a multiple of 16)");
+    CCST_REQUIRE(scale > 0.f, "pack_halo_split: the scale must be a positive power of two");
+    CCST_REQUIRE(cout_pad >= cout && cout_pad % 128 == 0, "pack_halo_split: cout_pad must be a multiple of 128 >= cout");
+    const long long total = 9LL * cin * cout_pad;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_weight_halo_split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, reinterpret_cast<unsigned*>(out), cout, cin,
+                       cout_pad, scale);
+    return ccst_launch_status("pack_weight_halo_split");
+}
+
 // x: NHWC source [N,Hs,Ws,Cin] (Hs = H/2 if CCST_CONV_UPS2), w: packed [9][Cin/4][cout_pad][4], y: NHWC
 // [N,H,W,Cout] or its 2x2 ceil-pooled form.  flags: CCST_CONV_RELU | POOL2 | UPS2 | REFLECT.
+static int halo_impl(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int cout_pad,
+                     uint32_t flags, void* stream, bool bf, float wscale, float* sums);
+
 extern "C" int ccst_conv3x3_halo_f32(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W,
                                      int Cin, int Cout, int cout_pad, uint32_t flags, void* stream) {
+    return halo_impl(x, w_packed, bias, y, N, H, W, Cin, Cout, cout_pad, flags, stream, false, 1.f, nullptr);
+}
+
+// The same convolution with every fp32 product as three products of IEEE-half pieces on the 16-bit MFMA (the SPLIT form of the kernel
+// above; fp32 accumulation, ~1e-6 of max |y| per layer): w_split and wscale from ccst_pack_conv_weight_halo_split_f32.
+// chan_sum_partials: NULL or [ccst_conv3x3_halo_split_tiles(N,H,W)][Cout][2], see include/ccst_hip.h.
+extern "C" int ccst_conv3x3_halo_split_f32(const float* x, const float* w_split, float wscale, const float* bias, float* y, int N, int H,
+                                           int W, int Cin, int Cout, int cout_pad, uint32_t flags, float* chan_sum_partials, void* stream) {
+    CCST_REQUIRE(wscale > 0.f, "conv3x3_halo_split: the weight scale of the pack call");
+    CCST_REQUIRE(!(chan_sum_partials && (flags & CCST_CONV_POOL2)), "conv3x3_halo_split: channel sums are of the un-pooled output");
+    return halo_impl(x, w_split, bias, y, N, H, W, Cin, Cout, cout_pad, flags, stream, true, wscale, chan_sum_partials);
+}
+
+// Rows of chan_sum_partials: one per (image, 8x16-pixel tile, wave row), an image's rows contiguous.
+extern "C" int ccst_conv3x3_halo_split_tiles(int N, int H, int W) { return N * ((H + 7) / 8) * ((W + 15) / 16) * 2; }
+
+static int halo_impl(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int cout_pad,
+                     uint32_t flags, void* stream, bool bf, float wscale, float* sums) {
     CCST_REQUIRE(x && w_packed && y, "conv3x3_halo: null pointer");
     CCST_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0, "conv3x3_halo: bad shape");
     CCST_REQUIRE(cout_pad >= Cout && cout_pad % 128 == 0, "conv3x3_halo: cout_pad must be a multiple of 128 >= cout");
@@ -411,7 +567,7 @@ extern "C" int ccst_conv3x3_halo_f32(const float* x, const float* w_packed, cons
     a.x = x; a.w = w_packed; a.bias = bias; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Hs = ups ? H / 2 : H; a.Ws = ups ? W / 2 : W; a.Cin = Cin; a.Cout = Cout; a.CoutPad = cout_pad;
     a.reflect = (flags & CCST_CONV_REFLECT) ? 1 : 0; a.ups = ups ? 1 : 0; a.relu = (flags & CCST_CONV_RELU) ? 1 : 0;
-    a.stats = nullptr; a.flip = 0; a.accum = 0;
+    a.stats = sums; a.flip = 0; a.accum = 0; a.oscale = 1.f / wscale;
     CCST_REQUIRE((long long)N * a.Hs * a.Ws * Cin < 0x7fffffffLL, "conv3x3_halo: input must have < 2^31 elements");
     const int oh = pool ? (H + 1) / 2 : H, ow = pool ? (W + 1) / 2 : W;
     a.ysW = Cout; a.ysH = ow * Cout; a.ysN = (long long)oh * ow * Cout;
@@ -424,6 +580,10 @@ extern "C" int ccst_conv3x3_halo_f32(const float* x, const float* w_packed, cons
         const double c222 = ceil(sp * ((Cout + 127) / 128) / 768.0) * 2.0 / 1.00;
         const double c221 = ceil(sp * ((Cout + 63) / 64) / 768.0) * 1.0 / 0.93;
         narrow = c221 < c222;
+    }
+    if (bf) {
+        if (narrow) return pool ? launch_halo<2, 2, 1, true, false, true>(a, s) : launch_halo<2, 2, 1, false, false, true>(a, s);
+        return pool ? launch_halo<2, 2, 2, true, false, true>(a, s) : launch_halo<2, 2, 2, false, false, true>(a, s);
     }
     if (narrow) return pool ? launch_halo<2, 2, 1, true>(a, s) : launch_halo<2, 2, 1, false>(a, s);
     return pool ? launch_halo<2, 2, 2, true>(a, s) : launch_halo<2, 2, 2, false>(a, s);
@@ -444,7 +604,7 @@ extern "C" int ccst_conv3x3_halo_train_f32(const float* x, const float* w_packed
     a.x = x; a.w = w_packed; a.bias = nullptr; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Hs = H; a.Ws = W; a.Cin = Cin; a.Cout = Cout; a.CoutPad = cout_pad;
     a.reflect = 0; a.ups = 0; a.relu = 0;
-    a.stats = stats; a.flip = (flags & CCST_CONV_FLIP) ? 1 : 0; a.accum = (flags & CCST_CONV_ACCUM) ? 1 : 0;
+    a.stats = stats; a.flip = (flags & CCST_CONV_FLIP) ? 1 : 0; a.accum = (flags & CCST_CONV_ACCUM) ? 1 : 0; a.oscale = 1.f;
     a.ysW = Cout; a.ysH = W * Cout; a.ysN = (long long)H * W * Cout;
     hipStream_t s = (hipStream_t)stream;
     if (ccst_conv3x3_halo_narrow(N, H, W, Cout)) return launch_halo<2, 2, 1, false, true>(a, s);

@@ -254,7 +254,7 @@ def from_api(x, cpad=1):
 class PackedConv(object):
     """Device-resident packed weight [kh*kw][K/4][n_pad][4] (+ optional bias).  `u` / `u_pad`: the Winograd-transformed
     copy (ccst_pack_conv_weight_wino_f32) of a 3x3 weight, built by pack_conv_weight(..., wino=True)."""
-    __slots__ = ("w", "bias", "cin", "cout", "kh", "kw", "k_pad", "n_pad", "transpose", "u", "u_pad", "u4", "u4_pad", "u4n")
+    __slots__ = ("w", "bias", "cin", "cout", "kh", "kw", "k_pad", "n_pad", "transpose", "u", "u_pad", "u4", "u4_pad", "u4n", "wsplit", "wsplit_scale")
 
     def __init__(self, w, bias, cin, cout, kh, kw, k_pad, n_pad, transpose):
         self.w, self.bias, self.cin, self.cout, self.kh, self.kw = w, bias, cin, cout, kh, kw
@@ -262,6 +262,8 @@ class PackedConv(object):
         self.u, self.u_pad = None, 0
         self.u4, self.u4_pad = None, 0   # F(4x4,3x3) transform for the 64-channel workgroups (ccst_pack_conv_weight_wino4w_f32)
         self.u4n = None                  # ... for the 32-channel workgroups (ccst_pack_conv_weight_wino4_f32), same padding; on demand
+        self.wsplit = None               # pre-split half (hi | lo) rows for the direct kernel on the 16-bit MFMA (ccst_pack_conv_weight_halo_split_f32)
+        self.wsplit_scale = 1.0          # ... packed as w * wsplit_scale (a power of two that puts max |w| near 2^10, inside half's normal range)
 
 
 # Fused Winograd for the 3x3 stride-1 layers of the AdaIN encoder / decoder.  CCST_CONV_WINO = 4 (default): F(4x4,3x3)
@@ -274,6 +276,47 @@ WINO_F4_MIN_CIN = int(os.environ.get("CCST_WINO4_MIN_CIN", "16"))
 # the F(4x4) kernel runs 64 output channels per workgroup (conv3x3_wino4w.hip); CCST_WINO4_NARROW=1 keeps the 32-channel workgroups
 # of conv3x3_wino4.hip (A/B runs).  The two kernels read differently ordered transformed weights.
 WINO_F4_NARROW = os.environ.get("CCST_WINO4_NARROW", "0") == "1"
+# The direct 3x3 kernel with every fp32 product as three products of IEEE-half pieces on the 16-bit MFMA (conv3x3_halo.hip SPLIT form:
+# x = hi + lo, 22 significant bits, fp32 accumulation; 5.3x the fp32 MFMA's rate at about its accuracy -- 1e-6 of max |y| per layer, 5x
+# tighter than F(4x4) Winograd in fp32) takes the layers where it beats the F(4x4) kernel.  Measured per layer at B=6 512x512
+# (tools/halo_layers.py): every layer whose input and output channel counts DIFFER (1.27-1.50x: the short-K, many-cout-group and
+# partly-filled-round cases of the F(4x4) kernel); where they are equal the two are within 0.93-1.02 and the F(4x4) kernel keeps them.
+# The rule uses the channel counts only, so a sample's result does not depend on the batch it is in.  Activations must stay below
+# half's largest value (65504).  CCST_HALO_SPLIT=0: off; =2: every 3x3 layer of the plan.
+HALO_SPLIT = os.environ.get("CCST_HALO_SPLIT", "1")
+
+
+def halo_split_wanted(pc):
+    if HALO_SPLIT == "0" or pc.wsplit is None or pc.kh != 3 or pc.kw != 3:
+        return False
+    return HALO_SPLIT == "2" or pc.cin != pc.cout
+
+
+def conv3x3_halo_split(x, pc, flags, sums=False):
+    """3x3 stride-1 pad-1 conv on the direct kernel's SPLIT form; x NHWC [N,Hs,Ws,Cin], pc packed with wino=4 (which also builds
+    pc.wsplit).  sums=True (no pool): also the per-tile (sum, sum of squares) partials [tiles, Cout, 2] of the output."""
+    N, Hs, Ws, Cx = x.shape
+    ups, pool = bool(flags & CONV_UPS2), bool(flags & CONV_POOL2)
+    Hi, Wi = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
+    oh, ow = ((Hi + 1) // 2, (Wi + 1) // 2) if pool else (Hi, Wi)
+    out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    part = None
+    if sums:
+        if pool:
+            raise ValueError("ccst_amd.ops: the statistics epilogue is of the un-pooled output")
+        part = torch.empty((int(lib.ccst_conv3x3_halo_split_tiles(N, Hi, Wi)), pc.cout, 2), device=x.device, dtype=torch.float32)
+    args = (ptr(x), ptr(pc.wsplit), pc.wsplit_scale, ptr(pc.bias), ptr(out), N, Hi, Wi, Cx, pc.cout, pc.n_pad, flags, ptr(part), stream_ptr())
+    if TIMING is None:
+        check(lib.ccst_conv3x3_halo_split_f32(*args), "conv3x3_halo_split")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.ccst_conv3x3_halo_split_f32(*args), "conv3x3_halo_split")
+        e1.record()
+        TIMING.append(("conv3x3_halo_split_kernel<%s>" % ("pool" if pool else "nopool"), 2.0 * N * Hi * Wi * pc.cout * pc.cin * 9, e0, e1,
+                       "n%d %dx%d cin%d cout%d taps3x3 flags%d" % (N, Hi, Wi, pc.cin, pc.cout, flags)))
+    return (out, part) if sums else out
 
 
 def wino4_ok(cin, cout, H, W):
@@ -311,6 +354,13 @@ def pack_conv_weight(w_oihw, bias=None, transpose=False, out=None, wino=False):
             if WINO_F4_NARROW or wino == "4n" or cin < 32:
                 pc.u4n = torch.empty(nfl, device=w.device, dtype=torch.float32)
                 check(lib.ccst_pack_conv_weight_wino4_f32(ptr(w), ptr(pc.u4n), cout, cin, pc.u4_pad, stream_ptr()), "pack_conv_weight_wino4")
+            if HALO_SPLIT != "0" and cin % 16 == 0:
+                import math
+                wmax = float(w.abs().max())
+                pc.wsplit_scale = 2.0 ** max(-8, min(14, 10 - math.ceil(math.log2(wmax)))) if wmax > 0.0 and math.isfinite(wmax) else 1.0
+                pc.wsplit = torch.empty(9 * cin * n_pad, device=w.device, dtype=torch.float32)
+                check(lib.ccst_pack_conv_weight_halo_split_f32(ptr(w), ptr(pc.wsplit), cout, cin, n_pad, pc.wsplit_scale, stream_ptr()),
+                      "pack_conv_weight_halo_split")
     return pc
 
 
@@ -365,9 +415,11 @@ def chan_sums_finalize(partials):
 
 
 def wino4w_sums_ok(pc, stride, pad, pool, out_nchw):
-    """Can this conv leave the per-channel sums of its output in its epilogue (the 64-channel F(4x4) kernel, un-pooled)?"""
-    return pc.u4 is not None and not WINO_F4_NARROW and stride == 1 and pad == 1 and not pool and not out_nchw and pc.kh == 3 and pc.kw == 3 \
-        and wino4_ok(pc.cin, pc.cout, 0, 0)
+    """Can this conv leave the per-channel sums of its output in its epilogue (the 64-channel F(4x4) kernel or the direct kernel's
+    SPLIT form, un-pooled)?"""
+    if stride != 1 or pad != 1 or pool or out_nchw or pc.kh != 3 or pc.kw != 3:
+        return False
+    return halo_split_wanted(pc) or (pc.u4 is not None and not WINO_F4_NARROW and wino4_ok(pc.cin, pc.cout, 0, 0))
 
 
 def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, ups=False, out_nchw=False, out=None,
@@ -404,7 +456,11 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
             and out is None and pc.bias is None and halo_train_ok(Hi, Wi, Cx, pc.cout):
         return conv3x3_halo_train(x, pc, want_stats=want_stats)
     if chan_sums:       # (the caller checked wino4w_sums_ok)
+        if halo_split_wanted(pc) and Cx == pc.cin and not pool:
+            return conv3x3_halo_split(x, pc, flags, sums=True)
         return conv3x3_wino4(x, pc, flags, sums=True)
+    if halo_split_wanted(pc) and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats and Cx == pc.cin:
+        return conv3x3_halo_split(x, pc, flags)
     if (pc.u4 is not None or pc.u4n is not None) and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats \
             and wino4_ok(pc.cin, pc.cout, Hi, Wi):
         return conv3x3_wino4(x, pc, flags)

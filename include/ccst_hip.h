@@ -95,6 +95,19 @@ int ccst_conv3x3_halo_f32(const float* x, const float* w_packed, const float* bi
 
 int ccst_conv3x3_halo_narrow(int N, int H, int W, int Cout);   /* 1: the 128x64 tile is dispatched, 0: 128x128 */
 
+/* The same convolution with every fp32 product computed as three products of 16-bit pieces on the half-precision MFMA (x = hi + lo,
+ * hi = half(x), lo = half(x - hi): 22 significant bits; a b ~ a_lo b_hi + a_hi b_lo + a_hi b_hi, fp32 accumulation): 5.3x the fp32
+ * MFMA's rate at about its accuracy while |x| < 65504 and the scaled weights stay in half's normal range.  w_split from
+ * ccst_pack_conv_weight_halo_split_f32 (9 * cin * cout_pad floats' worth of [tap][cin/16][cout_pad][16 k hi | lo] rows of w * wscale,
+ * wscale a power of two chosen by the caller so that max |w| * wscale is ~2^10); the conv call takes the same wscale and scales the
+ * accumulators back; otherwise the x / y / flags contract of ccst_conv3x3_halo_f32. */
+int ccst_pack_conv_weight_halo_split_f32(const float* w_oihw, float* w_split, int cout, int cin, int cout_pad, float wscale, void* stream);
+int ccst_conv3x3_halo_split_f32(const float* x, const float* w_split, float wscale, const float* bias, float* y, int N, int H, int W,
+                                int Cin, int Cout, int cout_pad, uint32_t flags, float* chan_sum_partials, void* stream);
+/* chan_sum_partials (may be NULL; not with POOL2): [ccst_conv3x3_halo_split_tiles(N,H,W)][Cout][2] per-(8x16-pixel tile, wave row)
+ * (sum, sum of squares) of the output after bias / ReLU, an image's rows contiguous -- the statistics ccst_adain_tile_sums_f32 and
+ * ccst_chan_sums_finalize_f32 take instead of a pass over the tensor. */
+int ccst_conv3x3_halo_split_tiles(int N, int H, int W);
 /* The same convolution as fused Winograd F(2x2,3x3) (16 multiplies per 2x2 output tile and input channel instead of
  * 36): transformed weights from ccst_pack_conv_weight_wino_f32 (ccst_wino_weight_floats(cin, cout_pad) floats,
  * cout_pad a multiple of 32), same x / y / flags contract as ccst_conv3x3_halo_f32.  fp32 throughout; differs from the

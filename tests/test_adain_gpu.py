@@ -840,3 +840,45 @@ def test_adain_from_the_conv_epilogue_tile_sums(dev, case):
         assert float((got - ref).abs().max()) < 2e-5 * scale
         t = (f64 - mu) / sd * s_.double() + m_.double()
         assert float((got.double() - (t * alpha + f64 * (1 - alpha))).abs().max()) < 2e-5 * scale
+
+
+@pytest.mark.parametrize("case", [(2, 32, 48, 64, 128, False, False), (1, 17, 23, 32, 96, False, False), (2, 24, 24, 128, 40, True, False),
+                                  (1, 22, 38, 64, 256, False, True), (1, 16, 32, 256, 512, False, False), (1, 9, 7, 16, 33, True, False),
+                                  (3, 50, 84, 64, 128, False, False), (1, 64, 64, 512, 256, False, True)])
+@pytest.mark.parametrize("reflect", [True, False])
+def test_conv3x3_halo_split_vs_fp64(dev, case, reflect):
+    """ops.conv3x3_halo_split (the direct kernel with every fp32 product as three products of IEEE-half pieces on the 16-bit MFMA)
+    against an fp64 convolution: reflection / zero padding, sizes that are not multiples of the tile, Cout not a multiple of 32, pool,
+    upsample; its error must be at the fp32 level (a few 1e-6 of max |y|), and the per-tile channel sums of its epilogue must add up
+    to the sums of its own output."""
+    from ccst_amd import ops
+    N, H, W, Cin, Cout, pool, ups = case
+    g = torch.Generator().manual_seed(19)
+    Hs, Ws = (H // 2, W // 2) if ups else (H, W)
+    x = torch.randn(N, Hs, Ws, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(dev)
+    b = (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    pc = ops.pack_conv_weight(w, b, wino=4)
+    assert pc.wsplit is not None and pc.wsplit_scale >= 1.0
+    flags = 1 | (2 if pool else 0) | (4 if ups else 0) | (8 if reflect else 0)
+    out = ops.conv3x3_halo_split(x, pc, flags)
+    xr = x.permute(0, 3, 1, 2).double()
+    if ups:
+        xr = F.interpolate(xr, scale_factor=2, mode="nearest")
+    xr = F.pad(xr, (1, 1, 1, 1), mode="reflect") if reflect else F.pad(xr, (1, 1, 1, 1))
+    ref = F.relu(F.conv2d(xr, w.double(), b.double()))
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2, 0, ceil_mode=True)
+    ref = ref.permute(0, 2, 3, 1)
+    assert out.shape == ref.shape
+    assert float((out.double() - ref).abs().max()) < 4e-6 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(out, ops.conv3x3_halo_split(x, pc, flags))
+    if not pool:
+        out2, part = ops.conv3x3_halo_split(x, pc, flags, sums=True)
+        assert torch.equal(out2, out) and part.shape[0] % N == 0 and part.shape[1] == Cout
+        tot = part.double().sum(0)
+        s_ref = torch.stack([out.double().sum(dim=(0, 1, 2)), (out.double() ** 2).sum(dim=(0, 1, 2))], dim=1)
+        assert float((tot - s_ref).abs().max()) < 1e-5 * max(1.0, float(s_ref.abs().max()))
+        tpi = part.shape[0] // N                                                 # an image's rows are contiguous
+        s0 = part[:tpi].double().sum(0)[:, 0]
+        assert float((s0 - out[0].double().sum(dim=(0, 1))).abs().max()) < 1e-5 * max(1.0, float(s0.abs().max()))
