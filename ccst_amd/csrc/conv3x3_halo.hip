@@ -100,13 +100,18 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     constexpr int TH = BM / 16, HH = TH + 2;
     constexpr int HPIX = HH * HW_;                         // halo pixels
+    // row stride of the halo image in LDS, in pixels: SPLIT pads 18 -> 24 so that the sixteen lanes of a ds_read_b128 pass (pixels
+    // (py, px), (py, px + 1), (py + 1, px), ..., px + 2 j) fall on 16 different 16-byte bank groups of the 64 banks -- with 18 the row
+    // step (360 words) and the two-pixel step (40 words) are the same distance modulo 64 and every read is two-way conflicted
+    // (PMC: 41 % of the LDS cycles of the first SPLIT version)
+    constexpr int HWS = (SPLIT && NT == 2) ? 24 : HW_;
     constexpr int HUNITS = HPIX * (CKH / 4);               // float4 units per chunk
     constexpr int HR = (HUNITS + 255) / 256;               // halo units per thread per chunk
     constexpr int BUNITS = (CKH / 4) * BN;
     constexpr int BR = (BUNITS + 255) / 256;
     static_assert(HR <= 9, "halo load rounds must fit the 9 tap steps of a chunk");
 
-    __shared__ __attribute__((aligned(16))) float Hs_[2][HPIX * PITCH];
+    __shared__ __attribute__((aligned(16))) float Hs_[2][HH * HWS * PITCH];
     __shared__ __attribute__((aligned(16))) float Bs[3][SPLIT ? BN * BPITCH : CKH * BN];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
     for (int mt = 0; mt < MT; ++mt) {
         const int Tt = wm * MT + mt;
         const int py = 2 * Tt + ((li & 3) >> 1), px = 2 * (li >> 2) + (li & 1);
-        aBase[mt] = (py * HW_ + px) * PITCH + lh * 4;
+        aBase[mt] = (py * HWS + px) * PITCH + lh * 4;
     }
     const float* bRd0 = &Bs[0][(lh * BN + wn * (32 * NT) + li) * 4];
 
@@ -205,14 +210,15 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
         if (u < HUNITS) {
             f32x4 v = rh;
             if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int pix_ = u >> 2, slot_ = (HWS == HW_) ? pix_ : (pix_ / HW_) * HWS + pix_ % HW_;
             if (SPLIT) {
                 u32x2h hi, lo;
                 split4h(v, hi, lo);
-                float* px_ = &Hs_[buf][(u >> 2) * PITCH + (u & 3) * 2];
+                float* px_ = &Hs_[buf][slot_ * PITCH + (u & 3) * 2];
                 *reinterpret_cast<u32x2h*>(px_) = hi;
                 *reinterpret_cast<u32x2h*>(px_ + 8) = lo;
             } else
-            *reinterpret_cast<f32x4*>(&Hs_[buf][(u >> 2) * PITCH + (u & 3) * 4]) = v;
+            *reinterpret_cast<f32x4*>(&Hs_[buf][slot_ * PITCH + (u & 3) * 4]) = v;
         }
     };
     f32x4 af[2][MT], bf[2][NT];
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
                 __builtin_amdgcn_sched_barrier(0);
                 {   // first fragments of the NEXT step (visible since the previous barrier: 3-deep weight ring, halo of this chunk)
                     const int tp = (tap + 1) % 9;
-                    read_frags_split(nxt, tap == 8 ? (c + 1) & 1 : c & 1, tp % 3, ((tp / 3) * HW_ + (tp % 3)) * PITCH);
+                    read_frags_split(nxt, tap == 8 ? (c + 1) & 1 : c & 1, tp % 3, ((tp / 3) * HWS + (tp % 3)) * PITCH);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_split(cur, 0, 1);                                             // a_hi b_lo
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
         const int cn = min(c + 1, nchunks - 1);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int tapoff = ((tap / 3) * HW_ + (tap % 3)) * PITCH;
+            const int tapoff = ((tap / 3) * HWS + (tap % 3)) * PITCH;
 #pragma unroll
             for (int pos = 0; pos <= 8; ++pos) {
                 if (pos == READ1_P) {
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
                 if (pos == PRE_P) {
                     __builtin_amdgcn_sched_barrier(0);
                     const int tp = (tap + 1) % 9;
-                    read_frags(tap == 8 ? (c + 1) & 1 : c & 1, tp % 3, ((tp / 3) * HW_ + (tp % 3)) * PITCH, 0);
+                    read_frags(tap == 8 ? (c + 1) & 1 : c & 1, tp % 3, ((tp / 3) * HWS + (tp % 3)) * PITCH, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (pos < 8) mfma_frags(pos >> 2, pos & 3, (pos & 3) + 1);
