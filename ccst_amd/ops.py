@@ -278,12 +278,13 @@ WINO_F4_MIN_CIN = int(os.environ.get("CCST_WINO4_MIN_CIN", "16"))
 WINO_F4_NARROW = os.environ.get("CCST_WINO4_NARROW", "0") == "1"
 # The direct 3x3 kernel with every fp32 product as three products of IEEE-half pieces on the 16-bit MFMA (conv3x3_halo.hip SPLIT form:
 # x = hi + lo, 22 significant bits, fp32 accumulation; 5.3x the fp32 MFMA's rate at about its accuracy -- 1e-6 of max |y| per layer, 5x
-# tighter than F(4x4) Winograd in fp32) takes the layers where it beats the F(4x4) kernel.  Measured per layer at B=6 512x512
-# (tools/halo_layers.py): every layer whose input and output channel counts DIFFER (1.27-1.50x: the short-K, many-cout-group and
-# partly-filled-round cases of the F(4x4) kernel); where they are equal the two are within 0.93-1.02 and the F(4x4) kernel keeps them.
-# The rule uses the channel counts only, so a sample's result does not depend on the batch it is in.  Activations must stay below
-# half's largest value (65504).  CCST_HALO_SPLIT=0: off; =2: every 3x3 layer of the plan.
-HALO_SPLIT = os.environ.get("CCST_HALO_SPLIT", "1")
+# tighter than F(4x4) Winograd in fp32) runs every 3x3 layer of the AdaIN plan by default (CCST_HALO_SPLIT=2).  Measured per layer at B=6
+# 512x512 (tools/halo_layers.py) against the 64-channel F(4x4) kernel: 1.23-1.49x on the six layers whose channel counts differ (the
+# short-K, many-cout-group and partly-filled-round cases of F(4x4)), 0.96-1.11x on the ten where they are equal; and over the whole
+# step, interleaved A/B on three boxes: all layers on SPLIT 1426-1442 images/s, all on F(4x4) 1382-1385, the per-layer mix
+# (CCST_HALO_SPLIT=1: SPLIT where Cin != Cout) 1369-1428 -- the F(4x4) launches run 2-6 % slower between SPLIT launches on some boxes.
+# Activations must stay below half's largest value (65504).  CCST_HALO_SPLIT=0: F(4x4) everywhere.
+HALO_SPLIT = os.environ.get("CCST_HALO_SPLIT", "2")
 
 
 def halo_split_wanted(pc):
