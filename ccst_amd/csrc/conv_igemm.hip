@@ -32,6 +32,7 @@ namespace {
 
 typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8s __attribute__((ext_vector_type(8)));
 
 
 struct ConvArgs {
@@ -492,10 +493,14 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
 // and two pieces (16 bits, error 5e-6 of max |y|) fail them; BFP = 2 is kept for inference-grade callers.
 template <bool STATS, bool ACCUM, int MASKED = 0, bool BSTATS = false, int BFP = 0>
 __global__ __launch_bounds__(256, BFP == 3 ? 3 : 4) void conv1x1_stream_kernel(const ConvArgs p, int ntiles) {
-    constexpr bool BF3 = BFP != 0;
+    // BFP = 4: TWO IEEE-half pieces (22 bits: 1e-6 of max |y|, the form the AdaIN path's direct kernel uses; the weights are scaled by
+    // 2^8 into half's normal range as they are split and the accumulators scaled back) -- for FORWARD convolutions only: gradients are
+    // outside half's range.
+    constexpr bool BF3 = BFP != 0, HALFP = BFP == 4;
+    constexpr int NPIECE = HALFP ? 2 : BFP;
     constexpr int BM = 64, BN = 64, CK = 32, PPR = CK / 4, AR = BM * PPR / 256, BR = (CK / 4) * BN / 256;
     constexpr int PW = CK / 2;                               // words per piece of a row (32 bf16)
-    constexpr int A_LD = BF3 ? BFP * PW + 4 : CK + 4;        // BF: a row = [32 channels piece 0 | piece 1 | ...] + 4 words of pad
+    constexpr int A_LD = BF3 ? NPIECE * PW + 4 : CK + 4;     // BF: a row = [32 channels piece 0 | piece 1 | ...] + 4 words of pad
     constexpr int B_LD = BF3 ? A_LD : 0;                     // BF: B rows are output channels, laid out like the A rows
     __shared__ __attribute__((aligned(16))) float As[2][BM * A_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BF3 ? BN * A_LD : CK * BN];
@@ -564,35 +569,42 @@ __global__ __launch_bounds__(256, BFP == 3 ? 3 : 4) void conv1x1_stream_kernel(c
         }
     };
     // four fp32 values -> their bf16 pieces (each the round-to-nearest bf16 of what the previous ones left), two bf16 per word
-    auto split4 = [](f32x4 v, u32x2s (&pc)[BF3 ? BFP : 1]) {
+    auto split4 = [](f32x4 v, u32x2s (&pc)[BF3 ? NPIECE : 1]) {
 #pragma unroll
-        for (int q = 0; q < (BF3 ? BFP : 1); ++q)
+        for (int q = 0; q < (BF3 ? NPIECE : 1); ++q)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const __bf16 b0 = (__bf16)v[2 * h], b1 = (__bf16)v[2 * h + 1];
-                pc[q][h] = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
-                v[2 * h] -= (float)b0;
-                v[2 * h + 1] -= (float)b1;
+                if (HALFP) {
+                    const _Float16 b0 = (_Float16)v[2 * h], b1 = (_Float16)v[2 * h + 1];
+                    pc[q][h] = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+                    v[2 * h] -= (float)b0;
+                    v[2 * h + 1] -= (float)b1;
+                } else {
+                    const __bf16 b0 = (__bf16)v[2 * h], b1 = (__bf16)v[2 * h + 1];
+                    pc[q][h] = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+                    v[2 * h] -= (float)b0;
+                    v[2 * h + 1] -= (float)b1;
+                }
             }
     };
     auto store_step = [&](int buf) {
         if (BF3) {
 #pragma unroll
             for (int a = 0; a < AR; ++a) {          // row = pixel
-                u32x2s pc[BF3 ? BFP : 1];
+                u32x2s pc[BF3 ? NPIECE : 1];
                 split4(ra[a], pc);
                 float* row = &As[buf][(tid / PPR + (256 / PPR) * a) * A_LD];
 #pragma unroll
-                for (int q = 0; q < (BF3 ? BFP : 1); ++q) *reinterpret_cast<u32x2s*>(row + q * PW + part * 2) = pc[q];
+                for (int q = 0; q < (BF3 ? NPIECE : 1); ++q) *reinterpret_cast<u32x2s*>(row + q * PW + part * 2) = pc[q];
             }
 #pragma unroll
             for (int b = 0; b < BR; ++b) {          // unit u = (k quad u / BN, column u % BN): row = output channel
                 const int u = tid + 256 * b;
-                u32x2s pc[BF3 ? BFP : 1];
-                split4(rb[b], pc);
+                u32x2s pc[BF3 ? NPIECE : 1];
+                split4(HALFP ? rb[b] * 256.f : rb[b], pc);
                 float* row = &Bs[buf][(u % BN) * B_LD];
 #pragma unroll
-                for (int q = 0; q < (BF3 ? BFP : 1); ++q) *reinterpret_cast<u32x2s*>(row + q * PW + (u / BN) * 2) = pc[q];
+                for (int q = 0; q < (BF3 ? NPIECE : 1); ++q) *reinterpret_cast<u32x2s*>(row + q * PW + (u / BN) * 2) = pc[q];
             }
             return;
         }
@@ -619,7 +631,7 @@ __global__ __launch_bounds__(256, BFP == 3 ? 3 : 4) void conv1x1_stream_kernel(c
     auto step_bf3 = [&](int buf, auto do_store, auto do_load) {
         const float* ar = aRdB + buf * (BM * A_LD);
         const float* br = bRdB + buf * (BN * B_LD);
-        constexpr int NPC = BF3 ? BFP : 1;
+        constexpr int NPC = BF3 ? NPIECE : 1;
         bf16x8s af_[2][NPC], bf_[2][NPC];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -633,7 +645,13 @@ __global__ __launch_bounds__(256, BFP == 3 ? 3 : 4) void conv1x1_stream_kernel(c
 #pragma unroll
             for (int sum = NPC - 1; sum >= 0; --sum)
 #pragma unroll
-                for (int i = sum; i >= 0; --i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af_[kb][i], bf_[kb][sum - i], acc, 0, 0, 0);
+                for (int i = sum; i >= 0; --i) {
+                    if (HALFP)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8s, af_[kb][i]), __builtin_bit_cast(f16x8s, bf_[kb][sum - i]),
+                                                                     acc, 0, 0, 0);
+                    else
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af_[kb][i], bf_[kb][sum - i], acc, 0, 0, 0);
+                }
         };
         block(0);
         if (decltype(do_store)::value) {
@@ -690,6 +708,10 @@ __global__ __launch_bounds__(256, BFP == 3 ? 3 : 4) void conv1x1_stream_kernel(c
         ct = 0;
         const int tm = tm0 + (ci++) * strideM;
         const int row0 = tm * BM + wm * 32;
+        if (HALFP) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] *= (1.f / 256.f);               // (the weights were split as w * 2^8: exact)
+        }
         if (STATS) {
             float s1 = 0.f, s2 = 0.f;
             if (tm * BM + BM <= p.M) {
@@ -927,17 +949,18 @@ static int choose_tile(int M, int cout, int cin, int taps, bool pool) {
 // The persistent pointwise kernel (conv1x1_stream_kernel) takes every 1x1 stride-1 convolution between dense NHWC tensors whose
 // channel counts fit its 64x64x32 step.  CCST_CONV_STREAM=0 keeps them on the per-tile kernel (A/B).
 // Workgroups of the streaming kernel for a problem: at most 4 per CU, a multiple of the column-tile count, never more than tiles.
-// CCST_CONV_BF = 2 / 3: the streaming kernel's products on the bf16 MFMA from two / three bf16 pieces per operand (OPT-IN; default 0 =
-// the fp32 MFMA).  Measured on the ResNet50 B=64 pointwise shapes (tools/igemm_time.py, 10 layers, 932 us on the fp32 MFMA):
-//   two pieces   638 us (1.46x; 147-167 TFLOP/s fp32-equivalent, above the fp32 MFMA's own peak), error 5e-6 of max |y| -- fine for
-//                the AdaIN path (F(4x4) Winograd in fp32 is at 3e-5) but the ResNet step's gradient gates amplify a conv's rounding
-//                ~1e3-fold and fail (stem bn1 weight-gradient aggregate off by 1.5e-3);
-//   three pieces 859 us (1.09x; the splits cost ~90 vector instructions per k-step next to 12 MFMAs), error = the fp32 MFMA's; the
-//                ResNet fixtures pass, the full-size gradient gate (8 x the reference's own fp32 noise) is missed by 24 % on one
-//                tensor -- a different but equally valid rounding sequence.
-// The conversion is what is left to remove (weights split once per optimiser step, activations split by their producer).
+// CCST_CONV_BF: how the streaming pointwise kernel forms its products.
+//   4 (default): the TRAINING FORWARD (the calls with a statistics epilogue) on the 16-bit MFMA from two IEEE-half pieces per operand
+//      (22 bits; weights scaled by 2^8 as they are split, accumulators scaled back): the ten ResNet50 B=64 pointwise shapes 932 -> 653 us
+//      (tools/igemm_time.py), error 4e-7..1.3e-6 of max |y| (the fp32 MFMA: 2e-7..2e-6), every ResNet fixture and the full-size gradient
+//      gate green, train step 3340 -> 3435 images/s.  Backward-data and the evaluation forward stay on the fp32 MFMA: gradients are
+//      outside half's range, and forward activations must stay below 65504 (BatchNorm keeps them O(1-10)).
+//   0: the fp32 MFMA everywhere.
+//   2 / 3 (experiments): two / three bf16 pieces for every form.  Two: 638 us, 147-167 TFLOP/s, but 16 bits (5e-6 of max |y|): the train
+//      step's gradient gates, which amplify a conv's rounding ~1e3-fold, fail (+5 % otherwise).  Three: the fp32 MFMA's accuracy at 859 us
+//      (the splits cost ~90 vector instructions per k-step next to 12 MFMAs): no gain on the step.
 static int stream_bfp() {
-    static const int bfp = [] { const char* e = getenv("CCST_CONV_BF"); const int v = e ? atoi(e) : 0; return (v == 2 || v == 3) ? v : 0; }();
+    static const int bfp = [] { const char* e = getenv("CCST_CONV_BF"); const int v = e ? atoi(e) : 4; return (v == 2 || v == 3 || v == 4) ? v : 0; }();
     return bfp;
 }
 static int stream_grid(int M, int cout) {
@@ -1067,11 +1090,12 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
         const bool acc = (a.flags & CCST_CONV_ACCUM) != 0;
         if (relu_mask) CCST_REQUIRE(acc && !stats, "conv: the ReLU mask goes with CCST_CONV_ACCUM (the sum is masked)");
         if (bn) CCST_REQUIRE(!stats && ((acc && relu_mask) || (!acc && bn->gamma)), "conv: BatchNorm link without its masked form");
-        // CCST_CONV_BF3=0: the fp32 MFMA (v_mfma_f32_32x32x2_f32) instead of three bf16 MFMA products per fp32 product
         const int bfp = stream_bfp();
+        const bool fwd_form = stats != nullptr;         // half pieces: the training forward only (the plain form also serves backward-data)
 #define CCST_STREAM(...)                                                                                                     \
     do {                                                                                                                     \
-        if (bfp == 3) hipLaunchKernelGGL((conv1x1_stream_kernel<__VA_ARGS__, 3>), dim3(grid), dim3(256), 0, s, a, ntiles);    \
+        if (bfp == 4 && fwd_form) hipLaunchKernelGGL((conv1x1_stream_kernel<__VA_ARGS__, 4>), dim3(grid), dim3(256), 0, s, a, ntiles); \
+        else if (bfp == 3) hipLaunchKernelGGL((conv1x1_stream_kernel<__VA_ARGS__, 3>), dim3(grid), dim3(256), 0, s, a, ntiles); \
         else if (bfp == 2) hipLaunchKernelGGL((conv1x1_stream_kernel<__VA_ARGS__, 2>), dim3(grid), dim3(256), 0, s, a, ntiles); \
         else hipLaunchKernelGGL((conv1x1_stream_kernel<__VA_ARGS__, 0>), dim3(grid), dim3(256), 0, s, a, ntiles);            \
     } while (0)

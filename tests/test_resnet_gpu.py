@@ -879,11 +879,12 @@ def test_wino4w_train_form_vs_gather(dev, shape):
     assert torch.equal(uf, pf[0]) and torch.equal(ub, pb[0])
 
 
-@pytest.mark.parametrize("pieces,tol", [(2, 3e-5), (3, 4e-6)])
+@pytest.mark.parametrize("pieces,tol", [(2, 3e-5), (3, 4e-6), (4, 4e-6), (0, 4e-6)])
 def test_pointwise_conv_on_the_bf16_mfma(dev, pieces, tol):
-    """CCST_CONV_BF=2 / 3 (opt-in): the streaming pointwise kernel with every fp32 product as three / six bf16 MFMA products of
-    bf16 pieces of the operands, fp32 accumulation: against an fp64 convolution, in a child process (the mode is read once per
-    process).  Two pieces carry 16 significant bits (error ~5e-6 of max |y|), three the fp32 MFMA's own accuracy."""
+    """CCST_CONV_BF: the streaming pointwise kernel's training forward with every fp32 product as three products of IEEE-half pieces
+    (4, the default), as three / six products of bf16 pieces (2 / 3, experiments) or on the fp32 MFMA (0): against an fp64
+    convolution, in a child process (the mode is read once per process).  bf16 x 2 carries 16 significant bits (error ~5e-6 of max
+    |y|); half x 2 (22 bits) and bf16 x 3 (24) are at the fp32 MFMA's own accuracy."""
     import os
     import subprocess
     import sys
