@@ -103,6 +103,51 @@ def conv3x3_wino_train(x, packed, want_stats=False, accumulate_into=None, tag=""
 # so the weight-gradient stream's kernels cannot share those CUs while it runs; and F(4x4)'s rounding (~20x that of F(2x2)) carried
 # through eight layers puts the ResNet18 fixture's gradient probes at 1.2e-3 of the tensor's largest gradient, outside the 1e-3 gate.
 RESNET_WINO4 = os.environ.get("CCST_RESNET_WINO4", "0") == "1"
+# The trunk's 3x3 stride-1 TRAINING FORWARD on the direct kernel's SPLIT form (fp32 products as three products of IEEE-half pieces on the
+# 16-bit MFMA, conv3x3_halo.hip; BatchNorm statistics from its epilogue), maps of at least 14x14; backward-data stays on the fp32 MFMA
+# (gradients are outside half's range); the weights are re-split once per optimiser step (one small launch per layer).  OPT-IN
+# (CCST_RESNET_SPLIT_FWD=1): +0.4-2.4 % on the ResNet50 step, every fixture green, but the full-size gradient gate (8 x the reference's
+# own fp32 noise per tensor) is then missed by 14 % on one ill-conditioned tensor (layer4.2.conv1.weight, whose reference noise is
+# already 0.3 % of its largest gradient) -- a different, not a worse, rounding sequence; the gate stays as it is and this stays off.
+RESNET_SPLIT_FWD = os.environ.get("CCST_RESNET_SPLIT_FWD", "0") == "1"
+
+
+def split_train_ok(H, W, cin, cout):
+    return RESNET_SPLIT_FWD and cin % 16 == 0 and H >= 14 and W >= 14
+
+
+def pack_halo_split(w_oihw, out=None, scale=256.0):
+    """Pre-split (hi | lo half pieces of w * scale) weight rows for conv3x3_halo_split_train: (buffer, n_pad, cout, scale)."""
+    cout, cin = w_oihw.shape[0], w_oihw.shape[1]
+    n_pad = round_up(cout, 128)
+    nfl = 9 * cin * n_pad
+    buf = out if out is not None and out.numel() == nfl else torch.empty(nfl, device=w_oihw.device, dtype=torch.float32)
+    check(_lib.load().ccst_pack_conv_weight_halo_split_f32(ptr(w_oihw.contiguous()), ptr(buf), cout, cin, n_pad, float(scale), stream_ptr()),
+          "pack_halo_split")
+    return buf, n_pad, cout, float(scale)
+
+
+def conv3x3_halo_split_train(x, packed, want_stats=False):
+    """3x3 stride-1 zero-padded bias-free conv on the direct kernel's SPLIT form (ResNet trunk, training forward); packed =
+    pack_halo_split(...).  The statistics are per-(8x16-pixel tile, wave row) (sum, sum^2) partials [rows, cout, 2]."""
+    buf, n_pad, cout, scale = packed
+    N, H, W, Cx = x.shape
+    lib = _lib.load()
+    y = torch.empty((N, H, W, cout), device=x.device, dtype=torch.float32)
+    stats = None
+    if want_stats:
+        stats = torch.empty((int(lib.ccst_conv3x3_halo_split_tiles(N, H, W)), cout, 2), device=x.device, dtype=torch.float32)
+    args = (ptr(x), ptr(buf), scale, None, ptr(y), N, H, W, Cx, cout, n_pad, 0, ptr(stats), stream_ptr())
+    if TIMING is None:
+        check(lib.ccst_conv3x3_halo_split_f32(*args), "conv3x3_halo_split_train")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.ccst_conv3x3_halo_split_f32(*args), "conv3x3_halo_split_train")
+        e1.record()
+        TIMING.append(("conv3x3_halo_split_kernel<train>", 2.0 * N * H * W * cout * Cx * 9, e0, e1,
+                       "n%d %dx%d cin%d cout%d taps3x3 s1" % (N, H, W, Cx, cout)))
+    return (y, stats) if want_stats else y
 
 
 def wino4w_train_ok(H, W, cin, cout):
