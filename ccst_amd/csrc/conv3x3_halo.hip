@@ -26,6 +26,7 @@
 //   prologue waits for the whole store drain, which the hardware dispatcher overlaps for free.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -100,18 +101,20 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     constexpr int TH = BM / 16, HH = TH + 2;
     constexpr int HPIX = HH * HW_;                         // halo pixels
-    // row stride of the halo image in LDS, in pixels: SPLIT pads 18 -> 24 so that the sixteen lanes of a ds_read_b128 pass (pixels
-    // (py, px), (py, px + 1), (py + 1, px), ..., px + 2 j) fall on 16 different 16-byte bank groups of the 64 banks -- with 18 the row
-    // step (360 words) and the two-pixel step (40 words) are the same distance modulo 64 and every read is two-way conflicted
-    // (PMC: 41 % of the LDS cycles of the first SPLIT version)
-    constexpr int HWS = (SPLIT && NT == 2) ? 24 : HW_;
+    // row stride of the halo image in LDS, in words: SPLIT pads the 18 pixels x 20 words = 360 to 416 so that the sixteen lanes of a
+    // ds_read_b128 pass (pixels (py, px), (py, px + 1), (py + 1, px), ..., px + 2 j) fall on 16 different 16-byte bank groups of the 64
+    // banks: in 16-byte units a pixel is 5, so the lanes sit at 5 (a + 2 j) + b * row, and the row must be 8 modulo 16 (104 units) --
+    // with 360 words (90 units) the row step and the two-pixel step are the same distance modulo 16 and every read is two-way
+    // conflicted (PMC: 41 % of the LDS cycles of the first SPLIT version).  (Padding whole pixels, 18 -> 24, costs 480 words a row and
+    // the 128x64 tile its third workgroup per CU.)
+    constexpr int HROW = SPLIT ? 416 : HW_ * PITCH;
     constexpr int HUNITS = HPIX * (CKH / 4);               // float4 units per chunk
     constexpr int HR = (HUNITS + 255) / 256;               // halo units per thread per chunk
     constexpr int BUNITS = (CKH / 4) * BN;
     constexpr int BR = (BUNITS + 255) / 256;
     static_assert(HR <= 9, "halo load rounds must fit the 9 tap steps of a chunk");
 
-    __shared__ __attribute__((aligned(16))) float Hs_[2][HH * HWS * PITCH];
+    __shared__ __attribute__((aligned(16))) float Hs_[2][HH * HROW];
     __shared__ __attribute__((aligned(16))) float Bs[3][SPLIT ? BN * BPITCH : CKH * BN];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -178,49 +181,53 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
     for (int mt = 0; mt < MT; ++mt) {
         const int Tt = wm * MT + mt;
         const int py = 2 * Tt + ((li & 3) >> 1), px = 2 * (li >> 2) + (li & 1);
-        aBase[mt] = (py * HWS + px) * PITCH + lh * 4;
+        aBase[mt] = py * HROW + px * PITCH + lh * 4;
     }
     const float* bRd0 = &Bs[0][(lh * BN + wn * (32 * NT) + li) * 4];
 
     const int nchunks = p.Cin / CKH;
     f32x4 rh, rb[BR];
+    f32x4 rh2[2], rb2[2][BR];      // SPLIT: two register sets, every global load two k-steps ahead of its LDS store
 
-    auto load_b = [&](int c_, int tap) {
+    auto load_b_to = [&](f32x4 (&r)[BR], int c_, int tap) {
         const int tw = (TRAIN && p.flip) ? 8 - tap : tap;
         const float* wc = SPLIT ? p.w + ((long long)tw * (p.Cin / CKH) + c_) * p.CoutPad * 16
                              : p.w + ((long long)tw * (p.Cin / 4) + c_ * (CKH / 4)) * p.CoutPad * 4;   // uniform
 #pragma unroll
-        for (int b = 0; b < BR; ++b) rb[b] = *reinterpret_cast<const f32x4*>(wc + boff[b]);
+        for (int b = 0; b < BR; ++b) r[b] = *reinterpret_cast<const f32x4*>(wc + boff[b]);
     };
-    auto store_b = [&](int buf) {
+    auto store_b_from = [&](const f32x4 (&r)[BR], int buf) {
 #pragma unroll
         for (int b = 0; b < BR; ++b) {
             const int u = tid + 256 * b;
             if (SPLIT) {           // unit u = (output channel u >> 2, 16-byte part u & 3) of a pre-split row
-                if (BUNITS % 256 == 0 || u < BUNITS) *reinterpret_cast<f32x4*>(&Bs[buf][(u >> 2) * BPITCH + (u & 3) * 4]) = rb[b];
+                if (BUNITS % 256 == 0 || u < BUNITS) *reinterpret_cast<f32x4*>(&Bs[buf][(u >> 2) * BPITCH + (u & 3) * 4]) = r[b];
                 continue;
             }
-            if (BUNITS % 256 == 0 || u < BUNITS) *reinterpret_cast<f32x4*>(&Bs[buf][u * 4]) = rb[b];
+            if (BUNITS % 256 == 0 || u < BUNITS) *reinterpret_cast<f32x4*>(&Bs[buf][u * 4]) = r[b];
         }
     };
+    auto load_b = [&](int c_, int tap) { load_b_to(rb, c_, tap); };
+    auto store_b = [&](int buf) { store_b_from(rb, buf); };
     // halo unit i of chunk c_: global -> register, register -> LDS
     auto load_h = [&](int c_, int i, unsigned off) { rh = *reinterpret_cast<const f32x4*>(p.x + off + c_ * CKH); (void)i; };
-    auto store_h = [&](int buf, int i, bool ok) {
+    auto store_h_from = [&](const f32x4& rsrc_, int buf, int i, bool ok) {
         const int u = tid + 256 * i;
         if (u < HUNITS) {
-            f32x4 v = rh;
+            f32x4 v = rsrc_;
             if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int pix_ = u >> 2, slot_ = (HWS == HW_) ? pix_ : (pix_ / HW_) * HWS + pix_ % HW_;
+            const int pix_ = u >> 2, slot_ = SPLIT ? (pix_ / HW_) * HROW + (pix_ % HW_) * PITCH : pix_ * PITCH;
             if (SPLIT) {
                 u32x2h hi, lo;
                 split4h(v, hi, lo);
-                float* px_ = &Hs_[buf][slot_ * PITCH + (u & 3) * 2];
+                float* px_ = &Hs_[buf][slot_ + (u & 3) * 2];
                 *reinterpret_cast<u32x2h*>(px_) = hi;
                 *reinterpret_cast<u32x2h*>(px_ + 8) = lo;
             } else
-            *reinterpret_cast<f32x4*>(&Hs_[buf][slot_ * PITCH + (u & 3) * 4]) = v;
+            *reinterpret_cast<f32x4*>(&Hs_[buf][slot_ + (u & 3) * 4]) = v;
         }
     };
+    auto store_h = [&](int buf, int i, bool ok) { store_h_from(rh, buf, i, ok); };
     f32x4 af[2][MT], bf[2][NT];
     auto read_frags = [&](int hbuf, int bbuf, int tapoff, int q) {
         const float* hb = &Hs_[hbuf][tapoff];
@@ -277,35 +284,68 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
     store_b(0);
     load_b(0, 1);
     store_b(1);
-    load_b(0, 2);
-    __syncthreads();
+    if (!SPLIT) load_b(0, 2);
     if (SPLIT) {
+        // SPLIT: k-step t = 9 c + tap stores the weights of step t + 2 from the register set t & 1 (fetched during step t - 2) and
+        // re-issues that set's loads for step t + 4; halo unit i is fetched at tap i and stored at tap i + 2.  With the fetch one step
+        // ahead of its store (the fp32 form) the waits on the loads were 25 % of this kernel: an L2 hit takes about as long as one
+        // k-step of 12 MFMAs x 2 waves (ablation: no weight loads -15 %, no halo loads -12 %, no barriers / LDS reads: nothing).
+        static_assert(!SPLIT || HR <= 6, "halo unit i is stored at tap i + 2 <= 7");
+        load_b_to(rb2[0], 0, 2);
+        load_b_to(rb2[1], 0, 3);
+        __syncthreads();
         FragsSplit cur, nxt;
         read_frags_split(cur, 0, 0, 0);
-        for (int c = 0; c < nchunks; ++c) {
-            const int cn = min(c + 1, nchunks - 1);
+        // one chunk (9 taps); P = parity of 9 c, so that the register set of a step is a compile-time index
+        auto chunk = [&](const int c, const int P) __attribute__((always_inline)) {
+            const int cn = min(c + 1, nchunks - 1), cnn = min(c + 2, nchunks - 1);
+            (void)cnn;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
+                const int q = (tap + P) & 1;
                 mfma_split(cur, 1, 0);                                             // a_lo b_hi
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef SPA_NO_READ
                 {   // first fragments of the NEXT step (visible since the previous barrier: 3-deep weight ring, halo of this chunk)
                     const int tp = (tap + 1) % 9;
-                    read_frags_split(nxt, tap == 8 ? (c + 1) & 1 : c & 1, tp % 3, ((tp / 3) * HWS + (tp % 3)) * PITCH);
+                    read_frags_split(nxt, tap == 8 ? (c + 1) & 1 : c & 1, tp % 3, (tp / 3) * HROW + (tp % 3) * PITCH);
                 }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_split(cur, 0, 1);                                             // a_hi b_lo
                 __builtin_amdgcn_sched_barrier(0);
-                store_b((tap + 2) % 3);
-                if (tap >= 1 && tap <= HR) store_h((c + 1) & 1, tap - 1, hok[tap - 1]);
-                if (tap + 3 < 9) load_b(c, tap + 3);
-                else load_b(cn, tap + 3 - 9);
-                if (tap < HR) load_h(cn, tap, hoff[tap]);
+#ifndef SPA_NO_STOREB
+                store_b_from(rb2[q], (tap + 2) % 3);
+#endif
+#ifndef SPA_NO_STOREH
+                if (tap >= 2 && tap <= HR + 1) store_h_from(rh2[tap & 1], (c + 1) & 1, tap - 2, hok[tap - 2]);
+#endif
+#ifndef SPA_NO_LOADB
+                if (tap + 4 < 9) load_b_to(rb2[q], c, tap + 4);
+                else load_b_to(rb2[q], cn, tap + 4 - 9);
+#endif
+#ifndef SPA_NO_LOADH
+                if (tap < HR) rh2[tap & 1] = *reinterpret_cast<const f32x4*>(p.x + hoff[tap] + cn * CKH);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_split(cur, 0, 0);                                             // a_hi b_hi
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef SPA_NO_BARRIER
                 __syncthreads();
+#endif
+#ifdef SPA_NO_READ
+                nxt = cur;
+#endif
                 cur = nxt;
             }
+        };
+        {   // (an if / else on the parity inside one loop made the compiler copy the accumulators at the join: 256 VGPRs + spills)
+            int c = 0;
+            for (; c + 1 < nchunks; c += 2) {
+                chunk(c, 0);
+                chunk(c + 1, 1);
+            }
+            if (c < nchunks) chunk(c, 0);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -314,6 +354,7 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= p.oscale;           // (a power of two: exact)
     } else {
+    __syncthreads();
     read_frags(0, 0, 0, 0);
 #ifdef ABLATE_LOOP_REPEAT
     for (int rep_ = 0; rep_ < ABLATE_LOOP_REPEAT; ++rep_)
@@ -322,7 +363,7 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
         const int cn = min(c + 1, nchunks - 1);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int tapoff = ((tap / 3) * HWS + (tap % 3)) * PITCH;
+            const int tapoff = (tap / 3) * HROW + (tap % 3) * PITCH;
 #pragma unroll
             for (int pos = 0; pos <= 8; ++pos) {
                 if (pos == READ1_P) {
@@ -346,7 +387,7 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
                 if (pos == PRE_P) {
                     __builtin_amdgcn_sched_barrier(0);
                     const int tp = (tap + 1) % 9;
-                    read_frags(tap == 8 ? (c + 1) & 1 : c & 1, tp % 3, ((tp / 3) * HWS + (tp % 3)) * PITCH, 0);
+                    read_frags(tap == 8 ? (c + 1) & 1 : c & 1, tp % 3, (tp / 3) * HROW + (tp % 3) * PITCH, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (pos < 8) mfma_frags(pos >> 2, pos & 3, (pos & 3) + 1);
@@ -588,6 +629,12 @@ static int halo_impl(const float* x, const float* w_packed, const float* bias, f
         narrow = c221 < c222;
     }
     if (bf) {
+        // Cout <= 64 (the 512 x 512 layers): 256 pixels (16 x 16) x 64 channels per workgroup, a wave 64 pixels x 64 channels -- the same 12
+        // MFMAs per wave and k-step as the 128x128 tile for a halo of 1.27 instead of 1.41 pixels per output pixel (the 128x64 tile has 6
+        // MFMAs per wave for the same halo conversion work: 3.2 other vector instructions per MFMA, 0.50 MFMA-busy)
+        static const bool tall_ok = !(getenv("CCST_HALO_TALL") && getenv("CCST_HALO_TALL")[0] == '0');
+        if (tall_ok && Cout <= 64 && sums == nullptr && H >= 16)
+            return pool ? launch_halo<4, 1, 2, true, false, true>(a, s) : launch_halo<4, 1, 2, false, false, true>(a, s);
         if (narrow) return pool ? launch_halo<2, 2, 1, true, false, true>(a, s) : launch_halo<2, 2, 1, false, false, true>(a, s);
         return pool ? launch_halo<2, 2, 2, true, false, true>(a, s) : launch_halo<2, 2, 2, false, false, true>(a, s);
     }

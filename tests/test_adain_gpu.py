@@ -844,7 +844,9 @@ def test_adain_from_the_conv_epilogue_tile_sums(dev, case):
 
 @pytest.mark.parametrize("case", [(2, 32, 48, 64, 128, False, False), (1, 17, 23, 32, 96, False, False), (2, 24, 24, 128, 40, True, False),
                                   (1, 22, 38, 64, 256, False, True), (1, 16, 32, 256, 512, False, False), (1, 9, 7, 16, 33, True, False),
-                                  (3, 50, 84, 64, 128, False, False), (1, 64, 64, 512, 256, False, True)])
+                                  (3, 50, 84, 64, 128, False, False), (1, 64, 64, 512, 256, False, True),
+                                  # Cout <= 64: the 256-pixel x 64-channel tile (ragged, pooled with odd extents, upsampled source)
+                                  (1, 40, 50, 64, 64, False, False), (2, 33, 17, 32, 64, True, False), (1, 32, 48, 128, 64, False, True)])
 @pytest.mark.parametrize("reflect", [True, False])
 def test_conv3x3_halo_split_vs_fp64(dev, case, reflect):
     """ops.conv3x3_halo_split (the direct kernel with every fp32 product as three products of IEEE-half pieces on the 16-bit MFMA)

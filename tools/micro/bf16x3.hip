@@ -70,6 +70,30 @@ __global__ __launch_bounds__(256) void rate(float* out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// Part 3: the same MFMA stream with DIFFERENT random operands on every instruction (eight register sets in rotation, unit-variance values
+// as half): what the 16-bit pipe sustains on real data -- the clock under the power limit, not the issue rate, sets it.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void rate_random(const float* __restrict__ src, float* out, int iters) {
+    f32x16 acc[4];
+    for (int a = 0; a < 4; ++a)
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    f16x8 av[8], bv[8];
+    for (int s = 0; s < 8; ++s)
+        for (int j = 0; j < 8; ++j) {
+            av[s][j] = (_Float16)src[((s * 8 + j) * 256 + threadIdx.x) % 16384];
+            bv[s][j] = (_Float16)src[((s * 8 + j) * 256 + threadIdx.x + 8192) % 16384];
+        }
+    for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[h * 4 + a], bv[(h * 4 + a + 3) & 7], acc[a], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int a = 0; a < 4; ++a) s += acc[a][0] + acc[a][15];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 static double urand() { return (rand() + 0.5) / (RAND_MAX + 1.0); }
 static double nrand() { return sqrt(-2.0 * log(urand())) * cos(6.283185307179586 * urand()); }
 
@@ -133,5 +157,28 @@ int main() {
             printf("%s  %d wave(s)/SIMD: %7.2f ms  %6.1f ns per MFMA per SIMD  %7.1f TFLOP/s%s\n", bf ? "v_mfma_f32_32x32x16_bf16" : "v_mfma_f32_32x32x2_f32  ",
                    w, ms, ms * 1e6 / (iters * 4.0 * w), flop / ms / 1e9, bf ? "  (/3 for the three-product fp32 emulation)" : "");
         }
+    {
+        std::vector<float> h(16384);
+        for (auto& v : h) v = (float)nrand();
+        float* src;
+        hipMalloc(&src, h.size() * 4);
+        hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+        for (int w = 1; w <= 2; ++w)
+            for (int len = 0; len < 2; ++len) {                     // a short launch (the clock has not settled) and a long one
+                const int it2 = len ? 8 * iters : iters;
+                hipEvent_t e0, e1;
+                hipEventCreate(&e0); hipEventCreate(&e1);
+                for (int rep = 0; rep < 2; ++rep) {
+                    hipEventRecord(e0);
+                    hipLaunchKernelGGL(rate_random, dim3(256 * w), dim3(256), 0, 0, src, out, it2);
+                    hipEventRecord(e1);
+                    hipEventSynchronize(e1);
+                }
+                float ms;
+                hipEventElapsedTime(&ms, e0, e1);
+                const double flop = (double)it2 * 4 * w * 1024 * 32.0 * 32.0 * 2.0 * 16;
+                printf("v_mfma_f32_32x32x16_f16, random operands  %d wave(s)/SIMD, %6d MFMAs per wave: %7.2f ms  %7.1f TFLOP/s\n", w, it2 * 4, ms, flop / ms / 1e9);
+            }
+    }
     return 0;
 }
