@@ -353,6 +353,11 @@ def main():
                     "bound_images_per_s": {"direct": round(bound_direct, 1), "winograd_f2x2": round(bound_w2, 1), "winograd_f4x4": round(bound_w4, 1),
                                            "direct_split_f16x3": round(bound_split, 1)},
                     "path_frac_of_bound": round(value / n_ranks_seen / (bound_wino if wino else bound_split if split else bound_direct), 4)}
+        if split:       # measured context for `frac` (it stays priced against the nominal peak)
+            roofline["pipe_sustained_on_random_operands"] = {
+                "tflops": [1062.4, 1592.2], "source": "profiles/r03_bf16x3_microbench.txt part 3 (tools/micro/bf16x3.hip)",
+                "note": "a bare stream of v_mfma_f32_32x32x16_f16 on random half operands sustains 1.06-1.59 PFLOP/s on this GPU (the clock "
+                        "under the power limit; 2.3-2.45 with constant operands): `peak` is the nominal figure"}
     adain_step = None
     if adain_us:
         nbytes = 2 * 4 * B * 512 * (S // 8) * (S // 8)       # read x once + write y once (SURVEY 8d "AdaIN-step roofline")
