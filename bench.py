@@ -40,6 +40,23 @@ GFLOP_PER_IMAGE_512 = 253.07      # 19 convs, encoder
 WINO_GFLOP_PER_IMAGE_512 = 1.812  # the two layers that do not run on the Winograd kernel (conv1_1 stem, last decoder 64->3)
 
 
+def traffic_keys(dom, tj):
+    """rocprofv3 kernel names in profiles/traffic.json (tj) that make up bench.py's kernel bucket `dom` (ops.TIMING's name, e.g.
+    'conv3x3_halo_split_kernel<nopool>'): a bucket may hold several template instantiations."""
+    base, targs = dom[:-1].split("<")
+    targs = targs.split(",")
+    nums, pooled = ", ".join(a for a in targs if a not in ("pool", "nopool")), ("true" if "pool" in targs else "false")
+    if base in ("conv3x3_wino_kernel", "conv3x3_wino4_kernel", "conv3x3_wino4w_kernel"):
+        return [k for k in tj if k.startswith("void %s<" % base) and k.rstrip(">").split("<")[1].split(",")[0].strip() == pooled]
+    if base == "conv3x3_halo_split_kernel":       # rocprofv3: conv3x3_halo_kernel<WM, WN, NT, POOL, TRAIN, SPLIT>
+        return [k for k in tj if k.startswith("void conv3x3_halo_kernel<") and k.rstrip(">").split(",")[-1].strip() == "true"
+                and k.rstrip(">").split(",")[3].strip() == pooled]
+    if base == "conv_igemm_kernel":
+        return ["void conv_igemm_kernel<%s, %s, 2, 16>" % (nums, pooled)]
+    # rocprofv3 prints every template argument: <WM, WN, NT, POOL, TRAIN>
+    return ["void %s<%s, %s, false>" % (base, nums, pooled), "void %s<%s, %s>" % (base, nums, pooled)]
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1,
@@ -320,18 +337,7 @@ def main():
             traffic_src = {"file": "profiles/traffic.json", "build_stamp": meta.get("build_stamp"), "date": meta.get("date"),
                            "profile": meta.get("profile"),
                            "current_build": meta.get("build_stamp") is not None and meta.get("build_stamp") == build_stamp()}
-            base, targs = dom[:-1].split("<")
-            targs = targs.split(",")
-            nums, pooled = ", ".join(a for a in targs if a not in ("pool", "nopool")), ("true" if "pool" in targs else "false")
-            if base in ("conv3x3_wino_kernel", "conv3x3_wino4_kernel", "conv3x3_wino4w_kernel"):
-                keys = [k for k in tj if k.startswith("void %s<" % base) and k.rstrip(">").split("<")[1].split(",")[0].strip() == pooled]
-            elif base == "conv3x3_halo_split_kernel":       # rocprofv3: conv3x3_halo_kernel<WM, WN, NT, POOL, TRAIN, SPLIT>
-                keys = [k for k in tj if k.startswith("void conv3x3_halo_kernel<") and k.rstrip(">").split(",")[-1].strip() == "true"
-                        and k.rstrip(">").split(",")[3].strip() == pooled]
-            elif base == "conv_igemm_kernel":
-                keys = ["void conv_igemm_kernel<%s, %s, 2, 16>" % (nums, pooled)]
-            else:       # rocprofv3 prints every template argument: <WM, WN, NT, POOL, TRAIN>
-                keys = ["void %s<%s, %s, false>" % (base, nums, pooled), "void %s<%s, %s>" % (base, nums, pooled)]
+            keys = traffic_keys(dom, tj)
             hits = [tj[key] for key in keys if key in tj]
             if hits and traffic_src["current_build"]:               # a committed profile of THIS build, else not reported
                 # (the bucket may hold several instantiations -- with / without the statistics epilogue: launch-weighted average)

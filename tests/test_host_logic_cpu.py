@@ -106,6 +106,25 @@ def test_bench_conv_kernel_name_mirror():
     assert ops._conv_kernel_name(64, False, 1572864, 16, 3) == "conv_igemm_kernel<2,2,1>"            # AdaIN stem
 
 
+def test_bench_traffic_keys_find_the_committed_profile():
+    """bench.py copies the dominant kernel's HBM bytes from profiles/traffic.json: the bucket name of ops.TIMING must map onto the
+    rocprofv3 names of the committed profile (a silent miss would print `traffic: null` in the driver's bench line)."""
+    import json
+    import os
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "traffic.json")) as fh:
+        tj = json.load(fh)
+    assert tj["_source"]["build_stamp"] and tj["_source"]["profile"].startswith("profiles/")
+    keys = bench.traffic_keys("conv3x3_halo_split_kernel<nopool>", tj)
+    assert keys and all(k.startswith("void conv3x3_halo_kernel<") and k.endswith("false, false, true>") for k in keys)
+    pooled = bench.traffic_keys("conv3x3_halo_split_kernel<pool>", tj)
+    assert pooled and all(k.endswith("true, false, true>") for k in pooled) and not set(pooled) & set(keys)
+    for k in keys + pooled:
+        assert tj[k]["total_bytes_per_launch"] > 0 and tj[k]["launches"] > 0
+    assert bench.traffic_keys("conv_igemm_kernel<2,2,1>", tj) == ["void conv_igemm_kernel<2, 2, 1, false, 2, 16>"]
+
+
 def test_flat_params_follow_the_model():
     """an arena whose tensors the model no longer holds (deepcopy, .to() round trip, assignment) is rebuilt, never
     silently updated in place of the model; kernels that need the GPU refuse a CPU arena."""
