@@ -8,11 +8,12 @@ rank per GPU) every rank stylises its own batch (content images are independent:
 collective), timing is barrier-bracketed and the max over ranks.
 
 Prints ONE JSON line on rank 0 (see the bench contract) including
-  roofline     : the dominant kernel (the Winograd 3x3 conv), HIP-event timed inside the timed region.
-                 ``achieved`` / ``frac`` are the FLOPs the MFMA pipe EXECUTES (Winograd F(2x2,3x3) = algorithmic / 2.25)
-                 against the fp32-MFMA peak -- a fraction of a real bound, <= 1; ``algorithmic_tflops`` is the
-                 convolution's 2*M*Cout*Cin*9 rate, and ``bound_images_per_s`` the whole-path ceilings of SURVEY 8d
-                 (direct form) and of the algorithm in use
+  roofline     : the dominant kernel (the 3x3 conv), HIP-event timed inside the timed region.  SURVEY 8(d): ``achieved`` =
+                 ALGORITHMIC FLOPs per launch (2*M*Cout*Cin*9) / the average launch duration, ``peak`` = the dense peak of the MFMA
+                 pipe the kernel runs on (16-bit MFMA 2516.6 TFLOP/s for the half-piece form, fp32 MFMA 157.3 otherwise), ``frac`` =
+                 achieved / peak -- reproducible from profiles/ with one division.  What the pipe actually issues (3 half-piece
+                 products per fp32 product; algorithmic / 4 for Winograd F(4x4)) is reported beside it as ``mfma_issue_tflops`` /
+                 ``mfma_issue_frac`` (the figure PMC's SQ_VALU_MFMA_BUSY reproduces); ``bound_images_per_s`` = whole-path ceilings
   adain_step   : the statistics + normalise step against its HBM roofline (100.66 MB algorithmic per B=6 batch)
   end_to_end   : images/sec including the H2D of the content batch and the D2H of the result (never ``value``)
   cpu_baseline : the CPU oracle (a port of the reference path) timed on the host cores, rank 0, N=1
@@ -67,6 +68,10 @@ def parse():
                     help="protocol check without a GPU: the launch / rendezvous / barrier / max-over-ranks / one-JSON-line path with a "
                          "stand-in step (CPU tests); measures nothing")
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="the timed region runs at least this long: K = max(--steps, what fills the time at the warm-up's rate); the JSON's "
+                         "`steps` is the K that was timed, `steps_requested` the flag.  20 steps are 80 ms -- shorter than the chip's clock "
+                         "ramp, so `value` then depends on what the box did before (VERDICT r3).  0 = exactly --steps")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=6)
     ap.add_argument("--two-stream", action="store_true", help="also time the step with the halves of the batch on two HIP streams "
@@ -100,6 +105,37 @@ def spawn_ranks(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+XGMI_LINK_GBPS = 153.0            # one xGMI link, one direction (7 per GPU, point to point)
+
+
+def rank_census(dist, world, rank, device_id, local_rate):
+    """The N-rank run validating itself (no multi-GPU run was possible from the build container): every rank reports
+    the identity of the device it ran on and its OWN images/s over the timed region; rank 0 gets the census.  Asserts that exactly
+    `world` ranks took part and that they sat on `world` DIFFERENT devices (N ranks on one GPU would still print a plausible line)."""
+    if world == 1:
+        return {"n_ranks_seen": 1, "device_ids": [device_id], "distinct_devices": 1, "per_rank_images_per_s": [round(local_rate, 2)],
+                "per_rank_min": round(local_rate, 2), "per_rank_max": round(local_rate, 2)}
+    rows = [None] * world
+    dist.all_gather_object(rows, {"rank": rank, "device": device_id, "rate": float(local_rate)})
+    rows = sorted(rows, key=lambda r: r["rank"])
+    ids = [r["device"] for r in rows]
+    assert [r["rank"] for r in rows] == list(range(world)), "bench.py: ranks %s took part, expected 0..%d" % ([r["rank"] for r in rows], world - 1)
+    assert len(set(ids)) == world, "bench.py: %d ranks ran on %d distinct devices: %s" % (world, len(set(ids)), ids)
+    rates = [round(r["rate"], 2) for r in rows]
+    return {"n_ranks_seen": len(rows), "device_ids": ids, "distinct_devices": len(set(ids)), "per_rank_images_per_s": rates,
+            "per_rank_min": min(rates), "per_rank_max": max(rates)}
+
+
+def allreduce_bounds(nbytes, world):
+    """xGMI bounds for one all-reduce of nbytes over `world` GPUs of a node: a ring moves 2 (N-1)/N S over ONE link per GPU; with a
+    direct link to every peer (reduce-scatter + all-gather, each peer pair on its own link) every link carries S/N per phase."""
+    if world < 2:
+        return None
+    ring_s = 2.0 * (world - 1) / world * nbytes / (XGMI_LINK_GBPS * 1e9)
+    direct_s = 2.0 * nbytes / world / (XGMI_LINK_GBPS * 1e9)
+    return {"link_GBps": XGMI_LINK_GBPS, "ring_bound_ms": round(ring_s * 1e3, 9), "direct_bound_ms": round(direct_s * 1e3, 9)}
+
+
 def dry_run(args, rank, world):
     """The contract's protocol with a stand-in step on the CPU (gloo): rendezvous, W warm-up steps, barrier, K timed steps, barrier,
     MAX over ranks, ONE JSON line from rank 0.  `value` is meaningless and flagged as such."""
@@ -121,6 +157,7 @@ def dry_run(args, rank, world):
     if distributed:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    local_elapsed = elapsed
     n_ranks_seen = 1
     if distributed:
         tt = torch.tensor([elapsed], dtype=torch.float64)
@@ -131,8 +168,22 @@ def dry_run(args, rank, world):
         seen[rank] = 1
         dist.all_reduce(seen)                                    # every rank really took part
         assert int(seen.sum()) == world
+    census = rank_census(dist if distributed else None, world, rank, "cpu-process-%d" % os.getpid(), args.batch * args.steps / local_elapsed)
+    # the N = 1 value beside the N-rank one, in the same line: rank 0 alone, the others waiting at the barrier
+    if distributed:
+        dist.barrier()
+    single = None
+    if rank == 0:
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        single = args.batch * args.steps / (time.perf_counter() - t1)
+    if distributed:
+        dist.barrier()
     if rank == 0:
         print(json.dumps({"metric": "AdaIN stylised images/sec @512x512 B=6", "dry_run": True, "value": None, "unit": "images/sec",
+                          "ranks": census, "single_gpu_reference": {"images_per_s": round(single, 2), "note": "stand-in step"},
+                          "fedavg_allreduce_bounds_example": allreduce_bounds(94.3e6, world),
                           "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
                           "vs_baseline": None, "dtype": "f32", "data": "none (stand-in step, gloo)", "backend": args.backend,
@@ -195,10 +246,18 @@ def main():
     # timed steps run 2-25 % slow while they ramp back (6.46 5.90 5.66 5.48 5.33 5.28 ms against 5.19 steady).  So: collect first,
     # then warm up straight into the timed region.
     gc.collect()
-    step_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    w0 = time.perf_counter()
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
+    steps_requested = args.steps
+    if args.min_seconds > 0 and args.warmup > 0:
+        est = (time.perf_counter() - w0) / args.warmup
+        want = torch.tensor([max(args.steps, int(np.ceil(args.min_seconds / max(est, 1e-6))))], device=dev, dtype=torch.int64)
+        if distributed:
+            dist.all_reduce(want, op=dist.ReduceOp.MAX)      # every rank times the same K
+        args.steps = int(want.item())
+    step_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if distributed:
         dist.barrier()
         torch.cuda.synchronize()
@@ -221,6 +280,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    local_elapsed = elapsed
     timing, ops.TIMING = ops.TIMING, None
     if os.environ.get("CCST_BENCH_STEP_TRACE") == "1":
         print("step trace (device ms): " + " ".join("%.2f" % a.elapsed_time(b) for a, b in step_ev) +
@@ -236,6 +296,24 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     n_ranks_seen = dist.get_world_size() if distributed else 1
     value = n_ranks_seen * B * args.steps / elapsed
+    props = torch.cuda.get_device_properties(dev)
+    device_id = str(getattr(props, "uuid", "")) or "%s@%s" % (props.name, getattr(props, "pci_bus_id", local_rank))
+    census = rank_census(dist if distributed else None, world, rank, device_id, B * args.steps / local_elapsed)
+    assert census["n_ranks_seen"] == world
+    # the N = 1 value in the same line as the N-rank one: rank 0 runs the same K steps alone while the others wait at the barrier
+    single = None
+    if distributed:
+        dist.barrier()
+        if rank == 0:
+            torch.cuda.synchronize()
+            s0 = time.perf_counter()
+            for _ in range(args.steps):
+                out = step()
+            torch.cuda.synchronize()
+            single = {"images_per_s": round(B * args.steps / (time.perf_counter() - s0), 2), "steps": args.steps,
+                      "note": "rank 0 alone right after the N-rank region (the other ranks idle at a barrier): value / (N x this) is the "
+                              "scaling efficiency of this very run"}
+        dist.barrier()
 
     # ---- end to end: H2D of the content batch + the step + D2H of the result, as the reference's loop does per batch
     # (data.to(device) ... output.cpu(), CCST_OverallStyleTransfer.py:152-157).  Reported beside `value`, never as it.
@@ -346,20 +424,24 @@ def main():
                 traffic_src["kernels"] = [key for key in keys if key in tj]
             if traffic is None:
                 traffic_src["note"] = "no profile of the running build: bytes not reported"
-        roofline = {"bound": "mfma", "achieved": round(executed, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(executed / peak, 4), "traffic": traffic, "traffic_source": traffic_src, "kernel": dom,
+        roofline = {"bound": "mfma", "achieved": round(alg, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(alg / peak, 4), "mfma_issue_tflops": round(executed, 2), "mfma_issue_frac": round(executed / peak, 4),
+                    "traffic": traffic, "traffic_source": traffic_src, "kernel": dom,
                     "launches_per_step": cnt / max(1, sampled_steps), "avg_launch_us": round(sec / cnt * 1e6, 2),
                     "event_timed_steps": "%d of the %d timed steps (every %d-th)" % (sampled_steps, args.steps, EVENTS_EVERY),
                     "gflop_per_launch": round(fl / cnt / 1e9, 3), "algorithmic_tflops": round(alg, 2),
-                    "algorithm": ("winograd F(%s,3x3): the MFMA pipe executes gflop_per_launch / %.4g; achieved and frac are the EXECUTED rate"
-                                  % ("4x4" if wfac == 4.0 else "2x2", wfac) if wino else
+                    "algorithm": ("winograd F(%s,3x3) on the fp32 MFMA: the pipe executes gflop_per_launch / %.4g (mfma_issue_*); achieved and "
+                                  "frac are the ALGORITHMIC rate (SURVEY 8d)" % ("4x4" if wfac == 4.0 else "2x2", wfac) if wino else
                                   "direct, every fp32 product as three half-precision MFMA products (fp32 accumulate): achieved and frac are the "
-                                  "EXECUTED 16-bit MFMA rate" if split else "direct"),
+                                  "ALGORITHMIC rate against the dense 16-bit MFMA peak (SURVEY 8d); mfma_issue_* = 3 x that, what the pipe issues"
+                                  if split else "direct"),
                     "executed_gflop_per_launch": round(fl / cnt / 1e9 * (3.0 if split else 1.0 / wfac), 3),
                     "bound_images_per_s": {"direct": round(bound_direct, 1), "winograd_f2x2": round(bound_w2, 1), "winograd_f4x4": round(bound_w4, 1),
                                            "direct_split_f16x3": round(bound_split, 1)},
                     "path_frac_of_bound": round(value / n_ranks_seen / (bound_wino if wino else bound_split if split else bound_direct), 4)}
         if split:       # measured context for `frac` (it stays priced against the nominal peak)
+            roofline["frac_note"] = ("the fp32-exact product costs three 16-bit MFMAs, so frac <= 1/3 for this form; the fp32-MFMA bound of "
+                                     "SURVEY 8d (157.3 TFLOP/s) is retired: achieved is %.2f x it" % (alg / PEAK_F32_MFMA_TFLOPS))
             roofline["pipe_sustained_on_random_operands"] = {
                 "tflops": [1062.4, 1592.2], "source": "profiles/r03_bf16x3_microbench.txt part 3 (tools/micro/bf16x3.hip)",
                 "note": "a bare stream of v_mfma_f32_32x32x16_f16 on random half operands sustains 1.06-1.59 PFLOP/s on this GPU (the clock "
@@ -397,11 +479,15 @@ def main():
 
     result = {
         "metric": "AdaIN stylised images/sec @512x512 B=6", "value": round(value, 3), "unit": "images/sec",
-        "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup, "init_passes": INIT_PASSES, "ms_per_step": round(ms_per_step, 3),
+        "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "steps_requested": steps_requested, "min_seconds": args.min_seconds,
+        "warmup": args.warmup, "init_passes": INIT_PASSES, "ms_per_step": round(ms_per_step, 3),
         "median_ms_per_step": round(median_ms, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": ("f32 (3xf16 split products, f32 accumulate)" if any(k.startswith("conv3x3_halo_split") for k in per_kernel) else "f32"),
+        "data": "synthetic",
         "config": {"workload": "CCST_OverallStyleTransfer PACS %dx%d batch=%d (encoder->AdaIN->decoder)" % (S, S, B),
                    "batch_per_gpu": B, "image_size": S, "sharding": "content batches per rank, no collective"},
+        "ranks": census, "single_gpu_reference": single,
         "roofline": roofline,
         "adain_step": adain_step,
         "end_to_end": e2e,

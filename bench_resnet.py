@@ -270,8 +270,30 @@ def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False
     if graph_choice is not None:
         out["graph_choice"] = graph_choice
     if distributed:
+        nbytes = int(fed.FlatParams.of(model).n_total * 4)
         out["fedavg_allreduce_ms"] = round(allreduce_ms, 3)
-        out["fedavg_bytes"] = int(fed.FlatParams.of(model).n_total * 4)
+        out["fedavg_bytes"] = nbytes
+        # the collective alone, against the xGMI bounds (point-to-point links: a ring is bound by ONE 153 GB/s link per GPU; with a
+        # direct link per peer pair every link carries S/N per phase): bus bandwidth = S x 2 (N-1)/N / time, the figure rccl-tests prints
+        from bench import allreduce_bounds
+        ar = allreduce_bounds(nbytes, world) or {}
+        flat = fed.FlatParams.of(model).flat.clone()           # a scratch copy of the flat state: 5 timed all-reduces after one warm-up
+        ts = []
+        for i in range(6):
+            sync()
+            h0 = time.perf_counter()
+            dist.all_reduce(flat)
+            sync()
+            ts.append((time.perf_counter() - h0) * 1e3)
+        ts = sorted(ts[1:])
+        tt = torch.tensor([ts[len(ts) // 2]], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        only = float(tt.item())
+        ar.update({"bytes": nbytes, "round_ms_with_prescale_and_host": round(allreduce_ms, 3),
+                   "collective_only_ms": round(only, 4) if only is not None else None,
+                   "bus_GBps": round(nbytes * 2.0 * (world - 1) / world / (only * 1e-3) / 1e9, 1) if only else None,
+                   "frac_of_one_link": round(nbytes * 2.0 * (world - 1) / world / (only * 1e-3) / 1e9 / 153.0, 3) if only else None})
+        out["fedavg_allreduce"] = ar
     if cpu_baseline and rank == 0 and world == 1:
         from oracle import resnet_ref as R
         torch.set_num_threads(host_cores())

@@ -48,9 +48,10 @@ _SIGNATURES = {
     "ccst_bn_relu_maxpool_train_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P],
     "ccst_bn_train_bwd_partials_f32": [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int64, c_int, _P, c_int64, _P],
     "ccst_conv3x3_halo_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
-    "ccst_conv3x3_halo_split_f32": [_P, _P, c_float, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P, _P],
+    "ccst_absmax_f32": [_P, c_int64, _P, _P],
+    "ccst_conv3x3_halo_split_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P, _P],
     "ccst_conv3x3_halo_split_tiles": [c_int, c_int, c_int],
-    "ccst_pack_conv_weight_halo_split_f32": [_P, _P, c_int, c_int, c_int, c_float, _P],
+    "ccst_pack_conv_weight_halo_split_f32": [_P, _P, c_int, c_int, c_int, _P, _P],
     "ccst_conv3x3_halo_narrow": [c_int, c_int, c_int, c_int],
     "ccst_wino_weight_floats": [c_int, c_int],
     "ccst_pack_conv_weight_wino_f32": [_P, _P, c_int, c_int, c_int, _P],
@@ -62,7 +63,7 @@ _SIGNATURES = {
     "ccst_conv3x3_wino4w_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P, _P],
     "ccst_wino4w_spatial_tiles": [c_int, c_int, c_int],
     "ccst_pack_stem3_weight_f32": [_P, _P, _P, c_int, _P],
-    "ccst_conv3x3_stem3_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P],
+    "ccst_conv3x3_stem3_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P],
     "ccst_chan_sums_finalize_f32": [_P, c_int, c_int, _P, _P, _P],
     "ccst_pack_conv_weight_wino_bwd_f32": [_P, _P, c_int, c_int, c_int, _P],
     "ccst_conv3x3_wino_train_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
@@ -87,9 +88,9 @@ _SIGNATURES = {
     "ccst_conv2d_bwd_weight_f32": [POINTER(CcstConvDesc), _P, _P, _P, c_int, c_int, _P, c_int64, _P],
     "ccst_conv2d_bwd_weight_splits": [c_int, c_int, c_int, c_int],
     "ccst_calc_mean_std_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, c_int64, _P],
-    "ccst_adain_tile_sums_f32": [_P, _P, c_int, _P, _P, c_int, c_float, _P, c_int, c_int, c_int, c_float, _P, _P, _P],
+    "ccst_adain_tile_sums_f32": [_P, _P, c_int, _P, _P, c_int, c_float, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P],
     "ccst_interp_blend_f32": [_P, _P, _P, c_int, c_int64, c_float, c_float, _P, _P],
-    "ccst_adain_f32": [_P, _P, _P, c_int, c_float, _P, c_int, c_int, c_int, c_int, c_float, _P, c_int64, _P],
+    "ccst_adain_f32": [_P, _P, _P, c_int, c_float, _P, c_int, c_int, c_int, c_int, c_float, _P, c_int64, _P, _P],
     "ccst_chan_sums_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _P],
     "ccst_stats_workspace_bytes": [c_int, c_int, c_int],
     "ccst_bn_train_fwd_f32": [_P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P, _P, _P, c_int64, c_int, _P, c_int, _P, c_int64, _P],

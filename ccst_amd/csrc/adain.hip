@@ -214,9 +214,11 @@ __device__ __forceinline__ float adain_one(float x, float mu, float sd, float sm
 __global__ __launch_bounds__(TPB) void adain_apply_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                const float* __restrict__ mean, const float* __restrict__ stdv,
                                                                const float* __restrict__ smean, const float* __restrict__ sstd,
-                                                               int style_per_n, float alpha, long long total4, int HW, int C) {
+                                                               int style_per_n, float alpha, long long total4, int HW, int C,
+                                                               unsigned* __restrict__ ymax) {
     const int cg = C / 4;
     const bool blend = (alpha != 1.f);
+    float amax = 0.f;
     for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total4; i += (long long)gridDim.x * TPB) {
         const int c = (int)(i % cg) * 4;
         const int n = (int)(i / ((long long)HW * cg));
@@ -229,14 +231,16 @@ __global__ __launch_bounds__(TPB) void adain_apply_nhwc_kernel(const float* __re
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = adain_one(v[j], mu[j], sd[j], sm[j], ss[j], alpha, blend);
+        amax = fmaxf(fmaxf(fmaxf(amax, fabsf(o[0])), fmaxf(fabsf(o[1]), fabsf(o[2]))), fabsf(o[3]));
         *reinterpret_cast<f32x4*>(y + i * 4) = o;
     }
+    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, blockIdx.x * (TPB / 64) + (threadIdx.x >> 6));
 }
 
 __global__ __launch_bounds__(TPB) void adain_apply_nchw_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                const float* __restrict__ mean, const float* __restrict__ stdv,
                                                                const float* __restrict__ smean, const float* __restrict__ sstd,
-                                                               int style_per_n, float alpha, int HW, int C) {
+                                                               int style_per_n, float alpha, int HW, int C, unsigned* __restrict__ ymax) {
     const int plane = blockIdx.y;
     const int c = plane % C;
     const float mu = mean[plane], sd = stdv[plane];
@@ -245,7 +249,13 @@ __global__ __launch_bounds__(TPB) void adain_apply_nchw_kernel(const float* __re
     const bool blend = (alpha != 1.f);
     const float* xb = x + (long long)plane * HW;
     float* yb = y + (long long)plane * HW;
-    for (int p = blockIdx.x * TPB + threadIdx.x; p < HW; p += gridDim.x * TPB) yb[p] = adain_one(xb[p], mu, sd, sm, ss, alpha, blend);
+    float amax = 0.f;
+    for (int p = blockIdx.x * TPB + threadIdx.x; p < HW; p += gridDim.x * TPB) {
+        const float o = adain_one(xb[p], mu, sd, sm, ss, alpha, blend);
+        amax = fmaxf(amax, fabsf(o));
+        yb[p] = o;
+    }
+    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, (blockIdx.y * gridDim.x + blockIdx.x) * (TPB / 64) + (threadIdx.x >> 6));
 }
 
 // ---- single-pass AdaIN (NHWC, H*W <= 4096): statistics AND normalise with the tensor read once and written once ------------------
@@ -274,7 +284,8 @@ __device__ __forceinline__ f32x4 quad_lane_sum(f32x4 v) {       // sum over the 
 __global__ __launch_bounds__(FP_T) void adain_fused_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                 const float* __restrict__ smean, const float* __restrict__ sstd,
                                                                 int style_per_n, float alpha, int HW, int C, float eps,
-                                                                float* __restrict__ mean_out, float* __restrict__ std_out) {
+                                                                float* __restrict__ mean_out, float* __restrict__ std_out,
+                                                                unsigned* __restrict__ ymax) {
     __shared__ double red[2][FP_W][FP_CQ][4];
     const int t = threadIdx.x, cq = t % FP_CQ, pl = t / FP_CQ, wave = t >> 6;
     const int n = blockIdx.y, c0 = blockIdx.x * (4 * FP_CQ) + cq * 4;
@@ -332,6 +343,7 @@ __global__ __launch_bounds__(FP_T) void adain_fused_nhwc_kernel(const float* __r
     const int so = (style_per_n ? n * C : 0) + c0;
     const f32x4 sm = *reinterpret_cast<const f32x4*>(smean + so), ss = *reinterpret_cast<const f32x4*>(sstd + so);
     const bool blend = (alpha != 1.f);
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < FP_PPT; ++i) {
         const int p = pl + i * FP_PL;
@@ -339,9 +351,11 @@ __global__ __launch_bounds__(FP_T) void adain_fused_nhwc_kernel(const float* __r
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = adain_one(v[i][j], mu[j], sd[j], sm[j], ss[j], alpha, blend);
+            amax = fmaxf(fmaxf(fmaxf(amax, fabsf(o[0])), fmaxf(fabsf(o[1]), fabsf(o[2]))), fabsf(o[3]));
             *reinterpret_cast<f32x4*>(yb + (long long)p * C) = o;
         }
     }
+    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, (blockIdx.y * gridDim.x + blockIdx.x) * (FP_T / 64) + wave);
 }
 
 int pick_splits(int N, int C, int HW, int layout) {
@@ -396,7 +410,8 @@ __global__ __launch_bounds__(TPB) void adain_tile_sums_nhwc_kernel(const float* 
                                                                    const float* __restrict__ part, int tpi,
                                                                    const float* __restrict__ smean, const float* __restrict__ sstd,
                                                                    int style_per_n, float alpha, int HW, int C, float eps,
-                                                                   float* __restrict__ mean_out, float* __restrict__ std_out) {
+                                                                   float* __restrict__ mean_out, float* __restrict__ std_out,
+                                                                   unsigned* __restrict__ ymax) {
     const int t = threadIdx.x, cq = t % TS_CQ, pl = t / TS_CQ;
     const int n = blockIdx.y, c0 = blockIdx.x * (4 * TS_CQ) + cq * 4;
     const float* xb = x + ((long long)n * HW) * C + c0;
@@ -460,6 +475,7 @@ __global__ __launch_bounds__(TPB) void adain_tile_sums_nhwc_kernel(const float* 
     const int so = (style_per_n ? n * C : 0) + c0;
     const f32x4 sm = *reinterpret_cast<const f32x4*>(smean + so), ss = *reinterpret_cast<const f32x4*>(sstd + so);
     const bool blend = (alpha != 1.f);
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < TS_PIX / TS_PL; ++i) {
         const int p = p0 + pl + i * TS_PL;
@@ -467,9 +483,11 @@ __global__ __launch_bounds__(TPB) void adain_tile_sums_nhwc_kernel(const float* 
             f32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = adain_one(v[i][j], mu[j], sd[j], sm[j], ss[j], alpha, blend);
+            amax = fmaxf(fmaxf(fmaxf(amax, fabsf(o[0])), fmaxf(fabsf(o[1]), fabsf(o[2]))), fabsf(o[3]));
             *reinterpret_cast<f32x4*>(yb + (long long)p * C) = o;
         }
     }
+    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (TPB / 64) + (t >> 6));
 }
 
 // CCST_OverallStyleTransfer.py:36-45, the interpolation branch: feat = sum_k w_k * base[k] (accumulated in the reference's order, from
@@ -513,7 +531,7 @@ extern "C" int ccst_calc_mean_std_f32(const float* x, float* mean, float* stdv, 
 }
 
 extern "C" int ccst_adain_f32(const float* x, const float* style_mean, const float* style_std, int style_per_n, float alpha,
-                              float* y, int N, int C, int HW, int layout, float eps, void* ws, int64_t ws_bytes, void* stream) {
+                              float* y, int N, int C, int HW, int layout, float eps, void* ws, int64_t ws_bytes, uint32_t* y_absmax, void* stream) {
     int rc = check_common(x, N, C, HW, layout);
     if (rc) return rc;
     CCST_REQUIRE(style_mean && style_std && y && ws, "adain: null pointer");
@@ -528,7 +546,7 @@ extern "C" int ccst_adain_f32(const float* x, const float* style_mean, const flo
     float* stdv = mean + (int64_t)N * C;
     if (layout == 1 && C % (4 * FP_CQ) == 0 && HW >= 2 && HW <= FP_PL * FP_PPT && N <= 65535) {      // the metric's shape: one pass, one launch
         hipLaunchKernelGGL(adain_fused_nhwc_kernel, dim3(C / (4 * FP_CQ), N), dim3(FP_T), 0, st, x, y, style_mean, style_std, style_per_n, alpha, HW,
-                           C, eps, mean, stdv);
+                           C, eps, mean, stdv, y_absmax);
         return ccst_launch_status("adain_fused");
     }
     rc = ccst_calc_mean_std_f32(x, mean, stdv, N, C, HW, layout, eps, ws, ws_bytes, stream);
@@ -537,11 +555,11 @@ extern "C" int ccst_adain_f32(const float* x, const float* style_mean, const flo
         const long long total4 = (long long)N * HW * (C / 4);
         const int grid = (int)((total4 + TPB - 1) / TPB < 4096 ? (total4 + TPB - 1) / TPB : 4096);
         hipLaunchKernelGGL(adain_apply_nhwc_kernel, dim3(grid), dim3(TPB), 0, st, x, y, mean, stdv, style_mean, style_std,
-                           style_per_n, alpha, total4, HW, C);
+                           style_per_n, alpha, total4, HW, C, y_absmax);
     } else {
         const int gx = (HW + TPB - 1) / TPB < 64 ? (HW + TPB - 1) / TPB : 64;
         hipLaunchKernelGGL(adain_apply_nchw_kernel, dim3(gx, N * C), dim3(TPB), 0, st, x, y, mean, stdv, style_mean, style_std,
-                           style_per_n, alpha, HW, C);
+                           style_per_n, alpha, HW, C, y_absmax);
     }
     return ccst_launch_status("adain_apply");
 }
@@ -551,7 +569,7 @@ extern "C" int ccst_adain_f32(const float* x, const float* style_mean, const flo
 // (ccst_conv3x3_wino4w_f32's chan_sum_partials).  C a multiple of 64.  mean_out / std_out: NULL or [N*C] (the content statistics).
 extern "C" int ccst_adain_tile_sums_f32(const float* x, const float* partials, int tiles_per_image, const float* style_mean,
                                         const float* style_std, int style_per_n, float alpha, float* y, int N, int C, int HW, float eps,
-                                        float* mean_out, float* std_out, void* stream) {
+                                        float* mean_out, float* std_out, uint32_t* y_absmax, void* stream) {
     CCST_REQUIRE(x && partials && style_mean && style_std && y, "adain_tile_sums: null pointer");
     CCST_REQUIRE(N > 0 && N <= 65535 && C > 0 && C % (4 * TS_CQ) == 0 && HW >= 2 && tiles_per_image > 0, "adain_tile_sums: bad shape (C %% 64 == 0, HW >= 2)");
     CCST_REQUIRE(alpha >= 0.f && alpha <= 1.f, "adain_tile_sums: alpha=%f outside [0,1]", (double)alpha);
@@ -559,7 +577,7 @@ extern "C" int ccst_adain_tile_sums_f32(const float* x, const float* partials, i
     const int chunks = (HW + TS_PIX - 1) / TS_PIX;
     CCST_REQUIRE(chunks <= 65535, "adain_tile_sums: plane too large");
     hipLaunchKernelGGL(adain_tile_sums_nhwc_kernel, dim3(C / (4 * TS_CQ), N, chunks), dim3(TPB), 0, (hipStream_t)stream, x, y, partials,
-                       tiles_per_image, style_mean, style_std, style_per_n, alpha, HW, C, eps, mean_out, std_out);
+                       tiles_per_image, style_mean, style_std, style_per_n, alpha, HW, C, eps, mean_out, std_out, y_absmax);
     return ccst_launch_status("adain_tile_sums");
 }
 

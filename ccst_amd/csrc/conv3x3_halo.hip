@@ -40,7 +40,9 @@ struct HaloArgs {
     long long ysN;
     int ysH, ysW;                                 // output strides (of the pooled tensor when POOL)
     int tilesX, tilesY, tilesN;
-    float oscale;        // SPLIT: the weights were packed scaled by 1 / oscale (a power of two): accumulators are scaled back before the epilogue
+    const unsigned* xmax;   // SPLIT: |max| words of x and of the OIHW weight (CCST_ABSMAX_WORDS each): the operands' power-of-two scales
+    const unsigned* wmax;   //        are derived from them in the kernel, the accumulators scaled back before the epilogue
+    unsigned* ymax;         // SPLIT: nullptr, or zeroed |max| words receiving max |y| of what this launch stores
     float* stats;        // TRAIN: per-(spatial tile, wave row) (sum, sum^2) partials of the output, or nullptr
     int flip, accum;     // TRAIN: taps read in reverse order (backward-data); y += conv
 };
@@ -62,16 +64,21 @@ constexpr int CKH = 16, PITCH = CKH + 4, HW_ = 18;
 constexpr int BPITCH = 20;      // SPLIT: words per output-channel row of the weight image (16 channels hi | lo as half = 16 words, + 4 of pad)
 typedef unsigned u32x2h __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8h __attribute__((ext_vector_type(8)));      // the 16-bit pieces are IEEE half: 11 significant bits each
+typedef _Float16 f16x2h __attribute__((ext_vector_type(2)));
+typedef float f32x2h __attribute__((ext_vector_type(2)));
 
-// four fp32 values -> two half pieces each (hi = half(x), lo = half(x - hi): 22 significant bits while |x| is in half's normal range),
-// two per word
-__device__ __forceinline__ void split4h(f32x4 v, u32x2h& hi, u32x2h& lo) {
+// four fp32 values, scaled by the tensor's power of two s (max |x| s < 2^14: nothing overflows half, and a tensor of small values is
+// lifted out of half's subnormals) -> two half pieces each (hi = half(x s), lo = half(x s - hi): 22 significant bits for every element
+// within 2^-17 of the tensor's largest, an absolute error of 2^-38 of that largest below), two per word.  Written on 2-vectors so that
+// hipcc emits v_pk_mul_f32 / v_cvt_pk_f16_f32 / v_pk_fma_f32: 12 vector instructions per four values (the scalar form took 21).
+__device__ __forceinline__ void split4h(f32x4 v, float s, u32x2h& hi, u32x2h& lo) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const _Float16 h0 = (_Float16)v[2 * h], h1 = (_Float16)v[2 * h + 1];
-        const _Float16 l0 = (_Float16)(v[2 * h] - (float)h0), l1 = (_Float16)(v[2 * h + 1] - (float)h1);
-        hi[h] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-        lo[h] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+        const f32x2h p = f32x2h{v[2 * h], v[2 * h + 1]} * s;
+        const f16x2h ph = __builtin_convertvector(p, f16x2h);
+        const f16x2h pl = __builtin_convertvector(p - __builtin_convertvector(ph, f32x2h), f16x2h);
+        hi[h] = __builtin_bit_cast(unsigned, ph);
+        lo[h] = __builtin_bit_cast(unsigned, pl);
     }
 }
 
@@ -92,7 +99,8 @@ __device__ __forceinline__ int reflect_h(int i, int n) {
 // 5e-6 and failed the wide-dynamic-range path test at 1.8e-3.  The halo is split where it passes from registers to LDS: a pixel is
 // [16 channels hi | 16 channels lo] as half -- the same 64 bytes (+ pad) as its fp32 form; the weights come pre-split (and scaled by a
 // power of two into half's normal range, the accumulators scaled back) as rows [output channel][16 k hi | lo]; a k-step (tap, 16
-// channels) is then 12 MFMAs of K = 16 per wave instead of 32 of K = 2.  Activations must stay below 65504.
+// channels) is then 12 MFMAs of K = 16 per wave instead of 32 of K = 2.  Range: the activations are scaled too, by the power of two
+// that puts the tensor's largest |value| (p.xmax, left by the producing kernel's epilogue) below 2^14 -- any finite fp32 input is safe.
 template <int WM, int WN, int NT, bool POOL, bool TRAIN = false, bool SPLIT = false>
 __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_kernel(const HaloArgs p) {
     static_assert(!(SPLIT && TRAIN), "the train form stays on the fp32 MFMA");
@@ -164,11 +172,21 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
                      : (unsigned)((g * p.CoutPad + co0 + col) * 4);
     }
 
+    // SPLIT: operand scales from the tensors' |max| words (wave-uniform), 2^kx for the activations, 2^kw was applied when the weights were packed
+    int kx = 0, kw = 0;
+    if (SPLIT) {
+        kx = ccst_scale_exp(ccst_absmax_read(p.xmax), CCST_SPLIT_X_TARGET);
+        kw = ccst_scale_exp(ccst_absmax_read(p.wmax), CCST_SPLIT_W_TARGET);
+    }
+    const float xs = __uint_as_float((unsigned)(127 + kx) << 23);
+
     f32x16 acc[MT][NT];
+    float biasv[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = co0 + wn * (32 * NT) + nt * 32 + li;
-        const float b = ((p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f) * (SPLIT ? 1.f / p.oscale : 1.f);
+        biasv[nt] = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+        const float b = SPLIT ? 0.f : biasv[nt];      // SPLIT adds the bias after the accumulators are scaled back
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -219,7 +237,7 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
             const int pix_ = u >> 2, slot_ = SPLIT ? (pix_ / HW_) * HROW + (pix_ % HW_) * PITCH : pix_ * PITCH;
             if (SPLIT) {
                 u32x2h hi, lo;
-                split4h(v, hi, lo);
+                split4h(v, xs, hi, lo);
                 float* px_ = &Hs_[buf][slot_ + (u & 3) * 2];
                 *reinterpret_cast<u32x2h*>(px_) = hi;
                 *reinterpret_cast<u32x2h*>(px_ + 8) = lo;
@@ -352,7 +370,7 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][nt][r] *= p.oscale;           // (a power of two: exact)
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = __builtin_ldexpf(acc[mt][nt][r], -(kx + kw)) + biasv[nt];   // (exact scaling)
     } else {
     __syncthreads();
     read_frags(0, 0, 0, 0);
@@ -409,6 +427,7 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
     // index -- go into the scalar offset, so a store is `buffer_store v, v_off, s[rsrc], s_row offen offset:nt*128`
     // with no vector address arithmetic and no predicate.  Edge tiles keep the predicated pointer path.
     const int cw = wn * (32 * NT);                                            // uniform (wn is)
+    float amax = 0.f;                                                         // SPLIT: largest |value| this lane stores (p.ymax)
     if (!POOL) {
         float* const tile = p.y + (long long)n * p.ysN + (long long)oy0 * p.ysH + (long long)ox0 * p.ysW + co0 + cw;
         const unsigned lane_off = (unsigned)(2 * lh * p.ysW + li);
@@ -467,6 +486,7 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
                     for (int nt = 0; nt < NT; ++nt) {
                         float v = acc[mt][nt][r];
                         if (relu) v = fmaxf(v, 0.f);
+                        if (SPLIT) amax = fmaxf(amax, fabsf(v));
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, lane_off * 4 + nt * 128, srow, 0);
                     }
                 } else if (oy0 + dy < p.H && ox0 + dx + 2 * lh < p.W) {
@@ -476,6 +496,7 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
                         if (relu) v = fmaxf(v, 0.f);
                         if (co0 + cw + nt * 32 + li < p.Cout) {
                             if (TRAIN && p.accum) v += rowp[lane_off + nt * 32];
+                            if (SPLIT) amax = fmaxf(amax, fabsf(v));
                             rowp[lane_off + nt * 32] = v;
                         }
                     }
@@ -501,6 +522,7 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
                     for (int nt = 0; nt < NT; ++nt) {
                         float v = fmaxf(fmaxf(acc[mt][nt][4 * g], acc[mt][nt][4 * g + 1]), fmaxf(acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]));
                         if (relu) v = fmaxf(v, 0.f);
+                        if (SPLIT) amax = fmaxf(amax, fabsf(v));
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, lane_off * 4 + nt * 128, srow, 0);
                     }
                 } else {
@@ -514,13 +536,17 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
                             if (oky) v = fmaxf(v, acc[mt][nt][4 * g + 2]);
                             if (okx && oky) v = fmaxf(v, acc[mt][nt][4 * g + 3]);
                             if (relu) v = fmaxf(v, 0.f);
-                            if (co0 + cw + nt * 32 + li < p.Cout) rowp[lane_off + nt * 32] = v;
+                            if (co0 + cw + nt * 32 + li < p.Cout) {
+                                if (SPLIT) amax = fmaxf(amax, fabsf(v));
+                                rowp[lane_off + nt * 32] = v;
+                            }
                         }
                     }
                 }
             }
         }
     }
+    if (SPLIT && p.ymax != nullptr) ccst_absmax_publish(p.ymax, amax, blockIdx.x * 4u + (unsigned)wave);
 }
 
 template <int WM, int WN, int NT, bool POOL, bool TRAIN = false, bool SPLIT = false>
@@ -540,7 +566,9 @@ int launch_halo(HaloArgs& a, hipStream_t s) {
 
 // OIHW 3x3 -> the pre-split weight image of the SPLIT kernels: [tap][Cin/16][cout_pad][16 words] with words 0..7 = the 16 input
 // channels of the chunk as half(w * scale) (two per word, even channel in the low half), words 8..15 = half(w * scale - hi)
-__global__ void pack_weight_halo_split_kernel(const float* __restrict__ w, unsigned* __restrict__ out, int cout, int cin, int cout_pad, float scale) {
+__global__ void pack_weight_halo_split_kernel(const float* __restrict__ w, unsigned* __restrict__ out, int cout, int cin, int cout_pad,
+                                              const unsigned* __restrict__ wmax) {
+    const int kw = ccst_scale_exp(ccst_absmax_read(wmax), CCST_SPLIT_W_TARGET);      // the conv kernel derives the same exponent
     const int nch = cin / 16;
     const long long total = 9LL * nch * cout_pad * 16;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -553,7 +581,7 @@ __global__ void pack_weight_halo_split_kernel(const float* __restrict__ w, unsig
         unsigned r = 0;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const float v = (co < cout) ? w[((long long)co * cin + k0 + e) * 9 + tap] * scale : 0.f;
+            const float v = (co < cout) ? __builtin_ldexpf(w[((long long)co * cin + k0 + e) * 9 + tap], kw) : 0.f;
             const _Float16 h = (_Float16)v;
             const _Float16 q = piece ? (_Float16)(v - (float)h) : h;
             r |= (unsigned)__builtin_bit_cast(unsigned short, q) << (16 * e);
@@ -568,42 +596,45 @@ extern "C" int ccst_conv3x3_halo_narrow(int N, int H, int W, int Cout);
 
 // Weights of ccst_conv3x3_halo_split_f32: 9 * cin * cout_pad floats (the same size as the fp32 packed form); cin a multiple of 16,
 // cout_pad a multiple of 128.
-extern "C" int ccst_pack_conv_weight_halo_split_f32(const float* w_oihw, float* out, int cout, int cin, int cout_pad, float scale, void* stream) {
+extern "C" int ccst_pack_conv_weight_halo_split_f32(const float* w_oihw, float* out, int cout, int cin, int cout_pad, const uint32_t* w_absmax,
+                                                    void* stream) {
     CCST_REQUIRE(w_oihw && out && cout > 0 && cin > 0 && cin % 16 == 0, "pack_halo_split: bad args (cin a multiple of 16)");
-    CCST_REQUIRE(scale > 0.f, "pack_halo_split: the scale must be a positive power of two");
+    CCST_REQUIRE(w_absmax, "pack_halo_split: the |max| words of the weight (ccst_absmax_f32)");
     CCST_REQUIRE(cout_pad >= cout && cout_pad % 128 == 0, "pack_halo_split: cout_pad must be a multiple of 128 >= cout");
     const long long total = 9LL * cin * cout_pad;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_weight_halo_split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, reinterpret_cast<unsigned*>(out), cout, cin,
-                       cout_pad, scale);
+                       cout_pad, w_absmax);
     return ccst_launch_status("pack_weight_halo_split");
 }
 
 // x: NHWC source [N,Hs,Ws,Cin] (Hs = H/2 if CCST_CONV_UPS2), w: packed [9][Cin/4][cout_pad][4], y: NHWC
 // [N,H,W,Cout] or its 2x2 ceil-pooled form.  flags: CCST_CONV_RELU | POOL2 | UPS2 | REFLECT.
 static int halo_impl(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int cout_pad,
-                     uint32_t flags, void* stream, bool bf, float wscale, float* sums);
+                     uint32_t flags, void* stream, bool bf, const uint32_t* xmax, const uint32_t* wmax, uint32_t* ymax, float* sums);
 
 extern "C" int ccst_conv3x3_halo_f32(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W,
                                      int Cin, int Cout, int cout_pad, uint32_t flags, void* stream) {
-    return halo_impl(x, w_packed, bias, y, N, H, W, Cin, Cout, cout_pad, flags, stream, false, 1.f, nullptr);
+    return halo_impl(x, w_packed, bias, y, N, H, W, Cin, Cout, cout_pad, flags, stream, false, nullptr, nullptr, nullptr, nullptr);
 }
 
 // The same convolution with every fp32 product as three products of IEEE-half pieces on the 16-bit MFMA (the SPLIT form of the kernel
-// above; fp32 accumulation, ~1e-6 of max |y| per layer): w_split and wscale from ccst_pack_conv_weight_halo_split_f32.
+// above; fp32 accumulation, ~1e-6 of max |y| per layer): w_split from ccst_pack_conv_weight_halo_split_f32; x_absmax / w_absmax: the
+// |max| words of x and of the OIHW weight (the operand scales are derived from them on the device); y_absmax: NULL or zeroed words for max |y|.
 // chan_sum_partials: NULL or [ccst_conv3x3_halo_split_tiles(N,H,W)][Cout][2], see include/ccst_hip.h.
-extern "C" int ccst_conv3x3_halo_split_f32(const float* x, const float* w_split, float wscale, const float* bias, float* y, int N, int H,
-                                           int W, int Cin, int Cout, int cout_pad, uint32_t flags, float* chan_sum_partials, void* stream) {
-    CCST_REQUIRE(wscale > 0.f, "conv3x3_halo_split: the weight scale of the pack call");
+extern "C" int ccst_conv3x3_halo_split_f32(const float* x, const uint32_t* x_absmax, const float* w_split, const uint32_t* w_absmax,
+                                           const float* bias, float* y, uint32_t* y_absmax, int N, int H, int W, int Cin, int Cout, int cout_pad,
+                                           uint32_t flags, float* chan_sum_partials, void* stream) {
+    CCST_REQUIRE(x_absmax && w_absmax, "conv3x3_halo_split: the |max| words of x and w are required (ccst_absmax_f32 or a producer's y_absmax)");
     CCST_REQUIRE(!(chan_sum_partials && (flags & CCST_CONV_POOL2)), "conv3x3_halo_split: channel sums are of the un-pooled output");
-    return halo_impl(x, w_split, bias, y, N, H, W, Cin, Cout, cout_pad, flags, stream, true, wscale, chan_sum_partials);
+    return halo_impl(x, w_split, bias, y, N, H, W, Cin, Cout, cout_pad, flags, stream, true, x_absmax, w_absmax, y_absmax, chan_sum_partials);
 }
 
 // Rows of chan_sum_partials: one per (image, 8x16-pixel tile, wave row), an image's rows contiguous.
 extern "C" int ccst_conv3x3_halo_split_tiles(int N, int H, int W) { return N * ((H + 7) / 8) * ((W + 15) / 16) * 2; }
 
 static int halo_impl(const float* x, const float* w_packed, const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int cout_pad,
-                     uint32_t flags, void* stream, bool bf, float wscale, float* sums) {
+                     uint32_t flags, void* stream, bool bf, const uint32_t* xmax, const uint32_t* wmax, uint32_t* ymax, float* sums) {
     CCST_REQUIRE(x && w_packed && y, "conv3x3_halo: null pointer");
     CCST_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0, "conv3x3_halo: bad shape");
     CCST_REQUIRE(cout_pad >= Cout && cout_pad % 128 == 0, "conv3x3_halo: cout_pad must be a multiple of 128 >= cout");
@@ -614,7 +645,7 @@ static int halo_impl(const float* x, const float* w_packed, const float* bias, f
     a.x = x; a.w = w_packed; a.bias = bias; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Hs = ups ? H / 2 : H; a.Ws = ups ? W / 2 : W; a.Cin = Cin; a.Cout = Cout; a.CoutPad = cout_pad;
     a.reflect = (flags & CCST_CONV_REFLECT) ? 1 : 0; a.ups = ups ? 1 : 0; a.relu = (flags & CCST_CONV_RELU) ? 1 : 0;
-    a.stats = sums; a.flip = 0; a.accum = 0; a.oscale = 1.f / wscale;
+    a.stats = sums; a.flip = 0; a.accum = 0; a.xmax = xmax; a.wmax = wmax; a.ymax = ymax;
     CCST_REQUIRE((long long)N * a.Hs * a.Ws * Cin < 0x7fffffffLL, "conv3x3_halo: input must have < 2^31 elements");
     const int oh = pool ? (H + 1) / 2 : H, ow = pool ? (W + 1) / 2 : W;
     a.ysW = Cout; a.ysH = ow * Cout; a.ysN = (long long)oh * ow * Cout;
@@ -657,7 +688,8 @@ extern "C" int ccst_conv3x3_halo_train_f32(const float* x, const float* w_packed
     a.x = x; a.w = w_packed; a.bias = nullptr; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Hs = H; a.Ws = W; a.Cin = Cin; a.Cout = Cout; a.CoutPad = cout_pad;
     a.reflect = 0; a.ups = 0; a.relu = 0;
-    a.stats = stats; a.flip = (flags & CCST_CONV_FLIP) ? 1 : 0; a.accum = (flags & CCST_CONV_ACCUM) ? 1 : 0; a.oscale = 1.f;
+    a.stats = stats; a.flip = (flags & CCST_CONV_FLIP) ? 1 : 0; a.accum = (flags & CCST_CONV_ACCUM) ? 1 : 0;
+    a.xmax = a.wmax = nullptr; a.ymax = nullptr;
     a.ysW = Cout; a.ysH = W * Cout; a.ysN = (long long)H * W * Cout;
     hipStream_t s = (hipStream_t)stream;
     if (ccst_conv3x3_halo_narrow(N, H, W, Cout)) return launch_halo<2, 2, 1, false, true>(a, s);

@@ -21,6 +21,7 @@ struct Stem3Args {
     int blocksPerRow;
     int nblocks;
     unsigned long long mBpr, mH;   // ceil(2^40 / blocksPerRow), ceil(2^40 / H): divisions by multiplication (launcher checks the ranges)
+    unsigned* ymax;      // nullptr, or zeroed |max| words (CCST_ABSMAX_WORDS) receiving max |y|: the next layer's half-piece kernel scales by it
 };
 
 typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
@@ -77,6 +78,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int stride = (int)gridDim.x * 4;
     int blk = (int)blockIdx.x * 4 + wave;
     float bv[18], bvn[18];
+    float amax = 0.f;         // largest |output| of this lane (lanes past the row's end hold copies of its last pixel)
     if (blk < p.nblocks) fetch(blk, bv);
     for (; blk < p.nblocks; blk += stride) {
         const bool more = blk + stride < p.nblocks;
@@ -105,6 +107,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 f32x4 o = {acc[nb][4 * g], acc[nb][4 * g + 1], acc[nb][4 * g + 2], acc[nb][4 * g + 3]};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) asm("v_max_f32 %0, %1, %2" : "=v"(o[i]) : "v"(o[i]), "v"(floor_));   // (fmaxf would canonicalise first)
+                amax = fmaxf(fmaxf(amax, fabsf(o[0])), fabsf(o[1]));        // (v_max3_f32 with |.| modifiers: 16 per block)
+                amax = fmaxf(fmaxf(amax, fabsf(o[2])), fabsf(o[3]));
                 *reinterpret_cast<f32x4*>(my + li * 256 + (((nb * 8 + 2 * g + lh) ^ (li & 15)) << 4)) = o;
             }
         // (same wave wrote and reads: no barrier; the compiler orders the LDS accesses by lgkmcnt)
@@ -126,6 +130,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int j = 0; j < 18; ++j) bv[j] = bvn[j];
         }
     }
+    if (p.ymax != nullptr) ccst_absmax_publish(p.ymax, amax, blockIdx.x * 4u + (unsigned)wave);
 }
 
 // OIHW [64,3,3,3] -> A operands [18 MFMAs][2 groups][64 lanes]: MFMA j = tap j >> 1, channel 2 (j & 1) + (lane >> 5) (zero for channel 3)
@@ -147,13 +152,14 @@ extern "C" int ccst_pack_stem3_weight_f32(const float* w_oihw, const float* bias
 
 // x NCHW [N,3,H,W] (contiguous), wa from ccst_pack_stem3_weight_f32 (18*2*64 floats), y NHWC [N,H,W,64]: reflection-padded 3x3 conv
 // + bias (+ ReLU) -- net.py:39-42 with the 1x1 colour conv folded into the weight.
-extern "C" int ccst_conv3x3_stem3_f32(const float* x_nchw, const float* wa, float* y_nhwc, int N, int H, int W, int relu, void* stream) {
+extern "C" int ccst_conv3x3_stem3_f32(const float* x_nchw, const float* wa, float* y_nhwc, int N, int H, int W, int relu, uint32_t* y_absmax,
+                                      void* stream) {
     CCST_REQUIRE(x_nchw && wa && y_nhwc && N > 0 && H >= 2 && W >= 2, "conv3x3_stem3: bad args");
     CCST_REQUIRE((long long)N * 3 * H * W * 4 < 0x7fffffffLL && (long long)N * H * W * 64 * 4 < 0x7fffffffLL,
                  "conv3x3_stem3: tensors must be < 2^31 bytes");
     Stem3Args a;
     a.x = x_nchw; a.wa = wa; a.y = y_nhwc;
-    a.N = N; a.H = H; a.W = W; a.relu = relu;
+    a.N = N; a.H = H; a.W = W; a.relu = relu; a.ymax = y_absmax;
     a.blocksPerRow = (W + 31) / 32;
     const long long nblocks = (long long)N * H * a.blocksPerRow;
     CCST_REQUIRE(nblocks * a.blocksPerRow < (1LL << 40) && (long long)N * H * H < (1LL << 40), "conv3x3_stem3: too many rows");

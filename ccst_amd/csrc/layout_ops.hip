@@ -131,7 +131,37 @@ int grid_for(long long total) {
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
 }
 
+// Largest |value| of a tensor as raw fp32 bits, max-accumulated into the caller's zeroed CCST_ABSMAX_WORDS words (common.h): the
+// stand-alone producer of the operand-scale words the half-piece conv kernels read, for tensors whose producing kernel did not leave them
+// (checkpoint weights at pack time, a feature map handed in from outside the plan).  One streaming read, 16 bytes per lane.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ slots) {
+    float m = 0.f;
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        m = fmaxf(fmaxf(fmaxf(m, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
+        // (fmaxf drops a NaN operand: keep it visible -- a NaN sorts above infinity as unsigned bits and clamps the consumer's scale)
+        if (v[0] != v[0] || v[1] != v[1] || v[2] != v[2] || v[3] != v[3]) m = __builtin_nanf("");
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {
+        const float v = x[(n4 << 2) + threadIdx.x];
+        m = (v != v) ? v : fmaxf(m, fabsf(v));
+    }
+    ccst_absmax_publish(slots, m, blockIdx.x * 4u + (threadIdx.x >> 6));
+}
+
 }  // namespace
+
+extern "C" int ccst_absmax_f32(const float* x, int64_t n, uint32_t* absmax, void* stream) {
+    CCST_REQUIRE(x && absmax && n > 0, "absmax: bad args");
+    CCST_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "absmax: x must be 16-byte aligned");
+    const long long blocks = (n / 4 + 255) / 256;
+    const long long cap = (long long)ccst_num_cus() * 8;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks < cap ? blocks : cap))), dim3(256), 0, (hipStream_t)stream, x,
+                       (long long)n, absmax);
+    return ccst_launch_status("absmax");
+}
+
 
 extern "C" int ccst_nchw_to_nhwc_f32(const float* x, float* y, int N, int C, int HW, int Cp, void* stream) {
     CCST_REQUIRE(x && y && N > 0 && C > 0 && HW > 0 && Cp >= C && N <= 65535, "nchw_to_nhwc: bad args");

@@ -240,11 +240,26 @@ def _run_steps(steps, x, sums_box):
     C = x.shape[1]
     cur = None          # NHWC buffer
     api = x             # logical NCHW tensor not yet converted
-    for s in steps:
+    # |max| words of `cur` (ops.absmax_words) where its producer left them: the half-piece (SPLIT) conv kernels scale their input by the
+    # power of two derived from them, on the device.  ReLU / pad / upsample / pool keep them valid (an upper bound suffices); a tensor
+    # that arrives without them costs ops.conv3x3_halo_split one extra pass (ops.absmax).
+    amax = ops.tagged_absmax(x)
+
+    def split_next(i):
+        """Does the next conv after step i run on the SPLIT kernel (i.e. is max |out| of step i wanted)?"""
+        for t in steps[i + 1:]:
+            if t.kind == "conv":
+                return t.stride == 1 and t.pad == 1 and not t.out_nchw and ops.halo_split_wanted(t.pc)
+            if t.kind not in ("relu", "pad", "up", "pool"):
+                return False
+        return False
+
+    for si, s in enumerate(steps):
         if s.kind == "stem3":
             if cur is not None:
                 api = ops.to_api(cur[..., :C]) if cur.shape[-1] != C else ops.to_api(cur)
-            cur = ops.conv3x3_stem3_nchw(ops.as_nchw_contiguous(api), s.wa, relu=s.relu)
+            amax = ops.absmax_words(x.device) if split_next(si) else None
+            cur = ops.conv3x3_stem3_nchw(ops.as_nchw_contiguous(api), s.wa, relu=s.relu, y_absmax=amax)
             C, api = 64, None
             continue
         if s.kind == "stem":
@@ -253,7 +268,7 @@ def _run_steps(steps, x, sums_box):
             img = ops.as_nchw_contiguous(api)
             cur = ops.conv2d_stem_nchw(img, s.pc, s.kwp, s.kw, stride=s.stride, pad=s.pad, reflect=s.reflect, relu=s.relu)
             C = s.pc.cout
-            api = None
+            api, amax = None, None
             continue
         if cur is None:
             cur = ops.from_api(api, cpad=16 if s.kind in ("conv", "smallco") else 4)
@@ -262,18 +277,21 @@ def _run_steps(steps, x, sums_box):
             if cur.shape[-1] % 16 != 0:
                 cur = ops.from_api(ops.to_api(cur[..., :C]), cpad=16)
             out = ops.conv3x3_smallco_nchw(cur, s.w_small, s.b_small, s.cout, reflect=s.reflect, relu=s.relu)
-            cur, api, C = None, out, s.cout
+            cur, api, C, amax = None, out, s.cout, None
             continue
         if s.kind == "conv":
             if cur.shape[-1] != s.pc.k_pad:
                 cur = ops.from_api(ops.to_api(cur[..., :C]), cpad=16)
+            split = s.stride == 1 and s.pad == 1 and not s.out_nchw and ops.halo_split_wanted(s.pc) and cur.shape[-1] == s.pc.cin
+            ymax = ops.absmax_words(x.device) if split and split_next(si) else None
             if sums_box is not None and s is steps[-1] and ops.wino4w_sums_ok(s.pc, s.stride, s.pad, s.pool, s.out_nchw):
                 out, part = ops.conv2d_nhwc(cur, s.pc, stride=s.stride, pad=s.pad, reflect=s.reflect, relu=s.relu, pool=s.pool,
-                                            ups=s.ups, chan_sums=True)
+                                            ups=s.ups, chan_sums=True, x_absmax=amax, y_absmax=ymax)
                 sums_box.append(part)
             else:
                 out = ops.conv2d_nhwc(cur, s.pc, stride=s.stride, pad=s.pad, reflect=s.reflect, relu=s.relu, pool=s.pool,
-                                      ups=s.ups, out_nchw=s.out_nchw)
+                                      ups=s.ups, out_nchw=s.out_nchw, x_absmax=amax, y_absmax=ymax)
+            amax = ymax
             C = s.pc.cout
             if s.out_nchw:
                 return out

@@ -56,13 +56,6 @@ class Conv2d(nn.Conv2d):
         return self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and \
             ops.wino_train_ok(H, W, self.in_channels, self.out_channels)
 
-    def split_ok(self, H, W):
-        return self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and \
-            ops.split_train_ok(H, W, self.in_channels, self.out_channels)
-
-    def split_fwd(self):
-        return self._cached("wsp", lambda w, prev: ops.pack_halo_split(w, out=None if prev is None else prev[0]))
-
     def wino4_ok(self, H, W):
         return self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and \
             ops.wino4w_train_ok(H, W, self.in_channels, self.out_channels)

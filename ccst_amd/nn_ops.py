@@ -351,12 +351,9 @@ class ConvFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)       # no zero tensor for the non-differentiable stats output
         ctx.wino4 = mod.wino4_ok(x.shape[1], x.shape[2])       # 64-channel F(4x4): the trunk's 56x56 and 28x28 maps
         ctx.wino = mod.wino_ok(x.shape[1], x.shape[2])
-        split = want_stats and mod.split_ok(x.shape[1], x.shape[2])       # training forward on the 16-bit MFMA (the backward is unchanged)
-        pc = None if (ctx.wino4 or ctx.wino or split) else mod.packed()      # (the direct layout is packed only where it is used)
+        pc = None if (ctx.wino4 or ctx.wino) else mod.packed()      # (the direct layout is packed only where it is used)
         if want_stats:      # BN batch statistics from the conv epilogue (non-differentiable side output)
-            if split:
-                y, stats = ops.conv3x3_halo_split_train(x, mod.split_fwd(), want_stats=True)
-            elif ctx.wino4:
+            if ctx.wino4:
                 y, stats = ops.conv3x3_wino4w_train(x, mod.wino4_fwd(), want_stats=True)
             elif ctx.wino:
                 y, stats = ops.conv3x3_wino_train(x, mod.wino_fwd(), want_stats=True)

@@ -103,51 +103,6 @@ def conv3x3_wino_train(x, packed, want_stats=False, accumulate_into=None, tag=""
 # so the weight-gradient stream's kernels cannot share those CUs while it runs; and F(4x4)'s rounding (~20x that of F(2x2)) carried
 # through eight layers puts the ResNet18 fixture's gradient probes at 1.2e-3 of the tensor's largest gradient, outside the 1e-3 gate.
 RESNET_WINO4 = os.environ.get("CCST_RESNET_WINO4", "0") == "1"
-# The trunk's 3x3 stride-1 TRAINING FORWARD on the direct kernel's SPLIT form (fp32 products as three products of IEEE-half pieces on the
-# 16-bit MFMA, conv3x3_halo.hip; BatchNorm statistics from its epilogue), maps of at least 14x14; backward-data stays on the fp32 MFMA
-# (gradients are outside half's range); the weights are re-split once per optimiser step (one small launch per layer).  OPT-IN
-# (CCST_RESNET_SPLIT_FWD=1): +0.4-2.4 % on the ResNet50 step, every fixture green, but the full-size gradient gate (8 x the reference's
-# own fp32 noise per tensor) is then missed by 14 % on one ill-conditioned tensor (layer4.2.conv1.weight, whose reference noise is
-# already 0.3 % of its largest gradient) -- a different, not a worse, rounding sequence; the gate stays as it is and this stays off.
-RESNET_SPLIT_FWD = os.environ.get("CCST_RESNET_SPLIT_FWD", "0") == "1"
-
-
-def split_train_ok(H, W, cin, cout):
-    return RESNET_SPLIT_FWD and cin % 16 == 0 and H >= 14 and W >= 14
-
-
-def pack_halo_split(w_oihw, out=None, scale=256.0):
-    """Pre-split (hi | lo half pieces of w * scale) weight rows for conv3x3_halo_split_train: (buffer, n_pad, cout, scale)."""
-    cout, cin = w_oihw.shape[0], w_oihw.shape[1]
-    n_pad = round_up(cout, 128)
-    nfl = 9 * cin * n_pad
-    buf = out if out is not None and out.numel() == nfl else torch.empty(nfl, device=w_oihw.device, dtype=torch.float32)
-    check(_lib.load().ccst_pack_conv_weight_halo_split_f32(ptr(w_oihw.contiguous()), ptr(buf), cout, cin, n_pad, float(scale), stream_ptr()),
-          "pack_halo_split")
-    return buf, n_pad, cout, float(scale)
-
-
-def conv3x3_halo_split_train(x, packed, want_stats=False):
-    """3x3 stride-1 zero-padded bias-free conv on the direct kernel's SPLIT form (ResNet trunk, training forward); packed =
-    pack_halo_split(...).  The statistics are per-(8x16-pixel tile, wave row) (sum, sum^2) partials [rows, cout, 2]."""
-    buf, n_pad, cout, scale = packed
-    N, H, W, Cx = x.shape
-    lib = _lib.load()
-    y = torch.empty((N, H, W, cout), device=x.device, dtype=torch.float32)
-    stats = None
-    if want_stats:
-        stats = torch.empty((int(lib.ccst_conv3x3_halo_split_tiles(N, H, W)), cout, 2), device=x.device, dtype=torch.float32)
-    args = (ptr(x), ptr(buf), scale, None, ptr(y), N, H, W, Cx, cout, n_pad, 0, ptr(stats), stream_ptr())
-    if TIMING is None:
-        check(lib.ccst_conv3x3_halo_split_f32(*args), "conv3x3_halo_split_train")
-    else:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(lib.ccst_conv3x3_halo_split_f32(*args), "conv3x3_halo_split_train")
-        e1.record()
-        TIMING.append(("conv3x3_halo_split_kernel<train>", 2.0 * N * H * W * cout * Cx * 9, e0, e1,
-                       "n%d %dx%d cin%d cout%d taps3x3 s1" % (N, H, W, Cx, cout)))
-    return (y, stats) if want_stats else y
 
 
 def wino4w_train_ok(H, W, cin, cout):
@@ -299,7 +254,7 @@ def from_api(x, cpad=1):
 class PackedConv(object):
     """Device-resident packed weight [kh*kw][K/4][n_pad][4] (+ optional bias).  `u` / `u_pad`: the Winograd-transformed
     copy (ccst_pack_conv_weight_wino_f32) of a 3x3 weight, built by pack_conv_weight(..., wino=True)."""
-    __slots__ = ("w", "bias", "cin", "cout", "kh", "kw", "k_pad", "n_pad", "transpose", "u", "u_pad", "u4", "u4_pad", "u4n", "wsplit", "wsplit_scale")
+    __slots__ = ("w", "bias", "cin", "cout", "kh", "kw", "k_pad", "n_pad", "transpose", "u", "u_pad", "u4", "u4_pad", "u4n", "wsplit", "wabsmax")
 
     def __init__(self, w, bias, cin, cout, kh, kw, k_pad, n_pad, transpose):
         self.w, self.bias, self.cin, self.cout, self.kh, self.kw = w, bias, cin, cout, kh, kw
@@ -308,7 +263,7 @@ class PackedConv(object):
         self.u4, self.u4_pad = None, 0   # F(4x4,3x3) transform for the 64-channel workgroups (ccst_pack_conv_weight_wino4w_f32)
         self.u4n = None                  # ... for the 32-channel workgroups (ccst_pack_conv_weight_wino4_f32), same padding; on demand
         self.wsplit = None               # pre-split half (hi | lo) rows for the direct kernel on the 16-bit MFMA (ccst_pack_conv_weight_halo_split_f32)
-        self.wsplit_scale = 1.0          # ... packed as w * wsplit_scale (a power of two that puts max |w| near 2^10, inside half's normal range)
+        self.wabsmax = None              # ... and the |max| words of the OIHW weight (CCST_ABSMAX_WORDS int32): pack and conv kernels derive the power-of-two weight scale from them on the device
 
 
 # Fused Winograd for the 3x3 stride-1 layers of the AdaIN encoder / decoder.  CCST_CONV_WINO = 4 (default): F(4x4,3x3)
@@ -328,8 +283,50 @@ WINO_F4_NARROW = os.environ.get("CCST_WINO4_NARROW", "0") == "1"
 # short-K, many-cout-group and partly-filled-round cases of F(4x4)), 0.96-1.11x on the ten where they are equal; and over the whole
 # step, interleaved A/B on three boxes: all layers on SPLIT 1426-1442 images/s, all on F(4x4) 1382-1385, the per-layer mix
 # (CCST_HALO_SPLIT=1: SPLIT where Cin != Cout) 1369-1428 -- the F(4x4) launches run 2-6 % slower between SPLIT launches on some boxes.
-# Activations must stay below half's largest value (65504).  CCST_HALO_SPLIT=0: F(4x4) everywhere.
+# Range: both operands are scaled by powers of two derived ON THE DEVICE from per-tensor |max| words (absmax_words / absmax below): the
+# producing kernel's epilogue leaves max |y| (conv3x3_halo_split, conv3x3_stem3_nchw, the AdaIN kernels), the consumer reads it -- any
+# finite fp32 magnitude is safe, nothing synchronises.  CCST_HALO_SPLIT=0: F(4x4) everywhere.
 HALO_SPLIT = os.environ.get("CCST_HALO_SPLIT", "2")
+ABSMAX_WORDS = 4096      # CCST_ABSMAX_WORDS of include/ccst_hip.h
+
+
+_ABSMAX_POOL = {}      # (device index, raw stream) -> [zeroed [64, ABSMAX_WORDS] int32 tensor, rows handed out]
+
+
+def absmax_words(device):
+    """One zeroed |max| word set ([ABSMAX_WORDS] int32) for a kernel that max-accumulates the largest |value| it writes.  Rows of a
+    [64, ABSMAX_WORDS] tensor zeroed by ONE fill on the current stream, handed out once each (a plan of 17 layers costs a quarter of a
+    fill launch per forward); a row is a view, so the block lives as long as any row of it does."""
+    key = (torch.cuda.current_device() if device.index is None else device.index, _lib.raw_stream())
+    ent = _ABSMAX_POOL.get(key)
+    if ent is None or ent[1] >= ent[0].shape[0]:
+        ent = [torch.zeros((64, ABSMAX_WORDS), device=device, dtype=torch.int32), 0]
+        _ABSMAX_POOL[key] = ent
+    row = ent[0][ent[1]]
+    ent[1] += 1
+    return row
+
+
+def absmax(t, out=None):
+    """The |max| words of a contiguous fp32 CUDA tensor (one streaming pass, ccst_absmax_f32) -- for tensors whose producer left none."""
+    _require_cuda(t, "tensor")
+    t = t if t.is_contiguous() else t.contiguous()
+    if out is None:
+        out = absmax_words(t.device)
+    if t.numel() > 0:
+        check(_lib.load().ccst_absmax_f32(ptr(t), t.numel(), ptr(out), stream_ptr()), "absmax")
+    return out
+
+
+def tag_absmax(t, words):
+    """Remember the |max| words a kernel left for tensor t (checked against t's version counter when they are used)."""
+    t._ccst_absmax = (words, t._version)
+    return t
+
+
+def tagged_absmax(t):
+    tag = getattr(t, "_ccst_absmax", None)
+    return tag[0] if tag is not None and tag[1] == t._version else None
 
 
 def halo_split_wanted(pc):
@@ -338,10 +335,14 @@ def halo_split_wanted(pc):
     return HALO_SPLIT == "2" or pc.cin != pc.cout
 
 
-def conv3x3_halo_split(x, pc, flags, sums=False):
+def conv3x3_halo_split(x, pc, flags, sums=False, x_absmax=None, y_absmax=None):
     """3x3 stride-1 pad-1 conv on the direct kernel's SPLIT form; x NHWC [N,Hs,Ws,Cin], pc packed with wino=4 (which also builds
-    pc.wsplit).  sums=True (no pool): also the per-tile (sum, sum of squares) partials [tiles, Cout, 2] of the output."""
+    pc.wsplit).  sums=True (no pool): also the per-tile (sum, sum of squares) partials [tiles, Cout, 2] of the output.
+    x_absmax: the |max| words of x left by its producer (None: one extra pass over x computes them); y_absmax: zeroed words that
+    receive max |out| for the next layer."""
     N, Hs, Ws, Cx = x.shape
+    if x_absmax is None:
+        x_absmax = absmax(x)
     ups, pool = bool(flags & CONV_UPS2), bool(flags & CONV_POOL2)
     Hi, Wi = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
     oh, ow = ((Hi + 1) // 2, (Wi + 1) // 2) if pool else (Hi, Wi)
@@ -352,7 +353,8 @@ def conv3x3_halo_split(x, pc, flags, sums=False):
         if pool:
             raise ValueError("ccst_amd.ops: the statistics epilogue is of the un-pooled output")
         part = torch.empty((int(lib.ccst_conv3x3_halo_split_tiles(N, Hi, Wi)), pc.cout, 2), device=x.device, dtype=torch.float32)
-    args = (ptr(x), ptr(pc.wsplit), pc.wsplit_scale, ptr(pc.bias), ptr(out), N, Hi, Wi, Cx, pc.cout, pc.n_pad, flags, ptr(part), stream_ptr())
+    args = (ptr(x), ptr(x_absmax), ptr(pc.wsplit), ptr(pc.wabsmax), ptr(pc.bias), ptr(out), ptr(y_absmax), N, Hi, Wi, Cx, pc.cout, pc.n_pad, flags,
+            ptr(part), stream_ptr())
     if TIMING is None:
         check(lib.ccst_conv3x3_halo_split_f32(*args), "conv3x3_halo_split")
     else:
@@ -401,11 +403,9 @@ def pack_conv_weight(w_oihw, bias=None, transpose=False, out=None, wino=False):
                 pc.u4n = torch.empty(nfl, device=w.device, dtype=torch.float32)
                 check(lib.ccst_pack_conv_weight_wino4_f32(ptr(w), ptr(pc.u4n), cout, cin, pc.u4_pad, stream_ptr()), "pack_conv_weight_wino4")
             if HALO_SPLIT != "0" and cin % 16 == 0:
-                import math
-                wmax = float(w.abs().max())
-                pc.wsplit_scale = 2.0 ** max(-8, min(14, 10 - math.ceil(math.log2(wmax)))) if wmax > 0.0 and math.isfinite(wmax) else 1.0
+                pc.wabsmax = absmax(w)          # (device side: the pack kernel and the conv kernel derive the same power-of-two scale from it)
                 pc.wsplit = torch.empty(9 * cin * n_pad, device=w.device, dtype=torch.float32)
-                check(lib.ccst_pack_conv_weight_halo_split_f32(ptr(w), ptr(pc.wsplit), cout, cin, n_pad, pc.wsplit_scale, stream_ptr()),
+                check(lib.ccst_pack_conv_weight_halo_split_f32(ptr(w), ptr(pc.wsplit), cout, cin, n_pad, ptr(pc.wabsmax), stream_ptr()),
                       "pack_conv_weight_halo_split")
     return pc
 
@@ -469,7 +469,7 @@ def wino4w_sums_ok(pc, stride, pad, pool, out_nchw):
 
 
 def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, ups=False, out_nchw=False, out=None,
-                want_stats=False, chan_sums=False):
+                want_stats=False, chan_sums=False, x_absmax=None, y_absmax=None):
     """Forward convolution of an NHWC tensor x [N,Hs,Ws,Cin_pad] with PackedConv pc.
 
     ups:  x is read through a nearest x2 upsample (logical input is [2Hs,2Ws]).
@@ -477,6 +477,8 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
     out_nchw: write a contiguous NCHW tensor (the image edge of the decoder).
     want_stats: also return the per-64-row (sum, sum^2) partials [groups, Cout, 2] of the output, produced in the
                 conv epilogue for the following BatchNorm2d (returns (out, stats)).
+    x_absmax / y_absmax: |max| words of x (from its producer) / zeroed words for max |out| -- used by the half-piece (SPLIT) kernel only;
+                a caller that passes y_absmax must check halo_split_wanted(pc) (other kernels leave the words untouched).
     """
     _require_cuda(x, "activation")
     assert x.is_contiguous() and x.dim() == 4 and not pc.transpose
@@ -503,10 +505,10 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
         return conv3x3_halo_train(x, pc, want_stats=want_stats)
     if chan_sums:       # (the caller checked wino4w_sums_ok)
         if halo_split_wanted(pc) and Cx == pc.cin and not pool:
-            return conv3x3_halo_split(x, pc, flags, sums=True)
+            return conv3x3_halo_split(x, pc, flags, sums=True, x_absmax=x_absmax, y_absmax=y_absmax)
         return conv3x3_wino4(x, pc, flags, sums=True)
     if halo_split_wanted(pc) and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats and Cx == pc.cin:
-        return conv3x3_halo_split(x, pc, flags)
+        return conv3x3_halo_split(x, pc, flags, x_absmax=x_absmax, y_absmax=y_absmax)
     if (pc.u4 is not None or pc.u4n is not None) and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats \
             and wino4_ok(pc.cin, pc.cout, Hi, Wi):
         return conv3x3_wino4(x, pc, flags)
@@ -631,8 +633,9 @@ def pack_stem3(w_oihw, bias=None):
     return wa
 
 
-def conv3x3_stem3_nchw(x_nchw, wa, relu=True):
-    """ReflectionPad2d(1) + Conv2d(3,64,3x3) (+ReLU) on a contiguous NCHW image -> NHWC [N,H,W,64]."""
+def conv3x3_stem3_nchw(x_nchw, wa, relu=True, y_absmax=None):
+    """ReflectionPad2d(1) + Conv2d(3,64,3x3) (+ReLU) on a contiguous NCHW image -> NHWC [N,H,W,64].  y_absmax: zeroed |max| words
+    that receive max |out| (absmax_words) for a half-piece conv that follows."""
     _require_cuda(x_nchw, "image")
     x = as_nchw_contiguous(x_nchw)
     N, C, H, W = x.shape
@@ -643,7 +646,7 @@ def conv3x3_stem3_nchw(x_nchw, wa, relu=True):
     lib = _lib.load()
     for n0 in range(0, N, per):
         n = min(per, N - n0)
-        args = (ptr(x[n0:]), ptr(wa), ptr(out[n0:]), n, H, W, int(relu), stream_ptr())
+        args = (ptr(x[n0:]), ptr(wa), ptr(out[n0:]), n, H, W, int(relu), ptr(y_absmax), stream_ptr())
         if TIMING is None:
             check(lib.ccst_conv3x3_stem3_f32(*args), "conv3x3_stem3")
         else:
@@ -767,7 +770,8 @@ def adain(feat, style_mean, style_std, alpha=1.0, eps=1e-5):
         raise RuntimeError("ccst_amd: style statistics must have C or N*C elements")
     out = torch.empty_like(buf)
     ws, nb = _stats_ws(N, C, H * W, feat.device)
-    args = (ptr(buf), ptr(sm), ptr(ss), per_n, float(alpha), ptr(out), N, C, H * W, layout, eps, ptr(ws), nb, stream_ptr())
+    amax = absmax_words(feat.device)      # the kernel leaves max |out|: the decoder's first half-piece conv scales by it
+    args = (ptr(buf), ptr(sm), ptr(ss), per_n, float(alpha), ptr(out), N, C, H * W, layout, eps, ptr(ws), nb, ptr(amax), stream_ptr())
     if TIMING is None:
         check(_lib.load().ccst_adain_f32(*args), "adain")
     else:       # bench.py: the whole statistics + normalise step (3 launches), HBM-bound: algorithmic bytes = read x + write y
@@ -776,7 +780,7 @@ def adain(feat, style_mean, style_std, alpha=1.0, eps=1e-5):
         check(_lib.load().ccst_adain_f32(*args), "adain")
         e1.record()
         TIMING.append(("adain_step", 0.0, e0, e1, "n%d c%d hw%d bytes%d" % (N, C, H * W, 2 * 4 * N * C * H * W)))
-    return out if layout == NCHW else to_api(out)
+    return tag_absmax(out if layout == NCHW else to_api(out), amax)
 
 
 def adain_tile_sums_ok(feat, partials):
@@ -803,8 +807,9 @@ def adain_from_tile_sums(feat, partials, style_mean, style_std, alpha=1.0, eps=1
     else:
         raise RuntimeError("ccst_amd: style statistics must have C or N*C elements")
     out = torch.empty_like(buf)
+    amax = absmax_words(feat.device)      # the kernel leaves max |out|: the decoder's first half-piece conv scales by it
     args = (ptr(buf), ptr(partials), int(partials.shape[0] // N), ptr(sm), ptr(ss), per_n, float(alpha), ptr(out), N, C, H * W, eps, None, None,
-            stream_ptr())
+            ptr(amax), stream_ptr())
     if TIMING is None:
         check(_lib.load().ccst_adain_tile_sums_f32(*args), "adain_tile_sums")
     else:       # bench.py: the AdaIN step of the path = this one launch; HBM-bound: algorithmic bytes = read x + write y
@@ -813,7 +818,7 @@ def adain_from_tile_sums(feat, partials, style_mean, style_std, alpha=1.0, eps=1
         check(_lib.load().ccst_adain_tile_sums_f32(*args), "adain_tile_sums")
         e1.record()
         TIMING.append(("adain_step", 0.0, e0, e1, "n%d c%d hw%d bytes%d" % (N, C, H * W, 2 * 4 * N * C * H * W)))
-    return to_api(out)
+    return tag_absmax(to_api(out), amax)
 
 
 def interp_blend(base, content_f, weights, alpha=1.0):

@@ -95,15 +95,29 @@ int ccst_conv3x3_halo_f32(const float* x, const float* w_packed, const float* bi
 
 int ccst_conv3x3_halo_narrow(int N, int H, int W, int Cout);   /* 1: the 128x64 tile is dispatched, 0: 128x128 */
 
+/* Per-tensor |max| words: CCST_ABSMAX_WORDS uint32 on the device, zeroed by the caller, into which a producing kernel max-accumulates
+ * the raw fp32 bits of the largest |value| it wrote (64 slots 256 B apart, one atomic per wave) and from which the half-piece kernels
+ * below derive their power-of-two operand scales ON THE DEVICE -- no host synchronisation anywhere.  ccst_absmax_f32 is the stand-alone
+ * producer (one pass over x) for tensors whose producer did not leave the words. */
+#define CCST_ABSMAX_WORDS 4096
+int ccst_absmax_f32(const float* x, int64_t n, uint32_t* absmax, void* stream);
+
 /* The same convolution with every fp32 product computed as three products of 16-bit pieces on the half-precision MFMA (x = hi + lo,
  * hi = half(x), lo = half(x - hi): 22 significant bits; a b ~ a_lo b_hi + a_hi b_lo + a_hi b_hi, fp32 accumulation): 5.3x the fp32
- * MFMA's rate at about its accuracy while |x| < 65504 and the scaled weights stay in half's normal range.  w_split from
- * ccst_pack_conv_weight_halo_split_f32 (9 * cin * cout_pad floats' worth of [tap][cin/16][cout_pad][16 k hi | lo] rows of w * wscale,
- * wscale a power of two chosen by the caller so that max |w| * wscale is ~2^10); the conv call takes the same wscale and scales the
- * accumulators back; otherwise the x / y / flags contract of ccst_conv3x3_halo_f32. */
-int ccst_pack_conv_weight_halo_split_f32(const float* w_oihw, float* w_split, int cout, int cin, int cout_pad, float wscale, void* stream);
-int ccst_conv3x3_halo_split_f32(const float* x, const float* w_split, float wscale, const float* bias, float* y, int N, int H, int W,
-                                int Cin, int Cout, int cout_pad, uint32_t flags, float* chan_sum_partials, void* stream);
+ * MFMA's rate at about its accuracy.  Range-safe by construction: both operands are scaled by powers of two derived from their |max|
+ * words (activations to < 2^14, weights to < 2^10: no finite fp32 input overflows half, and small tensors are lifted out of half's
+ * subnormals), the accumulators are scaled back exactly (v_ldexp) and the bias is added after that.  The result is what the fp32
+ * kernel gives to ~1e-6 of max |y| at ANY magnitude of x and w (tests/test_adain_gpu.py: 1e-30 .. 1e30).
+ *   w_split from ccst_pack_conv_weight_halo_split_f32 (9 * cin * cout_pad floats' worth of [tap][cin/16][cout_pad][16 k hi | lo] rows)
+ *   with w_absmax = the |max| words of w_oihw (ccst_absmax_f32), which the conv call takes too;
+ *   x_absmax: the |max| words of x (any upper bound of max |x| is valid; from the producer's y_absmax or ccst_absmax_f32);
+ *   y_absmax: NULL, or zeroed words receiving max |y| (of the stored, i.e. ReLU'd / pooled, output);
+ * otherwise the x / y / flags contract of ccst_conv3x3_halo_f32. */
+int ccst_pack_conv_weight_halo_split_f32(const float* w_oihw, float* w_split, int cout, int cin, int cout_pad, const uint32_t* w_absmax,
+                                         void* stream);
+int ccst_conv3x3_halo_split_f32(const float* x, const uint32_t* x_absmax, const float* w_split, const uint32_t* w_absmax, const float* bias,
+                                float* y, uint32_t* y_absmax, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags,
+                                float* chan_sum_partials, void* stream);
 /* chan_sum_partials (may be NULL; not with POOL2): [ccst_conv3x3_halo_split_tiles(N,H,W)][Cout][2] per-(8x16-pixel tile, wave row)
  * (sum, sum of squares) of the output after bias / ReLU, an image's rows contiguous -- the statistics ccst_adain_tile_sums_f32 and
  * ccst_chan_sums_finalize_f32 take instead of a pass over the tensor. */
@@ -128,7 +142,8 @@ int ccst_conv3x3_wino4_f32(const float* x, const float* u_packed, const float* b
  * contiguous NCHW image [N,3,H,W] to the NHWC map [N,H,W,64]; wa = ccst_pack_stem3_weight_f32(w [64,3,3,3], bias [64] or null)
  * (18*2*64 floats: the bias is packed with the weights, in the one k slot three channels leave unused). */
 int ccst_pack_stem3_weight_f32(const float* w_oihw, const float* bias, float* wa, int cout, void* stream);
-int ccst_conv3x3_stem3_f32(const float* x_nchw, const float* wa, float* y_nhwc, int N, int H, int W, int relu, void* stream);
+int ccst_conv3x3_stem3_f32(const float* x_nchw, const float* wa, float* y_nhwc, int N, int H, int W, int relu,
+                           uint32_t* y_absmax /* NULL or zeroed |max| words of y, see CCST_ABSMAX_WORDS */, void* stream);
 /* F(4x4,3x3) with 64 output channels per workgroup (conv3x3_wino4w.hip): the same convolution and flags as ccst_conv3x3_wino4_f32;
  * every transformed input value feeds two MFMAs and the halo is fetched once per 64 output channels.  cout_pad a multiple of 64, Cin >= 32;
  * u_packed from ccst_pack_conv_weight_wino4w_f32 ([Cin/16][36][4 channel pairs][2][cout_pad/64][32][2][2] floats: a lane's weights
@@ -280,7 +295,7 @@ int ccst_calc_mean_std_f32(const float* x, float* mean, float* std, int N, int C
  * style_mean/std: [C] if style_per_n==0 (broadcast over N) else [N*C] (function.py:16-24). */
 int ccst_adain_f32(const float* x, const float* style_mean, const float* style_std, int style_per_n,
                    float alpha, float* y, int N, int C, int HW, int layout, float eps,
-                   void* ws, int64_t ws_bytes, void* stream);
+                   void* ws, int64_t ws_bytes, uint32_t* y_absmax /* NULL or zeroed |max| words of y (CCST_ABSMAX_WORDS) */, void* stream);
 /* The same AdaIN (+ alpha blend) for an NHWC x [N][HW][C] whose producer already left the statistics: partials
  * [N * tiles_per_image][C][2] = per-(spatial tile, channel) (sum, sum of squares) of x, the tiles of image n contiguous -- what
  * ccst_conv3x3_wino4w_f32 writes into chan_sum_partials (tiles_per_image = ccst_wino4w_spatial_tiles(1, H, W)).  One launch, x read
@@ -288,7 +303,7 @@ int ccst_adain_f32(const float* x, const float* style_mean, const float* style_s
  * mean_out / std_out: NULL, or [N*C] receiving the content statistics. */
 int ccst_adain_tile_sums_f32(const float* x, const float* partials, int tiles_per_image, const float* style_mean,
                              const float* style_std, int style_per_n, float alpha, float* y, int N, int C, int HW, float eps,
-                             float* mean_out, float* std_out, void* stream);
+                             float* mean_out, float* std_out, uint32_t* y_absmax /* NULL or zeroed |max| words of y */, void* stream);
 /* CCST_OverallStyleTransfer.py:36-45, style_transfer's interpolation branch after the AdaIN of the K copies of one content image
  * against K styles: out[elems] = (sum_k weights[k] * base[k][elems], from zero in index order, products and sums rounded separately)
  * * alpha + content0[elems] * one_minus_alpha.  weights: K floats on the device.  Elementwise: any (common) layout. */

@@ -861,7 +861,7 @@ def test_conv3x3_halo_split_vs_fp64(dev, case, reflect):
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(dev)
     b = (torch.randn(Cout, generator=g) * 0.1).to(dev)
     pc = ops.pack_conv_weight(w, b, wino=4)
-    assert pc.wsplit is not None and pc.wsplit_scale >= 1.0
+    assert pc.wsplit is not None and pc.wabsmax is not None
     flags = 1 | (2 if pool else 0) | (4 if ups else 0) | (8 if reflect else 0)
     out = ops.conv3x3_halo_split(x, pc, flags)
     xr = x.permute(0, 3, 1, 2).double()
@@ -884,3 +884,144 @@ def test_conv3x3_halo_split_vs_fp64(dev, case, reflect):
         tpi = part.shape[0] // N                                                 # an image's rows are contiguous
         s0 = part[:tpi].double().sum(0)[:, 0]
         assert float((s0 - out[0].double().sum(dim=(0, 1))).abs().max()) < 1e-5 * max(1.0, float(s0.abs().max()))
+
+
+# ------------------------------------------------------------------ range safety of the half-piece (SPLIT) kernels
+def _absmax_value(words):
+    """The float the |max| words hold (max over the slots, raw fp32 bits)."""
+    return float(torch.tensor(int(words.max()), dtype=torch.int32).view(torch.float32))
+
+
+def _conv_ref64(x_nhwc, w, b, pool=False):
+    xr = F.pad(x_nhwc.permute(0, 3, 1, 2).double().cpu(), (1, 1, 1, 1), mode="reflect")
+    ref = F.relu(F.conv2d(xr, w.double().cpu(), b.double().cpu()))
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2, 0, ceil_mode=True)
+    return ref.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("xscale", [1e-30, 1e-4, 1.0, 1e3, 3e4, 1e5, 1e30])
+@pytest.mark.parametrize("wscale", [1e-6, 1.0, 300.0])
+def test_conv3x3_halo_split_any_magnitude(dev, xscale, wscale):
+    """VERDICT r3 #1 / ADVICE r3: the default 3x3 kernel computes on IEEE-half pieces; activations >= 65504 used to come out NaN and
+    activations far below 1 lost their low pieces to half's subnormals.  Both operands are now scaled by powers of two derived on the
+    device from per-tensor |max| words, so the result must be at the fp32 level (a few 1e-6 of max |y|) at ANY magnitude of x and w
+    (style_transfer/AdaIN/net.py:38-69 convolves whatever fp32 comes in) -- including the values 1e5 and 1e30 that no half can hold --
+    and bit-identical to the scale-1 result where the scales are powers of two (nothing but exponents change)."""
+    from ccst_amd import ops
+    g = torch.Generator().manual_seed(23)
+    N, H, W, Cin, Cout = 2, 24, 40, 64, 128
+    x0 = torch.randn(N, H, W, Cin, generator=g)
+    w0 = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    b0 = torch.randn(Cout, generator=g) * 0.1
+    x, w, b = (x0 * xscale).to(dev), (w0 * wscale).to(dev), (b0 * (xscale * wscale)).to(dev)
+    pc = ops.pack_conv_weight(w, b, wino=4)
+    ymax = ops.absmax_words(dev)
+    for pool in (False, True):
+        flags = 1 | 8 | (2 if pool else 0)
+        out = ops.conv3x3_halo_split(x, pc, flags, x_absmax=ops.absmax(x), y_absmax=ymax if not pool else None)
+        ref = _conv_ref64(x, w, b, pool)
+        assert bool(torch.isfinite(out).all()), "non-finite output at x scale %g, w scale %g" % (xscale, wscale)
+        err = float((out.double().cpu() - ref).abs().max()) / float(ref.abs().max())
+        assert err < 4e-6, (xscale, wscale, pool, err)
+        if not pool:       # the epilogue left max |y| for the next layer: exactly the largest stored value
+            assert _absmax_value(ymax) == float(out.abs().max())
+    # power-of-two scales change exponents only: same bits as the un-scaled problem, scaled
+    x2, w2, b2 = (x0 * 2.0 ** 40).to(dev), (w0 * 2.0 ** -30).to(dev), (b0 * 2.0 ** 10).to(dev)
+    pc1, pc2 = ops.pack_conv_weight(w0.to(dev), b0.to(dev), wino=4), ops.pack_conv_weight(w2, b2, wino=4)
+    o1, o2 = ops.conv3x3_halo_split(x0.to(dev), pc1, 1 | 8), ops.conv3x3_halo_split(x2, pc2, 1 | 8)
+    assert torch.equal(o1 * 2.0 ** 10, o2)
+
+
+def test_conv3x3_halo_split_degenerate_ranges(dev):
+    """All-zero input (y = relu(bias) exactly), a single huge outlier beside ordinary values, and an upper bound instead of the exact
+    |max| (allowed by the ABI): none of them may overflow, and non-finite inputs must stay non-finite (not turn into numbers)."""
+    from ccst_amd import ops
+    g = torch.Generator().manual_seed(29)
+    N, H, W, Cin, Cout = 1, 16, 16, 32, 64
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1).to(dev)
+    b = torch.randn(Cout, generator=g).to(dev)
+    pc = ops.pack_conv_weight(w, b, wino=4)
+    z = torch.zeros(N, H, W, Cin, device=dev)
+    out = ops.conv3x3_halo_split(z, pc, 1 | 8)
+    assert torch.equal(out, torch.relu(b).expand_as(out))
+    x = torch.randn(N, H, W, Cin, generator=g)
+    x[0, 5, 7, 3] = 3e38                                         # one element near fp32's largest value
+    xd = x.to(dev)
+    out = ops.conv3x3_halo_split(xd, pc, 8)                      # (no ReLU: both signs)
+    ref = F.conv2d(F.pad(x.permute(0, 3, 1, 2).double(), (1, 1, 1, 1), mode="reflect"), w.double().cpu(), b.double().cpu()).permute(0, 2, 3, 1)
+    fin = ref.abs() < 3e38
+    assert bool(torch.isfinite(out.cpu()[fin]).all())
+    assert float(((out.double().cpu() - ref)[fin]).abs().max()) < 4e-6 * 3e38 * float(w.abs().max()) * 9
+    bound = ops.absmax(xd * 1000.0)                              # a loose upper bound of max |x| is a valid x_absmax
+    x1 = torch.randn(N, H, W, Cin, generator=g).to(dev)
+    o_exact, o_loose = ops.conv3x3_halo_split(x1, pc, 1 | 8), ops.conv3x3_halo_split(x1, pc, 1 | 8, x_absmax=ops.absmax(x1 * 1000.0))
+    assert float((o_exact - o_loose).abs().max()) < 4e-6 * float(o_exact.abs().max())
+    del bound
+    xn = x1.clone()
+    xn[0, 3, 3, 0] = float("inf")
+    on = ops.conv3x3_halo_split(xn, pc, 8)
+    assert not bool(torch.isfinite(on[0, 3, 3]).all())           # the pixels that see the infinity are not finite (the reference: inf / nan)
+    assert bool(torch.isfinite(on[0, 10:, 10:]).all())           # ... and the others are untouched by it
+
+
+@pytest.mark.parametrize("fscale", [1e-4, 1e3, 3e4, 1e5])
+def test_style_transfer_activation_scales(dev, nets, A, fscale):
+    """The whole encoder -> AdaIN -> decoder path with the activations at 1e-4 ... 1e5 times their usual size (the real
+    vgg_normalised.pth is not available here; a 0-255 image through it puts relu4_1 in the 1e3-1e4 range): the first layer's weight and
+    every encoder bias scaled by f (ReLU, pooling and the convs are homogeneous, so relu4_1 is f times the usual one), style
+    statistics of that size, the decoder's first conv scaled back by 1/f.  Against the oracle in fp64, 1e-3 of the image's range;
+    nothing may be non-finite at 1e5 (relu4_1 ~ 2e6, relu1_1 ~ 4e5: far beyond half's 65504)."""
+    from ccst_amd import net, style
+    vgg_w = A.he_weights(A.VGG_TABLE, seed=1234)
+    dec_w = A.he_weights(A.DECODER_TABLE, seed=4321)
+    ekeys = [str(t[0]) for t in A.conv_keys(A.VGG_TABLE)]
+    dkeys = [str(t[0]) for t in A.conv_keys(A.DECODER_TABLE)]
+    vgg_w[ekeys[1] + ".weight"] = vgg_w[ekeys[1] + ".weight"] * fscale          # (ekeys[0] is the 1x1 colour conv)
+    for k in ekeys[1:]:
+        vgg_w[k + ".bias"] = vgg_w[k + ".bias"] * fscale
+    dec_w[dkeys[0] + ".weight"] = dec_w[dkeys[0] + ".weight"] / fscale
+    content = A.synth_content(2, 64, 80, seed=9)
+    stat = [t * fscale for t in A.synth_style_stat(512, seed=7)]
+    ref64 = A.style_transfer({k: v.double() for k, v in vgg_w.items()}, {k: v.double() for k, v in dec_w.items()}, content.double(),
+                             [t.double() for t in stat], 1.0)
+    net.vgg.load_state_dict(vgg_w)
+    net.decoder.load_state_dict(dec_w)
+    vgg31 = net.vgg[:31].to(dev).eval()
+    dec = net.decoder.to(dev).eval()
+    try:
+        with torch.no_grad():
+            out = style.style_transfer(vgg31, dec, content.to(dev), [t.to(dev) for t in stat], 1.0)
+            f_gpu = vgg31(content.to(dev))
+    finally:
+        net.vgg.load_state_dict(nets[2])
+        net.decoder.load_state_dict(nets[3])
+    f64 = A.encoder(content.double(), {k: v.double() for k, v in vgg_w.items()})
+    fmax = float(f64.abs().max())
+    assert bool(torch.isfinite(out).all()) and bool(torch.isfinite(f_gpu).all())
+    e_feat = float((f_gpu.cpu().double() - f64).abs().max()) / fmax
+    e_out = float((out.cpu().double() - ref64).abs().max())
+    print("activation scale %g: relu4_1 max %.3g, feature error %.3g of max, image error %.3g (|image| max %.3g)" % (
+        fscale, fmax, e_feat, e_out, float(ref64.abs().max())))
+    assert e_feat < 1e-4, e_feat
+    assert e_out < 1e-3 * max(1.0, float(ref64.abs().max())), e_out
+
+
+def test_plan_passes_absmax_between_layers(dev, nets, A):
+    """No layer of the default plan needs the stand-alone |max| pass: the stem, every SPLIT conv and the AdaIN step hand the words on
+    (ops.absmax is called for checkpoint weights only, at pack time)."""
+    from ccst_amd import ops, style
+    vgg31, dec, _, _ = nets
+    content = A.synth_content(1, 64, 64, seed=11).to(dev)
+    stat = [t.to(dev) for t in A.synth_style_stat(512, seed=7)]
+    with torch.no_grad():
+        style.style_transfer(vgg31, dec, content, stat, 1.0)        # (packs the weights)
+        calls = []
+        real = ops.absmax
+        ops.absmax = lambda t, out=None: (calls.append(tuple(t.shape)), real(t, out))[1]
+        try:
+            out = style.style_transfer(vgg31, dec, content, stat, 1.0)
+        finally:
+            ops.absmax = real
+    assert ops.HALO_SPLIT == "0" or calls == [], calls
+    assert bool(torch.isfinite(out).all())

@@ -158,6 +158,9 @@ def test_bench_fedavg_round_world4():
             assert o["fedavg_allreduce_ms"] > 0 and o["fedavg_bytes"] == 4 * ((12 * 16) + 16 + (16 * 7 + 3) // 4 * 4 + (7 + 3) // 4 * 4)
             assert abs(o["value"] - 4 * 8 / (o["ms_per_step"] * 1e-3)) < 1e-2 * o["value"]          # whole-job rate: ranks x batch / time
             assert "FedAvg all-reduce" in o["config"]["workload"]
+            ar = o["fedavg_allreduce"]          # the collective alone against the xGMI bounds (ring: one link; direct: a link per peer pair)
+            assert ar["bytes"] == o["fedavg_bytes"] and ar["collective_only_ms"] > 0 and ar["bus_GBps"] >= 0 and ar["link_GBps"] == 153.0
+            assert abs(ar["ring_bound_ms"] - 2 * 3 / 4 * ar["bytes"] / 153e9 * 1e3) < 1e-8 and 0 < ar["direct_bound_ms"] < ar["ring_bound_ms"]
         assert len({o["ms_per_step"] for o in outs}) == 1                                            # the MAX over ranks, on every rank
 
 
@@ -177,6 +180,14 @@ def test_bench_gpus_flag_starts_its_own_ranks():
     assert len(lines) == 1, r.stdout                                  # ONE JSON line, from rank 0
     o = json.loads(lines[0])
     assert o["n_gpus"] == 2 and o["n_ranks_seen"] == 2 and o["steps"] == 3 and o["warmup"] == 1 and o["dry_run"] is True
+    # the run validates itself: both ranks took part on two different devices (here: processes), each reports its own
+    # rate, and the N = 1 value sits in the same line
+    rk = o["ranks"]
+    assert rk["n_ranks_seen"] == 2 and rk["distinct_devices"] == 2 and len(set(rk["device_ids"])) == 2
+    assert len(rk["per_rank_images_per_s"]) == 2 and 0 < rk["per_rank_min"] <= rk["per_rank_max"]
+    assert o["single_gpu_reference"]["images_per_s"] > 0
+    b = o["fedavg_allreduce_bounds_example"]
+    assert b["link_GBps"] == 153.0 and b["ring_bound_ms"] == b["direct_bound_ms"]          # (N = 2: one peer, the two forms coincide)
     # a job whose size disagrees with --gpus is refused, not silently run at the wrong size
     env3 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env3, capture_output=True, text=True, timeout=120)

@@ -35,12 +35,13 @@ for (H, W, Cin, Cout, pool, ups) in LAYERS:
     flags = 1 | 8 | (2 if pool else 0) | (4 if ups else 0)
     oh, ow = ((H + 1) // 2, (W + 1) // 2) if pool else (H, W)
     yh = torch.empty(B, oh, ow, Cout, device=dev)
+    xmax, ymax = ops.absmax(x), ops.absmax_words(x.device)      # (ymax is max-accumulated over the repetitions: same value every time)
 
     def fh():
         if os.environ.get("HALO_FP32") == "1":
             check(lib.ccst_conv3x3_halo_f32(ptr(x), ptr(pc.w), ptr(pc.bias), ptr(yh), B, H, W, Cin, Cout, pc.n_pad, flags, stream_ptr()), "halo")
         else:
-            check(lib.ccst_conv3x3_halo_split_f32(ptr(x), ptr(pc.wsplit), pc.wsplit_scale, ptr(pc.bias), ptr(yh), B, H, W, Cin, Cout, pc.n_pad, flags, None, stream_ptr()), "halo_split")
+            check(lib.ccst_conv3x3_halo_split_f32(ptr(x), ptr(xmax), ptr(pc.wsplit), ptr(pc.wabsmax), ptr(pc.bias), ptr(yh), ptr(ymax), B, H, W, Cin, Cout, pc.n_pad, flags, None, stream_ptr()), "halo_split")
 
     def f4():
         return ops.conv3x3_wino4(x, pc, flags)
