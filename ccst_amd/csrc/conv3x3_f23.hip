@@ -1,0 +1,474 @@
+// 3x3 stride-1 "same" convolution as Winograd F(2,3) ALONG X ONLY, on half pieces on the 16-bit MFMA (round 4) -- the AdaIN encoder /
+// decoder layers with Cout >= 128 (style_transfer/AdaIN/net.py:6-36,38-69).
+//
+// Why this form.  The direct half-piece kernel (conv3x3_halo.hip, SPLIT) issues three 16-bit MFMAs per fp32 product and is bounded by
+// the energy of those MFMAs (the chip runs it power-capped at 1.7-1.8 GHz): only fewer executed MFMAs per output move
+// it.  2-D Winograd needs 16 (F(2x2)) or 36 (F(4x4)) accumulator sets per tile: at 16 registers per 32x32 tile a workgroup tile large
+// enough to amortise the weight stream does not fit the register file.  The 1-D form keeps the direct kernel's whole structure -- halo
+// rows in LDS, the ky taps as plain k-steps -- and replaces the three kx taps by FOUR transform positions per PAIR of output pixels:
+//     Y[y][2p + e] = sum_ky sum_q A[e][q] * ( V_q[y + ky][p] . U_q[ky] ),   V = B^T d (d = the four input pixels 2p-1 .. 2p+2),
+//     B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  U = G g = [g0; (g0+g1+g2)/2; (g0-g1+g2)/2; g2],  A^T = [1 1 1 0; 0 1 -1 -1]
+// i.e. 12 k-steps per 16-channel chunk and pixel pair instead of 18: 2.0 executed MFMA FLOPs per algorithmic FLOP instead of 3.0.
+// The price: four accumulator sets (128 registers per wave for a 64 x 32 wave tile), a transformed halo image twice the size of the
+// raw one (two positions per pixel), and F(2,3)'s rounding (one extra fp32 add on each side; per layer ~2e-6 of max |y|, test).
+//
+//   * workgroup = 8 rows x 32 pixels (= 128 GEMM rows: (row, pixel pair)) x 128 output channels, EIGHT waves (2 row halves x 4
+//     channel quarters; two waves per SIMD from ONE workgroup -- the LDS image leaves room for one workgroup per CU), wave tile = 64
+//     rows x 32 channels x 4 positions = 8 accumulators of 16 registers;
+//   * the loader fetches the four raw pixels of a (halo row, pixel pair, 4-channel part) unit, forms the four positions with fp32
+//     adds, scales by the tensor's power of two (per-tensor |max| words, common.h: range-safe at any fp32 magnitude), splits into
+//     (hi, lo) IEEE-half pieces and writes V[row][pair][position][16 ch hi | 16 ch lo]; pair pitch 272 B and row pitch 4480 B put the
+//     sixteen lanes of every ds_read_b128 pass on sixteen different 16-byte bank groups;
+//   * weights pre-transformed, scaled and split at pack time ([ky * 4 + q][chunk][cout][16 ch hi | lo], 8 KB per k-step and
+//     workgroup), staged through a 3-deep LDS ring two k-steps ahead exactly as in the direct kernel;
+//   * epilogue: accumulators scaled back (v_ldexp), A^T applied in registers, bias, ReLU, the 2x2 ceil max-pool (a pooling window =
+//     two rows of one pixel pair = four values of one lane), NHWC stores through a buffer resource, max |y| for the next layer.
+#include "common.h"
+
+namespace {
+
+struct F23Args {
+    const float* x;
+    const float* u;
+    const float* bias;
+    float* y;
+    const unsigned* xmax;
+    const unsigned* wmax;
+    unsigned* ymax;
+    int N, H, W, Hs, Ws, Cin, Cout, CoutPad;
+    int reflect, ups, relu;
+    long long ysN;
+    int ysH, ysW;
+    int tilesX, tilesY, tilesN;
+};
+
+typedef unsigned u32x2f __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8f __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2f __attribute__((ext_vector_type(2)));
+typedef float f32x2f __attribute__((ext_vector_type(2)));
+
+constexpr int F_TH = 8, F_TW = 32, F_XP = F_TW / 2, F_HH = F_TH + 2, F_BN = 128, F_NT = 512;
+constexpr int F_QW = 16;                          // words per (pixel pair, position): 16 channels hi (8 words) | 16 channels lo (8 words)
+constexpr int F_XPW = 4 * F_QW + 4;               // 68 words = 272 B per pixel pair: 17 sixteen-byte units (odd)
+constexpr int F_ROWW = F_XP * F_XPW + 32;         // 1120 words = 4480 B per halo row: 280 units = 8 modulo 16
+constexpr int F_VW = F_HH * F_ROWW;               // words per V buffer (44.8 KB)
+constexpr int F_BP = 20;                          // words per output-channel row of a weight stage (16 + 4 of pad)
+constexpr int F_BW = F_BN * F_BP;                 // words per weight stage (10 KB)
+constexpr int F_LDS_BYTES = (2 * F_VW + 3 * F_BW) * 4;      // 120 320 B
+constexpr int F_HUNITS = F_HH * F_XP * 4;         // loader units per chunk: (halo row, pixel pair, 4-channel part) = 640
+// operand scale targets (common.h): a position is a sum of two pixels, a transformed weight of up to three halves
+constexpr int F23_X_TARGET = CCST_SPLIT_X_TARGET - 1, F23_W_TARGET = CCST_SPLIT_W_TARGET - 1;
+
+__device__ __forceinline__ int reflect_f(int i, int n) {
+    i = (i < 0) ? -i : i;
+    i = (i >= n) ? 2 * n - 2 - i : i;
+    return min(max(i, 0), n - 1);
+}
+
+// four fp32 values scaled by s -> (hi, lo) half pieces, two per word (see split4h in conv3x3_halo.hip)
+__device__ __forceinline__ void split4f(f32x4 v, float s, u32x2f& hi, u32x2f& lo) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2f p = f32x2f{v[2 * h], v[2 * h + 1]} * s;
+        const f16x2f ph = __builtin_convertvector(p, f16x2f);
+        const f16x2f pl = __builtin_convertvector(p - __builtin_convertvector(ph, f32x2f), f16x2f);
+        hi[h] = __builtin_bit_cast(unsigned, ph);
+        lo[h] = __builtin_bit_cast(unsigned, pl);
+    }
+}
+
+template <bool POOL>
+__global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
+    extern __shared__ __attribute__((aligned(16))) float f23_lds[];
+    float* const Vs = f23_lds;                     // [2][F_VW]
+    float* const Bs = f23_lds + 2 * F_VW;          // [3][F_BW]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, lh = lane >> 5;
+
+    int bid = ccst_xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = bid % p.tilesN;
+    bid /= p.tilesN;
+    const int tx = bid % p.tilesX;
+    bid /= p.tilesX;
+    const int ty = bid % p.tilesY;
+    const int n = bid / p.tilesY;
+    const int co0 = tn * F_BN;
+    const int oy0 = ty * F_TH, ox0 = tx * F_TW;
+
+    const int kx = ccst_scale_exp(ccst_absmax_read(p.xmax), F23_X_TARGET);
+    const int kw = ccst_scale_exp(ccst_absmax_read(p.wmax), F23_W_TARGET);
+    const float xs = __uint_as_float((unsigned)(127 + kx) << 23);
+
+    // ---- staging roles.  Vector-memory loads return IN ORDER per wave: a wave that fetches both the raw pixels (HBM latency) and the
+    // weights (L2 latency) waits for its pixel loads whenever it needs a younger weight load -- with 6 MFMAs per k-step that exposed the
+    // HBM latency every chunk (ablation of the first version: no pixel loads +9 %, no weight loads +10 %).  So the waves specialise:
+    //   waves 0-4 (320 threads) stage V: 640 units per chunk = exactly two per thread, two register sets, each load ~8 k-steps ahead
+    //             of its transform + LDS store;
+    //   waves 5-7 (192 threads) stage the weights: 512 sixteen-byte parts per k-step = 3 per thread (the last wave 2), three register
+    //             sets, each load three k-steps ahead of its LDS store, five ahead of its use.
+    // All eight waves run the same MFMA work.  Both roles keep their staging data in the SAME registers (stage[], off[]).
+    const bool role_v = wave < 5;
+    constexpr int NV = 320, NWT = 192;
+    f32x4 stage[9];
+    // V role: off[i] = element offset of unit i's FIRST pixel, dxy[i] = the other three pixels' column distances from it in 4-bit fields
+    // (+3 biased: reflection and the upsample's >> 1 keep them within -3 .. 3) and the four validity bits (zero padding) above them
+    // -- one address register per unit instead of four; W role: off[0..2] = the three weight parts' offsets
+    unsigned off[3] = {0u, 0u, 0u};
+    unsigned dxy[2] = {0u, 0u};
+    int dst[3] = {0, 0, 0};
+    bool third = false;
+    if (role_v) {
+        // unit u = tid + 320 i -> (halo row u >> 6, pixel pair (u >> 2) & 15, channel part u & 3); its four raw pixels 2 xp - 1 .. 2 xp + 2
+        // (reflection / zero padding / nearest-x2 upsample applied to each)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int u = tid + NV * i;
+            const int part = u & 3, xp = (u >> 2) & 15, hy = u >> 6;
+            int gy = oy0 + hy - 1;
+            bool oky = true;
+            if (p.reflect) gy = reflect_f(gy, p.H);
+            else {
+                oky = (gy >= 0) & (gy < p.H);
+                gy = min(max(gy, 0), p.H - 1);
+            }
+            gy >>= p.ups;
+            unsigned m = 0;
+            int gx0 = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int gx = ox0 + 2 * xp - 1 + j;
+                bool ok = oky;
+                if (p.reflect) gx = reflect_f(gx, p.W);
+                else {
+                    ok = ok & (gx >= 0) & (gx < p.W);
+                    gx = min(max(gx, 0), p.W - 1);
+                }
+                gx >>= p.ups;
+                if (j == 0) gx0 = gx;
+                m |= (ok ? 1u : 0u) << (16 + j);
+                m |= (unsigned)(gx - gx0 + 3) << (4 * j);
+            }
+            dxy[i] = m;
+            off[i] = (unsigned)(((n * p.Hs + gy) * p.Ws + gx0) * p.Cin + part * 4);
+            dst[i] = hy * F_ROWW + xp * F_XPW + part * 2;
+        }
+    } else {
+        // weight unit u = tw + 192 i of the k-step's 8 KB slab: 16-byte part u & 3 of output-channel row u >> 2
+        const int tw = tid - NV;
+        third = tw < 512 - 2 * NWT;                                   // (waves 5 and 6: uniform per wave)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int u = min(tw + NWT * i, 511);
+            off[i] = (unsigned)((co0 + (u >> 2)) * 16 + (u & 3) * 4);
+            dst[i] = (u >> 2) * F_BP + (u & 3) * 4;
+        }
+    }
+    const int nchunks = p.Cin / 16;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][mt][r] = 0.f;
+
+    // fragment bases: GEMM row li of M tile Tt = 2 wm + mt is (row 2 Tt + (li & 1), pixel pair li >> 1)
+    int aBase[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) aBase[mt] = (2 * (2 * wm + mt) + (li & 1)) * F_ROWW + (li >> 1) * F_XPW + lh * 4;
+    const int bBase = (wn * 32 + li) * F_BP + lh * 4;
+
+    // weights of k-step t (= 12 c + s, clamped to the last chunk) -> register set `set`; set -> ring stage
+    auto load_w = [&](int set, int c_, int s) {
+        const int cc = min(c_ + s / 12, nchunks - 1), ss = s % 12;
+        const float* wc = p.u + ((long long)ss * nchunks + cc) * p.CoutPad * 16;         // uniform
+        stage[3 * set] = *reinterpret_cast<const f32x4*>(wc + off[0]);
+        stage[3 * set + 1] = *reinterpret_cast<const f32x4*>(wc + off[1]);
+        if (third) stage[3 * set + 2] = *reinterpret_cast<const f32x4*>(wc + off[2]);
+    };
+    auto store_w = [&](int set, int ring) {
+        *reinterpret_cast<f32x4*>(&Bs[ring * F_BW + dst[0]]) = stage[3 * set];
+        *reinterpret_cast<f32x4*>(&Bs[ring * F_BW + dst[1]]) = stage[3 * set + 1];
+        if (third) *reinterpret_cast<f32x4*>(&Bs[ring * F_BW + dst[2]]) = stage[3 * set + 2];
+    };
+    // the four raw pixels of unit i of channel chunk c_ -> register set i
+    auto load_d = [&](int i, int c_) {
+        const int cc = min(c_, nchunks - 1);
+        unsigned dd = dxy[i];
+        asm volatile("" : "+v"(dd));          // (opaque: hipcc would otherwise hoist the eight addresses out of the loop, into sixteen registers)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            stage[4 * i + j] = *reinterpret_cast<const f32x4*>(p.x + (off[i] + (unsigned)(((int)((dd >> (4 * j)) & 15u) - 3) * p.Cin)) + cc * 16);
+    };
+    // positions q0, q0 + 1 of unit i: B^T d, scale, split, store
+    auto store_v = [&](int buf, int i, int q0) {
+        f32x4 d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[j] = ((dxy[i] >> (16 + j)) & 1u) ? stage[4 * i + j] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = q0; q < q0 + 2; ++q) {
+            const f32x4 v = q == 0 ? d[0] - d[2] : q == 1 ? d[1] + d[2] : q == 2 ? d[2] - d[1] : d[1] - d[3];
+            u32x2f hi, lo;
+            split4f(v, xs, hi, lo);
+            float* o = &Vs[buf * F_VW + dst[i] + q * F_QW];
+            *reinterpret_cast<u32x2f*>(o) = hi;
+            *reinterpret_cast<u32x2f*>(o + 8) = lo;
+        }
+    };
+    struct Frags {
+        f16x8f a[2][2], b[2];         // [piece][M tile], [piece]
+    };
+    auto read_frags = [&](Frags& f, int vbuf, int ring, int s) {
+        const float* vb = &Vs[vbuf * F_VW + (s >> 2) * F_ROWW + (s & 3) * F_QW];
+        const float* bb = &Bs[ring * F_BW + bBase];
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) f.a[pc][mt] = __builtin_bit_cast(f16x8f, *reinterpret_cast<const f32x4*>(vb + aBase[mt] + 8 * pc));
+            f.b[pc] = __builtin_bit_cast(f16x8f, *reinterpret_cast<const f32x4*>(bb + 8 * pc));
+        }
+    };
+
+    // ---- prologue: V of chunk 0 in LDS and unit 0 of chunk 1 in flight; weights of k-steps 0, 1 in LDS and of 2, 3, 4 in flight ----
+    if (role_v) {
+        load_d(0, 0);
+        load_d(1, 0);
+        store_v(0, 0, 0);
+        store_v(0, 0, 2);
+        store_v(0, 1, 0);
+        store_v(0, 1, 2);
+        load_d(0, 1);
+    } else {
+        load_w(0, 0, 0);
+        load_w(1, 0, 1);
+        store_w(0, 0);
+        store_w(1, 1);
+        load_w(0, 0, 2);
+        load_w(1, 0, 3);
+        load_w(2, 0, 4);
+    }
+    __syncthreads();
+    Frags cur, nxt;
+    read_frags(cur, 0, 0, 0);
+
+    for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+        for (int s = 0; s < 12; ++s) {                 // k-step s = ky * 4 + q of chunk c; 12 is a multiple of 3: static ring / set indices
+            const int q = s & 3;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) acc[q][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[1][mt], cur.b[0], acc[q][mt], 0, 0, 0);   // a_lo b_hi
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef F23A_NO_READ
+            {   // fragments of the NEXT k-step (its weights are visible since the previous barrier: 3-deep ring; V of this chunk, or of the
+                // next one -- complete since k-step 10's stores, published by that step's barrier)
+                const int sn = (s + 1) % 12;
+                read_frags(nxt, s == 11 ? (c + 1) & 1 : c & 1, sn % 3, sn);
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) acc[q][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[0][mt], cur.b[1], acc[q][mt], 0, 0, 0);   // a_hi b_lo
+            __builtin_amdgcn_sched_barrier(0);
+            if (role_v) {
+                // V of chunk c + 1 (buffer (c + 1) & 1): unit 0 was fetched at k-step 8 of the previous chunk, unit 1 at k-step 2 of this one
+#ifndef F23A_NO_STOREV
+                if (s == 4) store_v((c + 1) & 1, 0, 0);
+                if (s == 5) store_v((c + 1) & 1, 0, 2);
+                if (s == 9) store_v((c + 1) & 1, 1, 0);
+                if (s == 10) store_v((c + 1) & 1, 1, 2);
+#endif
+#ifndef F23A_NO_LOADV
+                if (s == 2) load_d(1, c + 1);
+                if (s == 8) load_d(0, c + 2);
+#endif
+            } else {
+                // weights: the set fetched three k-steps ago holds k-step s + 2 -> ring stage (s + 2) % 3; then fetch k-step s + 5 into it
+#ifndef F23A_NO_STOREB
+                store_w(s % 3, (s + 2) % 3);
+#endif
+#ifndef F23A_NO_LOADB
+                load_w(s % 3, c, s + 5);
+#endif
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) acc[q][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[0][mt], cur.b[0], acc[q][mt], 0, 0, 0);   // a_hi b_hi
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef F23A_NO_BARRIER
+            __syncthreads();
+#endif
+#ifdef F23A_NO_READ
+            nxt = cur;
+#endif
+            cur = nxt;
+        }
+    }
+
+    // ---- epilogue: scale back, A^T over the four positions, bias --------------------------------------------------------------
+    const int co = co0 + wn * 32 + li;
+    const float bias = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+    const int ks = -(kx + kw);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m0 = __builtin_ldexpf(acc[0][mt][r], ks), m1 = __builtin_ldexpf(acc[1][mt][r], ks);
+            const float m2 = __builtin_ldexpf(acc[2][mt][r], ks), m3 = __builtin_ldexpf(acc[3][mt][r], ks);
+            acc[0][mt][r] = (m0 + m1 + m2) + bias;          // pixel 2 xp
+            acc[1][mt][r] = (m1 - m2 - m3) + bias;          // pixel 2 xp + 1
+        }
+    const bool relu = p.relu != 0;
+    float amax = 0.f;
+    const bool interior = (oy0 + F_TH <= p.H) && (ox0 + F_TW <= p.W) && (co0 + F_BN <= p.Cout);
+    const bool cok = co < p.Cout;
+    // accumulator register r of a lane is GEMM row (r & 3) + 8 (r >> 2) + 4 lh of its tile: row parity r & 1, pixel pair ((r & 3) >> 1) + 4 (r >> 2) + 2 lh
+    if (!POOL) {
+        float* const tile = p.y + (long long)n * p.ysN + (long long)oy0 * p.ysH + (long long)ox0 * p.ysW + co0 + wn * 32;
+        const unsigned lane_off = (unsigned)(4 * lh * p.ysW + li);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int Tt = 2 * wm + mt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dy = 2 * Tt + (r & 1), xpu = ((r & 3) >> 1) + 4 * (r >> 2);        // + 2 lh pairs = 4 lh pixels (lane_off)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    float v = acc[e][mt][r];
+                    if (relu) v = fmaxf(v, 0.f);
+                    const int dx = 2 * xpu + e;
+                    if (interior) {
+                        amax = fmaxf(amax, fabsf(v));
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, lane_off * 4, (dy * p.ysH + dx * p.ysW) * 4, 0);
+                    } else if (cok && oy0 + dy < p.H && ox0 + dx + 4 * lh < p.W) {
+                        amax = fmaxf(amax, fabsf(v));
+                        tile[(long long)dy * p.ysH + (long long)dx * p.ysW + lane_off] = v;
+                    }
+                }
+            }
+        }
+    } else {
+        const int Hp = (p.H + 1) >> 1, Wp = (p.W + 1) >> 1;
+        const int py0 = oy0 >> 1, px0 = ox0 >> 1;
+        float* const tile = p.y + (long long)n * p.ysN + (long long)py0 * p.ysH + (long long)px0 * p.ysW + co0 + wn * 32;
+        const unsigned lane_off = (unsigned)(2 * lh * p.ysW + li);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int dyp = 2 * wm + mt;                       // pooled row: the two image rows of M tile Tt
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {                      // registers 2 g, 2 g + 1: rows 2 Tt, 2 Tt + 1 of pixel pair xpu + 2 lh
+                const int xpu = (g & 1) + 4 * (g >> 1);
+                if (interior) {
+                    float v = fmaxf(fmaxf(acc[0][mt][2 * g], acc[1][mt][2 * g]), fmaxf(acc[0][mt][2 * g + 1], acc[1][mt][2 * g + 1]));
+                    if (relu) v = fmaxf(v, 0.f);
+                    amax = fmaxf(amax, fabsf(v));
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, lane_off * 4, (dyp * p.ysH + xpu * p.ysW) * 4, 0);
+                } else {
+                    const int pyp = py0 + dyp, pxp = px0 + xpu + 2 * lh;
+                    if (cok && pyp < Hp && pxp < Wp) {
+                        const bool okx = (2 * pxp + 1 < p.W), oky = (2 * pyp + 1 < p.H);
+                        float v = acc[0][mt][2 * g];
+                        if (okx) v = fmaxf(v, acc[1][mt][2 * g]);
+                        if (oky) v = fmaxf(v, acc[0][mt][2 * g + 1]);
+                        if (okx && oky) v = fmaxf(v, acc[1][mt][2 * g + 1]);
+                        if (relu) v = fmaxf(v, 0.f);
+                        amax = fmaxf(amax, fabsf(v));
+                        tile[(long long)dyp * p.ysH + (long long)xpu * p.ysW + lane_off] = v;
+                    }
+                }
+            }
+        }
+    }
+    if (p.ymax != nullptr) ccst_absmax_publish(p.ymax, amax, blockIdx.x * 8u + (unsigned)wave);
+}
+
+// OIHW 3x3 -> [ky * 4 + q][Cin/16][cout_pad][16 words]: words 0..7 = the chunk's 16 input channels of U_q[ky] = (G g[ky][.])_q as
+// half(u * 2^kw), two per word; words 8..15 = half(u * 2^kw - hi).  G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1].
+__global__ void pack_weight_f23_kernel(const float* __restrict__ w, unsigned* __restrict__ out, int cout, int cin, int cout_pad,
+                                       const unsigned* __restrict__ wmax) {
+    const int kw = ccst_scale_exp(ccst_absmax_read(wmax), F23_W_TARGET);
+    const int nch = cin / 16;
+    const long long total = 12LL * nch * cout_pad * 16;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int word = (int)(i & 15);
+        long long j = i >> 4;
+        const int co = (int)(j % cout_pad);
+        j /= cout_pad;
+        const int chunk = (int)(j % nch), s = (int)(j / nch);
+        const int ky = s >> 2, q = s & 3;
+        const int piece = word >> 3, k0 = chunk * 16 + 2 * (word & 7);
+        unsigned r = 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float u = 0.f;
+            if (co < cout) {
+                const float* g = w + ((long long)co * cin + k0 + e) * 9 + ky * 3;
+                u = q == 0 ? g[0] : q == 1 ? 0.5f * ((g[0] + g[2]) + g[1]) : q == 2 ? 0.5f * ((g[0] + g[2]) - g[1]) : g[2];
+            }
+            const float v = __builtin_ldexpf(u, kw);
+            const _Float16 h = (_Float16)v;
+            const _Float16 pq = piece ? (_Float16)(v - (float)h) : h;
+            r |= (unsigned)__builtin_bit_cast(unsigned short, pq) << (16 * e);
+        }
+        out[i] = r;
+    }
+}
+
+}  // namespace
+
+// Transformed, scaled and split weights of ccst_conv3x3_f23_f32: 12 * cin * cout_pad floats' worth; cin a multiple of 16, cout_pad of 128.
+extern "C" int ccst_pack_conv_weight_f23_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, const uint32_t* w_absmax,
+                                             void* stream) {
+    CCST_REQUIRE(w_oihw && u && w_absmax && cout > 0 && cin > 0 && cin % 16 == 0, "pack_f23: bad args (cin a multiple of 16)");
+    CCST_REQUIRE(cout_pad >= cout && cout_pad % 128 == 0, "pack_f23: cout_pad must be a multiple of 128 >= cout");
+    const long long total = 12LL * cin * cout_pad;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(pack_weight_f23_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, reinterpret_cast<unsigned*>(u), cout, cin,
+                       cout_pad, w_absmax);
+    return ccst_launch_status("pack_weight_f23");
+}
+
+// Workgroups the kernel launches for a layer: callers pick it where they fill whole rounds of the chip (one workgroup per CU).
+extern "C" int ccst_conv3x3_f23_workgroups(int N, int H, int W, int Cout) {
+    return N * ((H + F_TH - 1) / F_TH) * ((W + F_TW - 1) / F_TW) * ((Cout + F_BN - 1) / F_BN);
+}
+
+extern "C" int ccst_conv3x3_f23_f32(const float* x, const uint32_t* x_absmax, const float* u, const uint32_t* w_absmax, const float* bias,
+                                    float* y, uint32_t* y_absmax, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags,
+                                    void* stream) {
+    CCST_REQUIRE(x && u && y && x_absmax && w_absmax, "conv3x3_f23: null pointer (the |max| words of x and w are required)");
+    CCST_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0, "conv3x3_f23: bad shape");
+    CCST_REQUIRE(cout_pad >= Cout && cout_pad % 128 == 0, "conv3x3_f23: cout_pad must be a multiple of 128 >= cout");
+    const bool pool = (flags & CCST_CONV_POOL2) != 0, ups = (flags & CCST_CONV_UPS2) != 0;
+    if (ups) CCST_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv3x3_f23: upsampled extent must be even");
+    if (flags & CCST_CONV_REFLECT) CCST_REQUIRE(H >= 2 && W >= 2, "conv3x3_f23: reflection needs extent >= 2");
+    F23Args a;
+    a.x = x; a.u = u; a.bias = bias; a.y = y; a.xmax = x_absmax; a.wmax = w_absmax; a.ymax = y_absmax;
+    a.N = N; a.H = H; a.W = W; a.Hs = ups ? H / 2 : H; a.Ws = ups ? W / 2 : W; a.Cin = Cin; a.Cout = Cout; a.CoutPad = cout_pad;
+    a.reflect = (flags & CCST_CONV_REFLECT) ? 1 : 0; a.ups = ups ? 1 : 0; a.relu = (flags & CCST_CONV_RELU) ? 1 : 0;
+    CCST_REQUIRE((long long)N * a.Hs * a.Ws * Cin < 0x7fffffffLL, "conv3x3_f23: input must have < 2^31 elements");
+    const int oh = pool ? (H + 1) / 2 : H, ow = pool ? (W + 1) / 2 : W;
+    CCST_REQUIRE((long long)N * oh * ow * Cout < 0x7fffffffLL, "conv3x3_f23: output must have < 2^31 elements");
+    a.ysW = Cout; a.ysH = ow * Cout; a.ysN = (long long)oh * ow * Cout;
+    a.tilesN = (Cout + F_BN - 1) / F_BN;
+    a.tilesY = (H + F_TH - 1) / F_TH;
+    a.tilesX = (W + F_TW - 1) / F_TW;
+    const long long grid = (long long)N * a.tilesY * a.tilesX * a.tilesN;
+    CCST_REQUIRE(grid > 0 && grid <= 0x7fffffffLL, "conv3x3_f23: bad grid");
+    const void* kfn = pool ? reinterpret_cast<const void*>(&conv3x3_f23_kernel<true>) : reinterpret_cast<const void*>(&conv3x3_f23_kernel<false>);
+    // (the opt-in above the 64 KB default is per device and idempotent: set for the current device on every launch)
+    hipError_t e1 = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS_BYTES);
+    if (e1 != hipSuccess) {
+        ccst_set_error("conv3x3_f23: cannot reserve %d bytes of LDS: %s", F_LDS_BYTES, hipGetErrorString(e1));
+        return (int)e1;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (pool) hipLaunchKernelGGL((conv3x3_f23_kernel<true>), dim3((unsigned)grid), dim3(F_NT), F_LDS_BYTES, s, a);
+    else hipLaunchKernelGGL((conv3x3_f23_kernel<false>), dim3((unsigned)grid), dim3(F_NT), F_LDS_BYTES, s, a);
+    return ccst_launch_status("conv3x3_f23");
+}

@@ -380,28 +380,44 @@ class ImageWriterPool(object):
         import concurrent.futures as cf
         n = workers or max(1, min(16, (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4) - 1))
         self.futures = []
+        self.pids = None
         if torch.cuda.is_initialized():
             self.kind, self.pool = "threads", cf.ThreadPoolExecutor(max_workers=n)
         else:
+            # multiprocessing.Pool forks ALL n workers in its constructor (documented behaviour, not an executor's lazy start-up): they
+            # exist before this process touches the GPU and never see a HIP context.  A worker that dies would be replaced by a fork
+            # of a process that by then holds a HIP context and live streams: that is treated as fatal instead (check_workers).
             import multiprocessing as mp
-            self.kind, self.pool = "processes", cf.ProcessPoolExecutor(max_workers=n, mp_context=mp.get_context("fork"))
-            for f in [self.pool.submit(os.getpid) for _ in range(4 * n)]:      # start the workers NOW, before any GPU work
-                f.result()
+            self.kind, self.pool = "processes", mp.get_context("fork").Pool(n)
+            self.pids = sorted(p.pid for p in self.pool._pool)
+
+    def check_workers(self):
+        if self.pids is not None and sorted(p.pid for p in self.pool._pool) != self.pids:
+            raise RuntimeError("ccst_amd.data.ImageWriterPool: an encoder process died and was re-forked after GPU initialisation; "
+                               "output files may be missing -- rerun (or create the pool with threads)")
 
     def submit(self, u8_batch, paths):
+        # (the array is a view of a pinned buffer the pipeline reuses, and both pool kinds serialise / run a task later, on another
+        #  thread: the copy here is what makes that safe; pickling it for a worker process is the second, unavoidable one)
         for arr, name in zip(u8_batch, paths):
-            self.futures.append(self.pool.submit(_encode_one, np.ascontiguousarray(arr).copy(), name))
+            a = np.ascontiguousarray(arr).copy()
+            self.futures.append(self.pool.apply_async(_encode_one, (a, name)) if self.kind == "processes" else self.pool.submit(_encode_one, a, name))
         if len(self.futures) > 4096:
             self.drain()
 
     def drain(self):
         for f in self.futures:
-            f.result()
+            f.get() if self.kind == "processes" else f.result()
         self.futures = []
+        self.check_workers()
 
     def close(self):
         self.drain()
-        self.pool.shutdown()
+        if self.kind == "processes":
+            self.pool.close()
+            self.pool.join()
+        else:
+            self.pool.shutdown()
 
 
 # ---------------------------------------------------------------------------

@@ -252,18 +252,86 @@ def from_api(x, cpad=1):
 # convolution
 # ---------------------------------------------------------------------------
 class PackedConv(object):
-    """Device-resident packed weight [kh*kw][K/4][n_pad][4] (+ optional bias).  `u` / `u_pad`: the Winograd-transformed
-    copy (ccst_pack_conv_weight_wino_f32) of a 3x3 weight, built by pack_conv_weight(..., wino=True)."""
-    __slots__ = ("w", "bias", "cin", "cout", "kh", "kw", "k_pad", "n_pad", "transpose", "u", "u_pad", "u4", "u4_pad", "u4n", "wsplit", "wabsmax")
+    """A conv weight in the layouts the kernels read (+ optional bias).  `w`: [kh*kw][K/4][n_pad][4] for the implicit-GEMM kernels.
+    A weight packed with wino=... (the 3x3 layers of the AdaIN plan) keeps the OIHW source and builds each kernel's layout ON FIRST USE
+    -- `u` (F(2x2)), `u4` / `u4n` (F(4x4), 64- / 32-channel workgroups), `wsplit` (direct kernel on half pieces), `uf23` (F(2,3) on half
+    pieces), `wabsmax` (the weight's |max| words: the half-piece kernels derive their power-of-two weight scale from them on the
+    device) -- so a plan holds ONE packed copy per layer, that of the kernel it runs (all four were built before).
+    The can_* predicates say which layouts exist for this weight without building anything."""
 
-    def __init__(self, w, bias, cin, cout, kh, kw, k_pad, n_pad, transpose):
-        self.w, self.bias, self.cin, self.cout, self.kh, self.kw = w, bias, cin, cout, kh, kw
+    def __init__(self, w, bias, cin, cout, kh, kw, k_pad, n_pad, transpose, src=None, wino=False):
+        self._w, self.bias, self.cin, self.cout, self.kh, self.kw = w, bias, cin, cout, kh, kw
         self.k_pad, self.n_pad, self.transpose = k_pad, n_pad, transpose
-        self.u, self.u_pad = None, 0
-        self.u4, self.u4_pad = None, 0   # F(4x4,3x3) transform for the 64-channel workgroups (ccst_pack_conv_weight_wino4w_f32)
-        self.u4n = None                  # ... for the 32-channel workgroups (ccst_pack_conv_weight_wino4_f32), same padding; on demand
-        self.wsplit = None               # pre-split half (hi | lo) rows for the direct kernel on the 16-bit MFMA (ccst_pack_conv_weight_halo_split_f32)
-        self.wabsmax = None              # ... and the |max| words of the OIHW weight (CCST_ABSMAX_WORDS int32): pack and conv kernels derive the power-of-two weight scale from them on the device
+        self.src, self.wino = src, wino          # OIHW source (kept only for lazily packed weights) and the wino= argument
+        self.u_pad, self.u4_pad = round_up(cout, 32), round_up(cout, 64)
+        self._u = self._u4 = self._u4n = self._wsplit = self._wabsmax = self._uf23 = None
+
+    # ---- which layouts exist (no packing) ----
+    def can_wino2(self):
+        return self.src is not None and bool(self.wino) and self.kh == 3 and self.kw == 3 and not self.transpose
+
+    def can_wino4(self):
+        return self.can_wino2() and (self.wino in (4, "4n") or (WINO_F4 and self.cin >= WINO_F4_MIN_CIN))
+
+    def can_wino4w(self):          # the 64-channel kernel peels a first and a last 16-channel chunk
+        return self.can_wino4() and self.cin >= 32
+
+    def can_wino4n(self):
+        return self.can_wino4() and (WINO_F4_NARROW or self.wino == "4n" or self.cin < 32)
+
+    def can_split(self):
+        return self.can_wino4() and HALO_SPLIT != "0" and self.cin % 16 == 0
+
+    # ---- the layouts, built on first use ----
+    def _lazy(self, slot, nfloats, fn, what, *tail):
+        t = getattr(self, slot)
+        if t is None:
+            t = torch.empty(int(nfloats), device=self.src.device, dtype=torch.float32)
+            check(fn(ptr(self.src), ptr(t), self.cout, self.cin, *tail, stream_ptr()), what)
+            setattr(self, slot, t)
+        return t
+
+    @property
+    def w(self):
+        if self._w is None:
+            self._w = torch.empty(self.kh * self.kw * self.k_pad * self.n_pad, device=self.src.device, dtype=torch.float32)
+            check(_lib.load().ccst_pack_conv_weight_f32(ptr(self.src), ptr(self._w), self.cout, self.cin, self.kh, self.kw, int(self.transpose),
+                                                        self.k_pad, self.n_pad, stream_ptr()), "pack_conv_weight")
+        return self._w
+
+    @property
+    def u(self):
+        lib = _lib.load()
+        return self._lazy("_u", lib.ccst_wino_weight_floats(self.cin, self.u_pad), lib.ccst_pack_conv_weight_wino_f32, "pack_conv_weight_wino",
+                          self.u_pad) if self.can_wino2() else None
+
+    @property
+    def u4(self):
+        lib = _lib.load()
+        return self._lazy("_u4", lib.ccst_wino4_weight_floats(self.cin, self.u4_pad), lib.ccst_pack_conv_weight_wino4w_f32,
+                          "pack_conv_weight_wino4w", self.u4_pad) if self.can_wino4w() else None
+
+    @property
+    def u4n(self):
+        lib = _lib.load()
+        return self._lazy("_u4n", lib.ccst_wino4_weight_floats(self.cin, self.u4_pad), lib.ccst_pack_conv_weight_wino4_f32,
+                          "pack_conv_weight_wino4", self.u4_pad) if self.can_wino4n() else None
+
+    @property
+    def wabsmax(self):
+        if self._wabsmax is None and self.can_split():
+            self._wabsmax = absmax(self.src)
+        return self._wabsmax
+
+    @property
+    def wsplit(self):
+        return self._lazy("_wsplit", 9 * self.cin * self.n_pad, _lib.load().ccst_pack_conv_weight_halo_split_f32, "pack_conv_weight_halo_split",
+                          self.n_pad, ptr(self.wabsmax)) if self.can_split() else None
+
+    @property
+    def uf23(self):
+        return self._lazy("_uf23", 12 * self.cin * self.n_pad, _lib.load().ccst_pack_conv_weight_f23_f32, "pack_conv_weight_f23",
+                          self.n_pad, ptr(self.wabsmax)) if self.can_split() else None
 
 
 # Fused Winograd for the 3x3 stride-1 layers of the AdaIN encoder / decoder.  CCST_CONV_WINO = 4 (default): F(4x4,3x3)
@@ -330,9 +398,61 @@ def tagged_absmax(t):
 
 
 def halo_split_wanted(pc):
-    if HALO_SPLIT == "0" or pc.wsplit is None or pc.kh != 3 or pc.kw != 3:
+    if not pc.can_split():
         return False
     return HALO_SPLIT == "2" or pc.cin != pc.cout
+
+
+# Winograd F(2,3) along x on the half pieces (conv3x3_f23.hip): 2.0 instead of 3.0 executed MFMA FLOPs per algorithmic FLOP, for the
+# layers of the plan with Cout >= 128 whose grid of 8x32-pixel x 128-channel workgroups (ONE per CU: 120 KB of LDS) fills whole rounds
+# of the chip; the others stay on the direct kernel.  CCST_CONV_F23=0: direct everywhere.
+F23 = os.environ.get("CCST_CONV_F23", "1") != "0"
+F23_MIN_FILL = float(os.environ.get("CCST_F23_MIN_FILL", "0.85"))
+F23_FORCE = os.environ.get("CCST_CONV_F23", "1") == "2"       # every Cout >= 128 layer whatever its grid (tests: small images)
+_N_CU = {}
+
+
+def num_cus(device):
+    idx = torch.cuda.current_device() if device.index is None else device.index
+    if idx not in _N_CU:
+        _N_CU[idx] = int(torch.cuda.get_device_properties(idx).multi_processor_count) or 256
+    return _N_CU[idx]
+
+
+def f23_wanted(pc, N, H, W, device):
+    """Run this 3x3 layer (conv extent H x W) on the F(2,3) kernel?"""
+    if not (F23 and halo_split_wanted(pc)) or pc.cout < 128:
+        return False
+    if F23_FORCE:
+        return True
+    wgs = int(_lib.load().ccst_conv3x3_f23_workgroups(N, H, W, pc.cout))
+    cus = num_cus(device)
+    rounds = -(-wgs // cus)
+    return wgs >= 2 * cus and wgs >= F23_MIN_FILL * rounds * cus
+
+
+def conv3x3_f23(x, pc, flags, x_absmax=None, y_absmax=None):
+    """3x3 stride-1 pad-1 conv as Winograd F(2,3) along x on half pieces; same arguments as conv3x3_halo_split (no sums epilogue)."""
+    N, Hs, Ws, Cx = x.shape
+    if x_absmax is None:
+        x_absmax = absmax(x)
+    ups, pool = bool(flags & CONV_UPS2), bool(flags & CONV_POOL2)
+    Hi, Wi = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
+    oh, ow = ((Hi + 1) // 2, (Wi + 1) // 2) if pool else (Hi, Wi)
+    out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    args = (ptr(x), ptr(x_absmax), ptr(pc.uf23), ptr(pc.wabsmax), ptr(pc.bias), ptr(out), ptr(y_absmax), N, Hi, Wi, Cx, pc.cout, pc.n_pad, flags,
+            stream_ptr())
+    if TIMING is None:
+        check(lib.ccst_conv3x3_f23_f32(*args), "conv3x3_f23")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.ccst_conv3x3_f23_f32(*args), "conv3x3_f23")
+        e1.record()
+        TIMING.append(("conv3x3_f23_kernel<%s>" % ("pool" if pool else "nopool"), 2.0 * N * Hi * Wi * pc.cout * pc.cin * 9, e0, e1,
+                       "n%d %dx%d cin%d cout%d taps3x3 flags%d" % (N, Hi, Wi, pc.cin, pc.cout, flags)))
+    return out
 
 
 def conv3x3_halo_split(x, pc, flags, sums=False, x_absmax=None, y_absmax=None):
@@ -372,42 +492,25 @@ def wino4_ok(cin, cout, H, W):
 
 
 def pack_conv_weight(w_oihw, bias=None, transpose=False, out=None, wino=False):
-    """OIHW checkpoint tensor -> PackedConv.  transpose=True builds the backward-data operand; wino=True also builds the
-    Winograd-transformed copy of a 3x3 weight."""
+    """OIHW checkpoint tensor -> PackedConv.  transpose=True builds the backward-data operand.  wino (True, 4 or "4n"; 3x3 weights):
+    nothing is packed here -- the PackedConv keeps the source and builds the layout of whichever kernel ends up running the layer
+    (the implicit-GEMM one, F(2x2), F(4x4), the half-piece direct kernel, F(2,3) on half pieces) on first use."""
     _require_cuda(w_oihw, "weight")
     w = w_oihw.contiguous()
     cout, cin, kh, kw = w.shape
     kdim, ndim = (cout, cin) if transpose else (cin, cout)
     k_pad, n_pad = round_up(kdim, 16), round_up(ndim, 128)
-    if out is None:
-        out = torch.empty(kh * kw * k_pad * n_pad, device=w.device, dtype=torch.float32)
-    check(_lib.load().ccst_pack_conv_weight_f32(ptr(w), ptr(out), cout, cin, kh, kw, int(transpose), k_pad, n_pad,
-                                                stream_ptr()), "pack_conv_weight")
     b = None
     if bias is not None:
         _require_cuda(bias, "bias")
         b = bias.detach().contiguous()
-    pc = PackedConv(out, b, cin, cout, kh, kw, k_pad, n_pad, transpose)
-    if wino and kh == 3 and kw == 3 and not transpose:
-        lib = _lib.load()
-        pc.u_pad = round_up(cout, 32)
-        pc.u = torch.empty(int(lib.ccst_wino_weight_floats(cin, pc.u_pad)), device=w.device, dtype=torch.float32)
-        check(lib.ccst_pack_conv_weight_wino_f32(ptr(w), ptr(pc.u), cout, cin, pc.u_pad, stream_ptr()), "pack_conv_weight_wino")
-        if wino in (4, "4n") or (WINO_F4 and cin >= WINO_F4_MIN_CIN):
-            pc.u4_pad = round_up(cout, 64)
-            nfl = int(lib.ccst_wino4_weight_floats(cin, pc.u4_pad))
-            if cin >= 32:           # the 64-channel kernel peels a first and a last 16-channel chunk
-                pc.u4 = torch.empty(nfl, device=w.device, dtype=torch.float32)
-                check(lib.ccst_pack_conv_weight_wino4w_f32(ptr(w), ptr(pc.u4), cout, cin, pc.u4_pad, stream_ptr()), "pack_conv_weight_wino4w")
-            if WINO_F4_NARROW or wino == "4n" or cin < 32:
-                pc.u4n = torch.empty(nfl, device=w.device, dtype=torch.float32)
-                check(lib.ccst_pack_conv_weight_wino4_f32(ptr(w), ptr(pc.u4n), cout, cin, pc.u4_pad, stream_ptr()), "pack_conv_weight_wino4")
-            if HALO_SPLIT != "0" and cin % 16 == 0:
-                pc.wabsmax = absmax(w)          # (device side: the pack kernel and the conv kernel derive the same power-of-two scale from it)
-                pc.wsplit = torch.empty(9 * cin * n_pad, device=w.device, dtype=torch.float32)
-                check(lib.ccst_pack_conv_weight_halo_split_f32(ptr(w), ptr(pc.wsplit), cout, cin, n_pad, ptr(pc.wabsmax), stream_ptr()),
-                      "pack_conv_weight_halo_split")
-    return pc
+    if wino and kh == 3 and kw == 3 and not transpose and out is None:
+        return PackedConv(None, b, cin, cout, kh, kw, k_pad, n_pad, transpose, src=w.detach(), wino=wino)
+    if out is None:
+        out = torch.empty(kh * kw * k_pad * n_pad, device=w.device, dtype=torch.float32)
+    check(_lib.load().ccst_pack_conv_weight_f32(ptr(w), ptr(out), cout, cin, kh, kw, int(transpose), k_pad, n_pad,
+                                                stream_ptr()), "pack_conv_weight")
+    return PackedConv(out, b, cin, cout, kh, kw, k_pad, n_pad, transpose)
 
 
 def conv3x3_wino4(x, pc, flags=0, narrow=None, sums=False):
@@ -420,7 +523,7 @@ def conv3x3_wino4(x, pc, flags=0, narrow=None, sums=False):
     Hi, Wi = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
     oh, ow = ((Hi + 1) // 2, (Wi + 1) // 2) if pool else (Hi, Wi)
     out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
-    narrow = (pc.u4 is None or (WINO_F4_NARROW and pc.u4n is not None)) if narrow is None else (narrow or pc.u4 is None)
+    narrow = (not pc.can_wino4w() or (WINO_F4_NARROW and pc.can_wino4n())) if narrow is None else (narrow or not pc.can_wino4w())
     lib = _lib.load()
     part = None
     if sums:
@@ -465,7 +568,7 @@ def wino4w_sums_ok(pc, stride, pad, pool, out_nchw):
     SPLIT form, un-pooled)?"""
     if stride != 1 or pad != 1 or pool or out_nchw or pc.kh != 3 or pc.kw != 3:
         return False
-    return halo_split_wanted(pc) or (pc.u4 is not None and not WINO_F4_NARROW and wino4_ok(pc.cin, pc.cout, 0, 0))
+    return halo_split_wanted(pc) or (pc.can_wino4w() and not WINO_F4_NARROW and wino4_ok(pc.cin, pc.cout, 0, 0))
 
 
 def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, ups=False, out_nchw=False, out=None,
@@ -508,11 +611,13 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
             return conv3x3_halo_split(x, pc, flags, sums=True, x_absmax=x_absmax, y_absmax=y_absmax)
         return conv3x3_wino4(x, pc, flags, sums=True)
     if halo_split_wanted(pc) and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats and Cx == pc.cin:
+        if f23_wanted(pc, N, Hi, Wi, x.device):
+            return conv3x3_f23(x, pc, flags, x_absmax=x_absmax, y_absmax=y_absmax)
         return conv3x3_halo_split(x, pc, flags, x_absmax=x_absmax, y_absmax=y_absmax)
-    if (pc.u4 is not None or pc.u4n is not None) and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats \
+    if (pc.can_wino4w() or pc.can_wino4n()) and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats \
             and wino4_ok(pc.cin, pc.cout, Hi, Wi):
         return conv3x3_wino4(x, pc, flags)
-    if USE_WINO and pc.u is not None and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats:
+    if USE_WINO and pc.can_wino2() and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats:
         out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
         lib = _lib.load()
         args = (ptr(x), ptr(pc.u), ptr(pc.bias), ptr(out), N, Hi, Wi, Cx, pc.cout, pc.u_pad, flags, stream_ptr())

@@ -196,6 +196,9 @@ class StylePipeline(object):
             self.h2d.wait_event(slot["ev_c"])      # the slot's previous batch has been consumed by its kernels
             slot["dev_in"].copy_(src, non_blocking=True)
             slot["ev_in"].record(self.h2d)
+        # dev_in was allocated in the compute stream's order but is written on the copy stream: tell the caching allocator, so that a
+        # buffer dropped on a shape change (the short last batch of a list) is not handed out again before this copy has run
+        slot["dev_in"].record_stream(self.h2d)
         slot["keep"] = src                     # the pinned source stays alive until the copy has run
 
     def _compute(self, slot, style_stat, alpha):

@@ -1025,3 +1025,89 @@ def test_plan_passes_absmax_between_layers(dev, nets, A):
             ops.absmax = real
     assert ops.HALO_SPLIT == "0" or calls == [], calls
     assert bool(torch.isfinite(out).all())
+
+
+# ------------------------------------------------------------------ Winograd F(2,3) along x on the half pieces (conv3x3_f23.hip)
+@pytest.mark.parametrize("case", [(2, 32, 64, 64, 128, False, False), (1, 17, 23, 32, 128, False, False), (2, 24, 40, 128, 256, True, False),
+                                  (1, 22, 38, 64, 256, False, True), (1, 16, 32, 256, 512, False, False), (1, 9, 7, 16, 160, True, False),
+                                  (3, 50, 84, 64, 128, False, False), (1, 64, 64, 512, 256, False, True), (2, 33, 17, 32, 200, True, False),
+                                  (1, 8, 32, 16, 128, False, False), (1, 2, 2, 16, 128, True, False)])
+@pytest.mark.parametrize("reflect", [True, False])
+def test_conv3x3_f23_vs_fp64(dev, case, reflect):
+    """ops.conv3x3_f23 (F(2,3) along x, products on half pieces) against an fp64 convolution: reflection / zero padding, extents that are
+    not multiples of the 8 x 32 tile (odd widths: the last pixel pair is half outside), Cout not a multiple of 128, fused ceil pool with
+    odd extents, upsampled source, the smallest legal image.  Gate: 6e-6 of max |y| (the direct half-piece kernel: 4e-6; F(2,3) adds
+    one fp32 addition on each operand and two on the result).  The epilogue's max |y| words must hold exactly the largest stored value."""
+    from ccst_amd import ops
+    N, H, W, Cin, Cout, pool, ups = case
+    g = torch.Generator().manual_seed(31)
+    Hs, Ws = (H // 2, W // 2) if ups else (H, W)
+    x = torch.randn(N, Hs, Ws, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(dev)
+    b = (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    pc = ops.pack_conv_weight(w, b, wino=4)
+    flags = 1 | (2 if pool else 0) | (4 if ups else 0) | (8 if reflect else 0)
+    ymax = ops.absmax_words(dev)
+    out = ops.conv3x3_f23(x, pc, flags, y_absmax=ymax)
+    xr = x.permute(0, 3, 1, 2).double()
+    if ups:
+        xr = F.interpolate(xr, scale_factor=2, mode="nearest")
+    xr = F.pad(xr, (1, 1, 1, 1), mode="reflect") if reflect else F.pad(xr, (1, 1, 1, 1))
+    ref = F.relu(F.conv2d(xr, w.double(), b.double()))
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2, 0, ceil_mode=True)
+    ref = ref.permute(0, 2, 3, 1)
+    assert out.shape == ref.shape
+    err = float((out.double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+    assert err < 6e-6, err
+    assert _absmax_value(ymax) == float(out.abs().max())
+    assert torch.equal(out, ops.conv3x3_f23(x, pc, flags))
+    # and against the direct half-piece kernel on the same operands
+    assert float((out - ops.conv3x3_halo_split(x, pc, flags)).abs().max()) < 6e-6 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("xscale", [1e-30, 1e-4, 3e4, 1e5, 1e30])
+def test_conv3x3_f23_any_magnitude(dev, xscale):
+    """The F(2,3) kernel takes its operand scales from the same |max| words as the direct half-piece kernel (one bit of head room more:
+    a transform position is the sum of two pixels): any finite fp32 magnitude."""
+    from ccst_amd import ops
+    g = torch.Generator().manual_seed(37)
+    N, H, W, Cin, Cout = 1, 24, 64, 64, 128
+    x = (torch.randn(N, H, W, Cin, generator=g) * xscale).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).to(dev)
+    b = (torch.randn(Cout, generator=g) * 0.1 * xscale).to(dev)
+    pc = ops.pack_conv_weight(w, b, wino=4)
+    out = ops.conv3x3_f23(x, pc, 1 | 8)
+    ref = _conv_ref64(x, w, b)
+    assert bool(torch.isfinite(out).all())
+    assert float((out.double().cpu() - ref).abs().max()) < 6e-6 * float(ref.abs().max())
+
+
+def test_style_transfer_goldens_on_f23(dev, nets, A, golden):
+    """The golden images are too small for the plan to pick the F(2,3) kernel by itself (it wants whole rounds of 256 workgroups); forced
+    on every Cout >= 128 layer, the reference-made fixtures must still come out inside the 1e-3 contract."""
+    from ccst_amd import ops, style
+    vgg31, dec, _, _ = nets
+    old = ops.F23_FORCE
+    ops.F23_FORCE = True
+    try:
+        stat7 = [t.to(dev) for t in A.synth_style_stat(512, seed=7)]
+        g = golden("style_transfer_64")
+        with torch.no_grad():
+            c64 = A.synth_content(2, 64, 64, seed=int(g["seed"])).to(dev)
+            assert maxdiff(vgg31(c64), torch.from_numpy(g["relu4_1"])) < TOL
+            assert maxdiff(style.style_transfer(vgg31, dec, c64, stat7, 1.0), torch.from_numpy(g["out"])) < TOL
+            assert maxdiff(style.style_transfer(vgg31, dec, c64, stat7, 0.5), torch.from_numpy(g["out_alpha05"])) < TOL
+            g = golden("style_transfer_odd")
+            out = style.style_transfer(vgg31, dec, A.synth_content(1, 222, 222, seed=int(g["seed"])).to(dev), stat7, 1.0)
+            assert maxdiff(out[:, :, ::4, ::4], torch.from_numpy(g["out_sub4"])) < TOL
+            out2 = style.style_transfer(vgg31, dec, A.synth_content(1, 50, 84, seed=int(g["seed2"])).to(dev), stat7, 1.0)
+            assert maxdiff(out2, torch.from_numpy(g["out2"])) < TOL
+        content = A.synth_content(2, 96, 160, seed=17)
+        stat = A.synth_style_stat(512, seed=7)
+        with torch.no_grad():
+            out = style.style_transfer(vgg31, dec, content.to(dev), [t.to(dev) for t in stat], 1.0)
+        ref = A.style_transfer(nets[2], nets[3], content, stat, 1.0)
+        assert maxdiff(out, ref) < TOL
+    finally:
+        ops.F23_FORCE = old
