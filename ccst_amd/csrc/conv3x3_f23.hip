@@ -35,6 +35,7 @@ struct F23Args {
     const unsigned* xmax;
     const unsigned* wmax;
     unsigned* ymax;
+    float* stats;        // nullptr, or [ccst_conv3x3_f23_tiles(N,H,W)][Cout][2] per-(8x32-pixel tile, wave row) (sum, sum^2) of the output
     int N, H, W, Hs, Ws, Cin, Cout, CoutPad;
     int reflect, ups, relu;
     long long ysN;
@@ -52,9 +53,10 @@ constexpr int F_QW = 16;                          // words per (pixel pair, posi
 constexpr int F_XPW = 4 * F_QW + 4;               // 68 words = 272 B per pixel pair: 17 sixteen-byte units (odd)
 constexpr int F_ROWW = F_XP * F_XPW + 32;         // 1120 words = 4480 B per halo row: 280 units = 8 modulo 16
 constexpr int F_VW = F_HH * F_ROWW;               // words per V buffer (44.8 KB)
-constexpr int F_BP = 20;                          // words per output-channel row of a weight stage (16 + 4 of pad)
-constexpr int F_BW = F_BN * F_BP;                 // words per weight stage (10 KB)
-constexpr int F_LDS_BYTES = (2 * F_VW + 3 * F_BW) * 4;      // 120 320 B
+constexpr int F_RW = F_TW + 2;                    // raw halo pixels per row (34)
+constexpr int F_RAW_PIECES = 24;                  // 1 KiB LDS-DMA pieces of the raw halo image: 10 x 34 pixels x 64 B = 21.25, three per wave
+constexpr int F_RING = 6;                         // weight stages of 8 KB (128 output channels x 64 B, un-padded, XOR-swizzled parts)
+constexpr int F_LDS_BYTES = (2 * F_VW + F_RAW_PIECES * 256 + F_RING * 2048) * 4;      // 163 328 B of the CU's 163 840: one workgroup per CU
 constexpr int F_HUNITS = F_HH * F_XP * 4;         // loader units per chunk: (halo row, pixel pair, 4-channel part) = 640
 // operand scale targets (common.h): a position is a sum of two pixels, a transformed weight of up to three halves
 constexpr int F23_X_TARGET = CCST_SPLIT_X_TARGET - 1, F23_W_TARGET = CCST_SPLIT_W_TARGET - 1;
@@ -77,11 +79,30 @@ __device__ __forceinline__ void split4f(f32x4 v, float s, u32x2f& hi, u32x2f& lo
     }
 }
 
+// One LDS-DMA piece: 64 lanes x 16 bytes from (uniform base + per-lane byte offset) to 1 KiB of LDS at the wave-uniform byte address
+// lds_addr (lane i lands at + 16 i).  hipcc neither counts it in its s_waitcnt bookkeeping nor waits for it: the kernel's barriers
+// below carry hand-counted vmcnt values (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory");
+}
+// wait until all but the wave's N youngest vector-memory operations (= its LDS-DMA pieces) have landed and its own LDS accesses are
+// done, then the workgroup barrier: what landed before it may be read by every wave after it
+template <int N>
+__device__ __forceinline__ void dma_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
 template <bool POOL>
 __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
     extern __shared__ __attribute__((aligned(16))) float f23_lds[];
-    float* const Vs = f23_lds;                     // [2][F_VW]
-    float* const Bs = f23_lds + 2 * F_VW;          // [3][F_BW]
+    float* const Vs = f23_lds;                     // [2][F_VW]             transformed halo, double buffered
+    float* const Raw = f23_lds + 2 * F_VW;         // [F_RAW_PIECES * 256]  raw fp32 halo pixels of the NEXT chunk, 64 B per pixel
+    float* const Ws = Raw + F_RAW_PIECES * 256;    // [F_RING][2048]        weight stages, 64 B per output channel, 16-byte parts XOR-swizzled
+    const unsigned lds0 = (unsigned)(size_t)f23_lds;                           // LDS byte address of the dynamic segment
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -101,72 +122,90 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
     const int kx = ccst_scale_exp(ccst_absmax_read(p.xmax), F23_X_TARGET);
     const int kw = ccst_scale_exp(ccst_absmax_read(p.wmax), F23_W_TARGET);
     const float xs = __uint_as_float((unsigned)(127 + kx) << 23);
+    const int nchunks = p.Cin / 16;
 
-    // ---- staging roles.  Vector-memory loads return IN ORDER per wave: a wave that fetches both the raw pixels (HBM latency) and the
-    // weights (L2 latency) waits for its pixel loads whenever it needs a younger weight load -- with 6 MFMAs per k-step that exposed the
-    // HBM latency every chunk (ablation of the first version: no pixel loads +9 %, no weight loads +10 %).  So the waves specialise:
-    //   waves 0-4 (320 threads) stage V: 640 units per chunk = exactly two per thread, two register sets, each load ~8 k-steps ahead
-    //             of its transform + LDS store;
-    //   waves 5-7 (192 threads) stage the weights: 512 sixteen-byte parts per k-step = 3 per thread (the last wave 2), three register
-    //             sets, each load three k-steps ahead of its LDS store, five ahead of its use.
-    // All eight waves run the same MFMA work.  Both roles keep their staging data in the SAME registers (stage[], off[]).
-    const bool role_v = wave < 5;
-    constexpr int NV = 320, NWT = 192;
-    f32x4 stage[9];
-    // V role: off[i] = element offset of unit i's FIRST pixel, dxy[i] = the other three pixels' column distances from it in 4-bit fields
-    // (+3 biased: reflection and the upsample's >> 1 keep them within -3 .. 3) and the four validity bits (zero padding) above them
-    // -- one address register per unit instead of four; W role: off[0..2] = the three weight parts' offsets
-    unsigned off[3] = {0u, 0u, 0u};
-    unsigned dxy[2] = {0u, 0u};
-    int dst[3] = {0, 0, 0};
-    bool third = false;
-    if (role_v) {
-        // unit u = tid + 320 i -> (halo row u >> 6, pixel pair (u >> 2) & 15, channel part u & 3); its four raw pixels 2 xp - 1 .. 2 xp + 2
-        // (reflection / zero padding / nearest-x2 upsample applied to each)
+    // ---- staging: everything comes in by LDS-DMA (no staging registers, so the prefetch depth is LDS, not the register file) -------
+    // Why: one workgroup of eight waves per CU is ONE barrier domain -- a wave that waits for a load stalls all eight at the next
+    // barrier -- and 250 registers per wave left room for three k-steps of weights in flight (24 KB per CU): the first two versions of
+    // this kernel ran at 60 % of their MFMA-only time, waiting on L2.  Now per k-step every wave issues ONE piece of the weight slab of
+    // k-step t + 6 into a 6-stage ring (4 k-steps = 32 KB in flight across the barriers, counted vmcnt), and at k-steps 9-11 one piece
+    // each of the raw pixels of chunk c + 2; the transform B^T d runs LDS -> registers -> LDS at k-steps 5-8.
+    const float* const ximg = p.x + (long long)n * p.Hs * p.Ws * p.Cin;             // this image (uniform): per-lane offsets stay 32-bit
+    // weight piece `wave` of a k-step's 8 KB slab: lane -> row r = 16 wave + (lane >> 2), LDS slot k = lane & 3 holds part k ^ f(r),
+    // f(r) = (r >> 2) & 3 (the LDS image is lane-linear: the swizzle sits on the SOURCE address and on the fragment read)
+    unsigned wsrc;
+    {
+        const int r = wave * 16 + (lane >> 2), k = lane & 3;
+        wsrc = (unsigned)(((co0 + r) * 16 + ((k ^ ((r >> 2) & 3)) * 4)) * 4);
+    }
+    // raw pieces g = wave + 8 i (i = 0..2) of the 10 x 34-pixel halo: lane -> pixel P = 16 g + (lane >> 2) (clamped: pieces 21.25 .. 23
+    // are padding), part lane & 3; reflection / zero padding (the value is zeroed at the transform) / nearest-x2 upsample on the address
+    unsigned rsrc_[3];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int u = tid + NV * i;
-            const int part = u & 3, xp = (u >> 2) & 15, hy = u >> 6;
-            int gy = oy0 + hy - 1;
-            bool oky = true;
-            if (p.reflect) gy = reflect_f(gy, p.H);
-            else {
-                oky = (gy >= 0) & (gy < p.H);
-                gy = min(max(gy, 0), p.H - 1);
-            }
-            gy >>= p.ups;
-            unsigned m = 0;
-            int gx0 = 0;
+    for (int i = 0; i < 3; ++i) {
+        const int P = min((wave + 8 * i) * 16 + (lane >> 2), F_HH * F_RW - 1);
+        const int hy = P / F_RW, hx = P - hy * F_RW;
+        int gy = oy0 + hy - 1, gx = ox0 + hx - 1;
+        if (p.reflect) {
+            gy = reflect_f(gy, p.H);
+            gx = reflect_f(gx, p.W);
+        } else {
+            gy = min(max(gy, 0), p.H - 1);
+            gx = min(max(gx, 0), p.W - 1);
+        }
+        rsrc_[i] = (unsigned)((((gy >> p.ups) * p.Ws + (gx >> p.ups)) * p.Cin + (lane & 3) * 4) * 4);
+    }
+    // transform units u = tid (+ 512 for the first 128 threads): (halo row u >> 6, pixel pair (u >> 2) & 15, channel part u & 3)
+    int tsrc[2], tdst[2];
+    unsigned tok = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = min(tid + F_NT * i, F_HUNITS - 1);
+        const int part = u & 3, xp = (u >> 2) & 15, hy = u >> 6;
+        tsrc[i] = ((hy * F_RW + 2 * xp) * 16 + part * 4);
+        tdst[i] = hy * F_ROWW + xp * F_XPW + part * 2;
+        if (!p.reflect) {          // zero padding: which of the unit's four pixels are inside the image
+            const int gy = oy0 + hy - 1;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                int gx = ox0 + 2 * xp - 1 + j;
-                bool ok = oky;
-                if (p.reflect) gx = reflect_f(gx, p.W);
-                else {
-                    ok = ok & (gx >= 0) & (gx < p.W);
-                    gx = min(max(gx, 0), p.W - 1);
-                }
-                gx >>= p.ups;
-                if (j == 0) gx0 = gx;
-                m |= (ok ? 1u : 0u) << (16 + j);
-                m |= (unsigned)(gx - gx0 + 3) << (4 * j);
+                const int gx = ox0 + 2 * xp - 1 + j;
+                tok |= ((gy >= 0) & (gy < p.H) & (gx >= 0) & (gx < p.W) ? 1u : 0u) << (4 * i + j);
             }
-            dxy[i] = m;
-            off[i] = (unsigned)(((n * p.Hs + gy) * p.Ws + gx0) * p.Cin + part * 4);
-            dst[i] = hy * F_ROWW + xp * F_XPW + part * 2;
-        }
-    } else {
-        // weight unit u = tw + 192 i of the k-step's 8 KB slab: 16-byte part u & 3 of output-channel row u >> 2
-        const int tw = tid - NV;
-        third = tw < 512 - 2 * NWT;                                   // (waves 5 and 6: uniform per wave)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int u = min(tw + NWT * i, 511);
-            off[i] = (unsigned)((co0 + (u >> 2)) * 16 + (u & 3) * 4);
-            dst[i] = (u >> 2) * F_BP + (u & 3) * 4;
+        } else {
+            tok |= 0xfu << (4 * i);
         }
     }
-    const int nchunks = p.Cin / 16;
+    const bool unit1 = tid < F_HUNITS - F_NT;                       // (waves 0 and 1: uniform per wave)
+
+    auto dma_w = [&](int c_, int s_) {          // weights of k-step s_ (>= 12: of the next chunk; clamped at the end) -> ring stage s_ % 6
+        const int cc = min(c_ + s_ / 12, nchunks - 1), ss = s_ % 12;
+        const float* wc = p.u + ((long long)ss * nchunks + cc) * p.CoutPad * 16;         // uniform
+        glds16(wc, wsrc, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)((2 * F_VW + F_RAW_PIECES * 256 + (s_ % F_RING) * 2048) * 4 + wave * 1024))));
+    };
+    auto dma_raw = [&](int c_, int i) {         // raw piece wave + 8 i of chunk c_
+        const int cc = min(c_, nchunks - 1);
+        glds16(ximg + cc * 16, rsrc_[i], (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)((2 * F_VW) * 4 + (wave + 8 * i) * 1024))));
+    };
+    f32x4 d[4];
+    auto read_unit = [&](int i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            d[j] = *reinterpret_cast<const f32x4*>(&Raw[tsrc[i] + j * 16]);
+            if (!((tok >> (4 * i + j)) & 1u)) d[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // positions q0, q0 + 1 of the unit in d: B^T d, scale, split, store
+    auto store_v = [&](int buf, int i, int q0) {
+#pragma unroll
+        for (int q = q0; q < q0 + 2; ++q) {
+            const f32x4 v = q == 0 ? d[0] - d[2] : q == 1 ? d[1] + d[2] : q == 2 ? d[2] - d[1] : d[1] - d[3];
+            u32x2f hi, lo;
+            split4f(v, xs, hi, lo);
+            float* o = &Vs[buf * F_VW + tdst[i] + q * F_QW];
+            *reinterpret_cast<u32x2f*>(o) = hi;
+            *reinterpret_cast<u32x2f*>(o + 8) = lo;
+        }
+    };
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -176,130 +215,104 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][mt][r] = 0.f;
 
-    // fragment bases: GEMM row li of M tile Tt = 2 wm + mt is (row 2 Tt + (li & 1), pixel pair li >> 1)
-    int aBase[2];
+    // fragment bases: GEMM row li of M tile Tt = 2 wm + mt is (row 2 Tt + (li & 1), pixel pair li >> 1); weight row wn * 32 + li, piece
+    // pc = parts 2 pc + lh -> slot (2 pc + lh) ^ f(row)
+    int aBase[2], bBase[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) aBase[mt] = (2 * (2 * wm + mt) + (li & 1)) * F_ROWW + (li >> 1) * F_XPW + lh * 4;
-    const int bBase = (wn * 32 + li) * F_BP + lh * 4;
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) bBase[pc] = (wn * 32 + li) * 16 + (((2 * pc + lh) ^ ((li >> 2) & 3)) * 4);
 
-    // weights of k-step t (= 12 c + s, clamped to the last chunk) -> register set `set`; set -> ring stage
-    auto load_w = [&](int set, int c_, int s) {
-        const int cc = min(c_ + s / 12, nchunks - 1), ss = s % 12;
-        const float* wc = p.u + ((long long)ss * nchunks + cc) * p.CoutPad * 16;         // uniform
-        stage[3 * set] = *reinterpret_cast<const f32x4*>(wc + off[0]);
-        stage[3 * set + 1] = *reinterpret_cast<const f32x4*>(wc + off[1]);
-        if (third) stage[3 * set + 2] = *reinterpret_cast<const f32x4*>(wc + off[2]);
-    };
-    auto store_w = [&](int set, int ring) {
-        *reinterpret_cast<f32x4*>(&Bs[ring * F_BW + dst[0]]) = stage[3 * set];
-        *reinterpret_cast<f32x4*>(&Bs[ring * F_BW + dst[1]]) = stage[3 * set + 1];
-        if (third) *reinterpret_cast<f32x4*>(&Bs[ring * F_BW + dst[2]]) = stage[3 * set + 2];
-    };
-    // the four raw pixels of unit i of channel chunk c_ -> register set i
-    auto load_d = [&](int i, int c_) {
-        const int cc = min(c_, nchunks - 1);
-        unsigned dd = dxy[i];
-        asm volatile("" : "+v"(dd));          // (opaque: hipcc would otherwise hoist the eight addresses out of the loop, into sixteen registers)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            stage[4 * i + j] = *reinterpret_cast<const f32x4*>(p.x + (off[i] + (unsigned)(((int)((dd >> (4 * j)) & 15u) - 3) * p.Cin)) + cc * 16);
-    };
-    // positions q0, q0 + 1 of unit i: B^T d, scale, split, store
-    auto store_v = [&](int buf, int i, int q0) {
-        f32x4 d[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) d[j] = ((dxy[i] >> (16 + j)) & 1u) ? stage[4 * i + j] : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int q = q0; q < q0 + 2; ++q) {
-            const f32x4 v = q == 0 ? d[0] - d[2] : q == 1 ? d[1] + d[2] : q == 2 ? d[2] - d[1] : d[1] - d[3];
-            u32x2f hi, lo;
-            split4f(v, xs, hi, lo);
-            float* o = &Vs[buf * F_VW + dst[i] + q * F_QW];
-            *reinterpret_cast<u32x2f*>(o) = hi;
-            *reinterpret_cast<u32x2f*>(o + 8) = lo;
-        }
-    };
     struct Frags {
         f16x8f a[2][2], b[2];         // [piece][M tile], [piece]
     };
-    auto read_frags = [&](Frags& f, int vbuf, int ring, int s) {
-        const float* vb = &Vs[vbuf * F_VW + (s >> 2) * F_ROWW + (s & 3) * F_QW];
-        const float* bb = &Bs[ring * F_BW + bBase];
+    auto read_frags = [&](Frags& f, int vbuf, int ring, int s_) {
+        const float* vb = &Vs[vbuf * F_VW + (s_ >> 2) * F_ROWW + (s_ & 3) * F_QW];
+        const float* bb = &Ws[ring * 2048];
 #pragma unroll
         for (int pc = 0; pc < 2; ++pc) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) f.a[pc][mt] = __builtin_bit_cast(f16x8f, *reinterpret_cast<const f32x4*>(vb + aBase[mt] + 8 * pc));
-            f.b[pc] = __builtin_bit_cast(f16x8f, *reinterpret_cast<const f32x4*>(bb + 8 * pc));
+            f.b[pc] = __builtin_bit_cast(f16x8f, *reinterpret_cast<const f32x4*>(bb + bBase[pc]));
         }
     };
 
-    // ---- prologue: V of chunk 0 in LDS and unit 0 of chunk 1 in flight; weights of k-steps 0, 1 in LDS and of 2, 3, 4 in flight ----
-    if (role_v) {
-        load_d(0, 0);
-        load_d(1, 0);
-        store_v(0, 0, 0);
-        store_v(0, 0, 2);
+    // ---- prologue: raw pixels of chunk 0 and the weights of k-steps 0..5, transform chunk 0, then the raw pixels of chunk 1 ---------
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dma_raw(0, i);
+#pragma unroll
+    for (int s = 0; s < F_RING; ++s) dma_w(0, s);
+    dma_barrier<0>();
+    read_unit(0);
+    store_v(0, 0, 0);
+    store_v(0, 0, 2);
+    if (unit1) {
+        read_unit(1);
         store_v(0, 1, 0);
         store_v(0, 1, 2);
-        load_d(0, 1);
-    } else {
-        load_w(0, 0, 0);
-        load_w(1, 0, 1);
-        store_w(0, 0);
-        store_w(1, 1);
-        load_w(0, 0, 2);
-        load_w(1, 0, 3);
-        load_w(2, 0, 4);
     }
-    __syncthreads();
+    dma_barrier<0>();
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dma_raw(1, i);
     Frags cur, nxt;
     read_frags(cur, 0, 0, 0);
 
     for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
-        for (int s = 0; s < 12; ++s) {                 // k-step s = ky * 4 + q of chunk c; 12 is a multiple of 3: static ring / set indices
+        for (int s = 0; s < 12; ++s) {                 // k-step s = ky * 4 + q of chunk c; 12 is a multiple of the ring depth: static stages
             const int q = s & 3;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) acc[q][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[1][mt], cur.b[0], acc[q][mt], 0, 0, 0);   // a_lo b_hi
             __builtin_amdgcn_sched_barrier(0);
 #ifndef F23A_NO_READ
-            {   // fragments of the NEXT k-step (its weights are visible since the previous barrier: 3-deep ring; V of this chunk, or of the
-                // next one -- complete since k-step 10's stores, published by that step's barrier)
+            {   // fragments of the NEXT k-step: its weights landed before the previous barrier; V of this chunk, or of the next one -- complete
+                // since k-step 8's stores
                 const int sn = (s + 1) % 12;
-                read_frags(nxt, s == 11 ? (c + 1) & 1 : c & 1, sn % 3, sn);
+                read_frags(nxt, s == 11 ? (c + 1) & 1 : c & 1, sn % F_RING, sn);
             }
 #endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) acc[q][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[0][mt], cur.b[1], acc[q][mt], 0, 0, 0);   // a_hi b_lo
             __builtin_amdgcn_sched_barrier(0);
-            if (role_v) {
-                // V of chunk c + 1 (buffer (c + 1) & 1): unit 0 was fetched at k-step 8 of the previous chunk, unit 1 at k-step 2 of this one
-#ifndef F23A_NO_STOREV
-                if (s == 4) store_v((c + 1) & 1, 0, 0);
-                if (s == 5) store_v((c + 1) & 1, 0, 2);
-                if (s == 9) store_v((c + 1) & 1, 1, 0);
-                if (s == 10) store_v((c + 1) & 1, 1, 2);
-#endif
+            // staging.  The raw buffer holds chunk c + 1 (landed before barrier 4: its pieces are older than the weights of k-step 0);
+            // it is transformed into V[(c + 1) & 1] at k-steps 5-8 and refilled with chunk c + 2 at 9-11.  Order inside a k-step: raw
+            // piece first, weight piece second -- the vmcnt table below counts on it.
 #ifndef F23A_NO_LOADV
-                if (s == 2) load_d(1, c + 1);
-                if (s == 8) load_d(0, c + 2);
-#endif
-            } else {
-                // weights: the set fetched three k-steps ago holds k-step s + 2 -> ring stage (s + 2) % 3; then fetch k-step s + 5 into it
-#ifndef F23A_NO_STOREB
-                store_w(s % 3, (s + 2) % 3);
+            if (s >= 9) dma_raw(c + 2, s - 9);
 #endif
 #ifndef F23A_NO_LOADB
-                load_w(s % 3, c, s + 5);
+            dma_w(c, s + F_RING);                      // (stage s % 6: its fragments were read during k-step s - 1)
 #endif
+#ifndef F23A_NO_STOREV
+            if (s == 5) {
+                read_unit(0);
+                store_v((c + 1) & 1, 0, 0);
             }
+            if (s == 6) store_v((c + 1) & 1, 0, 2);
+            if (unit1) {
+                if (s == 7) {
+                    read_unit(1);
+                    store_v((c + 1) & 1, 1, 0);
+                }
+                if (s == 8) store_v((c + 1) & 1, 1, 2);
+            }
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) acc[q][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[0][mt], cur.b[0], acc[q][mt], 0, 0, 0);   // a_hi b_hi
             __builtin_amdgcn_sched_barrier(0);
-#ifndef F23A_NO_BARRIER
-            __syncthreads();
+            // barrier j: the weights of k-step j + 2 (issued at k-step j - 4) must have landed: all but the pieces issued since -- four
+            // weight pieces plus the raw pieces of k-steps j - 3 .. j -- may stay in flight
+#if defined(F23A_NO_LOADV) || defined(F23A_NO_LOADB)
+            dma_barrier<0>();
+#else
+            switch (s) {          // (folded once the k-step loop is unrolled; the asm operand must be a literal)
+                case 0: case 11: dma_barrier<7>(); break;
+                case 1: case 10: dma_barrier<6>(); break;
+                case 2: case 9: dma_barrier<5>(); break;
+                default: dma_barrier<4>(); break;
+            }
 #endif
 #ifdef F23A_NO_READ
             nxt = cur;
@@ -307,6 +320,7 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
             cur = nxt;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the clamped prefetches of the last k-steps must land before this workgroup's LDS is released
 
     // ---- epilogue: scale back, A^T over the four positions, bias --------------------------------------------------------------
     const int co = co0 + wn * 32 + li;
@@ -330,6 +344,7 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
         float* const tile = p.y + (long long)n * p.ysN + (long long)oy0 * p.ysH + (long long)ox0 * p.ysW + co0 + wn * 32;
         const unsigned lane_off = (unsigned)(4 * lh * p.ysW + li);
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile, 0, 0x7fffffff, 0x00020000);
+        float s1 = 0.f, s2 = 0.f;          // p.stats: this wave's 4 rows x 32 pixels of channel `co` (after bias / ReLU, pixels outside the image excluded)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int Tt = 2 * wm + mt;
@@ -343,12 +358,25 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
                     const int dx = 2 * xpu + e;
                     if (interior) {
                         amax = fmaxf(amax, fabsf(v));
+                        s1 += v;
+                        s2 += v * v;
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, lane_off * 4, (dy * p.ysH + dx * p.ysW) * 4, 0);
                     } else if (cok && oy0 + dy < p.H && ox0 + dx + 4 * lh < p.W) {
                         amax = fmaxf(amax, fabsf(v));
+                        s1 += v;
+                        s2 += v * v;
                         tile[(long long)dy * p.ysH + (long long)dx * p.ysW + lane_off] = v;
                     }
                 }
+            }
+        }
+        if (p.stats != nullptr) {          // the per-tile channel sums the AdaIN step and stage 1 take instead of a pass over the features
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (lh == 0 && cok) {
+                float* o = p.stats + ((long long)((((n * p.tilesY + ty) * p.tilesX + tx) * 2 + wm)) * p.Cout + co) * 2;
+                o[0] = s1;
+                o[1] = s2;
             }
         }
     } else {
@@ -438,20 +466,25 @@ extern "C" int ccst_conv3x3_f23_workgroups(int N, int H, int W, int Cout) {
     return N * ((H + F_TH - 1) / F_TH) * ((W + F_TW - 1) / F_TW) * ((Cout + F_BN - 1) / F_BN);
 }
 
+// Rows of chan_sum_partials: one per (image, 8x32-pixel tile, wave row), an image's rows contiguous.
+extern "C" int ccst_conv3x3_f23_tiles(int N, int H, int W) { return N * ((H + F_TH - 1) / F_TH) * ((W + F_TW - 1) / F_TW) * 2; }
+
 extern "C" int ccst_conv3x3_f23_f32(const float* x, const uint32_t* x_absmax, const float* u, const uint32_t* w_absmax, const float* bias,
                                     float* y, uint32_t* y_absmax, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags,
-                                    void* stream) {
+                                    float* chan_sum_partials, void* stream) {
     CCST_REQUIRE(x && u && y && x_absmax && w_absmax, "conv3x3_f23: null pointer (the |max| words of x and w are required)");
     CCST_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0, "conv3x3_f23: bad shape");
     CCST_REQUIRE(cout_pad >= Cout && cout_pad % 128 == 0, "conv3x3_f23: cout_pad must be a multiple of 128 >= cout");
     const bool pool = (flags & CCST_CONV_POOL2) != 0, ups = (flags & CCST_CONV_UPS2) != 0;
+    CCST_REQUIRE(!(chan_sum_partials && pool), "conv3x3_f23: channel sums are of the un-pooled output");
     if (ups) CCST_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv3x3_f23: upsampled extent must be even");
     if (flags & CCST_CONV_REFLECT) CCST_REQUIRE(H >= 2 && W >= 2, "conv3x3_f23: reflection needs extent >= 2");
     F23Args a;
-    a.x = x; a.u = u; a.bias = bias; a.y = y; a.xmax = x_absmax; a.wmax = w_absmax; a.ymax = y_absmax;
+    a.x = x; a.u = u; a.bias = bias; a.y = y; a.xmax = x_absmax; a.wmax = w_absmax; a.ymax = y_absmax; a.stats = chan_sum_partials;
     a.N = N; a.H = H; a.W = W; a.Hs = ups ? H / 2 : H; a.Ws = ups ? W / 2 : W; a.Cin = Cin; a.Cout = Cout; a.CoutPad = cout_pad;
     a.reflect = (flags & CCST_CONV_REFLECT) ? 1 : 0; a.ups = ups ? 1 : 0; a.relu = (flags & CCST_CONV_RELU) ? 1 : 0;
     CCST_REQUIRE((long long)N * a.Hs * a.Ws * Cin < 0x7fffffffLL, "conv3x3_f23: input must have < 2^31 elements");
+    CCST_REQUIRE((long long)a.Hs * a.Ws * Cin < (1LL << 30), "conv3x3_f23: one image must have < 2^30 elements (32-bit byte offsets per image)");
     const int oh = pool ? (H + 1) / 2 : H, ow = pool ? (W + 1) / 2 : W;
     CCST_REQUIRE((long long)N * oh * ow * Cout < 0x7fffffffLL, "conv3x3_f23: output must have < 2^31 elements");
     a.ysW = Cout; a.ysH = ow * Cout; a.ysN = (long long)oh * ow * Cout;

@@ -169,7 +169,8 @@ def _compile(mods):
 
 # The kernels address a tensor with 32-bit element offsets (one VGPR per address, no 64-bit adds per load).  A batch whose widest
 # activation (64 channels at full resolution) would not fit is run in slices of the batch dimension: every layer of this path and
-# the AdaIN statistics are per sample, so the result is the same.  (6 x 512 x 512: 100 M elements; the limit is reached at e.g.
+# the AdaIN statistics are per sample, so the result is the same (to a few 1e-7 of the output range: the half-piece kernels' operand
+# scale is a power of two derived from the whole tensor's largest |value|, test_sample_result_does_not_depend_on_its_batch).  (6 x 512 x 512: 100 M elements; the limit is reached at e.g.
 # 8 x 2048 x 2048.)
 MAX_ELEMS = 2 ** 31 - 1
 

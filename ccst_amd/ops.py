@@ -407,7 +407,7 @@ def halo_split_wanted(pc):
 # layers of the plan with Cout >= 128 whose grid of 8x32-pixel x 128-channel workgroups (ONE per CU: 120 KB of LDS) fills whole rounds
 # of the chip; the others stay on the direct kernel.  CCST_CONV_F23=0: direct everywhere.
 F23 = os.environ.get("CCST_CONV_F23", "1") != "0"
-F23_MIN_FILL = float(os.environ.get("CCST_F23_MIN_FILL", "0.85"))
+F23_MIN_FILL = float(os.environ.get("CCST_F23_MIN_FILL", "0.5"))
 F23_FORCE = os.environ.get("CCST_CONV_F23", "1") == "2"       # every Cout >= 128 layer whatever its grid (tests: small images)
 _N_CU = {}
 
@@ -421,18 +421,17 @@ def num_cus(device):
 
 def f23_wanted(pc, N, H, W, device):
     """Run this 3x3 layer (conv extent H x W) on the F(2,3) kernel?"""
-    if not (F23 and halo_split_wanted(pc)) or pc.cout < 128:
+    if not (F23 and halo_split_wanted(pc)) or pc.cout < 128 or H * W * pc.cin >= 2 ** 30:
         return False
     if F23_FORCE:
         return True
+    # (one workgroup per CU: measured faster than the direct kernel down to 0.75 rounds of the chip -- 64^2 512->256 at B=6, x1.16)
     wgs = int(_lib.load().ccst_conv3x3_f23_workgroups(N, H, W, pc.cout))
-    cus = num_cus(device)
-    rounds = -(-wgs // cus)
-    return wgs >= 2 * cus and wgs >= F23_MIN_FILL * rounds * cus
+    return wgs >= F23_MIN_FILL * num_cus(device)
 
 
-def conv3x3_f23(x, pc, flags, x_absmax=None, y_absmax=None):
-    """3x3 stride-1 pad-1 conv as Winograd F(2,3) along x on half pieces; same arguments as conv3x3_halo_split (no sums epilogue)."""
+def conv3x3_f23(x, pc, flags, sums=False, x_absmax=None, y_absmax=None):
+    """3x3 stride-1 pad-1 conv as Winograd F(2,3) along x on half pieces; same arguments and results as conv3x3_halo_split."""
     N, Hs, Ws, Cx = x.shape
     if x_absmax is None:
         x_absmax = absmax(x)
@@ -441,8 +440,13 @@ def conv3x3_f23(x, pc, flags, x_absmax=None, y_absmax=None):
     oh, ow = ((Hi + 1) // 2, (Wi + 1) // 2) if pool else (Hi, Wi)
     out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
     lib = _lib.load()
+    part = None
+    if sums:
+        if pool:
+            raise ValueError("ccst_amd.ops: the statistics epilogue is of the un-pooled output")
+        part = torch.empty((int(lib.ccst_conv3x3_f23_tiles(N, Hi, Wi)), pc.cout, 2), device=x.device, dtype=torch.float32)
     args = (ptr(x), ptr(x_absmax), ptr(pc.uf23), ptr(pc.wabsmax), ptr(pc.bias), ptr(out), ptr(y_absmax), N, Hi, Wi, Cx, pc.cout, pc.n_pad, flags,
-            stream_ptr())
+            ptr(part), stream_ptr())
     if TIMING is None:
         check(lib.ccst_conv3x3_f23_f32(*args), "conv3x3_f23")
     else:
@@ -452,7 +456,7 @@ def conv3x3_f23(x, pc, flags, x_absmax=None, y_absmax=None):
         e1.record()
         TIMING.append(("conv3x3_f23_kernel<%s>" % ("pool" if pool else "nopool"), 2.0 * N * Hi * Wi * pc.cout * pc.cin * 9, e0, e1,
                        "n%d %dx%d cin%d cout%d taps3x3 flags%d" % (N, Hi, Wi, pc.cin, pc.cout, flags)))
-    return out
+    return (out, part) if sums else out
 
 
 def conv3x3_halo_split(x, pc, flags, sums=False, x_absmax=None, y_absmax=None):
@@ -608,6 +612,8 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
         return conv3x3_halo_train(x, pc, want_stats=want_stats)
     if chan_sums:       # (the caller checked wino4w_sums_ok)
         if halo_split_wanted(pc) and Cx == pc.cin and not pool:
+            if f23_wanted(pc, N, Hi, Wi, x.device):
+                return conv3x3_f23(x, pc, flags, sums=True, x_absmax=x_absmax, y_absmax=y_absmax)
             return conv3x3_halo_split(x, pc, flags, sums=True, x_absmax=x_absmax, y_absmax=y_absmax)
         return conv3x3_wino4(x, pc, flags, sums=True)
     if halo_split_wanted(pc) and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats and Cx == pc.cin:

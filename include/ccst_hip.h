@@ -122,12 +122,17 @@ int ccst_conv3x3_halo_split_f32(const float* x, const uint32_t* x_absmax, const 
  * pieces: four transform positions per pair of output pixels replace the three kx taps -- 12 instead of 18 k-steps per pixel pair, 2.0
  * instead of 3.0 executed 16-bit MFMA FLOPs per algorithmic FLOP (conv3x3_f23.hip).  u from ccst_pack_conv_weight_f23_f32 (12 * cin *
  * cout_pad floats' worth of [ky * 4 + q][cin/16][cout_pad][16 k hi | lo] rows of G g scaled by the power of two derived from w_absmax).
- * One 512-thread workgroup per CU (120 KB of LDS) covers 8 x 32 pixels x 128 output channels: ccst_conv3x3_f23_workgroups tells a caller
- * how many a layer launches, so that it can keep layers that would not fill whole rounds of the chip on the direct kernel. */
+ * One 512-thread workgroup per CU (all of its LDS: transformed halo, raw halo and a six-stage weight ring, everything staged by LDS-DMA)
+ * covers 8 x 32 pixels x 128 output channels; ccst_conv3x3_f23_workgroups tells a caller how many a layer launches.  One image must
+ * have < 2^30 elements. */
 int ccst_pack_conv_weight_f23_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, const uint32_t* w_absmax, void* stream);
 int ccst_conv3x3_f23_f32(const float* x, const uint32_t* x_absmax, const float* u, const uint32_t* w_absmax, const float* bias, float* y,
-                         uint32_t* y_absmax, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags, void* stream);
+                         uint32_t* y_absmax, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags,
+                         float* chan_sum_partials /* NULL, or [ccst_conv3x3_f23_tiles(N,H,W)][Cout][2] (sum, sum^2) of the un-pooled output
+                                                     per (8x32-pixel tile, wave row), an image's rows contiguous */,
+                         void* stream);
 int ccst_conv3x3_f23_workgroups(int N, int H, int W, int Cout);
+int ccst_conv3x3_f23_tiles(int N, int H, int W);
 /* chan_sum_partials (may be NULL; not with POOL2): [ccst_conv3x3_halo_split_tiles(N,H,W)][Cout][2] per-(8x16-pixel tile, wave row)
  * (sum, sum of squares) of the output after bias / ReLU, an image's rows contiguous -- the statistics ccst_adain_tile_sums_f32 and
  * ccst_chan_sums_finalize_f32 take instead of a pass over the tensor. */

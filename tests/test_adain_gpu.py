@@ -623,9 +623,12 @@ def test_batch_slices_for_tensors_beyond_32bit_offsets(dev, nets, A, monkeypatch
 
 def test_sample_result_does_not_depend_on_its_batch(dev, nets, A):
     """Every layer of the path and the AdaIN statistics are per sample: an image stylised alone and inside a batch gives the same
-    bits -- also where the statistics take the split-partials path (feature planes above 4096 pixels), whose split count is a
-    function of the plane, not of the batch."""
-    from ccst_amd import style
+    result -- also where the statistics take the split-partials path (feature planes above 4096 pixels), whose split count is a
+    function of the plane, not of the batch.  Since round 4 the half-piece conv kernels scale their operands by a power of two
+    derived from the largest |value| of the WHOLE input tensor: where batch and single image give different exponents, the low pieces
+    of small elements round differently (they sit in half's subnormals), so the equality is to a few 1e-7 of the output range, not to
+    the bit (the fp32-MFMA plan, CCST_HALO_SPLIT=0, stays bit-identical)."""
+    from ccst_amd import ops, style
     vgg31, dec, _, _ = nets
     stat = [t.to(dev) for t in A.synth_style_stat(512, seed=11)]
     for (n, h, w) in ((3, 96, 160), (3, 768, 640)):
@@ -633,7 +636,12 @@ def test_sample_result_does_not_depend_on_its_batch(dev, nets, A):
         with torch.no_grad():
             whole = style.style_transfer(vgg31, dec, content, stat, 1.0)
             alone = style.style_transfer(vgg31, dec, content[1:2], stat, 1.0)
-        assert torch.equal(whole[1:2], alone), (n, h, w)
+        if ops.HALO_SPLIT == "0":
+            assert torch.equal(whole[1:2], alone), (n, h, w)
+        else:
+            d = float((whole[1:2] - alone).abs().max()) / float(alone.abs().max())
+            print("sample alone vs in a batch of %d at %dx%d: max difference %.2e of the output range" % (n, h, w, d))
+            assert d < 2e-6, (n, h, w, d)
 
 
 def test_no_cpu_fallback(nets):
@@ -1064,6 +1072,15 @@ def test_conv3x3_f23_vs_fp64(dev, case, reflect):
     assert torch.equal(out, ops.conv3x3_f23(x, pc, flags))
     # and against the direct half-piece kernel on the same operands
     assert float((out - ops.conv3x3_halo_split(x, pc, flags)).abs().max()) < 6e-6 * max(1.0, float(ref.abs().max()))
+    if not pool:       # the per-tile channel sums of the epilogue add up to the sums of the output, per image
+        out2, part = ops.conv3x3_f23(x, pc, flags, sums=True)
+        assert torch.equal(out2, out) and part.shape[0] % N == 0 and part.shape[1] == Cout
+        tot = part.double().sum(0)
+        s_ref = torch.stack([out.double().sum(dim=(0, 1, 2)), (out.double() ** 2).sum(dim=(0, 1, 2))], dim=1)
+        assert float((tot - s_ref).abs().max()) < 1e-5 * max(1.0, float(s_ref.abs().max()))
+        tpi = part.shape[0] // N
+        s0 = part[:tpi].double().sum(0)[:, 0]
+        assert float((s0 - out[0].double().sum(dim=(0, 1))).abs().max()) < 1e-5 * max(1.0, float(s0.abs().max()))
 
 
 @pytest.mark.parametrize("xscale", [1e-30, 1e-4, 3e4, 1e5, 1e30])
