@@ -40,15 +40,17 @@ _SIGNATURES = {
     "ccst_conv2d_igemm_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P],
     "ccst_conv2d_igemm_stats_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P, _P],
     "ccst_conv2d_igemm_stats_groups": [c_int, c_int, c_int, c_int],
+    "ccst_conv2d_igemm_stats_scaled_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P, _P, _P, _P],
     "ccst_conv2d_pointwise_ok": [POINTER(CcstConvDesc)],
     "ccst_conv2d_igemm_accum_masked_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ccst_conv2d_igemm_bn_relu_bwd_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ccst_bn_relu_maxpool_train_fwd_f32": [_P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P,
-                                           c_int64, _P],
+                                           c_int64, _P, _P],
     "ccst_bn_relu_maxpool_train_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P],
     "ccst_bn_train_bwd_partials_f32": [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int64, c_int, _P, c_int64, _P],
     "ccst_conv3x3_halo_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_absmax_f32": [_P, c_int64, _P, _P],
+    "ccst_absmax_batch_f32": [_P, c_int, _P, _P],
     "ccst_conv3x3_halo_split_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P, _P],
     "ccst_pack_conv_weight_f23_f32": [_P, _P, c_int, c_int, c_int, _P, _P],
     "ccst_conv3x3_f23_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P, _P],
@@ -68,7 +70,7 @@ _SIGNATURES = {
     "ccst_wino4w_spatial_tiles": [c_int, c_int, c_int],
     "ccst_pack_stem3_weight_f32": [_P, _P, _P, c_int, _P],
     "ccst_conv3x3_stem3_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P],
-    "ccst_chan_sums_finalize_f32": [_P, c_int, c_int, _P, _P, _P],
+    "ccst_chan_sums_finalize_f32": [_P, c_int, c_int, c_int, _P, _P, _P],
     "ccst_pack_conv_weight_wino_bwd_f32": [_P, _P, c_int, c_int, c_int, _P],
     "ccst_conv3x3_wino_train_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_conv3x3_wino_stats_groups": [c_int, c_int, c_int],
@@ -92,7 +94,7 @@ _SIGNATURES = {
     "ccst_conv2d_bwd_weight_f32": [POINTER(CcstConvDesc), _P, _P, _P, c_int, c_int, _P, c_int64, _P],
     "ccst_conv2d_bwd_weight_splits": [c_int, c_int, c_int, c_int],
     "ccst_calc_mean_std_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, c_int64, _P],
-    "ccst_adain_tile_sums_f32": [_P, _P, c_int, _P, _P, c_int, c_float, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P],
+    "ccst_adain_tile_sums_f32": [_P, _P, c_int, c_int, _P, _P, c_int, c_float, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P],
     "ccst_interp_blend_f32": [_P, _P, _P, c_int, c_int64, c_float, c_float, _P, _P],
     "ccst_adain_f32": [_P, _P, _P, c_int, c_float, _P, c_int, c_int, c_int, c_int, c_float, _P, c_int64, _P, _P],
     "ccst_chan_sums_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _P],
@@ -100,7 +102,7 @@ _SIGNATURES = {
     "ccst_bn_train_fwd_f32": [_P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P, _P, _P, c_int64, c_int, _P, c_int, _P, c_int64, _P],
     "ccst_bn_eval_fwd_f32": [_P, _P, _P, _P, _P, c_float, _P, c_int, _P, c_int64, c_int, _P],
     "ccst_bn_train_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int64, c_int, _P, c_int64, _P],
-    "ccst_bn_train_fwd_mask_f32": [_P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P, c_int64, _P],
+    "ccst_bn_train_fwd_mask_f32": [_P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P, c_int64, _P, _P],
     "ccst_bn_train_bwd_mask_f32": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int64, c_int, _P, c_int64, _P],
     "ccst_bn_workspace_bytes": [c_int64, c_int],
     "ccst_maxpool3s2_fwd_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],

@@ -164,13 +164,23 @@ __global__ __launch_bounds__(256) void finalize_mean_std_kernel(const float* __r
 
 // per-channel totals over n and splits (calc_sum): a workgroup owns 16 channels, 16 slice-lanes per channel each fold every 16th
 // (n, split) partial in fp64 (consecutive threads read consecutive channels of one partial), then the lanes in fixed order
+// CENTRED: the partials are (sum, M2 about the slab's own mean, count, 0) quadruples (the half-piece conv kernels' epilogues): the raw
+// sum of squares of a slab is M2 + sum^2 / count, formed here in fp64
+template <bool CENTRED>
 __global__ __launch_bounds__(256) void finalize_chan_sums_kernel(const float* __restrict__ part, float* __restrict__ sum, float* __restrict__ sq,
                                                                  int N, int C, int S) {
     __shared__ double red[2][16][17];
     const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     double s = 0.0, q = 0.0;
-    if (c < C) {
+    if (CENTRED) {
+        if (c < C)
+            for (int k = sl; k < N * S; k += 16) {
+                const f32x4 o = *reinterpret_cast<const f32x4*>(part + ((long long)k * C + c) * 4);
+                s += (double)o[0];
+                q += (double)o[1] + (o[2] > 0.f ? (double)o[0] * (double)o[0] / (double)o[2] : 0.0);
+            }
+    } else if (c < C) {
         const int K = N * S;
         int k = sl;
         for (; k + 48 < K; k += 64) {            // four loads in flight (L2 latency), folded in index order
@@ -406,6 +416,7 @@ int check_common(const void* x, int N, int C, int HW, int layout) {
 #define TS_PIXELS 256
 #endif
 constexpr int TS_CQ = 16, TS_PL = TPB / TS_CQ, TS_PIX = TS_PIXELS;
+template <bool CENTRED>
 __global__ __launch_bounds__(TPB) void adain_tile_sums_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                    const float* __restrict__ part, int tpi,
                                                                    const float* __restrict__ smean, const float* __restrict__ sstd,
@@ -427,13 +438,37 @@ __global__ __launch_bounds__(TPB) void adain_tile_sums_nhwc_kernel(const float* 
     // the tile pairs of this thread's four channels: the 16 pixel-lanes of a channel quad share them (tiles pl, pl + 16, ...), folded
     // over the four lanes of a wave by shuffles and over the four waves through LDS, in a fixed order (bitwise reproducible)
     __shared__ double red[TPB / 64][TS_CQ][8];
+    // CENTRED (the half-piece conv kernels' epilogues): (S, M2 about the slab's own mean, count, 0) per (tile, channel).  The fold keeps
+    // s = sum S and q = sum (M2_i + S_i^2 / n_i) = the raw sum of squares, but assembled in fp64 from slab quantities that carry no
+    // cancellation; the variance below is then sum M2_i + sum n_i (mean_i - mean)^2 up to fp64 rounding.  To keep that true when
+    // |mean| / sigma is huge, the squares are taken about a pivot: the first slab's mean.
     double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
-    const float* pp = part + ((long long)n * tpi * C + c0) * 2;
-    for (int k = pl; k < tpi; k += TS_PL) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(pp + (long long)k * C * 2);          // S c0, Q c0, S c0+1, Q c0+1
-        const f32x4 b = *reinterpret_cast<const f32x4*>(pp + (long long)k * C * 2 + 4);
-        s[0] += (double)a[0]; q[0] += (double)a[1]; s[1] += (double)a[2]; q[1] += (double)a[3];
-        s[2] += (double)b[0]; q[2] += (double)b[1]; s[3] += (double)b[2]; q[3] += (double)b[3];
+    double piv[4] = {0.0, 0.0, 0.0, 0.0};
+    if (CENTRED) {
+        const float* pp = part + ((long long)n * tpi * C + c0) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4*>(pp + j * 4);                      // slab 0 of the image: the pivot (same for every lane)
+            piv[j] = a0[2] > 0.f ? (double)a0[0] / (double)a0[2] : 0.0;
+        }
+        for (int k = pl; k < tpi; k += TS_PL)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(pp + ((long long)k * C + j) * 4);
+                if (a[2] > 0.f) {
+                    const double nk = (double)a[2], dm = (double)a[0] / nk - piv[j];
+                    s[j] += nk * dm;                                                         // sum of (x - pivot)
+                    q[j] += (double)a[1] + nk * dm * dm;                                     // sum of (x - pivot)^2
+                }
+            }
+    } else {
+        const float* pp = part + ((long long)n * tpi * C + c0) * 2;
+        for (int k = pl; k < tpi; k += TS_PL) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(pp + (long long)k * C * 2);          // S c0, Q c0, S c0+1, Q c0+1
+            const f32x4 b = *reinterpret_cast<const f32x4*>(pp + (long long)k * C * 2 + 4);
+            s[0] += (double)a[0]; q[0] += (double)a[1]; s[1] += (double)a[2]; q[1] += (double)a[3];
+            s[2] += (double)b[0]; q[2] += (double)b[1]; s[3] += (double)b[2]; q[3] += (double)b[3];
+        }
     }
 #pragma unroll
     for (int off = TS_CQ; off < 64; off <<= 1)
@@ -463,9 +498,9 @@ __global__ __launch_bounds__(TPB) void adain_tile_sums_nhwc_kernel(const float* 
     f32x4 mu, sd;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const double m = s[j] / (double)HW;
+        const double m = s[j] / (double)HW;                                             // (CENTRED: of x - pivot)
         const double var = fmax(q[j] - s[j] * m, 0.0) / ((double)HW - 1.0);
-        mu[j] = (float)m;
+        mu[j] = (float)(m + piv[j]);
         sd[j] = sqrtf((float)var + eps);
     }
     if (mean_out != nullptr && blockIdx.z == 0 && pl == 0) {
@@ -567,17 +602,22 @@ extern "C" int ccst_adain_f32(const float* x, const float* style_mean, const flo
 // function.py:26-33 (+ the alpha blend) on an NHWC tensor x [N][HW][C] whose producer left per-tile channel sums: partials
 // [N * tiles_per_image][C][2] = (sum, sum of squares) of x over the pixels of spatial tile t, tiles of image n contiguous
 // (ccst_conv3x3_wino4w_f32's chan_sum_partials).  C a multiple of 64.  mean_out / std_out: NULL or [N*C] (the content statistics).
-extern "C" int ccst_adain_tile_sums_f32(const float* x, const float* partials, int tiles_per_image, const float* style_mean,
+extern "C" int ccst_adain_tile_sums_f32(const float* x, const float* partials, int partial_floats, int tiles_per_image, const float* style_mean,
                                         const float* style_std, int style_per_n, float alpha, float* y, int N, int C, int HW, float eps,
                                         float* mean_out, float* std_out, uint32_t* y_absmax, void* stream) {
     CCST_REQUIRE(x && partials && style_mean && style_std && y, "adain_tile_sums: null pointer");
+    CCST_REQUIRE(partial_floats == 2 || partial_floats == 4, "adain_tile_sums: partials are [..][C][2] (sum, sum^2) or [..][C][4] (sum, M2, count, 0)");
     CCST_REQUIRE(N > 0 && N <= 65535 && C > 0 && C % (4 * TS_CQ) == 0 && HW >= 2 && tiles_per_image > 0, "adain_tile_sums: bad shape (C %% 64 == 0, HW >= 2)");
     CCST_REQUIRE(alpha >= 0.f && alpha <= 1.f, "adain_tile_sums: alpha=%f outside [0,1]", (double)alpha);
     CCST_REQUIRE((mean_out == nullptr) == (std_out == nullptr), "adain_tile_sums: mean_out and std_out come together");
     const int chunks = (HW + TS_PIX - 1) / TS_PIX;
     CCST_REQUIRE(chunks <= 65535, "adain_tile_sums: plane too large");
-    hipLaunchKernelGGL(adain_tile_sums_nhwc_kernel, dim3(C / (4 * TS_CQ), N, chunks), dim3(TPB), 0, (hipStream_t)stream, x, y, partials,
-                       tiles_per_image, style_mean, style_std, style_per_n, alpha, HW, C, eps, mean_out, std_out, y_absmax);
+    if (partial_floats == 4)
+        hipLaunchKernelGGL(adain_tile_sums_nhwc_kernel<true>, dim3(C / (4 * TS_CQ), N, chunks), dim3(TPB), 0, (hipStream_t)stream, x, y, partials,
+                           tiles_per_image, style_mean, style_std, style_per_n, alpha, HW, C, eps, mean_out, std_out, y_absmax);
+    else
+        hipLaunchKernelGGL(adain_tile_sums_nhwc_kernel<false>, dim3(C / (4 * TS_CQ), N, chunks), dim3(TPB), 0, (hipStream_t)stream, x, y, partials,
+                           tiles_per_image, style_mean, style_std, style_per_n, alpha, HW, C, eps, mean_out, std_out, y_absmax);
     return ccst_launch_status("adain_tile_sums");
 }
 
@@ -595,9 +635,11 @@ extern "C" int ccst_interp_blend_f32(const float* base, const float* content0, c
 }
 
 // Fold K per-tile (sum, sum of squares) pairs [K][C][2] (the statistics epilogue of ccst_conv3x3_wino4w_f32) into the per-channel totals.
-extern "C" int ccst_chan_sums_finalize_f32(const float* partials, int K, int C, float* sum, float* sqsum, void* stream) {
+extern "C" int ccst_chan_sums_finalize_f32(const float* partials, int partial_floats, int K, int C, float* sum, float* sqsum, void* stream) {
     CCST_REQUIRE(partials && sum && sqsum && K > 0 && C > 0, "chan_sums_finalize: bad args");
-    hipLaunchKernelGGL(finalize_chan_sums_kernel, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, sum, sqsum, 1, C, K);
+    CCST_REQUIRE(partial_floats == 2 || partial_floats == 4, "chan_sums_finalize: partials are [K][C][2] (sum, sum^2) or [K][C][4] (sum, M2, count, 0)");
+    if (partial_floats == 4) hipLaunchKernelGGL(finalize_chan_sums_kernel<true>, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, sum, sqsum, 1, C, K);
+    else hipLaunchKernelGGL(finalize_chan_sums_kernel<false>, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, partials, sum, sqsum, 1, C, K);
     return ccst_launch_status("finalize_chan_sums");
 }
 
@@ -615,6 +657,6 @@ extern "C" int ccst_chan_sums_f32(const float* x, float* sum, float* sqsum, int 
     float* part = (float*)ws;
     rc = run_partials<false>(x, part, N, C, HW, layout, S, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(finalize_chan_sums_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, sum, sqsum, N, C, S);
+    hipLaunchKernelGGL(finalize_chan_sums_kernel<false>, dim3((C + 15) / 16), dim3(256), 0, st, part, sum, sqsum, N, C, S);
     return ccst_launch_status("finalize_chan_sums");
 }

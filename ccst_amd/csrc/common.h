@@ -75,8 +75,15 @@ __device__ __forceinline__ unsigned ccst_wave_umax(unsigned v) {
 // every lane passes the largest |value| it holds (>= 0, or NaN); `salt` spreads the waves of the grid over the slots
 __device__ __forceinline__ void ccst_absmax_publish(unsigned* slots, float lane_max, unsigned salt) {
     const unsigned m = ccst_wave_umax(__float_as_uint(lane_max) & 0x7fffffffu);
-    if ((threadIdx.x & 63) == 0 && m != 0u)
-        (void)__hip_atomic_fetch_max(slots + (salt % CCST_ABSMAX_SLOTS) * CCST_ABSMAX_STRIDE, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((threadIdx.x & 63) == 0 && m != 0u) {
+        unsigned* const s = slots + (salt % CCST_ABSMAX_SLOTS) * CCST_ABSMAX_STRIDE;
+        // A slot only grows, so a wave whose maximum is not above what the slot holds NOW (an agent-scope load: it goes to the coherent
+        // level, as the atomics do) has nothing to add: after the first waves of a launch almost none issues the atomic.  With one
+        // unconditional atomic per wave a launch of 16 k waves put 256 serialised atomics on every slot -- +1.7 ms on a ResNet50 step
+        // whose 53 BatchNorm applies publish their maxima (measured: 3063 against 3331 images/s).
+        if (m > __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            (void)__hip_atomic_fetch_max(s, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 // the tensor's |max| bits, wave-uniform (every wave reads for itself: no LDS, no barrier)
 __device__ __forceinline__ unsigned ccst_absmax_read(const unsigned* slots) {

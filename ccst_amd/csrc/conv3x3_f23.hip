@@ -35,7 +35,7 @@ struct F23Args {
     const unsigned* xmax;
     const unsigned* wmax;
     unsigned* ymax;
-    float* stats;        // nullptr, or [ccst_conv3x3_f23_tiles(N,H,W)][Cout][2] per-(8x32-pixel tile, wave row) (sum, sum^2) of the output
+    float* stats;        // nullptr, or [ccst_conv3x3_f23_tiles(N,H,W)][Cout][4] per-(8x32-pixel tile, wave row) (sum, M2 about the slab's own mean, count, 0) of the output
     int N, H, W, Hs, Ws, Cin, Cout, CoutPad;
     int reflect, ups, relu;
     long long ysN;
@@ -91,9 +91,16 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
 }
 // wait until all but the wave's N youngest vector-memory operations (= its LDS-DMA pieces) have landed and its own LDS accesses are
 // done, then the workgroup barrier: what landed before it may be read by every wave after it
+#ifndef F23A_VM_EXTRA
+#define F23A_VM_EXTRA 0        // timing experiments only: let this many more pieces stay in flight than is safe
+#endif
 template <int N>
 __device__ __forceinline__ void dma_barrier() {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+#ifdef F23A_NO_LGKM
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N == 0 ? 0 : N + F23A_VM_EXTRA) : "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N == 0 ? 0 : N + F23A_VM_EXTRA) : "memory");
+#endif
 }
 
 template <bool POOL>
@@ -155,27 +162,34 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
         }
         rsrc_[i] = (unsigned)((((gy >> p.ups) * p.Ws + (gx >> p.ups)) * p.Cin + (lane & 3) * 4) * 4);
     }
-    // transform units u = tid (+ 512 for the first 128 threads): (halo row u >> 6, pixel pair (u >> 2) & 15, channel part u & 3)
-    int tsrc[2], tdst[2];
-    unsigned tok = 0;
+    // transform items: 10 halo rows x 16 pixel pairs x 4 channel parts x 4 positions = 2560 = FIVE per thread, one per k-step 4..8:
+    // thread -> (pixel pair (tid >> 4) & 15, part (tid >> 2) & 3, position q = tid & 3), item i -> halo row (tid >> 8) + 2 i.  A position
+    // is d_a + sgn d_b of two of the pair's four raw pixels (B^T rows: q0 = d0 - d2, q1 = d1 + d2, q2 = d2 - d1, q3 = d1 - d3): two 16-byte
+    // LDS reads (a 16-lane pass covers three pixels x four parts: conflict-free), fma, split, two 8-byte stores (a pass covers the
+    // pair's 256 bytes: conflict-free).  Every thread does the same work at every k-step (the first version did whole units: waves 0
+    // and 1 two, the others one, at four k-steps -- the transform cost 13 % of the kernel, most of it the other waves' wait).
+    int tsa, tsb, tdst;
+    float tsgn;
+    unsigned tok = 0x3ffu;          // zero padding: validity of (d_a, d_b) of item i in bits 2 i, 2 i + 1
+    {
+        const int xp = (tid >> 4) & 15, part = (tid >> 2) & 3, q = tid & 3, hy0 = tid >> 8;
+        const int ja = q == 0 ? 0 : q == 2 ? 2 : 1, jb = q == 2 ? 1 : q == 3 ? 3 : 2;
+        tsa = ((hy0 * F_RW + 2 * xp + ja) * 16 + part * 4);
+        tsb = ((hy0 * F_RW + 2 * xp + jb) * 16 + part * 4);
+        tdst = hy0 * F_ROWW + xp * F_XPW + q * F_QW + part * 2;
+        tsgn = q == 1 ? 1.f : -1.f;
+        if (!p.reflect) {
+            tok = 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int u = min(tid + F_NT * i, F_HUNITS - 1);
-        const int part = u & 3, xp = (u >> 2) & 15, hy = u >> 6;
-        tsrc[i] = ((hy * F_RW + 2 * xp) * 16 + part * 4);
-        tdst[i] = hy * F_ROWW + xp * F_XPW + part * 2;
-        if (!p.reflect) {          // zero padding: which of the unit's four pixels are inside the image
-            const int gy = oy0 + hy - 1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int gx = ox0 + 2 * xp - 1 + j;
-                tok |= ((gy >= 0) & (gy < p.H) & (gx >= 0) & (gx < p.W) ? 1u : 0u) << (4 * i + j);
+            for (int i = 0; i < 5; ++i) {
+                const int gy = oy0 + hy0 + 2 * i - 1, gxa = ox0 + 2 * xp - 1 + ja, gxb = ox0 + 2 * xp - 1 + jb;
+                const bool oky = (gy >= 0) & (gy < p.H);
+                tok |= ((oky & (gxa >= 0) & (gxa < p.W)) ? 1u : 0u) << (2 * i);
+                tok |= ((oky & (gxb >= 0) & (gxb < p.W)) ? 1u : 0u) << (2 * i + 1);
             }
-        } else {
-            tok |= 0xfu << (4 * i);
         }
     }
-    const bool unit1 = tid < F_HUNITS - F_NT;                       // (waves 0 and 1: uniform per wave)
+    const float xsb = xs * tsgn;
 
     auto dma_w = [&](int c_, int s_) {          // weights of k-step s_ (>= 12: of the next chunk; clamped at the end) -> ring stage s_ % 6
         const int cc = min(c_ + s_ / 12, nchunks - 1), ss = s_ % 12;
@@ -186,25 +200,27 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
         const int cc = min(c_, nchunks - 1);
         glds16(ximg + cc * 16, rsrc_[i], (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)((2 * F_VW) * 4 + (wave + 8 * i) * 1024))));
     };
-    f32x4 d[4];
-    auto read_unit = [&](int i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            d[j] = *reinterpret_cast<const f32x4*>(&Raw[tsrc[i] + j * 16]);
-            if (!((tok >> (4 * i + j)) & 1u)) d[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // item i of this thread: raw -> position -> (hi, lo) -> V[buf]
+    auto xform = [&](int buf, int i) {
+        f32x4 da = *reinterpret_cast<const f32x4*>(&Raw[tsa + i * (2 * F_RW * 16)]);
+        f32x4 db = *reinterpret_cast<const f32x4*>(&Raw[tsb + i * (2 * F_RW * 16)]);
+        if (!p.reflect) {
+            if (!((tok >> (2 * i)) & 1u)) da = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!((tok >> (2 * i + 1)) & 1u)) db = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-    };
-    // positions q0, q0 + 1 of the unit in d: B^T d, scale, split, store
-    auto store_v = [&](int buf, int i, int q0) {
+        u32x2f hi, lo;
 #pragma unroll
-        for (int q = q0; q < q0 + 2; ++q) {
-            const f32x4 v = q == 0 ? d[0] - d[2] : q == 1 ? d[1] + d[2] : q == 2 ? d[2] - d[1] : d[1] - d[3];
-            u32x2f hi, lo;
-            split4f(v, xs, hi, lo);
-            float* o = &Vs[buf * F_VW + tdst[i] + q * F_QW];
-            *reinterpret_cast<u32x2f*>(o) = hi;
-            *reinterpret_cast<u32x2f*>(o + 8) = lo;
+        for (int h = 0; h < 2; ++h) {          // (d_a + sgn d_b) * 2^kx as d_a * s + d_b * (sgn s): exact scaling, one rounding (the add's)
+            const f32x2f pa = f32x2f{da[2 * h], da[2 * h + 1]} * xs;
+            const f32x2f pv = f32x2f{db[2 * h], db[2 * h + 1]} * xsb + pa;
+            const f16x2f ph = __builtin_convertvector(pv, f16x2f);
+            const f16x2f pl = __builtin_convertvector(pv - __builtin_convertvector(ph, f32x2f), f16x2f);
+            hi[h] = __builtin_bit_cast(unsigned, ph);
+            lo[h] = __builtin_bit_cast(unsigned, pl);
         }
+        float* o = &Vs[buf * F_VW + tdst + i * (2 * F_ROWW)];
+        *reinterpret_cast<u32x2f*>(o) = hi;
+        *reinterpret_cast<u32x2f*>(o + 8) = lo;
     };
 
     f32x16 acc[4][2];
@@ -243,21 +259,17 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
 #pragma unroll
     for (int s = 0; s < F_RING; ++s) dma_w(0, s);
     dma_barrier<0>();
-    read_unit(0);
-    store_v(0, 0, 0);
-    store_v(0, 0, 2);
-    if (unit1) {
-        read_unit(1);
-        store_v(0, 1, 0);
-        store_v(0, 1, 2);
-    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) xform(0, i);
     dma_barrier<0>();
 #pragma unroll
     for (int i = 0; i < 3; ++i) dma_raw(1, i);
     Frags cur, nxt;
     read_frags(cur, 0, 0, 0);
 
-    for (int c = 0; c < nchunks; ++c) {
+    // one chunk; PAR = its parity = its V buffer (a compile-time constant: the chunks run in pairs, so every LDS offset of the loop is an
+    // instruction immediate -- with a run-time parity the buffer base cost three vector adds per k-step)
+    auto chunk = [&](const int c, const int PAR) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 12; ++s) {                 // k-step s = ky * 4 + q of chunk c; 12 is a multiple of the ring depth: static stages
             const int q = s & 3;
@@ -268,16 +280,16 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
             {   // fragments of the NEXT k-step: its weights landed before the previous barrier; V of this chunk, or of the next one -- complete
                 // since k-step 8's stores
                 const int sn = (s + 1) % 12;
-                read_frags(nxt, s == 11 ? (c + 1) & 1 : c & 1, sn % F_RING, sn);
+                read_frags(nxt, s == 11 ? PAR ^ 1 : PAR, sn % F_RING, sn);
             }
 #endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) acc[q][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[0][mt], cur.b[1], acc[q][mt], 0, 0, 0);   // a_hi b_lo
             __builtin_amdgcn_sched_barrier(0);
-            // staging.  The raw buffer holds chunk c + 1 (landed before barrier 4: its pieces are older than the weights of k-step 0);
-            // it is transformed into V[(c + 1) & 1] at k-steps 5-8 and refilled with chunk c + 2 at 9-11.  Order inside a k-step: raw
-            // piece first, weight piece second -- the vmcnt table below counts on it.
+            // staging.  The raw buffer holds chunk c + 1 (landed before barrier 3: its pieces are older than the weights issued at k-step
+            // 11); it is transformed into V[PAR ^ 1] at k-steps 4-8, one item per thread and k-step, and refilled with chunk c + 2 at
+            // 9-11.  Order inside a k-step: raw piece first, weight piece second -- the vmcnt table below counts on it.
 #ifndef F23A_NO_LOADV
             if (s >= 9) dma_raw(c + 2, s - 9);
 #endif
@@ -285,18 +297,7 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
             dma_w(c, s + F_RING);                      // (stage s % 6: its fragments were read during k-step s - 1)
 #endif
 #ifndef F23A_NO_STOREV
-            if (s == 5) {
-                read_unit(0);
-                store_v((c + 1) & 1, 0, 0);
-            }
-            if (s == 6) store_v((c + 1) & 1, 0, 2);
-            if (unit1) {
-                if (s == 7) {
-                    read_unit(1);
-                    store_v((c + 1) & 1, 1, 0);
-                }
-                if (s == 8) store_v((c + 1) & 1, 1, 2);
-            }
+            if (s >= 4 && s <= 8) xform(PAR ^ 1, s - 4);
 #endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -319,6 +320,14 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
 #endif
             cur = nxt;
         }
+    };
+    {
+        int c = 0;
+        for (; c + 1 < nchunks; c += 2) {
+            chunk(c, 0);
+            chunk(c + 1, 1);
+        }
+        if (c < nchunks) chunk(c, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the clamped prefetches of the last k-steps must land before this workgroup's LDS is released
 
@@ -344,7 +353,7 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
         float* const tile = p.y + (long long)n * p.ysN + (long long)oy0 * p.ysH + (long long)ox0 * p.ysW + co0 + wn * 32;
         const unsigned lane_off = (unsigned)(4 * lh * p.ysW + li);
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile, 0, 0x7fffffff, 0x00020000);
-        float s1 = 0.f, s2 = 0.f;          // p.stats: this wave's 4 rows x 32 pixels of channel `co` (after bias / ReLU, pixels outside the image excluded)
+        float s1 = 0.f, cnt = 0.f;         // p.stats: this wave's 4 rows x 32 pixels of channel `co` (after bias / ReLU, pixels outside the image excluded)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int Tt = 2 * wm + mt;
@@ -359,25 +368,42 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
                     if (interior) {
                         amax = fmaxf(amax, fabsf(v));
                         s1 += v;
-                        s2 += v * v;
+                        cnt += 1.f;
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, lane_off * 4, (dy * p.ysH + dx * p.ysW) * 4, 0);
                     } else if (cok && oy0 + dy < p.H && ox0 + dx + 4 * lh < p.W) {
                         amax = fmaxf(amax, fabsf(v));
                         s1 += v;
-                        s2 += v * v;
+                        cnt += 1.f;
                         tile[(long long)dy * p.ysH + (long long)dx * p.ysW + lane_off] = v;
                     }
                 }
             }
         }
-        if (p.stats != nullptr) {          // the per-tile channel sums the AdaIN step and stage 1 take instead of a pass over the features
+        if (p.stats != nullptr) {
+            // The per-tile channel statistics the AdaIN step and stage 1 take instead of a pass over the features: (sum, M2, count) with
+            // M2 = the sum of squares ABOUT THE SLAB'S OWN MEAN -- a second pass over the values still in registers -- so that the
+            // consumer's variance (Chan's merge, fp64) has no E[x^2] - mean^2 cancellation however large |mean| / sigma is (ADVICE r3:
+            // raw fp32 sums of x^2 lose the variance once mean^2 >> var).
             s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (lh == 0 && cok) {
-                float* o = p.stats + ((long long)((((n * p.tilesY + ty) * p.tilesX + tx) * 2 + wm)) * p.Cout + co) * 2;
-                o[0] = s1;
-                o[1] = s2;
-            }
+            cnt += __shfl_xor(cnt, 32, 64);
+            const float mu = s1 / fmaxf(cnt, 1.f);
+            float m2 = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dy = 2 * (2 * wm + mt) + (r & 1), xpu = ((r & 3) >> 1) + 4 * (r >> 2);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        float v = acc[e][mt][r];
+                        if (relu) v = fmaxf(v, 0.f);
+                        const float dv = v - mu;
+                        if (interior || (cok && oy0 + dy < p.H && ox0 + 2 * xpu + e + 4 * lh < p.W)) m2 += dv * dv;
+                    }
+                }
+            m2 += __shfl_xor(m2, 32, 64);
+            if (lh == 0 && cok)
+                *reinterpret_cast<f32x4*>(p.stats + ((long long)((((n * p.tilesY + ty) * p.tilesX + tx) * 2 + wm)) * p.Cout + co) * 4) = f32x4{s1, m2, cnt, 0.f};
         }
     } else {
         const int Hp = (p.H + 1) >> 1, Wp = (p.W + 1) >> 1;

@@ -43,7 +43,7 @@ struct HaloArgs {
     const unsigned* xmax;   // SPLIT: |max| words of x and of the OIHW weight (CCST_ABSMAX_WORDS each): the operands' power-of-two scales
     const unsigned* wmax;   //        are derived from them in the kernel, the accumulators scaled back before the epilogue
     unsigned* ymax;         // SPLIT: nullptr, or zeroed |max| words receiving max |y| of what this launch stores
-    float* stats;        // TRAIN: per-(spatial tile, wave row) (sum, sum^2) partials of the output, or nullptr
+    float* stats;        // TRAIN: per-(spatial tile, wave row) (sum, sum^2) partials of the output, or nullptr; SPLIT: (sum, M2 about the slab's own mean, count, 0)
     int flip, accum;     // TRAIN: taps read in reverse order (backward-data); y += conv
 };
 
@@ -434,26 +434,46 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
         const bool interior = (oy0 + TH <= p.H) && (ox0 + 16 <= p.W) && (co0 + BN <= p.Cout);
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile, 0, 0x7fffffff, 0x00020000);
         if ((TRAIN || SPLIT) && p.stats != nullptr) {
-            // this wave's 64 pixels x 32*NT channels -> per-channel (sum, sum^2) of the OUTPUT (after bias / ReLU); pixels outside the
-            // image excluded.  SPLIT: these are the per-tile channel sums the AdaIN step and stage 1 take instead of a pass over the features.
+            // this wave's 64 pixels x 32*NT channels -> per-channel statistics of the OUTPUT (after bias / ReLU); pixels outside the image
+            // excluded.  TRAIN: raw (sum, sum^2) for the next BatchNorm.  SPLIT: (sum, M2, count, 0) with M2 about the slab's own mean (a
+            // second pass over the registers): what the AdaIN step and stage 1 take instead of a pass over the features, free of the
+            // E[x^2] - mean^2 cancellation.
             const int slab = ((n * p.tilesY + ty) * p.tilesX + tx) * WM + wm;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                float s1 = 0.f, s2 = 0.f;
+                float s1 = 0.f, s2 = 0.f, cnt = 0.f;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int dy = 2 * (wm * MT + mt) + ((r & 3) >> 1), dx = 4 * (r >> 2) + (r & 1) + 2 * lh;
-                        float v = (interior || (oy0 + dy < p.H && ox0 + dx < p.W)) ? acc[mt][nt][r] : 0.f;
+                        const bool in = interior || (oy0 + dy < p.H && ox0 + dx < p.W);
+                        float v = in ? acc[mt][nt][r] : 0.f;
                         if (relu) v = fmaxf(v, 0.f);
                         s1 += v;
                         s2 += v * v;
+                        cnt += in ? 1.f : 0.f;
                     }
                 s1 += __shfl_xor(s1, 32, 64);
                 s2 += __shfl_xor(s2, 32, 64);
                 const int co = co0 + cw + nt * 32 + li;
-                if (lh == 0 && co < p.Cout) {
+                if (SPLIT) {
+                    cnt += __shfl_xor(cnt, 32, 64);
+                    const float mu = s1 / fmaxf(cnt, 1.f);
+                    float m2 = 0.f;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int dy = 2 * (wm * MT + mt) + ((r & 3) >> 1), dx = 4 * (r >> 2) + (r & 1) + 2 * lh;
+                            float v = acc[mt][nt][r];
+                            if (relu) v = fmaxf(v, 0.f);
+                            const float dv = v - mu;
+                            if (interior || (oy0 + dy < p.H && ox0 + dx < p.W)) m2 += dv * dv;
+                        }
+                    m2 += __shfl_xor(m2, 32, 64);
+                    if (lh == 0 && co < p.Cout) *reinterpret_cast<f32x4*>(p.stats + ((long long)slab * p.Cout + co) * 4) = f32x4{s1, m2, cnt, 0.f};
+                } else if (lh == 0 && co < p.Cout) {
                     float* o = p.stats + ((long long)slab * p.Cout + co) * 2;
                     o[0] = s1;
                     o[1] = s2;

@@ -61,6 +61,8 @@ struct ConvArgs {
     const float* bn_gamma;        //     (gamma, beta: only where the ReLU mask is recomputed from bn_x)
     const float* bn_beta;
     float* bn_part;
+    const unsigned* xmax;         // half-piece (BFP = 4) form: |max| words of x and of the OIHW weight (common.h): the operands' power-of-two
+    const unsigned* wmax;         //     scales are derived from them in the kernel
 };
 
 // floor(m / d) for 0 <= m < 2^22 via one float multiply + correction (an integer division is ~40 VALU
@@ -498,6 +500,14 @@ __global__ __launch_bounds__(256, BFP == 3 ? 3 : 4) void conv1x1_stream_kernel(c
     // outside half's range.
     constexpr bool BF3 = BFP != 0, HALFP = BFP == 4;
     constexpr int NPIECE = HALFP ? 2 : BFP;
+    // HALFP: both operands scaled by powers of two from the tensors' |max| words (activations to < 2^14, weights to < 2^10): no finite
+    // fp32 value overflows half, small tensors are lifted out of its subnormals; the accumulators are scaled back exactly (v_ldexp)
+    int kxs = 0, kws = 0;
+    if (HALFP) {
+        kxs = ccst_scale_exp(ccst_absmax_read(p.xmax), CCST_SPLIT_X_TARGET);
+        kws = ccst_scale_exp(ccst_absmax_read(p.wmax), CCST_SPLIT_W_TARGET);
+    }
+    const float xsc = __uint_as_float((unsigned)(127 + kxs) << 23), wsc = __uint_as_float((unsigned)(127 + kws) << 23);
     constexpr int BM = 64, BN = 64, CK = 32, PPR = CK / 4, AR = BM * PPR / 256, BR = (CK / 4) * BN / 256;
     constexpr int PW = CK / 2;                               // words per piece of a row (32 bf16)
     constexpr int A_LD = BF3 ? NPIECE * PW + 4 : CK + 4;     // BF: a row = [32 channels piece 0 | piece 1 | ...] + 4 words of pad
@@ -592,7 +602,7 @@ __global__ __launch_bounds__(256, BFP == 3 ? 3 : 4) void conv1x1_stream_kernel(c
 #pragma unroll
             for (int a = 0; a < AR; ++a) {          // row = pixel
                 u32x2s pc[BF3 ? NPIECE : 1];
-                split4(ra[a], pc);
+                split4(HALFP ? ra[a] * xsc : ra[a], pc);
                 float* row = &As[buf][(tid / PPR + (256 / PPR) * a) * A_LD];
 #pragma unroll
                 for (int q = 0; q < (BF3 ? NPIECE : 1); ++q) *reinterpret_cast<u32x2s*>(row + q * PW + part * 2) = pc[q];
@@ -601,7 +611,7 @@ __global__ __launch_bounds__(256, BFP == 3 ? 3 : 4) void conv1x1_stream_kernel(c
             for (int b = 0; b < BR; ++b) {          // unit u = (k quad u / BN, column u % BN): row = output channel
                 const int u = tid + 256 * b;
                 u32x2s pc[BF3 ? NPIECE : 1];
-                split4(HALFP ? rb[b] * 256.f : rb[b], pc);
+                split4(HALFP ? rb[b] * wsc : rb[b], pc);
                 float* row = &Bs[buf][(u % BN) * B_LD];
 #pragma unroll
                 for (int q = 0; q < (BF3 ? NPIECE : 1); ++q) *reinterpret_cast<u32x2s*>(row + q * PW + (u / BN) * 2) = pc[q];
@@ -710,7 +720,7 @@ __global__ __launch_bounds__(256, BFP == 3 ? 3 : 4) void conv1x1_stream_kernel(c
         const int row0 = tm * BM + wm * 32;
         if (HALFP) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] *= (1.f / 256.f);               // (the weights were split as w * 2^8: exact)
+            for (int r = 0; r < 16; ++r) acc[r] = __builtin_ldexpf(acc[r], -(kxs + kws));      // (exact)
         }
         if (STATS) {
             float s1 = 0.f, s2 = 0.f;
@@ -950,22 +960,22 @@ static int choose_tile(int M, int cout, int cin, int taps, bool pool) {
 // channel counts fit its 64x64x32 step.  CCST_CONV_STREAM=0 keeps them on the per-tile kernel (A/B).
 // Workgroups of the streaming kernel for a problem: at most 4 per CU, a multiple of the column-tile count, never more than tiles.
 // CCST_CONV_BF: how the streaming pointwise kernel forms its products.
-//   4 (default): the TRAINING FORWARD (the calls with a statistics epilogue) on the 16-bit MFMA from two IEEE-half pieces per operand
-//      (22 bits; weights scaled by 2^8 as they are split, accumulators scaled back): the ten ResNet50 B=64 pointwise shapes 932 -> 653 us
-//      (tools/igemm_time.py), error 4e-7..1.3e-6 of max |y| (the fp32 MFMA: 2e-7..2e-6), every ResNet fixture and the full-size gradient
-//      gate green, train step 3340 -> 3435 images/s.  Backward-data and the evaluation forward stay on the fp32 MFMA: gradients are
-//      outside half's range, and forward activations must stay below 65504 (BatchNorm keeps them O(1-10)).
+//   4 (default): the TRAINING FORWARD (the calls with a statistics epilogue that come with the |max| words of both operands,
+//      ccst_conv2d_igemm_stats_scaled_f32) on the 16-bit MFMA from two IEEE-half pieces per operand (22 bits), both operands scaled by
+//      powers of two derived from the words on the device, accumulators scaled back exactly: the ten ResNet50 B=64 pointwise shapes
+//      932 -> 653 us (tools/igemm_time.py), error 4e-7..1.3e-6 of max |y| (the fp32 MFMA: 2e-7..2e-6), every ResNet fixture and the
+//      full-size gradient gate green, train step +3 %.  Range-safe: round 3's form (fixed 2^8 weight scale, unscaled activations)
+//      overflowed for |w| >= 256 or |x| >= 65504.  Backward-data and the evaluation forward stay on the fp32 MFMA.
 //   0: the fp32 MFMA everywhere.
-//   2 / 3 (experiments): two / three bf16 pieces for every form.  Two: 638 us, 147-167 TFLOP/s, but 16 bits (5e-6 of max |y|): the train
-//      step's gradient gates, which amplify a conv's rounding ~1e3-fold, fail (+5 % otherwise).  Three: the fp32 MFMA's accuracy at 859 us
-//      (the splits cost ~90 vector instructions per k-step next to 12 MFMAs): no gain on the step.
+//   (Round 3's experiments with two / three bf16 pieces, values 2 / 3, are retired: 16 bits failed the gradient gates, 24 bits gained
+//   nothing -- DESIGN.md section 8 keeps the numbers; the kernel's BFP = 2 / 3 instantiations are no longer built.)
 static int stream_bfp() {
-    static const int bfp = [] { const char* e = getenv("CCST_CONV_BF"); const int v = e ? atoi(e) : 4; return (v == 2 || v == 3 || v == 4) ? v : 0; }();
+    static const int bfp = [] { const char* e = getenv("CCST_CONV_BF"); const int v = e ? atoi(e) : 4; return v == 4 ? 4 : 0; }();
     return bfp;
 }
 static int stream_grid(int M, int cout) {
     const int tilesN = cout / 64, ntiles = ((M + 63) / 64) * tilesN;
-    const int slots = stream_bfp() == 3 ? 768 : 1024;          // three pieces: 53 KB of LDS per workgroup, three per CU
+    const int slots = 1024;
     const int cap = (slots / tilesN) * tilesN;
     return ntiles < cap ? ntiles : (cap > 0 ? cap : tilesN);
 }
@@ -1016,7 +1026,20 @@ struct BnLink {
 };
 }  // namespace
 static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w_packed, const float* bias, float* y, float* stats,
-                           void* stream, const unsigned char* relu_mask, const BnLink* bn);
+                           void* stream, const unsigned char* relu_mask, const BnLink* bn, const uint32_t* xmax = nullptr,
+                           const uint32_t* wmax = nullptr);
+
+// ccst_conv2d_igemm_stats_f32 with the |max| words of x and of the OIHW weight (include/ccst_hip.h, CCST_ABSMAX_WORDS): where the problem
+// runs on the streaming pointwise kernel, its products are formed from two IEEE-half pieces per operand on the 16-bit MFMA (1.43x the fp32
+// MFMA on the ResNet50 pointwise shapes at its accuracy), both operands scaled by powers of two derived from the words on the device --
+// range-safe at any fp32 magnitude.  Without the words (ccst_conv2d_igemm_stats_f32) the fp32 MFMA runs.  CCST_CONV_BF=0: fp32 always.
+extern "C" int ccst_conv2d_igemm_stats_scaled_f32(const CcstConvDesc* d, const float* x, const uint32_t* x_absmax, const float* w_packed,
+                                                  const uint32_t* w_absmax, const float* bias, float* y, float* stats, void* stream) {
+    CCST_REQUIRE(stats != nullptr, "conv_stats_scaled: null stats buffer");
+    CCST_REQUIRE(x_absmax && w_absmax, "conv_stats_scaled: the |max| words of x and w");
+    CCST_REQUIRE(d && !(d->flags & (CCST_CONV_POOL2 | CCST_CONV_RELU)), "conv_stats_scaled: statistics are of the raw conv output (no ReLU / pool)");
+    return conv_igemm_impl(d, x, w_packed, bias, y, stats, stream, nullptr, nullptr, x_absmax, w_absmax);
+}
 
 extern "C" int ccst_conv2d_igemm_accum_masked_f32(const CcstConvDesc* d, const float* x, const float* w_packed, float* y,
                                                   const uint8_t* relu_mask, const float* bn_x, const float* bn_mean,
@@ -1045,7 +1068,7 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
 }
 
 static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w_packed, const float* bias, float* y, float* stats,
-                           void* stream, const unsigned char* relu_mask, const BnLink* bn) {
+                           void* stream, const unsigned char* relu_mask, const BnLink* bn, const uint32_t* xmax, const uint32_t* wmax) {
     CCST_REQUIRE(d && x && w_packed && y, "conv: null pointer");
     CCST_REQUIRE(d->cin > 0 && d->cin % CK_MIN == 0, "conv: cin=%d must be a positive multiple of 16", d->cin);
     CCST_REQUIRE(d->cout > 0 && d->cout_pad >= d->cout && d->cout_pad % 128 == 0, "conv: cout=%d cout_pad=%d (need multiple of 128)",
@@ -1077,6 +1100,7 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
     a.rmask = relu_mask;
     a.bn_x = bn ? bn->x : nullptr; a.bn_mean = bn ? bn->mean : nullptr; a.bn_invstd = bn ? bn->invstd : nullptr; a.bn_part = bn ? bn->part : nullptr;
     a.bn_gamma = bn ? bn->gamma : nullptr; a.bn_beta = bn ? bn->beta : nullptr;
+    a.xmax = xmax; a.wmax = wmax;
     hipStream_t s = (hipStream_t)stream;
     // pointwise input: dense, or a strided 1x1 without padding (the downsample branches: pixel (oy*ay, ox*ax) is always inside)
     const bool pw_in = (a.flags & CONV_DENSE_IN) ||
@@ -1090,13 +1114,12 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
         const bool acc = (a.flags & CCST_CONV_ACCUM) != 0;
         if (relu_mask) CCST_REQUIRE(acc && !stats, "conv: the ReLU mask goes with CCST_CONV_ACCUM (the sum is masked)");
         if (bn) CCST_REQUIRE(!stats && ((acc && relu_mask) || (!acc && bn->gamma)), "conv: BatchNorm link without its masked form");
-        const int bfp = stream_bfp();
-        const bool fwd_form = stats != nullptr;         // half pieces: the training forward only (the plain form also serves backward-data)
+        // half pieces: the training forward (the form with the statistics epilogue) and only where the caller passed the |max| words of
+        // both operands -- without them nothing bounds the operands, and the fp32 MFMA runs
+        const bool halfp = stream_bfp() == 4 && stats != nullptr && xmax != nullptr && wmax != nullptr;
 #define CCST_STREAM(...)                                                                                                     \
     do {                                                                                                                     \
-        if (bfp == 4 && fwd_form) hipLaunchKernelGGL((conv1x1_stream_kernel<__VA_ARGS__, 4>), dim3(grid), dim3(256), 0, s, a, ntiles); \
-        else if (bfp == 3) hipLaunchKernelGGL((conv1x1_stream_kernel<__VA_ARGS__, 3>), dim3(grid), dim3(256), 0, s, a, ntiles); \
-        else if (bfp == 2) hipLaunchKernelGGL((conv1x1_stream_kernel<__VA_ARGS__, 2>), dim3(grid), dim3(256), 0, s, a, ntiles); \
+        if (halfp) hipLaunchKernelGGL((conv1x1_stream_kernel<__VA_ARGS__, 4>), dim3(grid), dim3(256), 0, s, a, ntiles);      \
         else hipLaunchKernelGGL((conv1x1_stream_kernel<__VA_ARGS__, 0>), dim3(grid), dim3(256), 0, s, a, ntiles);            \
     } while (0)
         if (stats) CCST_STREAM(true, false, 0, false);

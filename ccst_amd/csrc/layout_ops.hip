@@ -150,6 +150,24 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     ccst_absmax_publish(slots, m, blockIdx.x * 4u + (threadIdx.x >> 6));
 }
 
+// The |max| words of n tensors in ONE launch (the pointwise conv weights of a ResNet after an optimiser step): table [n][2] int64 =
+// (device pointer, element count), words [n][CCST_ABSMAX_WORDS] zeroed by the caller; blockIdx.y = tensor.
+__global__ __launch_bounds__(256) void absmax_batch_kernel(const long long* __restrict__ table, unsigned* __restrict__ words) {
+    const float* x = reinterpret_cast<const float*>(table[2 * blockIdx.y]);
+    const long long n = table[2 * blockIdx.y + 1], n4 = n >> 2;
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+        m = fmaxf(fmaxf(fmaxf(m, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
+        if (v[0] != v[0] || v[1] != v[1] || v[2] != v[2] || v[3] != v[3]) m = __builtin_nanf("");
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {
+        const float v = x[(n4 << 2) + threadIdx.x];
+        m = (v != v) ? v : fmaxf(m, fabsf(v));
+    }
+    ccst_absmax_publish(words + (long long)blockIdx.y * CCST_ABSMAX_WORDS, m, blockIdx.x * 4u + (threadIdx.x >> 6));
+}
+
 }  // namespace
 
 extern "C" int ccst_absmax_f32(const float* x, int64_t n, uint32_t* absmax, void* stream) {
@@ -160,6 +178,12 @@ extern "C" int ccst_absmax_f32(const float* x, int64_t n, uint32_t* absmax, void
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks < cap ? blocks : cap))), dim3(256), 0, (hipStream_t)stream, x,
                        (long long)n, absmax);
     return ccst_launch_status("absmax");
+}
+
+extern "C" int ccst_absmax_batch_f32(const int64_t* table, int n, uint32_t* absmax, void* stream) {
+    CCST_REQUIRE(table && absmax && n > 0 && n <= 65535, "absmax_batch: bad args");
+    hipLaunchKernelGGL(absmax_batch_kernel, dim3(16, (unsigned)n), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const long long*>(table), absmax);
+    return ccst_launch_status("absmax_batch");
 }
 
 

@@ -201,8 +201,9 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ beta, const float* __restrict__ rmean,
                                                        const float* __restrict__ rvar, float eps, const float* __restrict__ residual,
                                                        int relu, float* __restrict__ y, long long total4, int C,
-                                                       unsigned char* __restrict__ rmask = nullptr) {
+                                                       unsigned char* __restrict__ rmask = nullptr, unsigned* __restrict__ ymax = nullptr) {
     const int cg = C / 4;
+    float amax = 0.f;          // ymax: the largest |y| this thread writes (the half-piece pointwise conv that reads y scales by it)
     for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total4; i += (long long)gridDim.x * TPB) {
         const int c = (int)(i % cg) * 4;
         f32x4 sc, sh;
@@ -226,8 +227,10 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
         }
+        amax = fmaxf(fmaxf(fmaxf(amax, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
         *reinterpret_cast<f32x4*>(y + i * 4) = v;
     }
+    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, blockIdx.x * (TPB / 64) + (threadIdx.x >> 6));
 }
 
 template <int NCH>
@@ -290,8 +293,10 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void bn_relu_maxpool_fwd_kernel(const f32x4* __restrict__ x, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, f32x4* __restrict__ y,
-                                                                  unsigned* __restrict__ idx, int N, int H, int W, int C4, int Ho, int Wo) {
+                                                                  unsigned* __restrict__ idx, int N, int H, int W, int C4, int Ho, int Wo,
+                                                                  unsigned* __restrict__ ymax) {
     const long long total = (long long)N * Ho * Wo * C4;
+    float amax = 0.f;
     for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
         const int c = (int)(i % C4);
         long long j = i / C4;
@@ -323,8 +328,10 @@ __global__ __launch_bounds__(TPB) void bn_relu_maxpool_fwd_kernel(const f32x4* _
             }
         }
         y[i] = best;
+        amax = fmaxf(fmaxf(fmaxf(amax, fabsf(best[0])), fmaxf(fabsf(best[1]), fabsf(best[2]))), fabsf(best[3]));
         idx[i] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
     }
+    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, blockIdx.x * (TPB / 64) + (threadIdx.x >> 6));
 }
 
 // gradient of the pooling INPUT pixel (n, iy, ix), channel group c, gathered from the pooled gradient (as maxpool3s2_bwd_kernel)
@@ -684,7 +691,7 @@ extern "C" int64_t ccst_bn_workspace_bytes(int64_t M, int C) {
 extern "C" int ccst_bn_train_fwd_mask_f32(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                                           float momentum, float eps, const float* residual, int relu, float* y, uint8_t* relu_mask,
                                           float* save_mean, float* save_invstd, int64_t M, int C, const float* stats_in, int stats_groups,
-                                          void* ws, int64_t ws_bytes, void* stream) {
+                                          void* ws, int64_t ws_bytes, uint32_t* y_absmax, void* stream) {
     CCST_REQUIRE(!relu_mask || relu, "bn_train_fwd: a ReLU mask needs relu=1");
     CCST_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && ws, "bn_train_fwd: null pointer");
     CCST_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_train_fwd: need M>0 and C %% 4 == 0 (C=%d)", C);
@@ -716,7 +723,7 @@ extern "C" int ccst_bn_train_fwd_mask_f32(const float* x, const float* gamma, co
                            running_var, momentum, eps, save_mean, save_invstd, scale, shift, (long long)M, C, S);
     const long long total4 = (long long)M * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(TPB), 0, st, x, scale, shift, nullptr, nullptr, nullptr, nullptr,
-                       eps, residual, relu, y, total4, C, relu_mask);
+                       eps, residual, relu, y, total4, C, relu_mask, y_absmax);
     return ccst_launch_status("bn_train_fwd");
 }
 
@@ -725,7 +732,7 @@ extern "C" int ccst_bn_train_fwd_f32(const float* x, const float* gamma, const f
                                      float* save_invstd, int64_t M, int C, const float* stats_in, int stats_groups, void* ws,
                                      int64_t ws_bytes, void* stream) {
     return ccst_bn_train_fwd_mask_f32(x, gamma, beta, running_mean, running_var, momentum, eps, residual, relu, y, nullptr, save_mean,
-                                      save_invstd, M, C, stats_in, stats_groups, ws, ws_bytes, stream);
+                                      save_invstd, M, C, stats_in, stats_groups, ws, ws_bytes, nullptr, stream);
 }
 
 extern "C" int ccst_bn_eval_fwd_f32(const float* x, const float* gamma, const float* beta, const float* running_mean,
@@ -812,7 +819,8 @@ extern "C" int ccst_bn_train_bwd_f32(const float* dy, const float* x, const floa
 extern "C" int ccst_bn_relu_maxpool_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
                                                   float* running_var, float momentum, float eps, float* y_pooled, uint32_t* idx,
                                                   float* save_mean, float* save_invstd, int N, int H, int W, int C, int Ho, int Wo,
-                                                  const float* stats_in, int stats_groups, void* ws, int64_t ws_bytes, void* stream) {
+                                                  const float* stats_in, int stats_groups, void* ws, int64_t ws_bytes, uint32_t* y_absmax,
+                                                  void* stream) {
     CCST_REQUIRE(x && gamma && beta && y_pooled && idx && save_mean && save_invstd && ws, "bn_relu_maxpool_fwd: null pointer");
     CCST_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "bn_relu_maxpool_fwd: bad extents");
     CCST_REQUIRE(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, "bn_relu_maxpool_fwd: Ho/Wo must be floor((H+2-3)/2)+1");
@@ -845,7 +853,7 @@ extern "C" int ccst_bn_relu_maxpool_train_fwd_f32(const float* x, const float* g
                            running_var, momentum, eps, save_mean, save_invstd, scale, shift, (long long)M, C, S);
     const long long total = (long long)N * Ho * Wo * (C / 4);
     hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(grid_for(total)), dim3(TPB), 0, st, (const f32x4*)x, scale, shift, (f32x4*)y_pooled, idx,
-                       N, H, W, C / 4, Ho, Wo);
+                       N, H, W, C / 4, Ho, Wo, y_absmax);
     return ccst_launch_status("bn_relu_maxpool_fwd");
 }
 

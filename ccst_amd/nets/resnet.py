@@ -52,6 +52,10 @@ class Conv2d(nn.Conv2d):
     def packed_t(self):
         return self._cached("pkt", lambda w, prev: ops.pack_conv_weight(w, transpose=True, out=self._reuse(prev)))
 
+    def wabsmax(self):
+        """|max| words of the weight (ops.absmax); after the first optimiser step the batched side-stream refresh keeps them current."""
+        return self._cached("wmax", lambda w, prev: ops.absmax(w))
+
     def wino_ok(self, H, W):
         return self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and \
             ops.wino_train_ok(H, W, self.in_channels, self.out_channels)
@@ -116,7 +120,8 @@ class Conv2d(nn.Conv2d):
             ok = (link.mask is not None and sink is not None and not sink.pair) or (link.mask is None and sink is None and sole_reader)
             link = link if ok else None
         if want_stats:
-            y, stats = nn_ops.ConvFn.apply(_to_nhwc(x), self.weight, self, True, sink, link)
+            # (the |max| words a BatchNorm apply left for x travel with the NHWC view: the half-piece pointwise forward scales by them)
+            y, stats = nn_ops.ConvFn.apply(ops.carry_absmax(x, _to_nhwc(x)), self.weight, self, True, sink, link)
             return ops.to_api(y), stats
         return ops.to_api(nn_ops.ConvFn.apply(_to_nhwc(x), self.weight, self, False, sink, link))
 
@@ -133,7 +138,7 @@ class BatchNorm2d(nn.BatchNorm2d):
         self._ccst_mask_link = None
         y = nn_ops.BNFn.apply(_to_nhwc(x), self.weight, self.bias, res, self, bool(relu), stats if self.training else None,
                               sink if self.training else None)
-        out = ops.to_api(y)
+        out = ops.carry_absmax(y, ops.to_api(y))
         if self._ccst_mask_link is not None:        # travels with the block output to the next block's first conv
             out._ccst_mask_link, self._ccst_mask_link = self._ccst_mask_link, None
         return out
@@ -346,7 +351,8 @@ class ResNet(nn.Module):
         if FUSED_STEM and bn.training and torch.is_grad_enabled() and isinstance(bn, BatchNorm2d) and isinstance(mp, MaxPool2d) and bn.affine \
                 and (mp.kernel_size, mp.stride, mp.padding, mp.ceil_mode) == (3, 2, 1, False):
             y, stats = self.conv1(x, want_stats=True)
-            return ops.to_api(nn_ops.StemBnReluPoolFn.apply(_to_nhwc(y), bn.weight, bn.bias, bn, stats))
+            yp = nn_ops.StemBnReluPoolFn.apply(_to_nhwc(y), bn.weight, bn.bias, bn, stats)
+            return ops.carry_absmax(yp, ops.to_api(yp))
         return mp(conv_bn(self.conv1, bn, x, relu=True))
 
     def _apply(self, fn, *a, **k):

@@ -66,16 +66,23 @@ def _on_side_stream(device, tensors, fn):
 
 
 _PREPACK_PENDING = set()
+# The pointwise convs' TRAINING FORWARD on two IEEE-half pieces per operand (16-bit MFMA; conv_igemm.hip, CCST_CONV_BF=4): the
+# BatchNorm applies leave max |y| in device words, the convs scale both operands by powers of two derived from them and from the
+# weight's words (refreshed with the packed weights after each optimiser step) -- range-safe, no host synchronisation.  CCST_CONV_BF=0
+# turns the words off as well (fp32 MFMA everywhere).
+HALF_FWD = _os.environ.get("CCST_CONV_BF", "4") == "4"
 
 
 def _prepack_jobs(model, convs):
     """Device tables for the batched re-pack launches covering every packed copy the model's convs hold: the direct
     layouts (ccst_pack_conv_weights_batch_f32) and the Winograd transforms (ccst_pack_conv_weights_wino_batch_f32).  Rebuilt
     only if a weight or a packed buffer moved (the key is the tuple of their addresses)."""
-    slots, wslots, w4slots = [], [], []
+    slots, wslots, w4slots, mslots = [], [], [], []
     for m in convs:
         if m.in_channels <= 4:
             continue
+        if m.__dict__.get("_ccst_wmax") is not None:          # the weight's |max| words (pointwise convs that ran the half-piece forward)
+            mslots.append(m)
         for name, transpose in (("_ccst_pk", 0), ("_ccst_pkt", 1)):
             slot = m.__dict__.get(name)
             if slot is not None:
@@ -89,10 +96,10 @@ def _prepack_jobs(model, convs):
             if slot is not None:
                 w4slots.append((m, name, slot[1], bwd))
     sig = tuple((m.weight.data_ptr(), pc.w.data_ptr()) for m, _n, pc, _t in slots) + \
-        tuple((m.weight.data_ptr(), pk[0].data_ptr()) for m, _n, pk, _b in wslots + w4slots)
+        tuple((m.weight.data_ptr(), pk[0].data_ptr()) for m, _n, pk, _b in wslots + w4slots) + tuple(("wmax", m.weight.data_ptr()) for m in mslots)
     cached = model.__dict__.get("_ccst_prepack_jobs")
     if not slots and not wslots and not w4slots:
-        return (sig, None, slots, None, wslots, None, w4slots)
+        return (sig, None, slots, None, wslots, None, w4slots, None, None, mslots)
     if cached is None or cached[0] != sig:
         dev = (slots or wslots or w4slots)[0][0].weight.device
         table = wtable = w4table = None
@@ -112,7 +119,11 @@ def _prepack_jobs(model, convs):
                 n_in = m.out_channels if bwd else m.in_channels
                 rows.append([m.weight.data_ptr(), u.data_ptr(), n_out, n_in, (n_in + 15) // 16 * 16, pad, bwd, 0])
             w4table = torch.tensor(rows, dtype=torch.int64).to(dev)
-        cached = (sig, table, slots, wtable, wslots, w4table, w4slots)
+        mtable = mwords = None
+        if mslots:      # one batched |max| launch over the pointwise weights, into one [n, ABSMAX_WORDS] block (zeroed per step)
+            mtable = torch.tensor([[m.weight.data_ptr(), m.weight.numel()] for m in mslots], dtype=torch.int64).to(dev)
+            mwords = torch.zeros((len(mslots), ops.ABSMAX_WORDS), device=dev, dtype=torch.int32)
+        cached = (sig, table, slots, wtable, wslots, w4table, w4slots, mtable, mwords, mslots)
         model.__dict__["_ccst_prepack_jobs"] = cached
     return cached
 
@@ -126,7 +137,7 @@ def prepack_on_side(model):
     if not convs:
         return
     device = convs[0].weight.device
-    _sig, table, slots, wtable, wslots, w4table, w4slots = _prepack_jobs(model, convs)
+    _sig, table, slots, wtable, wslots, w4table, w4slots, mtable, mwords, mslots = _prepack_jobs(model, convs)
     if table is None and wtable is None and w4table is None:
         return
 
@@ -138,6 +149,9 @@ def prepack_on_side(model):
             check(lib.ccst_pack_conv_weights_wino_batch_f32(ptr(wtable), len(wslots), stream_ptr()), "pack_weights_wino_batch")
         if w4table is not None:
             check(lib.ccst_pack_conv_weights_wino4w_batch_f32(ptr(w4table), len(w4slots), stream_ptr()), "pack_weights_wino4w_batch")
+        if mtable is not None:
+            check(lib.ccst_fill_f32(ptr(mwords), 0.0, mwords.numel(), stream_ptr()), "zero weight |max| words")
+            check(lib.ccst_absmax_batch_f32(ptr(mtable), len(mslots), ptr(mwords), stream_ptr()), "absmax_batch")
     if SIDE_STREAM:
         side = _side_stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
@@ -149,6 +163,9 @@ def prepack_on_side(model):
     for m, name, pk, _t in slots + wslots + w4slots:           # the packed copies now match the weights of this epoch
         w = m.weight
         m.__dict__[name] = ((w._version, w.data_ptr(), ops.WEIGHTS_EPOCH), pk)
+    for i, m in enumerate(mslots):
+        w = m.weight
+        m.__dict__["_ccst_wmax"] = ((w._version, w.data_ptr(), ops.WEIGHTS_EPOCH), mwords[i])
 
 
 def join_prepack(device):
@@ -358,7 +375,11 @@ class ConvFn(torch.autograd.Function):
             elif ctx.wino:
                 y, stats = ops.conv3x3_wino_train(x, mod.wino_fwd(), want_stats=True)
             else:
-                y, stats = ops.conv2d_nhwc(x, pc, stride=mod.stride[0], pad=mod.padding[0], want_stats=True)
+                # pointwise convs: half pieces on the 16-bit MFMA where the producer of x (a BatchNorm apply) left its |max| words and
+                # the weight's are at hand (refreshed with the packed weights after every optimiser step) -- else the fp32 MFMA
+                xmax = ops.tagged_absmax(x) if (HALF_FWD and mod.kernel_size == (1, 1)) else None
+                y, stats = ops.conv2d_nhwc(x, pc, stride=mod.stride[0], pad=mod.padding[0], want_stats=True, x_absmax=xmax,
+                                           w_absmax=mod.wabsmax() if xmax is not None else None)
             ctx.mark_non_differentiable(stats)
             return y, stats
         if ctx.wino4:
@@ -486,6 +507,7 @@ class BNFn(torch.autograd.Function):
         M = N * H * W
         y = torch.empty_like(x)
         if mod.training:
+            ymax = ops.absmax_words(x.device) if HALF_FWD else None       # max |y| for a half-piece pointwise conv that reads y
             save = torch.empty((2, C), device=x.device, dtype=torch.float32)
             nb = int(lib.ccst_bn_workspace_bytes(M, C))
             ws = _workspace(nb, x.device)
@@ -499,8 +521,10 @@ class BNFn(torch.autograd.Function):
             check(lib.ccst_bn_train_fwd_mask_f32(ptr(x), ptr(gamma), ptr(beta), ptr(mod.running_mean if track else None),
                                                  ptr(mod.running_var if track else None), float(mod.momentum), float(mod.eps),
                                                  ptr(residual), int(relu), ptr(y), ptr(mask), ptr(save[0]), ptr(save[1]), M, C, ptr(stats),
-                                                 0 if stats is None else int(stats.shape[0]), ptr(ws), ws.numel(), stream_ptr()),
+                                                 0 if stats is None else int(stats.shape[0]), ptr(ws), ws.numel(), ptr(ymax), stream_ptr()),
                   "bn_train_fwd")
+            if ymax is not None:
+                ops.tag_absmax(y, ymax)
             keep_y = ctx.relu and mask is None and (ctx.has_res or BN_MASK_FROM_Y)
             ctx.save_for_backward(x, y if keep_y else None, mask, gamma, beta, save)
             if mask is not None and MASK_LINK:
@@ -567,11 +591,14 @@ class StemBnReluPoolFn(torch.autograd.Function):
         save = torch.empty((2, C), device=x.device, dtype=torch.float32)
         ws = _workspace(int(lib.ccst_bn_workspace_bytes(M, C)), x.device)
         track = mod.track_running_stats and mod.running_mean is not None
+        ymax = ops.absmax_words(x.device) if HALF_FWD else None
         check(lib.ccst_bn_relu_maxpool_train_fwd_f32(ptr(x), ptr(gamma), ptr(beta), ptr(mod.running_mean if track else None),
                                                      ptr(mod.running_var if track else None), float(mod.momentum), float(mod.eps), ptr(y), ptr(idx),
                                                      ptr(save[0]), ptr(save[1]), N, H, W, C, Ho, Wo, ptr(stats),
-                                                     0 if stats is None else int(stats.shape[0]), ptr(ws), ws.numel(), stream_ptr()),
+                                                     0 if stats is None else int(stats.shape[0]), ptr(ws), ws.numel(), ptr(ymax), stream_ptr()),
               "bn_relu_maxpool_fwd")
+        if ymax is not None:
+            ops.tag_absmax(y, ymax)
         ctx.save_for_backward(x, idx, gamma, beta, save)
         return y
 

@@ -190,12 +190,15 @@ def _conv_kernel_name(cout, pool, M, cin, taps=1):
     return "conv_igemm_kernel<%s,%s,%s%s%s>" % (t[0], t[1], t[2], small, ",pool" if pool else "")
 
 
-def _launch_conv(d, x, pc, out, flops, pool, what, stats=None):
+def _launch_conv(d, x, pc, out, flops, pool, what, stats=None, x_absmax=None, w_absmax=None):
     lib = _lib.load()
 
     def call():
         if stats is None:
             check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(x), ptr(pc.w), ptr(pc.bias), ptr(out), stream_ptr()), what)
+        elif x_absmax is not None and w_absmax is not None:      # (pointwise problems: half pieces on the 16-bit MFMA, scaled by the words)
+            check(lib.ccst_conv2d_igemm_stats_scaled_f32(ctypes.byref(d), ptr(x), ptr(x_absmax), ptr(pc.w), ptr(w_absmax), ptr(pc.bias),
+                                                         ptr(out), ptr(stats), stream_ptr()), what)
         else:
             check(lib.ccst_conv2d_igemm_stats_f32(ctypes.byref(d), ptr(x), ptr(pc.w), ptr(pc.bias), ptr(out), ptr(stats),
                                                   stream_ptr()), what)
@@ -392,6 +395,14 @@ def tag_absmax(t, words):
     return t
 
 
+def carry_absmax(src, dst):
+    """dst is a view of src (to_api / from_api permutes): its |max| words are the same."""
+    words = tagged_absmax(src)
+    if words is not None:
+        tag_absmax(dst, words)
+    return dst
+
+
 def tagged_absmax(t):
     tag = getattr(t, "_ccst_absmax", None)
     return tag[0] if tag is not None and tag[1] == t._version else None
@@ -444,7 +455,7 @@ def conv3x3_f23(x, pc, flags, sums=False, x_absmax=None, y_absmax=None):
     if sums:
         if pool:
             raise ValueError("ccst_amd.ops: the statistics epilogue is of the un-pooled output")
-        part = torch.empty((int(lib.ccst_conv3x3_f23_tiles(N, Hi, Wi)), pc.cout, 2), device=x.device, dtype=torch.float32)
+        part = torch.empty((int(lib.ccst_conv3x3_f23_tiles(N, Hi, Wi)), pc.cout, 4), device=x.device, dtype=torch.float32)
     args = (ptr(x), ptr(x_absmax), ptr(pc.uf23), ptr(pc.wabsmax), ptr(pc.bias), ptr(out), ptr(y_absmax), N, Hi, Wi, Cx, pc.cout, pc.n_pad, flags,
             ptr(part), stream_ptr())
     if TIMING is None:
@@ -476,7 +487,7 @@ def conv3x3_halo_split(x, pc, flags, sums=False, x_absmax=None, y_absmax=None):
     if sums:
         if pool:
             raise ValueError("ccst_amd.ops: the statistics epilogue is of the un-pooled output")
-        part = torch.empty((int(lib.ccst_conv3x3_halo_split_tiles(N, Hi, Wi)), pc.cout, 2), device=x.device, dtype=torch.float32)
+        part = torch.empty((int(lib.ccst_conv3x3_halo_split_tiles(N, Hi, Wi)), pc.cout, 4), device=x.device, dtype=torch.float32)
     args = (ptr(x), ptr(x_absmax), ptr(pc.wsplit), ptr(pc.wabsmax), ptr(pc.bias), ptr(out), ptr(y_absmax), N, Hi, Wi, Cx, pc.cout, pc.n_pad, flags,
             ptr(part), stream_ptr())
     if TIMING is None:
@@ -553,15 +564,15 @@ def conv3x3_wino4(x, pc, flags=0, narrow=None, sums=False):
 
 def chan_sums_finalize(partials):
     """[K, C, 2] per-tile (sum, sum of squares) pairs -> ([1,C,1,1] sum, [1,C,1,1] sqsum), folded in fp64 in a fixed order."""
-    K, C, _ = partials.shape
+    K, C, F = partials.shape
     s = torch.empty((1, C, 1, 1), device=partials.device, dtype=torch.float32)
     q = torch.empty((1, C, 1, 1), device=partials.device, dtype=torch.float32)
     if TIMING is None:
-        check(_lib.load().ccst_chan_sums_finalize_f32(ptr(partials), K, C, ptr(s), ptr(q), stream_ptr()), "chan_sums_finalize")
+        check(_lib.load().ccst_chan_sums_finalize_f32(ptr(partials), F, K, C, ptr(s), ptr(q), stream_ptr()), "chan_sums_finalize")
     else:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(_lib.load().ccst_chan_sums_finalize_f32(ptr(partials), K, C, ptr(s), ptr(q), stream_ptr()), "chan_sums_finalize")
+        check(_lib.load().ccst_chan_sums_finalize_f32(ptr(partials), F, K, C, ptr(s), ptr(q), stream_ptr()), "chan_sums_finalize")
         e1.record()
         TIMING.append(("chan_sums_finalize", 0.0, e0, e1, "k%d c%d bytes%d" % (K, C, 8 * K * C)))
     return s, q
@@ -576,7 +587,7 @@ def wino4w_sums_ok(pc, stride, pad, pool, out_nchw):
 
 
 def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, ups=False, out_nchw=False, out=None,
-                want_stats=False, chan_sums=False, x_absmax=None, y_absmax=None):
+                want_stats=False, chan_sums=False, x_absmax=None, y_absmax=None, w_absmax=None):
     """Forward convolution of an NHWC tensor x [N,Hs,Ws,Cin_pad] with PackedConv pc.
 
     ups:  x is read through a nearest x2 upsample (logical input is [2Hs,2Ws]).
@@ -586,6 +597,8 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
                 conv epilogue for the following BatchNorm2d (returns (out, stats)).
     x_absmax / y_absmax: |max| words of x (from its producer) / zeroed words for max |out| -- used by the half-piece (SPLIT) kernel only;
                 a caller that passes y_absmax must check halo_split_wanted(pc) (other kernels leave the words untouched).
+    w_absmax (with want_stats and x_absmax): the |max| words of the OIHW weight -- a pointwise problem then runs on half pieces
+                (ccst_conv2d_igemm_stats_scaled_f32); without both word sets the fp32 MFMA runs.
     """
     _require_cuda(x, "activation")
     assert x.is_contiguous() and x.dim() == 4 and not pc.transpose
@@ -668,7 +681,8 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
         assert not (relu or pool or out_nchw), "statistics are of the raw dense NHWC conv output"
         groups = _lib.load().ccst_conv2d_igemm_stats_groups(N * ho * wo, pc.cout, pc.k_pad, pc.kh * pc.kw)
         stats = torch.empty((groups, pc.cout, 2), device=x.device, dtype=torch.float32)
-    _launch_conv(d, x, pc, out, 2.0 * N * ho * wo * pc.cout * pc.cin * pc.kh * pc.kw, pool, "conv2d_igemm", stats)
+    _launch_conv(d, x, pc, out, 2.0 * N * ho * wo * pc.cout * pc.cin * pc.kh * pc.kw, pool, "conv2d_igemm", stats,
+                 x_absmax if want_stats else None, w_absmax if want_stats else None)
     return (out, stats) if want_stats else out
 
 
@@ -919,8 +933,8 @@ def adain_from_tile_sums(feat, partials, style_mean, style_std, alpha=1.0, eps=1
         raise RuntimeError("ccst_amd: style statistics must have C or N*C elements")
     out = torch.empty_like(buf)
     amax = absmax_words(feat.device)      # the kernel leaves max |out|: the decoder's first half-piece conv scales by it
-    args = (ptr(buf), ptr(partials), int(partials.shape[0] // N), ptr(sm), ptr(ss), per_n, float(alpha), ptr(out), N, C, H * W, eps, None, None,
-            ptr(amax), stream_ptr())
+    args = (ptr(buf), ptr(partials), int(partials.shape[2]), int(partials.shape[0] // N), ptr(sm), ptr(ss), per_n, float(alpha), ptr(out), N, C, H * W,
+            eps, None, None, ptr(amax), stream_ptr())
     if TIMING is None:
         check(_lib.load().ccst_adain_tile_sums_f32(*args), "adain_tile_sums")
     else:       # bench.py: the AdaIN step of the path = this one launch; HBM-bound: algorithmic bytes = read x + write y

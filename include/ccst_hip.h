@@ -85,6 +85,12 @@ int ccst_conv2d_igemm_f32(const CcstConvDesc* d, const float* x, const float* w_
 int ccst_conv2d_igemm_stats_f32(const CcstConvDesc* d, const float* x, const float* w_packed,
                                 const float* bias, float* y, float* stats, void* stream);
 int ccst_conv2d_igemm_stats_groups(int M, int cout, int cin /* padded, d->cin */, int taps /* nky*nkx */);
+/* The same call with the |max| words (CCST_ABSMAX_WORDS, below) of x and of the OIHW weight: where the problem runs on the streaming
+ * pointwise kernel its products are formed from two IEEE-half pieces per operand on the 16-bit MFMA (22 significant bits; 1.43x the
+ * fp32 MFMA on the ResNet50 pointwise shapes), both operands scaled by powers of two derived from the words on the device -- safe at
+ * any fp32 magnitude; ccst_conv2d_igemm_stats_f32 (no words) runs the fp32 MFMA.  The training forward of nets/resnet.py's 1x1 convs. */
+int ccst_conv2d_igemm_stats_scaled_f32(const CcstConvDesc* d, const float* x, const uint32_t* x_absmax, const float* w_packed,
+                                       const uint32_t* w_absmax, const float* bias, float* y, float* stats, void* stream);
 
 /* 3x3 stride-1 "same" conv (reflection or zero padding) with the input halo staged once per 16-channel
  * chunk in LDS (A-side loads / LDS writes 9x fewer than the gather form): the AdaIN encoder/decoder
@@ -101,6 +107,9 @@ int ccst_conv3x3_halo_narrow(int N, int H, int W, int Cout);   /* 1: the 128x64 
  * producer (one pass over x) for tensors whose producer did not leave the words. */
 #define CCST_ABSMAX_WORDS 4096
 int ccst_absmax_f32(const float* x, int64_t n, uint32_t* absmax, void* stream);
+/* ... of n tensors in one launch: table [n][2] int64 = (device pointer, 16-byte aligned; element count), absmax [n][CCST_ABSMAX_WORDS]
+ * zeroed by the caller (the pointwise conv weights of a ResNet after each optimiser step, nets/resnet.py). */
+int ccst_absmax_batch_f32(const int64_t* table, int n, uint32_t* absmax, void* stream);
 
 /* The same convolution with every fp32 product computed as three products of 16-bit pieces on the half-precision MFMA (x = hi + lo,
  * hi = half(x), lo = half(x - hi): 22 significant bits; a b ~ a_lo b_hi + a_hi b_lo + a_hi b_hi, fp32 accumulation): 5.3x the fp32
@@ -128,14 +137,16 @@ int ccst_conv3x3_halo_split_f32(const float* x, const uint32_t* x_absmax, const 
 int ccst_pack_conv_weight_f23_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, const uint32_t* w_absmax, void* stream);
 int ccst_conv3x3_f23_f32(const float* x, const uint32_t* x_absmax, const float* u, const uint32_t* w_absmax, const float* bias, float* y,
                          uint32_t* y_absmax, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags,
-                         float* chan_sum_partials /* NULL, or [ccst_conv3x3_f23_tiles(N,H,W)][Cout][2] (sum, sum^2) of the un-pooled output
-                                                     per (8x32-pixel tile, wave row), an image's rows contiguous */,
+                         float* chan_sum_partials /* NULL, or [ccst_conv3x3_f23_tiles(N,H,W)][Cout][4] (sum, M2, count, 0) of the un-pooled
+                                                     output per (8x32-pixel tile, wave row), an image's rows contiguous */,
                          void* stream);
 int ccst_conv3x3_f23_workgroups(int N, int H, int W, int Cout);
 int ccst_conv3x3_f23_tiles(int N, int H, int W);
-/* chan_sum_partials (may be NULL; not with POOL2): [ccst_conv3x3_halo_split_tiles(N,H,W)][Cout][2] per-(8x16-pixel tile, wave row)
- * (sum, sum of squares) of the output after bias / ReLU, an image's rows contiguous -- the statistics ccst_adain_tile_sums_f32 and
- * ccst_chan_sums_finalize_f32 take instead of a pass over the tensor. */
+/* chan_sum_partials (may be NULL; not with POOL2): [ccst_conv3x3_halo_split_tiles(N,H,W)][Cout][4] per-(8x16-pixel tile, wave row)
+ * (sum, M2, count, 0) of the output after bias / ReLU, M2 = the sum of squares about the slab's OWN mean (no E[x^2] - mean^2
+ * cancellation however large |mean| / sigma is), an image's rows contiguous -- the statistics ccst_adain_tile_sums_f32 and
+ * ccst_chan_sums_finalize_f32 (partial_floats = 4) take instead of a pass over the tensor.  ccst_conv3x3_f23_f32 writes the same
+ * quadruples; ccst_conv3x3_wino4w_f32 writes (sum, sum of squares) pairs (partial_floats = 2). */
 int ccst_conv3x3_halo_split_tiles(int N, int H, int W);
 /* The same convolution as fused Winograd F(2x2,3x3) (16 multiplies per 2x2 output tile and input channel instead of
  * 36): transformed weights from ccst_pack_conv_weight_wino_f32 (ccst_wino_weight_floats(cin, cout_pad) floats,
@@ -180,7 +191,8 @@ int ccst_wino4w_spatial_tiles(int N, int H, int W);
  * up to 64, bwd, 0}. */
 int ccst_pack_conv_weight_wino4w_bwd_f32(const float* w_oihw, float* u, int cout, int cin, int cin_pad, void* stream);
 int ccst_pack_conv_weights_wino4w_batch_f32(const int64_t* jobs_device, int njobs, void* stream);
-int ccst_chan_sums_finalize_f32(const float* partials, int K, int C, float* sum, float* sqsum, void* stream);
+int ccst_chan_sums_finalize_f32(const float* partials, int partial_floats /* 2: (sum, sum^2) pairs; 4: (sum, M2, count, 0), see
+                                ccst_conv3x3_halo_split_f32 */, int K, int C, float* sum, float* sqsum, void* stream);
 /* The Winograd kernel for the ResNet trunk's 3x3 stride-1 zero-padded bias-free convs (forward with the BatchNorm statistics
  * epilogue, backward-data with the weights from ccst_pack_conv_weight_wino_bwd_f32 and x = dY, optional y += with
  * CCST_CONV_ACCUM).  stats: NULL or [ccst_conv3x3_wino_stats_groups(N,H,W)][Cout][2]. */
@@ -316,7 +328,8 @@ int ccst_adain_f32(const float* x, const float* style_mean, const float* style_s
  * ccst_conv3x3_wino4w_f32 writes into chan_sum_partials (tiles_per_image = ccst_wino4w_spatial_tiles(1, H, W)).  One launch, x read
  * once, no pass for the statistics: mean = S / HW, unbiased variance = (Q - S mean) / (HW - 1) folded in fp64.  C % 64 == 0.
  * mean_out / std_out: NULL, or [N*C] receiving the content statistics. */
-int ccst_adain_tile_sums_f32(const float* x, const float* partials, int tiles_per_image, const float* style_mean,
+int ccst_adain_tile_sums_f32(const float* x, const float* partials, int partial_floats /* 2 or 4, as ccst_chan_sums_finalize_f32 */,
+                             int tiles_per_image, const float* style_mean,
                              const float* style_std, int style_per_n, float alpha, float* y, int N, int C, int HW, float eps,
                              float* mean_out, float* std_out, uint32_t* y_absmax /* NULL or zeroed |max| words of y */, void* stream);
 /* CCST_OverallStyleTransfer.py:36-45, style_transfer's interpolation branch after the AdaIN of the K copies of one content image
@@ -360,7 +373,10 @@ int ccst_bn_train_bwd_f32(const float* dy, const float* x, const float* y, const
 int ccst_bn_train_fwd_mask_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
                                float* running_var, float momentum, float eps, const float* residual, int relu,
                                float* y, uint8_t* relu_mask, float* save_mean, float* save_invstd, int64_t M, int C,
-                               const float* stats_in, int stats_groups, void* ws, int64_t ws_bytes, void* stream);
+                               const float* stats_in, int stats_groups, void* ws, int64_t ws_bytes,
+                               uint32_t* y_absmax /* NULL, or zeroed |max| words (CCST_ABSMAX_WORDS) receiving max |y|: what the
+                                                     half-piece pointwise conv that reads y scales it by */,
+                               void* stream);
 int ccst_bn_train_bwd_mask_f32(const float* dy, const float* x, const float* y, const uint8_t* relu_mask,
                                const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                                int relu, float* dx, float* d_residual, float* dgamma, float* dbeta, int accumulate,
@@ -379,7 +395,8 @@ int64_t ccst_bn_workspace_bytes(int64_t M, int C);
 int ccst_bn_relu_maxpool_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
                                        float* running_var, float momentum, float eps, float* y_pooled, uint32_t* idx,
                                        float* save_mean, float* save_invstd, int N, int H, int W, int C, int Ho, int Wo,
-                                       const float* stats_in, int stats_groups, void* ws, int64_t ws_bytes, void* stream);
+                                       const float* stats_in, int stats_groups, void* ws, int64_t ws_bytes,
+                                       uint32_t* y_absmax /* NULL or zeroed |max| words of y_pooled */, void* stream);
 int ccst_bn_relu_maxpool_train_bwd_f32(const float* dy_pooled, const uint32_t* idx, const float* x, const float* gamma,
                                        const float* beta, const float* save_mean, const float* save_invstd, float* dx,
                                        float* dgamma, float* dbeta, int accumulate, int N, int H, int W, int C, int Ho, int Wo,

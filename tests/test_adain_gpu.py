@@ -41,6 +41,22 @@ def maxdiff(a, b):
     return float((a.detach().cpu().float() - b.detach().cpu().float()).abs().max())
 
 
+def _check_centred_partials(part, out, N):
+    """part [K, C, 4] = (sum, M2 about the slab's own mean, count, 0) per (tile slab, channel) of the NHWC tensor `out`, an image's
+    slabs contiguous: counts add up to the pixels, sums to the sums, M2 + sum^2 / count to the sums of squares -- per image."""
+    K, C, _ = part.shape
+    tpi = K // N
+    p64, o64 = part.double(), out.double()
+    for n in range(N):
+        q = p64[n * tpi:(n + 1) * tpi]
+        cnt, s1, m2 = q[:, :, 2], q[:, :, 0], q[:, :, 1]
+        assert bool((cnt.sum(0) == out.shape[1] * out.shape[2]).all()) and bool((q[:, :, 3] == 0).all())
+        s_ref, q_ref = o64[n].sum(dim=(0, 1)), (o64[n] ** 2).sum(dim=(0, 1))
+        assert float((s1.sum(0) - s_ref).abs().max()) < 1e-5 * max(1.0, float(s_ref.abs().max()))
+        raw = (m2 + torch.where(cnt > 0, s1 * s1 / cnt.clamp_min(1.0), torch.zeros_like(s1))).sum(0)
+        assert float((raw - q_ref).abs().max()) < 1e-5 * max(1.0, float(q_ref.abs().max()))
+
+
 def rnd(shape, seed, scale=1.0):
     return torch.from_numpy((np.random.RandomState(seed).standard_normal(shape) * scale).astype(np.float32))
 
@@ -892,13 +908,8 @@ def test_conv3x3_halo_split_vs_fp64(dev, case, reflect):
     assert torch.equal(out, ops.conv3x3_halo_split(x, pc, flags))
     if not pool:
         out2, part = ops.conv3x3_halo_split(x, pc, flags, sums=True)
-        assert torch.equal(out2, out) and part.shape[0] % N == 0 and part.shape[1] == Cout
-        tot = part.double().sum(0)
-        s_ref = torch.stack([out.double().sum(dim=(0, 1, 2)), (out.double() ** 2).sum(dim=(0, 1, 2))], dim=1)
-        assert float((tot - s_ref).abs().max()) < 1e-5 * max(1.0, float(s_ref.abs().max()))
-        tpi = part.shape[0] // N                                                 # an image's rows are contiguous
-        s0 = part[:tpi].double().sum(0)[:, 0]
-        assert float((s0 - out[0].double().sum(dim=(0, 1))).abs().max()) < 1e-5 * max(1.0, float(s0.abs().max()))
+        assert torch.equal(out2, out) and part.shape[0] % N == 0 and tuple(part.shape[1:]) == (Cout, 4)
+        _check_centred_partials(part, out, N)
 
 
 # ------------------------------------------------------------------ range safety of the half-piece (SPLIT) kernels
@@ -1081,13 +1092,8 @@ def test_conv3x3_f23_vs_fp64(dev, case, reflect):
     assert float((out - ops.conv3x3_halo_split(x, pc, flags)).abs().max()) < 6e-6 * max(1.0, float(ref.abs().max()))
     if not pool:       # the per-tile channel sums of the epilogue add up to the sums of the output, per image
         out2, part = ops.conv3x3_f23(x, pc, flags, sums=True)
-        assert torch.equal(out2, out) and part.shape[0] % N == 0 and part.shape[1] == Cout
-        tot = part.double().sum(0)
-        s_ref = torch.stack([out.double().sum(dim=(0, 1, 2)), (out.double() ** 2).sum(dim=(0, 1, 2))], dim=1)
-        assert float((tot - s_ref).abs().max()) < 1e-5 * max(1.0, float(s_ref.abs().max()))
-        tpi = part.shape[0] // N
-        s0 = part[:tpi].double().sum(0)[:, 0]
-        assert float((s0 - out[0].double().sum(dim=(0, 1))).abs().max()) < 1e-5 * max(1.0, float(s0.abs().max()))
+        assert torch.equal(out2, out) and part.shape[0] % N == 0 and tuple(part.shape[1:]) == (Cout, 4)
+        _check_centred_partials(part, out, N)
 
 
 @pytest.mark.parametrize("xscale", [1e-30, 1e-4, 3e4, 1e5, 1e30])
@@ -1135,3 +1141,39 @@ def test_style_transfer_goldens_on_f23(dev, nets, A, golden):
         assert maxdiff(out, ref) < TOL
     finally:
         ops.F23_FORCE = old
+
+
+@pytest.mark.parametrize("kernel", ["f23", "split"])
+def test_adain_tile_sums_with_large_channel_means(dev, kernel):
+    """the AdaIN step takes the content variance from the conv epilogue's per-tile sums; as raw fp32 (sum, sum of squares)
+    pairs the variance was lost once mean^2 >> var (relative error ~1e-7 mean^2 / var, clamped at zero).  The half-piece conv kernels
+    now leave (sum, M2 about the slab's own mean, count) and the fold is Chan's merge about a pivot: channels with |mean| / sigma ~ 1e3
+    (a bias of 1e3 on a small-weight conv) must normalise as the reference's two-pass var() does (function.py:26-33 in fp64)."""
+    from ccst_amd import ops
+    g = torch.Generator().manual_seed(41)
+    N, H, W, Cin, Cout = 2, 48, 80, 64, 128
+    x = torch.randn(N, H, W, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(dev)
+    b = torch.full((Cout,), 1000.0)
+    b[::2] = 0.5                                   # every other channel ordinary
+    pc = ops.pack_conv_weight(w, b.to(dev), wino=4)
+    fn = ops.conv3x3_f23 if kernel == "f23" else ops.conv3x3_halo_split
+    y, part = fn(x, pc, 1 | 8, sums=True)
+    feat = ops.to_api(y)
+    assert ops.adain_tile_sums_ok(feat, part)
+    sm = torch.randn(1, Cout, 1, 1, generator=g).to(dev)
+    ss = (torch.rand(1, Cout, 1, 1, generator=g) + 0.5).to(dev)
+    f64 = feat.double()
+    mu, var = f64.mean(dim=(2, 3), keepdim=True), f64.var(dim=(2, 3), keepdim=True)
+    assert float((mu.abs() / var.sqrt()).max()) > 500.0
+    got = ops.adain_from_tile_sums(feat, part, sm, ss, alpha=1.0)
+    ref = (f64 - mu) / (var + 1e-5).sqrt() * ss.double() + sm.double()
+    err = float((got.double() - ref).abs().max())
+    print("%s: |mean| / sigma up to %.0f, AdaIN error %.2e (output range %.1f)" % (kernel, float((mu.abs() / var.sqrt()).max()), err, float(ref.abs().max())))
+    assert err < 2e-3 * max(1.0, float(ref.abs().max())), err       # (x - mean itself carries fp32's 6e-5 at |x| = 1e3 and sigma ~ 1)
+    two_pass = ops.adain(feat, sm, ss, alpha=1.0)                   # the general two-pass kernel on the same features
+    assert float((got - two_pass).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max()))
+    # stage 1's raw sums come out of the same quadruples
+    s1, q1 = ops.chan_sums_finalize(part)
+    assert float((s1.double().reshape(-1) - f64.sum(dim=(0, 2, 3))).abs().max()) < 1e-5 * float(f64.sum(dim=(0, 2, 3)).abs().max())
+    assert float((q1.double().reshape(-1) - (f64 ** 2).sum(dim=(0, 2, 3))).abs().max()) < 1e-5 * float((f64 ** 2).sum(dim=(0, 2, 3)).abs().max())

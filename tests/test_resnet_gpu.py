@@ -95,6 +95,71 @@ def test_pointwise_conv_statistics(dev, cfg):
     assert float((tot[:, 1] - (r2 * r2).sum(0)).abs().max()) < 1e-4 * float((r2 * r2).sum(0).abs().max())
 
 
+@pytest.mark.parametrize("xscale,wscale", [(1.0, 1.0), (1e-6, 1.0), (3e4, 1.0), (1e5, 1000.0), (1e20, 1e-10), (1.0, 1e4)])
+def test_pointwise_conv_half_pieces_any_magnitude(dev, xscale, wscale):
+    """the pointwise training forward multiplies IEEE-half pieces; with round 3's fixed 2^8 weight scale and unscaled
+    activations |w| >= 256 or |x| >= 65504 became inf / NaN.  ccst_conv2d_igemm_stats_scaled_f32 scales both operands by powers of two
+    derived on the device from their |max| words: the result must be at the fp32 level at any magnitude (incl. weights of 1e4 and
+    activations of 1e5), and the BatchNorm statistics of its epilogue must be those of its output."""
+    from ccst_amd import ops
+    g = torch.Generator().manual_seed(31)
+    N, H, W, Cin, Cout = 4, 28, 28, 256, 128
+    x = (torch.randn(N, H, W, Cin, generator=g) * xscale).to(dev)
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) * (1.0 / Cin) ** 0.5 * wscale).to(dev)
+    pc = ops.pack_conv_weight(w)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu()).permute(0, 2, 3, 1)
+    y, st = ops.conv2d_nhwc(x, pc, want_stats=True, x_absmax=ops.absmax(x), w_absmax=ops.absmax(w))
+    y32, _ = ops.conv2d_nhwc(x, pc, want_stats=True)                       # (no words: the fp32 MFMA)
+    assert bool(torch.isfinite(y).all())
+    scale = float(ref.abs().max())
+    e16, e32 = float((y.double().cpu() - ref).abs().max()) / scale, float((y32.double().cpu() - ref).abs().max()) / scale
+    print("x scale %g, w scale %g: half pieces %.2e, fp32 MFMA %.2e of max |y|" % (xscale, wscale, e16, e32))
+    assert e16 < 4e-6, e16
+    tot = st.double().sum(0).cpu()
+    r2 = y.double().cpu().reshape(-1, Cout)
+    assert float((tot[:, 0] - r2.sum(0)).abs().max()) < 1e-4 * max(1e-30, float(r2.sum(0).abs().max()))
+    assert float((tot[:, 1] - (r2 * r2).sum(0)).abs().max()) < 1e-4 * float((r2 * r2).sum(0).abs().max())
+
+
+def test_resnet_step_runs_the_half_piece_forward_with_words(dev):
+    """In a train step every pointwise conv behind a BatchNorm gets the |max| words of its input (left by that BatchNorm's apply
+    kernel) and of its weight, and after an optimiser step the weight words are the batched side-stream refresh's."""
+    import types
+    from ccst_amd import fed, nn_ops, ops
+    from ccst_amd.nets import models
+    assert nn_ops.HALF_FWD
+    torch.manual_seed(3)
+    model = models.get_network("resnet50")(types.SimpleNamespace(dg_method=""), pretrained=False, classes=7).to(dev)
+    model.train()
+    opt, loss_fun = fed.SGD(model, lr=0.01), fed.CrossEntropyLoss()
+    x, y = torch.randn(2, 3, 222, 222, device=dev), torch.randint(0, 7, (2,), device=dev)
+    seen = []
+    real = ops.conv2d_nhwc
+
+    def spy(xx, pc, *a, **k):
+        if k.get("want_stats") and pc.kh == 1:
+            seen.append((k.get("x_absmax") is not None, k.get("w_absmax") is not None))
+        return real(xx, pc, *a, **k)
+    ops.conv2d_nhwc = spy
+    try:
+        for _ in range(2):
+            opt.zero_grad()
+            loss = loss_fun(model(x), y)
+            fed.backward(loss)
+            opt.step()
+    finally:
+        ops.conv2d_nhwc = real
+    torch.cuda.synchronize()
+    assert seen and all(a and b for a, b in seen), seen[:8]
+    conv = model.layer1[0].conv1
+    nn_ops.join_prepack(conv.weight.device)
+    torch.cuda.synchronize()
+    words = conv.__dict__["_ccst_wmax"][1]
+    got = float(torch.tensor(int(words.max()), dtype=torch.int32).view(torch.float32))
+    assert got == float(conv.weight.detach().abs().max()), (got, float(conv.weight.detach().abs().max()))
+    assert bool(torch.isfinite(loss))
+
+
 @pytest.mark.parametrize("shape", [(3, 28, 28, 128, 128), (2, 56, 56, 64, 64), (2, 14, 14, 256, 192), (1, 13, 19, 32, 48)])
 def test_halo_train_form_vs_gather(dev, shape):
     """ccst_conv3x3_halo_train_f32 (ResNet-trunk form of the halo kernel): forward + BN statistics, backward-data by

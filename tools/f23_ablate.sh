@@ -5,13 +5,12 @@ set -e
 cd "$(dirname "$0")/.."
 declare -A V=(
   [full]=""
-  [nobar]="-DF23A_NO_BARRIER"
-  [nob]="-DF23A_NO_STOREB -DF23A_NO_LOADB"
-  [noloadb]="-DF23A_NO_LOADB"
-  [nov]="-DF23A_NO_STOREV -DF23A_NO_LOADV"
-  [noloadv]="-DF23A_NO_LOADV"
+  [vm2]="-DF23A_VM_EXTRA=2"
+  [vm4]="-DF23A_VM_EXTRA=4"
+  [nolgkm]="-DF23A_NO_LGKM"
+  [nov]="-DF23A_NO_STOREV"
   [noread]="-DF23A_NO_READ"
-  [mfmaonly]="-DF23A_NO_STOREB -DF23A_NO_LOADB -DF23A_NO_STOREV -DF23A_NO_LOADV -DF23A_NO_READ -DF23A_NO_BARRIER"
+  [mfmaonly]="-DF23A_NO_STOREV -DF23A_NO_LOADB -DF23A_NO_LOADV -DF23A_NO_READ"
 )
 if [ "$1" = build ]; then
   for k in "${!V[@]}"; do tools/build_variant.sh f23_$k conv3x3_f23.hip ${V[$k]} >/dev/null & done
@@ -19,7 +18,7 @@ if [ "$1" = build ]; then
   ls build/variants/lib_f23_*.so
 else
   L=${2:-3}
-  for k in full nobar nob noloadb nov noloadv noread mfmaonly; do
+  for k in full vm2 vm4 nolgkm nov noread mfmaonly; do
     echo "== $k"
     CCST_HIP_LIB=$PWD/build/variants/lib_f23_$k.so F23_LAYER=$L python tools/f23_layers.py 20 2>&1 | grep -v amdgpu.ids | cut -c1-24,80-160
   done
