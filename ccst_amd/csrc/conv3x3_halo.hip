@@ -441,23 +441,40 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
             const int slab = ((n * p.tilesY + ty) * p.tilesX + tx) * WM + wm;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                float s1 = 0.f, s2 = 0.f, cnt = 0.f;
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int dy = 2 * (wm * MT + mt) + ((r & 3) >> 1), dx = 4 * (r >> 2) + (r & 1) + 2 * lh;
-                        const bool in = interior || (oy0 + dy < p.H && ox0 + dx < p.W);
-                        float v = in ? acc[mt][nt][r] : 0.f;
-                        if (relu) v = fmaxf(v, 0.f);
-                        s1 += v;
-                        s2 += v * v;
-                        cnt += in ? 1.f : 0.f;
-                    }
-                s1 += __shfl_xor(s1, 32, 64);
-                s2 += __shfl_xor(s2, 32, 64);
                 const int co = co0 + cw + nt * 32 + li;
-                if (SPLIT) {
+                if (!SPLIT) {
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int dy = 2 * (wm * MT + mt) + ((r & 3) >> 1), dx = 4 * (r >> 2) + (r & 1) + 2 * lh;
+                            float v = (interior || (oy0 + dy < p.H && ox0 + dx < p.W)) ? acc[mt][nt][r] : 0.f;
+                            if (relu) v = fmaxf(v, 0.f);
+                            s1 += v;
+                            s2 += v * v;
+                        }
+                    s1 += __shfl_xor(s1, 32, 64);
+                    s2 += __shfl_xor(s2, 32, 64);
+                    if (lh == 0 && co < p.Cout) {
+                        float* o = p.stats + ((long long)slab * p.Cout + co) * 2;
+                        o[0] = s1;
+                        o[1] = s2;
+                    }
+                } else {
+                    float s1 = 0.f, cnt = 0.f;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int dy = 2 * (wm * MT + mt) + ((r & 3) >> 1), dx = 4 * (r >> 2) + (r & 1) + 2 * lh;
+                            const bool inside = interior || (oy0 + dy < p.H && ox0 + dx < p.W);
+                            float v = acc[mt][nt][r];
+                            if (relu) v = fmaxf(v, 0.f);
+                            s1 += inside ? v : 0.f;
+                            cnt += inside ? 1.f : 0.f;
+                        }
+                    s1 += __shfl_xor(s1, 32, 64);
                     cnt += __shfl_xor(cnt, 32, 64);
                     const float mu = s1 / fmaxf(cnt, 1.f);
                     float m2 = 0.f;
@@ -473,10 +490,6 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
                         }
                     m2 += __shfl_xor(m2, 32, 64);
                     if (lh == 0 && co < p.Cout) *reinterpret_cast<f32x4*>(p.stats + ((long long)slab * p.Cout + co) * 4) = f32x4{s1, m2, cnt, 0.f};
-                } else if (lh == 0 && co < p.Cout) {
-                    float* o = p.stats + ((long long)slab * p.Cout + co) * 2;
-                    o[0] = s1;
-                    o[1] = s2;
                 }
             }
         }

@@ -364,6 +364,15 @@ def test_pools_linear_ce(dev):
         resnet.AvgPool2d(7, stride=1)(torch.zeros(1, 8, 3, 3, device=dev))      # fed: image_size < 193
 
 
+# Multiplier of the reference's OWN fp32-vs-fp64 difference that the gradient gates allow on top of 1e-3 of the tensor's largest
+# gradient.  Two fp32 evaluations differ by the sum of their rounding errors (>= 2 x), and single elements sit behind ~50 ReLU /
+# max-pool masks that a different rounding sequence flips.  Round 3 used 8 for both criteria; the default path's measured need is
+# printed by test_resnet50_full_size_step_vs_oracle (round 4, VERDICT r3 #8: element-wise 5.49 on layer3.4.conv2.weight, 2-norm 1.12 on
+# layer3.4.bn1.weight) and each gate is the smallest integer above its need plus a margin of one.
+NOISE_MULT = 7.0          # element-wise criteria (and the fixtures' 16-element gradient probes)
+NOISE_MULT_L2 = 3.0       # 2-norm of a whole gradient tensor
+
+
 def _model_case(dev, g, arch):
     """One train step vs the reference's own outputs (tests/golden/resnet*_step.npz).  Logits (eval, train, post-step) and
     the loss are held to BASELINE.json's 1e-3 flat: the fixture's weights are conditioned like a trained net (small closing-BN
@@ -404,7 +413,7 @@ def _model_case(dev, g, arch):
         if k.startswith("grad_abs/"):
             name = k[9:]
             got = float(named[name].grad.abs().sum())
-            assert abs(got - float(g[k])) < 1e-3 * float(g[k]) + 8.0 * float(g["noise/" + k]) + 1e-6, (name, got, float(g[k]))
+            assert abs(got - float(g[k])) < 1e-3 * float(g[k]) + NOISE_MULT * float(g["noise/" + k]) + 1e-6, (name, got, float(g[k]))
         if k.startswith("grad_head/"):
             name = k[10:]
             ref = torch.from_numpy(g[k])
@@ -414,7 +423,7 @@ def _model_case(dev, g, arch):
             # conditioning: 8x the reference's own fp32 error on these 16 elements, or 2x its worst fp32 error over the
             # whole tensor (the 16-element sample under-estimates it up to 36x: layer2.0.downsample.0.weight of resnet18
             # has 2.7e-5 on the head but 9.9e-4 over the tensor)
-            noise = max(8.0 * float(g["noise/" + k]), 2.0 * float(g["noise_full/grad/" + name]))
+            noise = max(NOISE_MULT * float(g["noise/" + k]), 2.0 * float(g["noise_full/grad/" + name]))
             assert d < 1e-3 * max(scale, float(ref.abs().max())) + noise + 1e-6, (name, d)
     opt.step()
     sd = model.state_dict()
@@ -471,21 +480,26 @@ def test_resnet50_full_size_step_vs_oracle(dev):
     loss = ce(logit, y.to(dev))
     loss.backward()
     # every one of the 161 gradient tensors, element by element and in the 2-norm, against the oracle's: within 1e-3 of the
-    # tensor's largest gradient (norm) plus 8x what the reference's OWN fp32 run loses against fp64 on that tensor -- two fp32
+    # tensor's largest gradient (norm) plus NOISE_MULT (7; 2-norm: 3) x what the reference's OWN fp32 run loses against fp64 on that tensor -- two fp32
     # evaluations differ by the sum of their rounding errors, and single elements sit behind ~50 ReLU / max-pool masks.  (The
     # step's lr = 1e-3 would hide a gradient error of 1.0 in the weight comparison further down.)
     n_checked, worst = 0, (0.0, "")
+    need_max, need_l2 = (0.0, ""), (0.0, "")       # the noise multiplier each criterion actually needs (printed; the gate below is NOISE_MULT)
     for k, prm in model.named_parameters():
         g32 = grads_ref[k]
         dg = prm.grad.detach().cpu() - g32
         d_max, d_l2 = float(dg.abs().max()), float(dg.double().norm())
         gmax, gl2 = float(noise["gmax/" + k]), float(noise["g_l2/" + k])
         assert abs(float(g32.abs().max()) - gmax) <= 1e-3 * gmax + float(noise["noise_max/" + k]), k    # the fixture is of THIS step
-        assert d_max <= 1e-3 * gmax + 8.0 * float(noise["noise_max/" + k]), (k, d_max, float(noise["noise_max/" + k]), gmax)
-        assert d_l2 <= 1e-3 * gl2 + 8.0 * float(noise["noise_l2/" + k]), (k, d_l2, float(noise["noise_l2/" + k]), gl2)
+        need_max = max(need_max, ((d_max - 1e-3 * gmax) / max(float(noise["noise_max/" + k]), 1e-30), k))
+        need_l2 = max(need_l2, ((d_l2 - 1e-3 * gl2) / max(float(noise["noise_l2/" + k]), 1e-30), k))
+        assert d_max <= 1e-3 * gmax + NOISE_MULT * float(noise["noise_max/" + k]), (k, d_max, float(noise["noise_max/" + k]), gmax)
+        assert d_l2 <= 1e-3 * gl2 + NOISE_MULT_L2 * float(noise["noise_l2/" + k]), (k, d_l2, float(noise["noise_l2/" + k]), gl2)
         worst = max(worst, (d_l2 / gl2, k))
         n_checked += 1
     print("worst relative 2-norm gradient difference: %.3g (%s)" % worst)
+    print("noise multiplier needed beyond 1e-3 of the tensor's largest gradient: element-wise %.2f (%s), 2-norm %.2f (%s); gate %.1f" % (
+        need_max + need_l2 + (NOISE_MULT,)) + " / %.1f" % NOISE_MULT_L2)
     assert n_checked == len(grads_ref) == 161
     opt.step()
     assert float(logit_ref.abs().max()) > 0.5                                      # the 1e-3 below is not vacuous
@@ -975,3 +989,42 @@ print("WORST %.3e" % worst)
     assert out.returncode == 0, out.stderr[-2000:]
     worst = float(out.stdout.strip().split("WORST")[-1])
     assert worst < tol, worst
+
+
+@pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
+def test_reference_initialisation_within_twice_the_references_own_rounding(dev, arch):
+    """every other fixture conditions the weights like a trained net (closing-BN gammas x 0.25, classifier x 8).  This
+    one uses the REFERENCE'S OWN initialisation (nets/resnet.py:149-154: kaiming-normal fan_out convolutions, every BatchNorm gamma = 1,
+    beta = 0), on which the reference's own fp32 and fp64 runs differ by ~1e-3 in the logits -- so the gate is relative to that:
+    train-mode logits and the loss within TWICE |oracle fp32 - oracle fp64| of the oracle's fp64 result (an fp32 implementation
+    cannot be asked for less than the reference's own fp32 run delivers; twice = a different, not a worse, rounding sequence)."""
+    import copy
+    from ccst_amd import fed
+    from ccst_amd.nets import models
+    from oracle import resnet_ref as R
+    torch.set_num_threads(max(1, len(__import__("os").sched_getaffinity(0))))
+    classes, nb = 7, 8
+    torch.manual_seed(5)
+    oracle = R.resnet18(classes) if arch == "resnet18" else R.resnet50(classes)      # the reference's initialisation
+    sd = {k: v.clone() for k, v in oracle.state_dict().items()}
+    gam = [v for k, v in sd.items() if k.endswith("bn2.weight") or k.endswith("bn3.weight")]
+    assert gam and all(bool((g_ == 1).all()) for g_ in gam)                            # gamma = 1 everywhere, as the reference initialises
+    x, y = R.synth_batch(nb, 222, classes, seed=9)
+    o64 = copy.deepcopy(oracle).double().train()
+    oracle.train()
+    with torch.no_grad():
+        l32, l64 = oracle(x), o64(x.double())
+    loss32, loss64 = float(F.cross_entropy(l32, y)), float(F.cross_entropy(l64, y))
+    n_logit, n_loss = float((l32.double() - l64).abs().max()), abs(loss32 - loss64)
+    model = models.get_network(arch)(ARGS, pretrained=False, classes=classes)
+    model.load_state_dict(sd)
+    model.to(dev).train()
+    ce = fed.CrossEntropyLoss()
+    with torch.no_grad():
+        logit = model(x.to(dev))
+        loss = ce(logit, y.to(dev))
+    d_logit, d_loss = float((logit.double().cpu() - l64).abs().max()), abs(float(loss) - loss64)
+    print("%s, reference initialisation: max |logit| %.3g; reference fp32 vs fp64: logits %.3g, loss %.3g; HIP vs fp64: logits %.3g (%.2fx), loss %.3g (%.2fx)" % (
+        arch, float(l64.abs().max()), n_logit, n_loss, d_logit, d_logit / max(n_logit, 1e-30), d_loss, d_loss / max(n_loss, 1e-30)))
+    assert d_logit <= 2.0 * n_logit + 1e-6 * float(l64.abs().max()), (d_logit, n_logit)
+    assert d_loss <= 2.0 * n_loss + 2e-6 * max(1.0, abs(loss64)), (d_loss, n_loss)
