@@ -244,7 +244,7 @@ __global__ __launch_bounds__(TPB) void adain_apply_nhwc_kernel(const float* __re
         amax = fmaxf(fmaxf(fmaxf(amax, fabsf(o[0])), fmaxf(fabsf(o[1]), fabsf(o[2]))), fabsf(o[3]));
         *reinterpret_cast<f32x4*>(y + i * 4) = o;
     }
-    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, blockIdx.x * (TPB / 64) + (threadIdx.x >> 6));
+    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, blockIdx.x);
 }
 
 __global__ __launch_bounds__(TPB) void adain_apply_nchw_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(TPB) void adain_apply_nchw_kernel(const float* __re
         amax = fmaxf(amax, fabsf(o));
         yb[p] = o;
     }
-    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, (blockIdx.y * gridDim.x + blockIdx.x) * (TPB / 64) + (threadIdx.x >> 6));
+    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // ---- single-pass AdaIN (NHWC, H*W <= 4096): statistics AND normalise with the tensor read once and written once ------------------
@@ -354,6 +354,7 @@ __global__ __launch_bounds__(FP_T) void adain_fused_nhwc_kernel(const float* __r
     const f32x4 sm = *reinterpret_cast<const f32x4*>(smean + so), ss = *reinterpret_cast<const f32x4*>(sstd + so);
     const bool blend = (alpha != 1.f);
     float amax = 0.f;
+    const unsigned peeked = ymax != nullptr ? ccst_absmax_peek(ymax, blockIdx.y * gridDim.x + blockIdx.x) : 0u;
 #pragma unroll
     for (int i = 0; i < FP_PPT; ++i) {
         const int p = pl + i * FP_PL;
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(FP_T) void adain_fused_nhwc_kernel(const float* __r
             *reinterpret_cast<f32x4*>(yb + (long long)p * C) = o;
         }
     }
-    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, (blockIdx.y * gridDim.x + blockIdx.x) * (FP_T / 64) + wave);
+    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, blockIdx.y * gridDim.x + blockIdx.x, peeked);
 }
 
 int pick_splits(int N, int C, int HW, int layout) {
@@ -511,6 +512,8 @@ __global__ __launch_bounds__(TPB) void adain_tile_sums_nhwc_kernel(const float* 
     const f32x4 sm = *reinterpret_cast<const f32x4*>(smean + so), ss = *reinterpret_cast<const f32x4*>(sstd + so);
     const bool blend = (alpha != 1.f);
     float amax = 0.f;
+    const unsigned bid_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const unsigned peeked = ymax != nullptr ? ccst_absmax_peek(ymax, bid_) : 0u;       // (compared after the stores: nobody waits for it)
 #pragma unroll
     for (int i = 0; i < TS_PIX / TS_PL; ++i) {
         const int p = p0 + pl + i * TS_PL;
@@ -522,7 +525,7 @@ __global__ __launch_bounds__(TPB) void adain_tile_sums_nhwc_kernel(const float* 
             *reinterpret_cast<f32x4*>(yb + (long long)p * C) = o;
         }
     }
-    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (TPB / 64) + (t >> 6));
+    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, bid_, peeked);
 }
 
 // CCST_OverallStyleTransfer.py:36-45, the interpolation branch: feat = sum_k w_k * base[k] (accumulated in the reference's order, from

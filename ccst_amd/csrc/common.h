@@ -58,11 +58,17 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-// ---- per-tensor |max| slots (CCST_ABSMAX_WORDS unsigned words, include/ccst_hip.h) ------------------------------------------------
+// ---- per-tensor |max| words (CCST_ABSMAX_WORDS = 64 unsigned words = 256 bytes, include/ccst_hip.h) -------------------------------------
 // A producer kernel leaves the largest |value| it wrote as raw fp32 bits (monotone as unsigned for non-negative floats; a NaN sorts above
-// infinity) with one atomic max per wave, spread over 64 slots 256 B apart so that no address sees more than 1/64 of the atomics; the
-// consumer's waves read the 64 slots with one gather and reduce them.  The caller zeroes the words before the producer runs.
-constexpr int CCST_ABSMAX_SLOTS = 64, CCST_ABSMAX_STRIDE = CCST_ABSMAX_WORDS / CCST_ABSMAX_SLOTS;
+// infinity): ONE conditional atomic max per WORKGROUP into word (workgroup id) % 64.  The consumer's waves read all 64 words with one
+// coalesced 256-byte load and reduce them.  The caller zeroes the words before the producer runs.
+//   Why this shape (round 4, measured on the AdaIN step with the operands kept real by a fixed scale: the first form -- 64 slots 256 B
+//   apart, one unconditional-then-conditional atomic per WAVE, a dependent load at every wave's end, a 64-line gather at every wave's
+//   start -- cost 6.5 % of the step, ~12 us per conv launch): the words are contiguous so that reading them is one request per wave;
+//   one atomic per workgroup keeps the burst of a launch's first round (every workgroup sees zeros) at 4 per word; the word's current
+//   value is PEEKED before the epilogue's stores and only compared after them, so that nobody waits for that load; the atomic itself
+//   is fire-and-forget.  A word only grows, so a stale peek can only cause a superfluous atomic, never a missed one.
+constexpr int CCST_ABSMAX_SLOTS = CCST_ABSMAX_WORDS;
 
 __device__ __forceinline__ unsigned ccst_wave_umax(unsigned v) {
 #pragma unroll
@@ -72,22 +78,48 @@ __device__ __forceinline__ unsigned ccst_wave_umax(unsigned v) {
     }
     return v;
 }
-// every lane passes the largest |value| it holds (>= 0, or NaN); `salt` spreads the waves of the grid over the slots
-__device__ __forceinline__ void ccst_absmax_publish(unsigned* slots, float lane_max, unsigned salt) {
+constexpr unsigned CCST_NOT_PEEKED = 0xffffffffu;
+// the current value of this workgroup's word (meaningful in thread 0 only); block = the workgroup's linear id
+__device__ __forceinline__ unsigned ccst_absmax_peek(const unsigned* slots, unsigned block) {
+    return threadIdx.x == 0 ? __hip_atomic_load(slots + block % CCST_ABSMAX_SLOTS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+}
+// every lane passes the largest |value| it holds (>= 0, or NaN).  Called by ALL threads of the workgroup (it contains a barrier -- a raw
+// s_barrier behind lgkmcnt(0) only: __syncthreads() would also wait for the epilogue's stores).
+__device__ __forceinline__ void ccst_absmax_publish(unsigned* slots, float lane_max, unsigned block, unsigned peeked = CCST_NOT_PEEKED) {
+#ifdef CCST_ABSMAX_NOPUBLISH      // timing experiment only (tools): what publishing costs; the consumers then use a fixed scale
+    return;
+#endif
+    __shared__ unsigned ccst_amax_wave_[16];
     const unsigned m = ccst_wave_umax(__float_as_uint(lane_max) & 0x7fffffffu);
-    if ((threadIdx.x & 63) == 0 && m != 0u) {
-        unsigned* const s = slots + (salt % CCST_ABSMAX_SLOTS) * CCST_ABSMAX_STRIDE;
-        // A slot only grows, so a wave whose maximum is not above what the slot holds NOW (an agent-scope load: it goes to the coherent
-        // level, as the atomics do) has nothing to add: after the first waves of a launch almost none issues the atomic.  With one
-        // unconditional atomic per wave a launch of 16 k waves put 256 serialised atomics on every slot -- +1.7 ms on a ResNet50 step
-        // whose 53 BatchNorm applies publish their maxima (measured: 3063 against 3331 images/s).
-        if (m > __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            (void)__hip_atomic_fetch_max(s, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((threadIdx.x & 63) == 0) ccst_amax_wave_[threadIdx.x >> 6] = m;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (threadIdx.x == 0) {
+        unsigned mm = 0u;
+        for (unsigned w = 0; w < (blockDim.x + 63u) / 64u; ++w) mm = mm > ccst_amax_wave_[w] ? mm : ccst_amax_wave_[w];
+        unsigned* const s = slots + block % CCST_ABSMAX_SLOTS;
+        if (mm != 0u) {
+            const unsigned cur = peeked != CCST_NOT_PEEKED ? peeked : __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mm > cur) (void)__hip_atomic_fetch_max(s, mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
-// the tensor's |max| bits, wave-uniform (every wave reads for itself: no LDS, no barrier)
+// the two halves of ccst_absmax_read for kernels that want the load in flight behind other work: every lane loads its word early
+// (ccst_absmax_load), the wave reduces it where the value is first needed (ccst_absmax_reduce)
+__device__ __forceinline__ unsigned ccst_absmax_load(const unsigned* slots) {
+#ifdef CCST_ABSMAX_NOPUBLISH
+    return 0x46000000u;
+#endif
+    return slots[threadIdx.x & 63];
+}
+__device__ __forceinline__ unsigned ccst_absmax_reduce(unsigned lane_word) {
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)ccst_wave_umax(lane_word));
+}
+// the tensor's |max| bits, wave-uniform (every wave reads for itself: one 256-byte load, no LDS, no barrier)
 __device__ __forceinline__ unsigned ccst_absmax_read(const unsigned* slots) {
-    const unsigned v = slots[(threadIdx.x & 63) * CCST_ABSMAX_STRIDE];
+#ifdef CCST_ABSMAX_NOPUBLISH      // (the timing experiment: a fixed plausible maximum, 8192, so that the operands stay real data)
+    return 0x46000000u;
+#endif
+    const unsigned v = slots[threadIdx.x & 63];
     return (unsigned)__builtin_amdgcn_readfirstlane((int)ccst_wave_umax(v));
 }
 // k such that 2^k * max lies in [2^target, 2^(target+1)) for a normal max; clamped to +-126 so that 2^k is a normal float (the clamp is

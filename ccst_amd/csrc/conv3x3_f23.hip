@@ -126,9 +126,9 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
     const int co0 = tn * F_BN;
     const int oy0 = ty * F_TH, ox0 = tx * F_TW;
 
-    const int kx = ccst_scale_exp(ccst_absmax_read(p.xmax), F23_X_TARGET);
-    const int kw = ccst_scale_exp(ccst_absmax_read(p.wmax), F23_W_TARGET);
-    const float xs = __uint_as_float((unsigned)(127 + kx) << 23);
+    // the |max| words of x and w: loaded here, reduced after the prologue's first barrier -- their latency (the words were written by the
+    // previous kernel's atomics: an L2 miss) hides behind the first pieces instead of standing in front of them
+    unsigned xword = ccst_absmax_load(p.xmax), wword = ccst_absmax_load(p.wmax);
     const int nchunks = p.Cin / 16;
 
     // ---- staging: everything comes in by LDS-DMA (no staging registers, so the prefetch depth is LDS, not the register file) -------
@@ -189,7 +189,6 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
             }
         }
     }
-    const float xsb = xs * tsgn;
 
     auto dma_w = [&](int c_, int s_) {          // weights of k-step s_ (>= 12: of the next chunk; clamped at the end) -> ring stage s_ % 6
         const int cc = min(c_ + s_ / 12, nchunks - 1), ss = s_ % 12;
@@ -200,6 +199,7 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
         const int cc = min(c_, nchunks - 1);
         glds16(ximg + cc * 16, rsrc_[i], (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)((2 * F_VW) * 4 + (wave + 8 * i) * 1024))));
     };
+    float xs = 1.f, xsb = 1.f;       // 2^kx and sgn 2^kx (set after the prologue's first barrier)
     // item i of this thread: raw -> position -> (hi, lo) -> V[buf]
     auto xform = [&](int buf, int i) {
         f32x4 da = *reinterpret_cast<const f32x4*>(&Raw[tsa + i * (2 * F_RW * 16)]);
@@ -259,6 +259,11 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
 #pragma unroll
     for (int s = 0; s < F_RING; ++s) dma_w(0, s);
     dma_barrier<0>();
+    asm volatile("" : "+v"(xword), "+v"(wword));      // (opaque here: hipcc otherwise schedules the reduction, and its wait, in front of the first pieces)
+    const int kx = ccst_scale_exp(ccst_absmax_reduce(xword), F23_X_TARGET);
+    const int kw = ccst_scale_exp(ccst_absmax_reduce(wword), F23_W_TARGET);
+    xs = __uint_as_float((unsigned)(127 + kx) << 23);
+    xsb = xs * tsgn;
 #pragma unroll
     for (int i = 0; i < 5; ++i) xform(0, i);
     dma_barrier<0>();
@@ -346,6 +351,7 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
         }
     const bool relu = p.relu != 0;
     float amax = 0.f;
+    const unsigned peeked = p.ymax != nullptr ? ccst_absmax_peek(p.ymax, blockIdx.x) : 0u;      // (compared after the stores: nobody waits for it)
     const bool interior = (oy0 + F_TH <= p.H) && (ox0 + F_TW <= p.W) && (co0 + F_BN <= p.Cout);
     const bool cok = co < p.Cout;
     // accumulator register r of a lane is GEMM row (r & 3) + 8 (r >> 2) + 4 lh of its tile: row parity r & 1, pixel pair ((r & 3) >> 1) + 4 (r >> 2) + 2 lh
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
             }
         }
     }
-    if (p.ymax != nullptr) ccst_absmax_publish(p.ymax, amax, blockIdx.x * 8u + (unsigned)wave);
+    if (p.ymax != nullptr) ccst_absmax_publish(p.ymax, amax, blockIdx.x, peeked);
 }
 
 // OIHW 3x3 -> [ky * 4 + q][Cin/16][cout_pad][16 words]: words 0..7 = the chunk's 16 input channels of U_q[ky] = (G g[ky][.])_q as

@@ -173,12 +173,15 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
     }
 
     // SPLIT: operand scales from the tensors' |max| words (wave-uniform), 2^kx for the activations, 2^kw was applied when the weights were packed
+    // (the words are LOADED here and reduced behind the prologue's first halo load: written by the previous kernel's atomics, they are an
+    //  L2 miss, and reduced here that miss would stand in front of the prologue's own loads)
     int kx = 0, kw = 0;
+    unsigned xword = 0u, wword = 0u;
     if (SPLIT) {
-        kx = ccst_scale_exp(ccst_absmax_read(p.xmax), CCST_SPLIT_X_TARGET);
-        kw = ccst_scale_exp(ccst_absmax_read(p.wmax), CCST_SPLIT_W_TARGET);
+        xword = ccst_absmax_load(p.xmax);
+        wword = ccst_absmax_load(p.wmax);
     }
-    const float xs = __uint_as_float((unsigned)(127 + kx) << 23);
+    float xs = 1.f;
 
     f32x16 acc[MT][NT];
     float biasv[NT];
@@ -292,6 +295,12 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
 #pragma unroll
     for (int i = 0; i < HR; ++i) {
         load_h(0, i, hoff[i]);
+        if (SPLIT && i == 0) {
+            asm volatile("" : "+v"(xword), "+v"(wword));      // (opaque: keeps the reduction, and its wait, behind the load just issued)
+            kx = ccst_scale_exp(ccst_absmax_reduce(xword), CCST_SPLIT_X_TARGET);
+            kw = ccst_scale_exp(ccst_absmax_reduce(wword), CCST_SPLIT_W_TARGET);
+            xs = __uint_as_float((unsigned)(127 + kx) << 23);
+        }
         store_h(0, i, hok[i]);
     }
     // 3-deep weight ring: step t computes from Bs[t%3]; the registers fetched during step t-1 (weights of step
@@ -428,6 +437,7 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
     // with no vector address arithmetic and no predicate.  Edge tiles keep the predicated pointer path.
     const int cw = wn * (32 * NT);                                            // uniform (wn is)
     float amax = 0.f;                                                         // SPLIT: largest |value| this lane stores (p.ymax)
+    const unsigned peeked = (SPLIT && p.ymax != nullptr) ? ccst_absmax_peek(p.ymax, blockIdx.x) : 0u;     // (compared after the stores)
     if (!POOL) {
         float* const tile = p.y + (long long)n * p.ysN + (long long)oy0 * p.ysH + (long long)ox0 * p.ysW + co0 + cw;
         const unsigned lane_off = (unsigned)(2 * lh * p.ysW + li);
@@ -579,7 +589,7 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
             }
         }
     }
-    if (SPLIT && p.ymax != nullptr) ccst_absmax_publish(p.ymax, amax, blockIdx.x * 4u + (unsigned)wave);
+    if (SPLIT && p.ymax != nullptr) ccst_absmax_publish(p.ymax, amax, blockIdx.x, peeked);
 }
 
 template <int WM, int WN, int NT, bool POOL, bool TRAIN = false, bool SPLIT = false>

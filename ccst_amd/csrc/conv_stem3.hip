@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int j = 0; j < 18; ++j) bv[j] = bvn[j];
         }
     }
-    if (p.ymax != nullptr) ccst_absmax_publish(p.ymax, amax, blockIdx.x * 4u + (unsigned)wave);
+    if (p.ymax != nullptr) ccst_absmax_publish(p.ymax, amax, blockIdx.x);
 }
 
 // OIHW [64,3,3,3] -> A operands [18 MFMAs][2 groups][64 lanes]: MFMA j = tap j >> 1, channel 2 (j & 1) + (lane >> 5) (zero for channel 3)

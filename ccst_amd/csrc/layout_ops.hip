@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
         const float v = x[(n4 << 2) + threadIdx.x];
         m = (v != v) ? v : fmaxf(m, fabsf(v));
     }
-    ccst_absmax_publish(slots, m, blockIdx.x * 4u + (threadIdx.x >> 6));
+    ccst_absmax_publish(slots, m, blockIdx.x);
 }
 
 // The |max| words of n tensors in ONE launch (the pointwise conv weights of a ResNet after an optimiser step): table [n][2] int64 =
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void absmax_batch_kernel(const long long* __re
         const float v = x[(n4 << 2) + threadIdx.x];
         m = (v != v) ? v : fmaxf(m, fabsf(v));
     }
-    ccst_absmax_publish(words + (long long)blockIdx.y * CCST_ABSMAX_WORDS, m, blockIdx.x * 4u + (threadIdx.x >> 6));
+    ccst_absmax_publish(words + (long long)blockIdx.y * CCST_ABSMAX_WORDS, m, blockIdx.x);
 }
 
 }  // namespace

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__
         amax = fmaxf(fmaxf(fmaxf(amax, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
         *reinterpret_cast<f32x4*>(y + i * 4) = v;
     }
-    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, blockIdx.x * (TPB / 64) + (threadIdx.x >> 6));
+    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, blockIdx.x);
 }
 
 template <int NCH>
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(TPB) void bn_relu_maxpool_fwd_kernel(const f32x4* _
         amax = fmaxf(fmaxf(fmaxf(amax, fabsf(best[0])), fmaxf(fabsf(best[1]), fabsf(best[2]))), fabsf(best[3]));
         idx[i] = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
     }
-    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, blockIdx.x * (TPB / 64) + (threadIdx.x >> 6));
+    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, blockIdx.x);
 }
 
 // gradient of the pooling INPUT pixel (n, iy, ix), channel group c, gathered from the pooled gradient (as maxpool3s2_bwd_kernel)

@@ -358,20 +358,20 @@ WINO_F4_NARROW = os.environ.get("CCST_WINO4_NARROW", "0") == "1"
 # producing kernel's epilogue leaves max |y| (conv3x3_halo_split, conv3x3_stem3_nchw, the AdaIN kernels), the consumer reads it -- any
 # finite fp32 magnitude is safe, nothing synchronises.  CCST_HALO_SPLIT=0: F(4x4) everywhere.
 HALO_SPLIT = os.environ.get("CCST_HALO_SPLIT", "2")
-ABSMAX_WORDS = 4096      # CCST_ABSMAX_WORDS of include/ccst_hip.h
+ABSMAX_WORDS = 64        # CCST_ABSMAX_WORDS of include/ccst_hip.h
 
 
-_ABSMAX_POOL = {}      # (device index, raw stream) -> [zeroed [64, ABSMAX_WORDS] int32 tensor, rows handed out]
+_ABSMAX_POOL = {}      # (device index, raw stream) -> [zeroed [1024, ABSMAX_WORDS] int32 tensor, rows handed out]
 
 
 def absmax_words(device):
     """One zeroed |max| word set ([ABSMAX_WORDS] int32) for a kernel that max-accumulates the largest |value| it writes.  Rows of a
-    [64, ABSMAX_WORDS] tensor zeroed by ONE fill on the current stream, handed out once each (a plan of 17 layers costs a quarter of a
-    fill launch per forward); a row is a view, so the block lives as long as any row of it does."""
+    [1024, ABSMAX_WORDS] tensor (256 KB) zeroed by ONE fill on the current stream, handed out once each (a plan of 17 layers costs a
+    sixtieth of a fill launch per forward); a row is a view, so the block lives as long as any row of it does."""
     key = (torch.cuda.current_device() if device.index is None else device.index, _lib.raw_stream())
     ent = _ABSMAX_POOL.get(key)
     if ent is None or ent[1] >= ent[0].shape[0]:
-        ent = [torch.zeros((64, ABSMAX_WORDS), device=device, dtype=torch.int32), 0]
+        ent = [torch.zeros((1024, ABSMAX_WORDS), device=device, dtype=torch.int32), 0]
         _ABSMAX_POOL[key] = ent
     row = ent[0][ent[1]]
     ent[1] += 1

@@ -101,11 +101,12 @@ int ccst_conv3x3_halo_f32(const float* x, const float* w_packed, const float* bi
 
 int ccst_conv3x3_halo_narrow(int N, int H, int W, int Cout);   /* 1: the 128x64 tile is dispatched, 0: 128x128 */
 
-/* Per-tensor |max| words: CCST_ABSMAX_WORDS uint32 on the device, zeroed by the caller, into which a producing kernel max-accumulates
- * the raw fp32 bits of the largest |value| it wrote (64 slots 256 B apart, one atomic per wave) and from which the half-piece kernels
- * below derive their power-of-two operand scales ON THE DEVICE -- no host synchronisation anywhere.  ccst_absmax_f32 is the stand-alone
- * producer (one pass over x) for tensors whose producer did not leave the words. */
-#define CCST_ABSMAX_WORDS 4096
+/* Per-tensor |max| words: CCST_ABSMAX_WORDS = 64 uint32 (256 bytes) on the device, zeroed by the caller, into which a producing kernel
+ * max-accumulates the raw fp32 bits of the largest |value| it wrote (one conditional atomic per workgroup into word id % 64) and from
+ * which the half-piece kernels below derive their power-of-two operand scales ON THE DEVICE (one coalesced load per wave) -- no host
+ * synchronisation anywhere.  ccst_absmax_f32 is the stand-alone producer (one pass over x) for tensors whose producer did not leave
+ * the words. */
+#define CCST_ABSMAX_WORDS 64
 int ccst_absmax_f32(const float* x, int64_t n, uint32_t* absmax, void* stream);
 /* ... of n tensors in one launch: table [n][2] int64 = (device pointer, 16-byte aligned; element count), absmax [n][CCST_ABSMAX_WORDS]
  * zeroed by the caller (the pointwise conv weights of a ResNet after each optimiser step, nets/resnet.py). */
