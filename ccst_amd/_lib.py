@@ -82,6 +82,9 @@ _SIGNATURES = {
     "ccst_conv2d_igemm_tile": [c_int, c_int, c_int, c_int, c_int],
     "ccst_pack_conv_weights_batch_f32": [_P, c_int, _P],
     "ccst_conv3x3_smallco_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
+    "ccst_conv3x3_zform_weight_floats": [c_int],
+    "ccst_pack_conv_weight_zform_f32": [_P, _P, _P, c_int, c_int, _P],
+    "ccst_conv3x3_zform_f32": [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "ccst_pack_conv_weight_f32": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "ccst_nchw_to_nhwc4_pad_f32": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "ccst_nhwc_layer_f32": [c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
@@ -121,7 +124,7 @@ _SIGNATURES = {
 }
 _RESTYPES = {"ccst_last_error": c_char_p, "ccst_stats_workspace_bytes": c_int64, "ccst_bn_workspace_bytes": c_int64,
              "ccst_wino_weight_floats": c_int64, "ccst_image_plan": c_int64,
-             "ccst_wino4_weight_floats": c_int64}
+             "ccst_wino4_weight_floats": c_int64, "ccst_conv3x3_zform_weight_floats": c_int64}
 EXPORTS = tuple(_SIGNATURES)
 
 _lib = None

@@ -57,7 +57,6 @@ constexpr int F_RW = F_TW + 2;                    // raw halo pixels per row (34
 constexpr int F_RAW_PIECES = 24;                  // 1 KiB LDS-DMA pieces of the raw halo image: 10 x 34 pixels x 64 B = 21.25, three per wave
 constexpr int F_RING = 6;                         // weight stages of 8 KB (128 output channels x 64 B, un-padded, XOR-swizzled parts)
 constexpr int F_LDS_BYTES = (2 * F_VW + F_RAW_PIECES * 256 + F_RING * 2048) * 4;      // 163 328 B of the CU's 163 840: one workgroup per CU
-constexpr int F_HUNITS = F_HH * F_XP * 4;         // loader units per chunk: (halo row, pixel pair, 4-channel part) = 640
 // operand scale targets (common.h): a position is a sum of two pixels, a transformed weight of up to three halves
 constexpr int F23_X_TARGET = CCST_SPLIT_X_TARGET - 1, F23_W_TARGET = CCST_SPLIT_W_TARGET - 1;
 

@@ -56,11 +56,11 @@ def _is_up2(m):
 class _Step(object):
     """One launch (or launch pair) of the plan."""
     __slots__ = ("kind", "pc", "kw", "kwp", "stride", "pad", "reflect", "relu", "pool", "ups", "out_nchw",
-                 "w_small", "b_small", "cout", "wa")
+                 "w_small", "b_small", "cout", "wa", "pz")
 
     def __init__(self, kind, **kw):
         self.kind = kind
-        self.pc = self.kw = self.kwp = self.w_small = self.b_small = self.cout = self.wa = None
+        self.pc = self.kw = self.kwp = self.w_small = self.b_small = self.cout = self.wa = self.pz = None
         self.stride, self.pad = 1, 0
         self.reflect = self.relu = self.pool = self.ups = self.out_nchw = False
         for k, v in kw.items():
@@ -120,7 +120,9 @@ def _compile(mods):
                 steps.append(_Step("stem", pc=ops.pack_conv_weight(wv, conv.bias), kw=3, kwp=kwp, pad=1, reflect=True, relu=relu))
             elif conv.out_channels <= 4 and conv.in_channels % 16 == 0 and not pending_up:
                 # image edge of the decoder (net.py:35): direct VALU kernel writing NCHW
-                steps.append(_Step("smallco", w_small=conv.weight.detach().permute(2, 3, 0, 1).contiguous(),
+                w_small = conv.weight.detach().permute(2, 3, 0, 1).contiguous()
+                steps.append(_Step("smallco", w_small=w_small,
+                                   pz=ops.PackedZform(w_small) if ops.zform_wanted(conv.in_channels, conv.out_channels) else None,
                                    b_small=None if conv.bias is None else conv.bias.detach().contiguous(),
                                    cout=conv.out_channels, reflect=True, relu=relu))
             else:
@@ -251,6 +253,8 @@ def _run_steps(steps, x, sums_box):
         for t in steps[i + 1:]:
             if t.kind == "conv":
                 return t.stride == 1 and t.pad == 1 and not t.out_nchw and ops.halo_split_wanted(t.pc)
+            if t.kind == "smallco":
+                return t.pz is not None
             if t.kind not in ("relu", "pad", "up", "pool"):
                 return False
         return False
@@ -277,7 +281,10 @@ def _run_steps(steps, x, sums_box):
         if s.kind == "smallco":
             if cur.shape[-1] % 16 != 0:
                 cur = ops.from_api(ops.to_api(cur[..., :C]), cpad=16)
-            out = ops.conv3x3_smallco_nchw(cur, s.w_small, s.b_small, s.cout, reflect=s.reflect, relu=s.relu)
+            if s.pz is not None and cur.shape[-1] == s.w_small.shape[-1]:
+                out = ops.conv3x3_zform_nchw(cur, s.pz, s.b_small, s.cout, reflect=s.reflect, relu=s.relu, x_absmax=amax)
+            else:
+                out = ops.conv3x3_smallco_nchw(cur, s.w_small, s.b_small, s.cout, reflect=s.reflect, relu=s.relu)
             cur, api, C, amax = None, out, s.cout, None
             continue
         if s.kind == "conv":

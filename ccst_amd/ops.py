@@ -706,6 +706,59 @@ def conv3x3_smallco_nchw(x, w_tap_co_ci, bias, cout, reflect=True, relu=False):
     return out
 
 
+# The same layer as a 1x1 convolution to 9 * Cout tap planes on the 16-bit MFMA + nine shifted adds (conv3x3_zform.hip): the default for
+# Cin 32 / 64, Cout <= 3; CCST_CONV_ZFORM=0: the VALU kernel above.
+ZFORM = os.environ.get("CCST_CONV_ZFORM", "1") != "0"
+
+
+def zform_wanted(cin, cout):
+    return ZFORM and cin in (32, 64) and 1 <= cout <= 3
+
+
+class PackedZform:
+    """The tap-plane weight of conv3x3_zform_nchw: |max| words and fragment-order half pieces of a [3][3][Cout][Cin] weight (built on first use)."""
+
+    def __init__(self, w_tap_co_ci):
+        self.w = w_tap_co_ci
+        self._packed = None
+
+    def get(self):
+        if self._packed is None:
+            w = self.w
+            cout, cin = int(w.shape[2]), int(w.shape[3])
+            lib = _lib.load()
+            words = absmax(w, out=torch.zeros(ABSMAX_WORDS, device=w.device, dtype=torch.int32))
+            packed = torch.empty(int(lib.ccst_conv3x3_zform_weight_floats(cin)), device=w.device, dtype=torch.float32)
+            check(lib.ccst_pack_conv_weight_zform_f32(ptr(w), ptr(words), ptr(packed), cin, cout, stream_ptr()), "pack_conv_weight_zform")
+            self._packed = (packed, words)
+        return self._packed
+
+
+def conv3x3_zform_nchw(x, pz, bias, cout, reflect=True, relu=False, x_absmax=None):
+    """conv3x3_smallco_nchw's layer through ccst_conv3x3_zform_f32; x_absmax: the |max| words of x (one extra pass if None)."""
+    _require_cuda(x, "activation")
+    assert x.is_contiguous() and x.dim() == 4
+    N, H, W, Cin = x.shape
+    if x_absmax is None:
+        x_absmax = tagged_absmax(x)
+    if x_absmax is None:
+        x_absmax = absmax(x)
+    packed, words = pz.get()
+    out = torch.empty((N, cout, H, W), device=x.device, dtype=torch.float32)
+    lib = _lib.load()
+    args = (ptr(x), ptr(x_absmax), ptr(packed), ptr(words), ptr(bias), ptr(out), N, H, W, Cin, cout, int(reflect), int(relu), stream_ptr())
+    if TIMING is None:
+        check(lib.ccst_conv3x3_zform_f32(*args), "conv3x3_zform")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.ccst_conv3x3_zform_f32(*args), "conv3x3_zform")
+        e1.record()
+        TIMING.append(("conv3x3_zform_kernel<%d>" % cout, 2.0 * N * H * W * cout * Cin * 9, e0, e1,
+                       "n%d %dx%d cin%d cout%d taps3x3" % (N, H, W, Cin, cout)))
+    return out
+
+
 def stem_virtual_weight(w_oihw):
     """[Cout,C<=4,kh,kw] -> [Cout, KWP*4, kh, 1]: the kx taps of a row become channels of a
     'virtual pixel' of the NHWC4 image (K per row = KWP*4, a multiple of 16)."""

@@ -243,6 +243,17 @@ int ccst_conv2d_igemm_bn_relu_bwd_f32(const CcstConvDesc* d, const float* x, con
 int ccst_conv3x3_smallco_f32(const float* x, const float* w_tap_co_ci, const float* bias, float* y,
                              int N, int H, int W, int Cin, int Cout, int reflect, int relu, void* stream);
 
+/* The same layer as a 1x1 convolution to 9*Cout "tap planes" on the 16-bit MFMA (fp32 products as three half-piece products,
+ * fp32 accumulate; 27 planes padded to 32 for Cout = 3) followed by the nine shifted fp32 adds (conv3x3_zform.hip, round 4): every
+ * pixel's record is read once, whole.  Cin 32 or 64, Cout 1..3.  x_absmax / w_absmax: the |max| words of x and of the weight
+ * (CCST_ABSMAX_WORDS each: the operands' power-of-two scales are derived from them on the device, any finite fp32 magnitude is safe).
+ * w_packed: ccst_pack_conv_weight_zform_f32 of the [3][3][Cout][Cin] weight, ccst_conv3x3_zform_weight_floats(Cin) floats.
+ * Replaces the same reference lines as ccst_conv3x3_smallco_f32 (style_transfer/AdaIN/net.py:34-35). */
+int64_t ccst_conv3x3_zform_weight_floats(int Cin);
+int ccst_pack_conv_weight_zform_f32(const float* w_tap_co_ci, const uint32_t* w_absmax, float* packed, int Cin, int Cout, void* stream);
+int ccst_conv3x3_zform_f32(const float* x, const uint32_t* x_absmax, const float* w_packed, const uint32_t* w_absmax,
+                           const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int reflect, int relu, void* stream);
+
 /* OIHW [cout][cin][kh][kw] -> packed [kh*kw][cin/4][cout_pad][4] (transpose=0), or the
  * backward-data operand [kh*kw][cout/4][cin_pad][4] (transpose=1: GEMM-K runs over cout).
  * The K-side extent (cin, or cout when transposed) must be a multiple of 4; it is padded

@@ -238,6 +238,35 @@ def test_conv3x3_smallco(dev, shape, reflect):
     assert maxdiff(y, ref) < 1e-4
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 12, 10, 3), (1, 32, 40, 70, 3), (1, 64, 33, 67, 2), (1, 64, 8, 32, 1), (1, 64, 2, 2, 3)])
+@pytest.mark.parametrize("reflect", [True, False])
+@pytest.mark.parametrize("scale", [1.0, 1e-4, 3e4, 1e30])
+def test_conv3x3_zform_vs_fp64(dev, shape, reflect, scale):
+    """The decoder's image edge as tap planes on the 16-bit MFMA (ccst_conv3x3_zform_f32, net.py:34-35): three half-piece products per
+    fp32 product, so held to fp32's own accuracy against fp64 -- 2e-6 of sum |terms| -- at any input magnitude (|max| words)."""
+    from ccst_amd import ops
+    N, Cin, H, W, Cout = shape
+    x = rnd((N, Cin, H, W), 18) * scale
+    w = rnd((Cout, Cin, 3, 3), 19, 0.05)
+    b = rnd((Cout,), 20, 0.1) * scale
+    xd, wd = x.double(), w.double()
+    if reflect:
+        ref = F.conv2d(F.pad(xd, (1,) * 4, mode="reflect"), wd, b.double())
+        mag = F.conv2d(F.pad(xd.abs(), (1,) * 4, mode="reflect"), wd.abs(), b.double().abs())
+    else:
+        ref = F.conv2d(xd, wd, b.double(), padding=1)
+        mag = F.conv2d(xd.abs(), wd.abs(), b.double().abs(), padding=1)
+    xn = ops.from_api(x.to(dev), 16)
+    pz = ops.PackedZform(w.to(dev).permute(2, 3, 0, 1).contiguous())
+    y = ops.conv3x3_zform_nchw(xn, pz, b.to(dev), Cout, reflect=reflect)
+    assert y.is_contiguous() and tuple(y.shape) == tuple(ref.shape)
+    err = float(((y.cpu().double() - ref).abs() / mag.clamp_min(1e-300)).max())
+    assert err < 2e-6, err
+    # and against the VALU kernel it replaces (both are fp32-accurate)
+    y0 = ops.conv3x3_smallco_nchw(xn, w.to(dev).permute(2, 3, 0, 1).contiguous(), b.to(dev), Cout, reflect=reflect)
+    assert float(((y.cpu().double() - y0.cpu().double()).abs() / mag.clamp_min(1e-300)).max()) < 4e-6
+
+
 # ------------------------------------------------------------------ statistics / AdaIN
 @pytest.mark.parametrize("channels_last", [False, True])
 def test_calc_mean_std_golden(dev, golden, channels_last):

@@ -20,6 +20,10 @@ b2 = torch.randn(3, generator=g).to(dev)
 w2t = w2.permute(2, 3, 0, 1).contiguous()       # [3][3][Cout][Cin], as net.py hands it over
 
 
+pz = ops.PackedZform(w2t) if hasattr(ops, "PackedZform") else None
+fwords = ops.absmax(feat)
+
+
 def timed(fn):
     for _ in range(3):
         fn()
@@ -37,6 +41,7 @@ def timed(fn):
 out_bytes = B * S * S * 64 * 4
 for name, fn, nbytes in (("stem3", lambda: ops.conv3x3_stem3_nchw(img, wa, relu=True), out_bytes + B * 3 * S * S * 4),
                          ("smallco", lambda: ops.conv3x3_smallco_nchw(feat, w2t, b2, 3, reflect=True, relu=False), out_bytes + B * 3 * S * S * 4),
+                         ("zform", lambda: ops.conv3x3_zform_nchw(feat, pz, b2, 3, reflect=True, relu=False, x_absmax=fwords), out_bytes + B * 3 * S * S * 4),
                          ("fill", lambda: feat.fill_(1.0), out_bytes),
                          ("copy", lambda: feat.clone(), 2 * out_bytes)):
     try:
