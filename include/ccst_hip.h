@@ -167,7 +167,8 @@ int ccst_conv3x3_wino4_f32(const float* x, const float* u_packed, const float* b
                            int Cout, int cout_pad, uint32_t flags, void* stream);
 /* The AdaIN encoder's first layer (net.py:39-42: the 1x1 colour conv folded into ReflectionPad2d(1) + Conv2d(3,64,3x3) + ReLU) from the
  * contiguous NCHW image [N,3,H,W] to the NHWC map [N,H,W,64]; wa = ccst_pack_stem3_weight_f32(w [64,3,3,3], bias [64] or null)
- * (18*2*64 floats: the bias is packed with the weights, in the one k slot three channels leave unused). */
+ * (18*2*64 floats: a header with the weights' power-of-two scale, the half-piece fragments of the 16-bit MFMA's A operand and the bias;
+ * fp32 products as three half-piece products, every pixel scaled by the power of two of its own largest tap: any finite fp32 image). */
 int ccst_pack_stem3_weight_f32(const float* w_oihw, const float* bias, float* wa, int cout, void* stream);
 int ccst_conv3x3_stem3_f32(const float* x_nchw, const float* wa, float* y_nhwc, int N, int H, int W, int relu,
                            uint32_t* y_absmax /* NULL or zeroed |max| words of y, see CCST_ABSMAX_WORDS */, void* stream);

@@ -870,6 +870,27 @@ def test_stem3_first_layer_kernel(dev, shape):
         assert float((y.permute(0, 3, 1, 2).cpu().double() - r).abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize("scale", [1.0, 1e-4, 255.0, 3e4, 1e30])
+def test_stem3_any_magnitude(dev, scale):
+    """The first layer's products are three half-piece products on the 16-bit MFMA, every pixel scaled by the power of two of its own
+    largest tap: fp32's accuracy against fp64 (2e-6 of sum |terms|) at any image magnitude, also when the magnitude varies by 1e8
+    across one image, and max |y| (the next layer's scale) is what was stored."""
+    from ccst_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(2, 3, 37, 70, generator=g) - 0.3) * scale
+    x[1, :, 10:20] *= 1e-8           # a band of tiny values inside a large image
+    wt = torch.randn(64, 3, 3, 3, generator=g) * 0.3
+    b = torch.randn(64, generator=g) * 0.1 * scale
+    xp = F.pad(x.double(), (1, 1, 1, 1), mode="reflect")
+    ref = F.conv2d(xp, wt.double(), b.double()).clamp_min(0)
+    mag = F.conv2d(xp.abs(), wt.double().abs(), b.double().abs())
+    words = ops.absmax_words(dev)
+    y = ops.conv3x3_stem3_nchw(x.to(dev), ops.pack_stem3(wt.to(dev), b.to(dev)), relu=True, y_absmax=words)
+    yd = y.permute(0, 3, 1, 2).cpu().double()
+    assert float(((yd - ref).abs() / mag).max()) < 2e-6
+    assert float(torch.from_numpy(words.cpu().numpy().view(np.float32)).max()) == float(y.abs().max())
+
+
 @pytest.mark.parametrize("case", [(2, 64, 64, 64, 512), (3, 40, 70, 32, 128), (1, 17, 33, 64, 64)])
 def test_adain_from_the_conv_epilogue_tile_sums(dev, case):
     """ops.adain_from_tile_sums (one streaming launch, the content statistics folded from the per-tile channel sums that the
