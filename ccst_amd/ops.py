@@ -419,6 +419,7 @@ def halo_split_wanted(pc):
 # of the chip; the others stay on the direct kernel.  CCST_CONV_F23=0: direct everywhere.
 F23 = os.environ.get("CCST_CONV_F23", "1") != "0"
 F23_MIN_FILL = float(os.environ.get("CCST_F23_MIN_FILL", "0.5"))
+F23_MIN_COUT = int(os.environ.get("CCST_F23_MIN_COUT", "128"))
 F23_FORCE = os.environ.get("CCST_CONV_F23", "1") == "2"       # every Cout >= 128 layer whatever its grid (tests: small images)
 _N_CU = {}
 
@@ -432,7 +433,7 @@ def num_cus(device):
 
 def f23_wanted(pc, N, H, W, device):
     """Run this 3x3 layer (conv extent H x W) on the F(2,3) kernel?"""
-    if not (F23 and halo_split_wanted(pc)) or pc.cout < 128 or H * W * pc.cin >= 2 ** 30:
+    if not (F23 and halo_split_wanted(pc)) or pc.cout < F23_MIN_COUT or H * W * pc.cin >= 2 ** 30:
         return False
     if F23_FORCE:
         return True
