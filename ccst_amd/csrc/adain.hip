@@ -450,16 +450,18 @@ __global__ __launch_bounds__(TPB) void adain_tile_sums_nhwc_kernel(const float* 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f32x4 a0 = *reinterpret_cast<const f32x4*>(pp + j * 4);                      // slab 0 of the image: the pivot (same for every lane)
-            piv[j] = a0[2] > 0.f ? (double)a0[0] / (double)a0[2] : 0.0;
+            piv[j] = a0[2] > 0.f ? (double)(a0[0] / a0[2]) : 0.0;                              // (any pivot near the data will do: fp32 division)
         }
         for (int k = pl; k < tpi; k += TS_PL)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(pp + ((long long)k * C + j) * 4);
                 if (a[2] > 0.f) {
-                    const double nk = (double)a[2], dm = (double)a[0] / nk - piv[j];
-                    s[j] += nk * dm;                                                         // sum of (x - pivot)
-                    q[j] += (double)a[1] + nk * dm * dm;                                     // sum of (x - pivot)^2
+                    // sum of (x - pivot) = S - n pivot, exactly in fp64; sum of (x - pivot)^2 = M2 + (S - n pivot)^2 / n with 1 / n from
+                    // v_rcp_f32 (n is a pixel count: exact as float; 1 ulp on a term of the variance) -- no fp64 division in the fold
+                    const double tk = (double)a[0] - (double)a[2] * piv[j];
+                    s[j] += tk;
+                    q[j] += (double)a[1] + tk * tk * (double)__builtin_amdgcn_rcpf(a[2]);
                 }
             }
     } else {
@@ -497,10 +499,11 @@ __global__ __launch_bounds__(TPB) void adain_tile_sums_nhwc_kernel(const float* 
         }
     }
     f32x4 mu, sd;
+    const double inv_hw = 1.0 / (double)HW, inv_hw1 = 1.0 / ((double)HW - 1.0);        // (uniform: two divisions per thread instead of eight)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const double m = s[j] / (double)HW;                                             // (CENTRED: of x - pivot)
-        const double var = fmax(q[j] - s[j] * m, 0.0) / ((double)HW - 1.0);
+        const double m = s[j] * inv_hw;                                                 // (CENTRED: of x - pivot)
+        const double var = fmax(q[j] - s[j] * m, 0.0) * inv_hw1;
         mu[j] = (float)(m + piv[j]);
         sd[j] = sqrtf((float)var + eps);
     }

@@ -17,7 +17,8 @@
 //     whole kilobytes of four pixels; bias, ReLU and max |y| on that side (a lane then holds the same four channels of eight pixels).
 //   Measured (B=6, 512x512): 86-89 us against 115-118 for the fp32-MFMA form on the same box (a 403 MB fill: 61).  Timing experiments:
 //   without the stores 50 us (63 % of the vector-issue slots busy, PMC: the splits, the scale and the transposition are what is left
-//   of the arithmetic), without the MFMAs -7 us; four waves per SIMD need 128 registers and spill (158 us).
+//   of the arithmetic), without the MFMAs -7 us; four waves per SIMD need 128 registers and spill (158 us); with the weight fragments
+//   in LDS instead (8 KB per eight-wave workgroup, re-read per block) they fit, and measure 92 us.
 #include "common.h"
 
 namespace {
