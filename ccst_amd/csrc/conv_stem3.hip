@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STEM_WAVES,
             const unsigned o = (unsigned)__shfl_xor((int)mb, 32, 64);
             mb = mb > o ? mb : o;
         }
-        const int kx = ccst_scale_exp(mb, CCST_SPLIT_X_TARGET);
+        const int kx = mb == 0u ? 0 : ccst_scale_exp(mb, CCST_SPLIT_X_TARGET);      // (an all-zero neighbourhood -- black borders -- needs no scale, and should not send its block down the v_ldexp path below)
         const float xs = __uint_as_float((unsigned)(127 + kx) << 23);
         f16x8s bhi[2], blo[2];
 #pragma unroll

@@ -879,6 +879,7 @@ def test_stem3_any_magnitude(dev, scale):
     g = torch.Generator().manual_seed(11)
     x = (torch.rand(2, 3, 37, 70, generator=g) - 0.3) * scale
     x[1, :, 10:20] *= 1e-8           # a band of tiny values inside a large image
+    x[0, :, 25:, :30] = 0.0          # and a black corner (all-zero neighbourhoods)
     wt = torch.randn(64, 3, 3, 3, generator=g) * 0.3
     b = torch.randn(64, generator=g) * 0.1 * scale
     xp = F.pad(x.double(), (1, 1, 1, 1), mode="reflect")
