@@ -70,13 +70,19 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 //   is fire-and-forget.  A word only grows, so a stale peek can only cause a superfluous atomic, never a missed one.
 constexpr int CCST_ABSMAX_SLOTS = CCST_ABSMAX_WORDS;
 
+// The largest value of the wave, in every lane (wave-uniform).  Six v_max_u32_dpp + a v_readlane: within a row of 16 lanes by row_shr
+// 1, 2, 4 (lanes 4-15), 8 (lanes 8-15), across rows by row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 -- lane 63
+// holds the maximum.  (The __shfl_xor form was six dependent ds_bpermute round trips through the LDS crossbar, ~0.3 us at the very end
+// of every workgroup that publishes |max| words and at the start of every kernel that reads them.)
 __device__ __forceinline__ unsigned ccst_wave_umax(unsigned v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned t = (unsigned)__shfl_xor((int)v, o, 64);
-        v = v > t ? v : t;
-    }
-    return v;
+    unsigned t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); v = v > t ? v : t;   // row_shr:1
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true); v = v > t ? v : t;   // row_shr:2
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, true); v = v > t ? v : t;   // row_shr:4, lanes 4-15 of a row
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, true); v = v > t ? v : t;   // row_shr:8, lanes 8-15
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true); v = v > t ? v : t;   // row_bcast:15 into rows 1, 3
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true); v = v > t ? v : t;   // row_bcast:31 into rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 constexpr unsigned CCST_NOT_PEEKED = 0xffffffffu;
 // the current value of this workgroup's word (meaningful in thread 0 only); block = the workgroup's linear id
