@@ -9,18 +9,20 @@
 // z has 27 rows for Cout = 3: padded to 32 it IS an MFMA shape with 16 % waste (v_mfma_f32_16x16x32_f16: M = 16 tap planes, N = 16
 // pixels, K = 32 channels), z of a pixel needs no neighbours -- every pixel's 256-byte record is read ONCE, whole, straight into the B
 // operand's registers -- and the 3x3 neighbourhood is nine shifted fp32 adds on the z planes in LDS.
-//   * workgroup = 8 x 32 output pixels, four waves, FOUR workgroups per CU (38 KB of LDS, <= 128 registers); z is computed for the
-//     10 x 34 halo (the ring's records are L2 hits of the neighbouring tiles: 427 MB fetched for 403 MB of input, PMC) in 22 groups of
-//     16 pixels, wave w takes groups w, w + 4, ... with three groups of loads in flight;
+//   * tile = 8 x 32 output pixels, four waves, FOUR PERSISTENT workgroups per CU (39 KB of LDS, <= 128 registers) walking the tiles of
+//     their XCD's eighth of the image; z is computed for the tile's 10 x 34 halo (the ring's records are L2 hits of the neighbouring
+//     tiles: 440 MB fetched for 403 MB of input, PMC) in 22 groups of 16 pixels, wave w takes groups w, w + 4, ... with two groups of
+//     loads in flight ACROSS tiles: the next tile's first groups are requested before this tile's planes are summed;
 //   * fp32 products as three half-piece products (x = hi + lo as IEEE half after a power-of-two scale from the tensor's |max| words,
 //     common.h: range-safe at any fp32 magnitude), fp32 accumulate; the weights come pre-split in fragment order (27 x Cin: 8 KB);
 //   * z planes in LDS [27 + 1][356] (the planes past 9 Cout of the padded M tile land in a plane nobody reads, so the stores carry no
 //     predicate; every address of the loop is an instruction immediate), then each thread sums 9 taps x Cout for one pixel: lanes
 //     along x, 128-byte NCHW row stores; the power-of-two scale comes off after the sum.
-//   Measured (B=6, 512x512, 64 -> 3): 98-100 us against 133-137 for conv_small.hip on the same box.  Timing experiments on this kernel:
-//   2 / 3 / 4 groups of loads in flight 99 / 100 / 98 us; 16-row tiles at two workgroups per CU 115; without the MFMAs and the
-//   splits 94; without the shifted sum 97; without both and with every load instruction 1 KB contiguous (wrong data) 90 -- the tile
-//   walk itself reads at 4.5-4.7 TB/s, the arithmetic costs the last 8 us.
+//   Measured (B=6, 512x512, 64 -> 3): 93-96 us against 133-137 for conv_small.hip on the same boxes; a plain linear read of the same
+//   403 MB (absmax_kernel) takes 81 us there, a fill 60.  History / timing experiments: one workgroup per tile 98-101 us (2 / 3 / 4
+//   groups of loads in flight 99 / 100 / 98; 16-row tiles at two workgroups per CU 115; without the MFMAs and the splits 94; without
+//   the shifted sum 97; without both and with every load instruction 1 KB contiguous (wrong data) 90); persistent workgroups -5 us,
+//   three groups in flight at three or four waves per SIMD +-0.
 #include "common.h"
 #include <stdint.h>
 
@@ -41,7 +43,7 @@ constexpr int Z_PIX = Z_HH * Z_HW;                      // 340 halo pixels (612 
 constexpr int Z_GROUPS = (Z_PIX + 15) / 16;             // 22 groups of 16 pixels
 constexpr int Z_GPW = (Z_GROUPS + 3) / 4;               // groups per wave (6)
 #ifndef Z_DEPTH
-#define Z_DEPTH 3                                       // groups of loads in flight per wave
+#define Z_DEPTH 2                                       // groups of loads in flight per wave
 #endif
 constexpr int Z_PLANES = 27;
 constexpr int Z_PITCH = Z_GROUPS * 16 + 4;              // words per z plane: the 16-pixel groups whole (the last one runs past the halo) + 4, so that the pitch is 4 modulo 8
@@ -86,54 +88,75 @@ __device__ __forceinline__ void split8z(const f32x4 a, const f32x4 b, float s, f
 
 template <int NKS, bool REFLECT>          // 32-channel k-steps: Cin = 32 NKS
 __global__ __launch_bounds__(256, Z_WGS) void conv3x3_zform_kernel(const ZArgs p) {
+    static_assert(Z_GPW % Z_DEPTH == 0, "the register ring keeps its phase from tile to tile");
     __shared__ float Z[(Z_PLANES + 1) * Z_PITCH];          // + a plane nobody reads
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pn = lane & 15, kg = lane >> 4;
 
-    int bid = ccst_xcd_remap(blockIdx.x, gridDim.x);
-    const int bx = bid % p.tilesX;
-    bid /= p.tilesX;
-    const int by = bid % p.tilesY;
-    const int n = bid / p.tilesY;
-    const int oy0 = by * Z_TH, ox0 = bx * Z_TW;
+    // PERSISTENT workgroups: a workgroup walks a sequence of tiles and its loads simply run on -- the first groups of the next tile
+    // are in flight while this tile's planes are summed and stored (as separate workgroups, each tile paid its address arithmetic,
+    // the first loads' latency and its shifted sum with nothing in flight: the tile walk alone read at 4.5 TB/s).  The tiles an XCD
+    // runs side by side (hardware XCD = blockIdx % 8) are neighbours: each XCD owns a contiguous eighth of the tile list.
+    const int ntiles = p.N * p.tilesY * p.tilesX;
+    const bool by_xcd = ((int)gridDim.x & 7) == 0;
+    const int chunk = by_xcd ? (ntiles + 7) >> 3 : ntiles;
+    const int first = by_xcd ? ((int)blockIdx.x & 7) * chunk : 0;
+    const int slot0 = by_xcd ? (int)blockIdx.x >> 3 : (int)blockIdx.x, per = by_xcd ? (int)gridDim.x >> 3 : (int)gridDim.x;
+    auto tile_of = [&](int k) {                 // k-th tile of this workgroup, or -1
+        const int idx = slot0 + k * per;
+        return (idx < chunk && first + idx < ntiles) ? first + idx : -1;
+    };
 
     unsigned xword = ccst_absmax_load(p.xmax), wword = ccst_absmax_load(p.wmax);
 
-    // this wave's pixel groups: byte-free float offsets of the lane's pixel (+ its first channel run), and whether the pixel is inside
-    // the image (zero padding: an outside pixel has z = 0)
-    unsigned poff[Z_GPW];
-    unsigned okbits = 0u;
-    const bool inside = oy0 >= 1 && ox0 >= 1 && oy0 + Z_TH + 1 <= p.H && ox0 + Z_TW + 1 <= p.W;      // the whole halo is inside the image (uniform)
+    // a tile's pixel groups for this wave: float offsets of the lane's pixel (+ its first channel run), and whether the pixel is inside
+    // the image (zero padding: an outside pixel has z = 0).  Waves 2 and 3 own five groups; their sixth is a copy of the tile's last
+    // pixel, loaded (the ring keeps its phase) and not stored.
+    struct Tile {
+        int n, oy0, ox0;
+        unsigned poff[Z_GPW], okbits;
+    };
+    auto offsets = [&](int t, Tile& T) {
+        const int bx = t % p.tilesX, r = t / p.tilesX;
+        const int by = r % p.tilesY;
+        T.n = r / p.tilesY;
+        T.oy0 = by * Z_TH;
+        T.ox0 = bx * Z_TW;
+        T.okbits = 0u;
+        const bool inside = T.oy0 >= 1 && T.ox0 >= 1 && T.oy0 + Z_TH + 1 <= p.H && T.ox0 + Z_TW + 1 <= p.W;      // the whole halo is inside the image (uniform)
 #pragma unroll
-    for (int i = 0; i < Z_GPW; ++i) {
-        const int P = min((wave + 4 * i) * 16 + pn, Z_PIX - 1);
-        const int hy = P / Z_HW, hx = P - hy * Z_HW;
-        int gy = oy0 + hy - 1, gx = ox0 + hx - 1;
-        bool ok = true;
-        if (!inside) {
-            if (REFLECT) {
-                gy = reflect_z(gy, p.H);
-                gx = reflect_z(gx, p.W);
-            } else {
-                ok = (gy >= 0) & (gy < p.H) & (gx >= 0) & (gx < p.W);
-                gy = min(max(gy, 0), p.H - 1);
-                gx = min(max(gx, 0), p.W - 1);
+        for (int i = 0; i < Z_GPW; ++i) {
+            const int P = min((wave + 4 * i) * 16 + pn, Z_PIX - 1);
+            const int hy = P / Z_HW, hx = P - hy * Z_HW;
+            int gy = T.oy0 + hy - 1, gx = T.ox0 + hx - 1;
+            bool ok = true;
+            if (!inside) {
+                if (REFLECT) {
+                    gy = reflect_z(gy, p.H);
+                    gx = reflect_z(gx, p.W);
+                } else {
+                    ok = (gy >= 0) & (gy < p.H) & (gx >= 0) & (gx < p.W);
+                    gy = min(max(gy, 0), p.H - 1);
+                    gx = min(max(gx, 0), p.W - 1);
+                }
             }
+            T.okbits |= (ok ? 1u : 0u) << i;
+            T.poff[i] = (((unsigned)T.n * (unsigned)p.H + (unsigned)gy) * (unsigned)p.W + (unsigned)gx) * (unsigned)p.Cin + 4u * kg;      // < 2^32 elements (checked by the launcher)
         }
-        okbits |= (ok ? 1u : 0u) << i;
-        poff[i] = (((unsigned)n * (unsigned)p.H + (unsigned)gy) * (unsigned)p.W + (unsigned)gx) * (unsigned)p.Cin + 4u * kg;      // < 2^32 elements (checked by the launcher)
-    }
+    };
     f32x4 st[Z_DEPTH][2 * NKS];
-    auto load_group = [&](int d, int i) {
+    auto load_group = [&](int d, unsigned off) {
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) st[d][2 * ks + h] = *reinterpret_cast<const f32x4*>(p.x + poff[i] + ks * 32 + h * 16);
+            for (int h = 0; h < 2; ++h) st[d][2 * ks + h] = *reinterpret_cast<const f32x4*>(p.x + off + ks * 32 + h * 16);
     };
+    int t = tile_of(0);           // >= 0: the grid never exceeds the tile count
+    Tile cur, nxt;
+    offsets(t, cur);
 #pragma unroll
-    for (int d = 0; d < Z_DEPTH; ++d)
-        if (wave + 4 * d < Z_GROUPS) load_group(d, d);
+    for (int d = 0; d < Z_DEPTH; ++d) load_group(d, cur.poff[d]);
 
     // the weight fragments (A operand: M = tap plane), [plane tile][k-step][piece]
     f16x8z wa[2][NKS][2];
@@ -160,14 +183,20 @@ __global__ __launch_bounds__(256, Z_WGS) void conv3x3_zform_kernel(const ZArgs p
             const int j = jt * 16 + 4 * kg + r;
             zaddr[jt][r] = min(j, j < nplanes ? j : Z_PLANES) * Z_PITCH + pn + wave * 16;      // + 64 i: an instruction immediate
         }
-
+    float bias3[3];          // (loaded once: a load inside the tile loop would sit behind the prefetches in the in-order vmcnt queue)
 #pragma unroll
-    for (int i = 0; i < Z_GPW; ++i) {
-        const int g = wave + 4 * i;                    // wave-uniform
-        if (g < Z_GROUPS) {
+    for (int co = 0; co < 3; ++co) bias3[co] = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+    constexpr int RPT = Z_TH / 8;          // output rows per thread
+    const int tx = tid & 31, ty = (tid >> 5) * RPT;
+
+    for (int k = 0; t >= 0; ++k) {
+        const int tn = tile_of(k + 1);
+        offsets(tn >= 0 ? tn : t, nxt);         // (past the end the prefetch re-reads this tile: unconditional loads, exact wait counts)
+#pragma unroll
+        for (int i = 0; i < Z_GPW; ++i) {
             const int d = i % Z_DEPTH;
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-            const bool ok = REFLECT || ((okbits >> i) & 1u);
+            const bool ok = REFLECT || ((cur.okbits >> i) & 1u);
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
@@ -180,34 +209,37 @@ __global__ __launch_bounds__(256, Z_WGS) void conv3x3_zform_kernel(const ZArgs p
                     acc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[jt][ks][0], bhi, acc[jt], 0, 0, 0);
                 }
             }
-            if (i + Z_DEPTH < Z_GPW && g + 4 * Z_DEPTH < Z_GROUPS) load_group(d, i + Z_DEPTH);
+            load_group(d, i + Z_DEPTH < Z_GPW ? cur.poff[i + Z_DEPTH] : nxt.poff[i + Z_DEPTH - Z_GPW]);
             // (still scaled by 2^(kx + kw): scaled back after the shifted sum)
+            if (wave + 4 * i < Z_GROUPS) {          // wave-uniform
 #pragma unroll
-            for (int jt = 0; jt < 2; ++jt)
+                for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) Z[zaddr[jt][r] + i * 64] = acc[jt][r];
-        }
-    }
-    __syncthreads();
-
-    // ---- the shifted sum: thread -> column tx, rows ty, ty + 1 of the tile -----------------------------------------------------------
-    constexpr int RPT = Z_TH / 8;          // rows per thread
-    const int tx = tid & 31, ty = (tid >> 5) * RPT;
-    const int ox = ox0 + tx;
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) {
-        const int oy = oy0 + ty + r;
-#pragma unroll
-        for (int co = 0; co < 3; ++co) {
-            if (co < p.Cout) {
-                float v = 0.f;
-#pragma unroll
-                for (int tap = 0; tap < 9; ++tap) v += Z[(tap * p.Cout + co) * Z_PITCH + (ty + r + tap / 3) * Z_HW + tx + tap % 3];
-                v = __builtin_ldexpf(v, kd) + (p.bias != nullptr ? p.bias[co] : 0.f);
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (ox < p.W && oy < p.H) p.y[(((long long)n * p.Cout + co) * p.H + oy) * p.W + ox] = v;
+                    for (int r = 0; r < 4; ++r) Z[zaddr[jt][r] + i * 64] = acc[jt][r];
             }
         }
+        __syncthreads();
+
+        // ---- the shifted sum: thread -> column tx, rows ty .. of the tile -----------------------------------------------------------
+        const int ox = cur.ox0 + tx;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+            const int oy = cur.oy0 + ty + r;
+#pragma unroll
+            for (int co = 0; co < 3; ++co) {
+                if (co < p.Cout) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) v += Z[(tap * p.Cout + co) * Z_PITCH + (ty + r + tap / 3) * Z_HW + tx + tap % 3];
+                    v = __builtin_ldexpf(v, kd) + bias3[co];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (ox < p.W && oy < p.H) p.y[(((long long)cur.n * p.Cout + co) * p.H + oy) * p.W + ox] = v;
+                }
+            }
+        }
+        __syncthreads();          // the planes are free for the next tile
+        cur = nxt;
+        t = tn;
     }
 }
 
@@ -277,8 +309,10 @@ extern "C" int ccst_conv3x3_zform_f32(const float* x, const unsigned* x_absmax, 
     a.relu = relu;
     a.tilesX = (W + Z_TW - 1) / Z_TW;
     a.tilesY = (H + Z_TH - 1) / Z_TH;
-    const long long grid = (long long)N * a.tilesX * a.tilesY;
-    CCST_REQUIRE(grid < 0x7fffffffLL, "conv3x3_zform: grid too large");
+    const long long ntiles = (long long)N * a.tilesX * a.tilesY;
+    CCST_REQUIRE(ntiles < 0x7fffffffLL, "conv3x3_zform: too many tiles");
+    const long long resident = (long long)ccst_num_cus() * Z_WGS;               // persistent: Z_WGS workgroups per CU (a multiple of 8 on this chip)
+    const long long grid = ntiles < resident ? ntiles : resident;
     hipStream_t s = (hipStream_t)stream;
     if (Cin == 64 && reflect)
         hipLaunchKernelGGL((conv3x3_zform_kernel<2, true>), dim3((unsigned)grid), dim3(256), 0, s, a);
