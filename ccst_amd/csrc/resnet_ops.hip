@@ -196,6 +196,26 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __res
 
 // y = x*scale + shift (+ residual) (ReLU).  scale/shift either precomputed (train) or derived from
 // running stats on the fly (eval: scale==nullptr).
+// Round 4: the grid-stride loop carried ONE 16-byte load per thread and iteration behind a 64-bit modulo for the channel index and two
+// 16-byte scale / shift loads (2.85 TB/s over the ResNet50 step's 52 launches).  Now the stride (grid x 256 threads) is a multiple of
+// the channel-group count, so a thread's four channels -- and its scale / shift -- never change, and four independent elements are
+// loaded per iteration before any is used.
+__device__ __forceinline__ void bn_scale_shift(const float* scale, const float* shift, const float* gamma, const float* beta, const float* rmean,
+                                               const float* rvar, float eps, int c, f32x4& sc, f32x4& sh) {
+    if (scale) {
+        sc = *reinterpret_cast<const f32x4*>(scale + c);
+        sh = *reinterpret_cast<const f32x4*>(shift + c);
+    } else {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
+        const f32x4 m = *reinterpret_cast<const f32x4*>(rmean + c), v = *reinterpret_cast<const f32x4*>(rvar + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sc[j] = g[j] / sqrtf(v[j] + eps);
+            sh[j] = b[j] - m[j] * sc[j];
+        }
+    }
+}
+constexpr int BN_UNROLL = 4;
 __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ rmean,
@@ -204,24 +224,11 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__
                                                        unsigned char* __restrict__ rmask = nullptr, unsigned* __restrict__ ymax = nullptr) {
     const int cg = C / 4;
     float amax = 0.f;          // ymax: the largest |y| this thread writes (the half-piece pointwise conv that reads y scales by it)
-    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total4; i += (long long)gridDim.x * TPB) {
-        const int c = (int)(i % cg) * 4;
-        f32x4 sc, sh;
-        if (scale) {
-            sc = *reinterpret_cast<const f32x4*>(scale + c);
-            sh = *reinterpret_cast<const f32x4*>(shift + c);
-        } else {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), b = *reinterpret_cast<const f32x4*>(beta + c);
-            const f32x4 m = *reinterpret_cast<const f32x4*>(rmean + c), v = *reinterpret_cast<const f32x4*>(rvar + c);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                sc[j] = g[j] / sqrtf(v[j] + eps);
-                sh[j] = b[j] - m[j] * sc[j];
-            }
-        }
-        f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
+    const long long stride = (long long)gridDim.x * TPB;
+    const long long i0 = (long long)blockIdx.x * TPB + threadIdx.x;
+    auto finish = [&](f32x4 v, const f32x4 sc, const f32x4 sh, const f32x4 res, long long i) {
         v = v * sc + sh;
-        if (residual) v += *reinterpret_cast<const f32x4*>(residual + i * 4);
+        if (residual) v += res;
         if (relu) {
             if (rmask) rmask[i] = (unsigned char)((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u));
 #pragma unroll
@@ -229,9 +236,33 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__
         }
         amax = fmaxf(fmaxf(fmaxf(amax, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
         *reinterpret_cast<f32x4*>(y + i * 4) = v;
+    };
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    if (stride % cg == 0) {            // (uniform) the launcher's grids: this thread's channels are fixed
+        f32x4 sc, sh;
+        bn_scale_shift(scale, shift, gamma, beta, rmean, rvar, eps, (int)(i0 % cg) * 4, sc, sh);
+        long long i = i0;
+        for (; i + (BN_UNROLL - 1) * stride < total4; i += BN_UNROLL * stride) {
+            f32x4 v[BN_UNROLL], r[BN_UNROLL];
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + (i + u * stride) * 4);
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u) r[u] = residual ? *reinterpret_cast<const f32x4*>(residual + (i + u * stride) * 4) : z4;
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u) finish(v[u], sc, sh, r[u], i + u * stride);
+        }
+        for (; i < total4; i += stride)
+            finish(*reinterpret_cast<const f32x4*>(x + i * 4), sc, sh, residual ? *reinterpret_cast<const f32x4*>(residual + i * 4) : z4, i);
+    } else {
+        for (long long i = i0; i < total4; i += stride) {
+            f32x4 sc, sh;
+            bn_scale_shift(scale, shift, gamma, beta, rmean, rvar, eps, (int)(i % cg) * 4, sc, sh);
+            finish(*reinterpret_cast<const f32x4*>(x + i * 4), sc, sh, residual ? *reinterpret_cast<const f32x4*>(residual + i * 4) : z4, i);
+        }
     }
     if (ymax != nullptr) ccst_absmax_publish(ymax, amax, blockIdx.x);
 }
+static int bn_grid(long long total4, int C, int per_thread);
 
 template <int NCH>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
@@ -253,6 +284,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 }
 
 // dx = gamma*invstd*(dy' - mean(dy') - xhat*mean(dy'*xhat));  d_residual = dy'
+// (as bn_apply_kernel since round 4: the stride is a multiple of the channel-group count, a thread's per-channel constants stay in
+//  registers and two elements' loads are issued before either is used)
 template <int MASK>
 __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            const float* __restrict__ y, const float* __restrict__ gamma,
@@ -261,28 +294,70 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dx, float* __restrict__ dres, long long total4, int C,
                                                            float invM, const unsigned char* __restrict__ rmask = nullptr) {
     const int cg = C / 4;
-    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total4; i += (long long)gridDim.x * TPB) {
-        const int c = (int)(i % cg) * 4;
-        f32x4 g = *reinterpret_cast<const f32x4*>(dy + i * 4);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
-        const f32x4 xh = (v - mu) * is;
+    const long long stride = (long long)gridDim.x * TPB;
+    const long long i0 = (long long)blockIdx.x * TPB + threadIdx.x;
+    struct Chan {
+        f32x4 mu, is, ga, be, k1, k2;           // k1 = mean(dy'), k2 = mean(dy' * xhat)
+    };
+    auto chan = [&](int c, Chan& k) {
+        k.mu = *reinterpret_cast<const f32x4*>(mean + c);
+        k.is = *reinterpret_cast<const f32x4*>(invstd + c);
+        k.ga = *reinterpret_cast<const f32x4*>(gamma + c);
+        k.be = MASK == 2 ? *reinterpret_cast<const f32x4*>(beta + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        k.k1 = *reinterpret_cast<const f32x4*>(sums + c) * invM;
+        k.k2 = *reinterpret_cast<const f32x4*>(sums + C + c) * invM;
+    };
+    auto finish = [&](f32x4 g, const f32x4 v, const f32x4 o_in, unsigned bits, const Chan& k, long long i) {
+        const f32x4 xh = (v - k.mu) * k.is;
         if (MASK == 3) {
-            const unsigned bits = rmask[i];
 #pragma unroll
             for (int j = 0; j < 4; ++j) g[j] = ((bits >> j) & 1u) ? g[j] : 0.f;
         } else if (MASK != 0) {
-            f32x4 o;
-            if (MASK == 1) o = *reinterpret_cast<const f32x4*>(y + i * 4);
-            else o = xh * ga + *reinterpret_cast<const f32x4*>(beta + c);
+            const f32x4 o = (MASK == 1) ? o_in : xh * k.ga + k.be;
 #pragma unroll
             for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
         }
         if (dres) *reinterpret_cast<f32x4*>(dres + i * 4) = g;
-        const f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + c), s2 = *reinterpret_cast<const f32x4*>(sums + C + c);
-        *reinterpret_cast<f32x4*>(dx + i * 4) = ga * is * (g - s1 * invM - xh * (s2 * invM));
+        *reinterpret_cast<f32x4*>(dx + i * 4) = k.ga * k.is * (g - k.k1 - xh * k.k2);
+    };
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    auto one = [&](long long i, const Chan& k) {
+        finish(*reinterpret_cast<const f32x4*>(dy + i * 4), *reinterpret_cast<const f32x4*>(x + i * 4),
+               MASK == 1 ? *reinterpret_cast<const f32x4*>(y + i * 4) : z4, MASK == 3 ? (unsigned)rmask[i] : 0u, k, i);
+    };
+    if (stride % cg == 0) {            // (uniform) the launcher's grids
+        Chan k;
+        chan((int)(i0 % cg) * 4, k);
+        long long i = i0;
+        for (; i + stride < total4; i += 2 * stride) {
+            const long long i1 = i + stride;
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(dy + i * 4), g1 = *reinterpret_cast<const f32x4*>(dy + i1 * 4);
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + i * 4), v1 = *reinterpret_cast<const f32x4*>(x + i1 * 4);
+            const f32x4 o0 = MASK == 1 ? *reinterpret_cast<const f32x4*>(y + i * 4) : z4, o1 = MASK == 1 ? *reinterpret_cast<const f32x4*>(y + i1 * 4) : z4;
+            const unsigned b0 = MASK == 3 ? (unsigned)rmask[i] : 0u, b1 = MASK == 3 ? (unsigned)rmask[i1] : 0u;
+            finish(g0, v0, o0, b0, k, i);
+            finish(g1, v1, o1, b1, k, i1);
+        }
+        if (i < total4) one(i, k);
+    } else {
+        for (long long i = i0; i < total4; i += stride) {
+            Chan k;
+            chan((int)(i % cg) * 4, k);
+            one(i, k);
+        }
     }
+}
+// grid of the BatchNorm apply kernels: enough workgroups for per_thread elements per thread, at most 2048, and such that grid x 256 is a
+// multiple of the channel-group count (256 is a multiple of every C / 4 <= 256 of the ResNets; an even grid covers C / 4 = 512)
+static int bn_grid(long long total4, int C, int per_thread) {
+    const int cg = C / 4;
+    long long g = (total4 + (long long)TPB * per_thread - 1) / ((long long)TPB * per_thread);
+    g = g < 1 ? 1 : (g > 2048 ? 2048 : g);
+    if (cg > TPB && cg % TPB == 0) {
+        const long long m = cg / TPB;
+        g = (g + m - 1) / m * m;
+    }
+    return (int)g;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -298,12 +373,8 @@ __global__ __launch_bounds__(TPB) void bn_relu_maxpool_fwd_kernel(const f32x4* _
     const long long total = (long long)N * Ho * Wo * C4;
     float amax = 0.f;
     for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
-        const int c = (int)(i % C4);
-        long long j = i / C4;
-        const int ox = (int)(j % Wo);
-        j /= Wo;
-        const int oy = (int)(j % Ho);
-        const int n = (int)(j / Ho);
+        const unsigned iu = (unsigned)i, j0 = iu / (unsigned)C4, j1 = j0 / (unsigned)Wo, nn = j1 / (unsigned)Ho;      // (total < 2^31: launcher)
+        const int c = (int)(iu - j0 * (unsigned)C4), ox = (int)(j0 - j1 * (unsigned)Wo), oy = (int)(j1 - nn * (unsigned)Ho), n = (int)nn;
         const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c * 4), sh = *reinterpret_cast<const f32x4*>(shift + c * 4);
         f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         unsigned bi[4] = {0, 0, 0, 0};
@@ -380,11 +451,11 @@ __global__ __launch_bounds__(TPB) void stem_bwd_partials_kernel(const float* __r
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + cg * 4), is = *reinterpret_cast<const f32x4*>(invstd + cg * 4);
         const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + cg * 4), be = *reinterpret_cast<const f32x4*>(beta + cg * 4);
         for (long long r = r0 + pl; r < r1; r += PL) {
-            const int ix = (int)(r % W);
-            const long long q = r / W;
-            const int iy = (int)(q % H), n = (int)(q / H);
+            // (32-bit index arithmetic: M < 2^31 is checked by the launcher; the 64-bit divisions were most of this loop's instructions)
+            const unsigned ru = (unsigned)r, q = ru / (unsigned)W, n = q / (unsigned)H;
+            const int ix = (int)(ru - q * (unsigned)W), iy = (int)(q - n * (unsigned)H);
             const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * C + cg * 4);
-            f32x4 g = pool_grad_at(dyp, idx, n, iy, ix, cg, C / 4, Ho, Wo);
+            f32x4 g = pool_grad_at(dyp, idx, (int)n, iy, ix, cg, C / 4, Ho, Wo);
             const f32x4 xh = (v - mu) * is;
             const f32x4 o = xh * ga + be;
 #pragma unroll
@@ -418,12 +489,10 @@ __global__ __launch_bounds__(TPB) void stem_bwd_apply_kernel(const float* __rest
                                                              int Wo) {
     const int cg = C / 4;
     for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total4; i += (long long)gridDim.x * TPB) {
-        const int cq = (int)(i % cg), c = cq * 4;
-        const long long r = i / cg;
-        const int ix = (int)(r % W);
-        const long long q = r / W;
-        const int iy = (int)(q % H), n = (int)(q / H);
-        f32x4 g = pool_grad_at(dyp, idx, n, iy, ix, cq, cg, Ho, Wo);
+        const unsigned iu = (unsigned)i, r = iu / (unsigned)cg, q = r / (unsigned)W, n = q / (unsigned)H;      // (total4 < 2^31: launcher)
+        const int cq = (int)(iu - r * (unsigned)cg), c = cq * 4;
+        const int ix = (int)(r - q * (unsigned)W), iy = (int)(q - n * (unsigned)H);
+        f32x4 g = pool_grad_at(dyp, idx, (int)n, iy, ix, cq, cg, Ho, Wo);
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
         const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
@@ -722,7 +791,7 @@ extern "C" int ccst_bn_train_fwd_mask_f32(const float* x, const float* gamma, co
         hipLaunchKernelGGL(bn_fwd_finalize_kernel<16>, dim3((C + 15) / 16), dim3(256), 0, st, fin, gamma, beta, running_mean,
                            running_var, momentum, eps, save_mean, save_invstd, scale, shift, (long long)M, C, S);
     const long long total4 = (long long)M * (C / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(TPB), 0, st, x, scale, shift, nullptr, nullptr, nullptr, nullptr,
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_grid(total4, C, BN_UNROLL)), dim3(TPB), 0, st, x, scale, shift, nullptr, nullptr, nullptr, nullptr,
                        eps, residual, relu, y, total4, C, relu_mask, y_absmax);
     return ccst_launch_status("bn_train_fwd");
 }
@@ -741,7 +810,7 @@ extern "C" int ccst_bn_eval_fwd_f32(const float* x, const float* gamma, const fl
     CCST_REQUIRE(x && gamma && beta && running_mean && running_var && y, "bn_eval_fwd: null pointer");
     CCST_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_eval_fwd: need M>0 and C %% 4 == 0");
     const long long total4 = (long long)M * (C / 4);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(TPB), 0, (hipStream_t)stream, x, nullptr, nullptr, gamma, beta,
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_grid(total4, C, BN_UNROLL)), dim3(TPB), 0, (hipStream_t)stream, x, nullptr, nullptr, gamma, beta,
                        running_mean, running_var, eps, residual, relu, y, total4, C);
     return ccst_launch_status("bn_eval_fwd");
 }
@@ -777,7 +846,7 @@ extern "C" int ccst_bn_train_bwd_mask_f32(const float* dy, const float* x, const
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<16>, dim3((C + 15) / 16), dim3(256), 0, st, part, dgamma, dbeta, sums, C, sp.S, accumulate);
     const long long total4 = (long long)M * (C / 4);
 #define CCST_BWD_APPLY(MK)                                                                                                          \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<MK>), dim3(grid_for(total4)), dim3(TPB), 0, st, dy, x, y, gamma, beta, save_mean, save_invstd, \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<MK>), dim3(bn_grid(total4, C, 2)), dim3(TPB), 0, st, dy, x, y, gamma, beta, save_mean, save_invstd, \
                        sums, relu, dx, d_residual, total4, C, 1.f / (float)M, relu_mask)
     if (mask == 0) CCST_BWD_APPLY(0);
     else if (mask == 1) CCST_BWD_APPLY(1);
@@ -803,7 +872,7 @@ extern "C" int ccst_bn_train_bwd_partials_f32(const float* dy, const float* x, c
     else
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<16>, dim3((C + 15) / 16), dim3(256), 0, st, partials, dgamma, dbeta, sums, C, groups, accumulate);
     const long long total4 = (long long)M * (C / 4);
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), dim3(grid_for(total4)), dim3(TPB), 0, st, dy, x, nullptr, gamma, nullptr, save_mean, save_invstd,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), dim3(bn_grid(total4, C, 2)), dim3(TPB), 0, st, dy, x, nullptr, gamma, nullptr, save_mean, save_invstd,
                        sums, 0, dx, nullptr, total4, C, 1.f / (float)M, nullptr);
     return ccst_launch_status("bn_train_bwd_partials");
 }
@@ -824,6 +893,7 @@ extern "C" int ccst_bn_relu_maxpool_train_fwd_f32(const float* x, const float* g
     CCST_REQUIRE(x && gamma && beta && y_pooled && idx && save_mean && save_invstd && ws, "bn_relu_maxpool_fwd: null pointer");
     CCST_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "bn_relu_maxpool_fwd: bad extents");
     CCST_REQUIRE(Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, "bn_relu_maxpool_fwd: Ho/Wo must be floor((H+2-3)/2)+1");
+    CCST_REQUIRE((long long)N * H * W * (C / 4) < 0x7fffffffLL, "bn_relu_maxpool_fwd: the conv output must have < 2^31 channel quads (32-bit index arithmetic)");
     CCST_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_relu_maxpool_fwd: running stats must come together");
     const int64_t M = (int64_t)N * H * W;
     if (ws_bytes < ccst_bn_workspace_bytes(M, C)) {
@@ -863,6 +933,7 @@ extern "C" int ccst_bn_relu_maxpool_train_bwd_f32(const float* dy_pooled, const 
                                                   void* ws, int64_t ws_bytes, void* stream) {
     CCST_REQUIRE(dy_pooled && idx && x && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta && ws, "bn_relu_maxpool_bwd: null pointer");
     CCST_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, "bn_relu_maxpool_bwd: bad extents");
+    CCST_REQUIRE((long long)N * H * W * (C / 4) < 0x7fffffffLL, "bn_relu_maxpool_bwd: the conv output must have < 2^31 channel quads (32-bit index arithmetic)");
     const int64_t M = (int64_t)N * H * W;
     if (ws_bytes < ccst_bn_workspace_bytes(M, C)) {
         ccst_set_error("bn_relu_maxpool_bwd: workspace too small");
