@@ -238,7 +238,9 @@ def test_conv3x3_smallco(dev, shape, reflect):
     assert maxdiff(y, ref) < 1e-4
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 12, 10, 3), (1, 32, 40, 70, 3), (1, 64, 33, 67, 2), (1, 64, 8, 32, 1), (1, 64, 2, 2, 3)])
+@pytest.mark.parametrize("shape", [(2, 64, 12, 10, 3), (1, 32, 40, 70, 3), (1, 64, 33, 67, 2), (1, 64, 8, 32, 1), (1, 64, 2, 2, 3),
+                                   (1, 64, 64, 96, 3),        # 24 tiles: a grid that is a multiple of 8 (tiles dealt to the XCDs in chunks)
+                                   (2, 32, 256, 544, 3)])     # 1088 tiles on 1024 persistent workgroups: a second tile for some, uneven chunks
 @pytest.mark.parametrize("reflect", [True, False])
 @pytest.mark.parametrize("scale", [1.0, 1e-4, 3e4, 1e30])
 def test_conv3x3_zform_vs_fp64(dev, shape, reflect, scale):
@@ -246,6 +248,8 @@ def test_conv3x3_zform_vs_fp64(dev, shape, reflect, scale):
     fp32 product, so held to fp32's own accuracy against fp64 -- 2e-6 of sum |terms| -- at any input magnitude (|max| words)."""
     from ccst_amd import ops
     N, Cin, H, W, Cout = shape
+    if H * W > 100000 and (scale != 1.0):
+        pytest.skip("the large image runs at one scale")
     x = rnd((N, Cin, H, W), 18) * scale
     w = rnd((Cout, Cin, 3, 3), 19, 0.05)
     b = rnd((Cout,), 20, 0.1) * scale
