@@ -1232,3 +1232,58 @@ def test_adain_tile_sums_with_large_channel_means(dev, kernel):
     s1, q1 = ops.chan_sums_finalize(part)
     assert float((s1.double().reshape(-1) - f64.sum(dim=(0, 2, 3))).abs().max()) < 1e-5 * float(f64.sum(dim=(0, 2, 3)).abs().max())
     assert float((q1.double().reshape(-1) - (f64 ** 2).sum(dim=(0, 2, 3))).abs().max()) < 1e-5 * float((f64 ** 2).sum(dim=(0, 2, 3)).abs().max())
+
+
+@pytest.mark.parametrize("kernel", ["f23", "split", "zform", "stem3"])
+@pytest.mark.parametrize("k", [-40, 7, 60])
+def test_half_piece_kernels_are_exactly_homogeneous_in_powers_of_two(dev, kernel, k):
+    """A size-independent property at the BENCH shapes (B=6; 128x128x256 / 256x256 / 512x512): the half-piece kernels scale their operands
+    by powers of two derived from the tensors' |max| words (per pixel in the first layer), so conv(2^k x) must equal 2^k conv(x) BIT FOR
+    BIT (zero bias) -- whatever the magnitude, nothing is rounded differently.  No reference needed; any range-dependent rounding,
+    overflow or subnormal piece shows up as a difference."""
+    from ccst_amd import ops
+    g = torch.Generator().manual_seed(43)
+    s = 2.0 ** k
+    if kernel in ("f23", "split"):
+        x = torch.randn(6, 128, 128, 256, generator=g).to(dev)
+        w = (torch.randn(256, 256, 3, 3, generator=g) * 0.02).to(dev)
+        pc = ops.pack_conv_weight(w, None, wino=4)
+        fn = (lambda t: ops.conv3x3_f23(t, pc, 1 | 8)) if kernel == "f23" else (lambda t: ops.conv3x3_halo_split(t, pc, 1 | 8))
+    elif kernel == "zform":
+        x = torch.randn(6, 512, 512, 64, generator=g).to(dev)
+        wt = (torch.randn(3, 64, 3, 3, generator=g) * 0.05).to(dev).permute(2, 3, 0, 1).contiguous()
+        pz = ops.PackedZform(wt)
+        fn = lambda t: ops.conv3x3_zform_nchw(t, pz, None, 3, reflect=True)
+    else:
+        x = torch.rand(6, 3, 512, 512, generator=g).to(dev)
+        wa = ops.pack_stem3((torch.randn(64, 3, 3, 3, generator=g) * 0.3).to(dev), None)
+        fn = lambda t: ops.conv3x3_stem3_nchw(t, wa, relu=True)
+    y0 = fn(x)
+    y1 = fn(x * s)
+    assert bool(torch.isfinite(y1).all())
+    assert torch.equal(y1, y0 * s)
+
+
+def test_adain_output_statistics_equal_the_style_statistics_at_full_size(dev, nets, A):
+    """Size-independent property of the AdaIN step at the bench shape (B=6, 512x512 -> relu4_1 64x64x512), through the path's own
+    launches (encoder with per-tile statistics from conv4_1's epilogue, then ccst_adain_tile_sums_f32): whatever the content, every
+    (image, channel) plane of the result has the STYLE's mean and unbiased standard deviation (function.py:26-33)."""
+    from ccst_amd import ops
+    vgg31, dec, vgg_w, dec_w = nets
+    content = A.synth_content(6, 512, 512, seed=3).to(dev)
+    sm, ss = [t.to(dev) for t in A.synth_style_stat(512, seed=9)]
+    feat, part = vgg31.forward_with_tile_sums(content)
+    if part is None:
+        pytest.skip("this plan leaves no per-tile statistics")
+    out = ops.adain_from_tile_sums(feat, part, sm, ss, 1.0)
+    o = out.double().flatten(2)
+    m, sd = o.mean(dim=2), o.var(dim=2, unbiased=True).sqrt()
+    tm, ts = sm.double().reshape(1, -1), ss.double().reshape(1, -1)
+    assert float(((m - tm).abs() / (tm.abs() + ts)).max()) < 2e-5
+    # the standard deviation: where the content plane has one (a dead ReLU channel of the random-weight encoder is constant: eps rules there)
+    cs = feat.double().flatten(2).var(dim=2, unbiased=True).sqrt()
+    live = cs > 1e-3 * cs.mean()
+    assert int(live.sum()) > live.numel() // 4
+    # (1e-5 under the square root, function.py:12: relative effect eps / (2 var) on the result's deviation)
+    tol = 2e-4 + 1e-5 / (2.0 * cs[live] ** 2)
+    assert bool((((sd - ts).abs() / ts)[live] < tol).all())
