@@ -46,8 +46,8 @@ _SIGNATURES = {
     "ccst_conv2d_igemm_bn_relu_bwd_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ccst_bn_relu_maxpool_train_fwd_f32": [_P, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P,
                                            c_int64, _P, _P],
-    "ccst_bn_relu_maxpool_train_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P],
-    "ccst_bn_train_bwd_partials_f32": [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int64, c_int, _P, c_int64, _P],
+    "ccst_bn_relu_maxpool_train_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P, _P],
+    "ccst_bn_train_bwd_partials_f32": [_P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, c_int64, c_int, _P, c_int64, _P, _P],
     "ccst_conv3x3_halo_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_absmax_f32": [_P, c_int64, _P, _P],
     "ccst_absmax_batch_f32": [_P, c_int, _P, _P],
@@ -96,6 +96,8 @@ _SIGNATURES = {
     "ccst_crop_resize_norm_u8_f32": [_P, _P, _P, _P, _P, c_int, c_int, c_int, _P, _P, _P],
     "ccst_conv2d_bwd_weight_f32": [POINTER(CcstConvDesc), _P, _P, _P, c_int, c_int, _P, c_int64, _P],
     "ccst_conv2d_bwd_weight_splits": [c_int, c_int, c_int, c_int],
+    "ccst_conv2d_bwd_weight_split_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P, c_int, c_int, _P, c_int64, _P],
+    "ccst_conv2d_bwd_weight_split_splits": [c_int, c_int, c_int, c_int],
     "ccst_calc_mean_std_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_float, _P, c_int64, _P],
     "ccst_adain_tile_sums_f32": [_P, _P, c_int, c_int, _P, _P, c_int, c_float, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P],
     "ccst_interp_blend_f32": [_P, _P, _P, c_int, c_int64, c_float, c_float, _P, _P],
@@ -106,7 +108,7 @@ _SIGNATURES = {
     "ccst_bn_eval_fwd_f32": [_P, _P, _P, _P, _P, c_float, _P, c_int, _P, c_int64, c_int, _P],
     "ccst_bn_train_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int64, c_int, _P, c_int64, _P],
     "ccst_bn_train_fwd_mask_f32": [_P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P, c_int64, _P, _P],
-    "ccst_bn_train_bwd_mask_f32": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int64, c_int, _P, c_int64, _P],
+    "ccst_bn_train_bwd_mask_f32": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int64, c_int, _P, c_int64, _P, _P],
     "ccst_bn_workspace_bytes": [c_int64, c_int],
     "ccst_maxpool3s2_fwd_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "ccst_maxpool3s2_bwd_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],

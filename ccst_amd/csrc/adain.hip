@@ -406,111 +406,67 @@ int check_common(const void* x, int N, int C, int HW, int layout) {
     return CCST_OK;
 }
 
-// AdaIN where the producer of x has already left the statistics: per-(spatial tile, channel) sums (S, Q) of x and x^2 from the epilogue of
-// the conv that wrote x (ccst_conv3x3_wino4w_f32 with chan_sum_partials; tiles n * tpi .. (n + 1) * tpi - 1 belong to image n, pixels
-// outside the image excluded).  A workgroup = (64 channels, image, 256 pixels): every thread folds the tpi tile pairs of its four
-// channels in fp64 -- mean = S / HW, unbiased variance = (Q - S * mean) / (HW - 1): 4 KB of partials per workgroup -- and then the
-// tensor is streamed ONCE, every CU busy, no load-everything-then-store phase; function.py:26-33's four separately rounded operations.
-// (Raw moments are fine here and only here: the sums are over 512-pixel tiles in fp32, folded in fp64, of a feature map whose
-//  producer is known -- the general entry ccst_adain_f32 keeps the two-pass / pivot-shifted forms for arbitrary planes.)
-#ifndef TS_PIXELS
-#define TS_PIXELS 256
-#endif
-constexpr int TS_CQ = 16, TS_PL = TPB / TS_CQ, TS_PIX = TS_PIXELS;
+// AdaIN where the producer of x has already left the statistics: per-(spatial tile, channel) records from the epilogue of the conv that
+// wrote x (tiles n * tpi .. (n + 1) * tpi - 1 belong to image n, pixels outside the image excluded).  Two launches (round 5; one until
+// round 4): tile_stats_fold_kernel folds the records ONCE -- a thread per (image, channel), fp64 -- into mu[N][C], sigma[N][C]; the
+// streaming kernel then reads two floats per channel and streams the tensor once, every CU busy, no LDS, no barrier, no fp64.  (The
+// one-launch form made every one of its 768 workgroups re-fold its image's records behind the loads it had issued: 27.6 us against
+// 23.4 with the raw pairs -- the centred records are the right numerics, folding them in every pixel block was the price.)
+//   records: CENTRED (the half-piece conv kernels): (S, M2 about the slab's own mean, count, 0) per (tile, channel); the fold keeps
+//   s = sum of (x - pivot) and q = sum of (x - pivot)^2 about a pivot (the first slab's mean), assembled in fp64 from slab quantities
+//   that carry no cancellation: the variance is sum M2_i + sum n_i (mean_i - mean)^2 up to fp64 rounding however large |mean| / sigma.
+//   Raw (sum, sum of squares) pairs (ccst_conv3x3_wino4w_f32): mean = S / HW, unbiased variance = (Q - S mean) / (HW - 1) in fp64.
 template <bool CENTRED>
-__global__ __launch_bounds__(TPB) void adain_tile_sums_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                                   const float* __restrict__ part, int tpi,
-                                                                   const float* __restrict__ smean, const float* __restrict__ sstd,
-                                                                   int style_per_n, float alpha, int HW, int C, float eps,
-                                                                   float* __restrict__ mean_out, float* __restrict__ std_out,
-                                                                   unsigned* __restrict__ ymax) {
+__global__ __launch_bounds__(TPB) void tile_stats_fold_kernel(const float* __restrict__ part, int tpi, int HW, int C, int NC, float eps,
+                                                              float* __restrict__ mean_out, float* __restrict__ std_out) {
+    const int i = blockIdx.x * TPB + threadIdx.x;          // (image, channel): consecutive threads = consecutive channels
+    if (i >= NC) return;
+    const int n = i / C, c = i - n * C;
+    double s = 0.0, q = 0.0, piv = 0.0;
+    if (CENTRED) {
+        const f32x4* pp = reinterpret_cast<const f32x4*>(part) + (long long)n * tpi * C + c;
+        const f32x4 a0 = pp[0];
+        piv = a0[2] > 0.f ? (double)(a0[0] / a0[2]) : 0.0;          // (any pivot near the data will do: fp32 division)
+        for (int k = 0; k < tpi; ++k) {
+            const f32x4 a = pp[(long long)k * C];
+            if (a[2] > 0.f) {
+                // sum of (x - pivot) = S - n pivot, exactly in fp64; sum of (x - pivot)^2 = M2 + (S - n pivot)^2 / n
+                const double tk = (double)a[0] - (double)a[2] * piv;
+                s += tk;
+                q += (double)a[1] + tk * tk / (double)a[2];
+            }
+        }
+    } else {
+        const float* pp = part + ((long long)n * tpi * C + c) * 2;
+        for (int k = 0; k < tpi; ++k) {
+            s += (double)pp[(long long)k * C * 2];
+            q += (double)pp[(long long)k * C * 2 + 1];
+        }
+    }
+    const double m = s / (double)HW;                                            // (CENTRED: of x - pivot)
+    const double var = fmax(q - s * m, 0.0) / ((double)HW - 1.0);
+    mean_out[i] = (float)(m + piv);
+    std_out[i] = sqrtf((float)var + eps);
+}
+
+constexpr int TS_CQ = 16, TS_PL = TPB / TS_CQ, TS_PIX = 256;
+__global__ __launch_bounds__(TPB) void adain_stream_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                const float* __restrict__ cmean, const float* __restrict__ cstd,
+                                                                const float* __restrict__ smean, const float* __restrict__ sstd,
+                                                                int style_per_n, float alpha, int HW, int C,
+                                                                unsigned* __restrict__ ymax) {
     const int t = threadIdx.x, cq = t % TS_CQ, pl = t / TS_CQ;
     const int n = blockIdx.y, c0 = blockIdx.x * (4 * TS_CQ) + cq * 4;
     const float* xb = x + ((long long)n * HW) * C + c0;
     float* yb = y + ((long long)n * HW) * C + c0;
     const int p0 = blockIdx.z * TS_PIX;
-    // the tensor first: its loads are in flight while the statistics are folded
     f32x4 v[TS_PIX / TS_PL];
 #pragma unroll
     for (int i = 0; i < TS_PIX / TS_PL; ++i) {
         const int p = p0 + pl + i * TS_PL;
         if (p < HW) v[i] = *reinterpret_cast<const f32x4*>(xb + (long long)p * C);
     }
-    // the tile pairs of this thread's four channels: the 16 pixel-lanes of a channel quad share them (tiles pl, pl + 16, ...), folded
-    // over the four lanes of a wave by shuffles and over the four waves through LDS, in a fixed order (bitwise reproducible)
-    __shared__ double red[TPB / 64][TS_CQ][8];
-    // CENTRED (the half-piece conv kernels' epilogues): (S, M2 about the slab's own mean, count, 0) per (tile, channel).  The fold keeps
-    // s = sum S and q = sum (M2_i + S_i^2 / n_i) = the raw sum of squares, but assembled in fp64 from slab quantities that carry no
-    // cancellation; the variance below is then sum M2_i + sum n_i (mean_i - mean)^2 up to fp64 rounding.  To keep that true when
-    // |mean| / sigma is huge, the squares are taken about a pivot: the first slab's mean.
-    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
-    double piv[4] = {0.0, 0.0, 0.0, 0.0};
-    if (CENTRED) {
-        const float* pp = part + ((long long)n * tpi * C + c0) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(pp + j * 4);                      // slab 0 of the image: the pivot (same for every lane)
-            piv[j] = a0[2] > 0.f ? (double)(a0[0] / a0[2]) : 0.0;                              // (any pivot near the data will do: fp32 division)
-        }
-        for (int k = pl; k < tpi; k += TS_PL)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(pp + ((long long)k * C + j) * 4);
-                if (a[2] > 0.f) {
-                    // sum of (x - pivot) = S - n pivot, exactly in fp64; sum of (x - pivot)^2 = M2 + (S - n pivot)^2 / n with 1 / n from
-                    // v_rcp_f32 (n is a pixel count: exact as float; 1 ulp on a term of the variance) -- no fp64 division in the fold
-                    const double tk = (double)a[0] - (double)a[2] * piv[j];
-                    s[j] += tk;
-                    q[j] += (double)a[1] + tk * tk * (double)__builtin_amdgcn_rcpf(a[2]);
-                }
-            }
-    } else {
-        const float* pp = part + ((long long)n * tpi * C + c0) * 2;
-        for (int k = pl; k < tpi; k += TS_PL) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(pp + (long long)k * C * 2);          // S c0, Q c0, S c0+1, Q c0+1
-            const f32x4 b = *reinterpret_cast<const f32x4*>(pp + (long long)k * C * 2 + 4);
-            s[0] += (double)a[0]; q[0] += (double)a[1]; s[1] += (double)a[2]; q[1] += (double)a[3];
-            s[2] += (double)b[0]; q[2] += (double)b[1]; s[3] += (double)b[2]; q[3] += (double)b[3];
-        }
-    }
-#pragma unroll
-    for (int off = TS_CQ; off < 64; off <<= 1)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s[j] += __shfl_xor(s[j], off, 64);
-            q[j] += __shfl_xor(q[j], off, 64);
-        }
-    if ((t & 63) < TS_CQ) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            red[t >> 6][cq][j] = s[j];
-            red[t >> 6][cq][4 + j] = q[j];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        s[j] = red[0][cq][j];
-        q[j] = red[0][cq][4 + j];
-#pragma unroll
-        for (int w = 1; w < TPB / 64; ++w) {
-            s[j] += red[w][cq][j];
-            q[j] += red[w][cq][4 + j];
-        }
-    }
-    f32x4 mu, sd;
-    const double inv_hw = 1.0 / (double)HW, inv_hw1 = 1.0 / ((double)HW - 1.0);        // (uniform: two divisions per thread instead of eight)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const double m = s[j] * inv_hw;                                                 // (CENTRED: of x - pivot)
-        const double var = fmax(q[j] - s[j] * m, 0.0) * inv_hw1;
-        mu[j] = (float)(m + piv[j]);
-        sd[j] = sqrtf((float)var + eps);
-    }
-    if (mean_out != nullptr && blockIdx.z == 0 && pl == 0) {
-        *reinterpret_cast<f32x4*>(mean_out + n * C + c0) = mu;
-        *reinterpret_cast<f32x4*>(std_out + n * C + c0) = sd;
-    }
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(cmean + n * C + c0), sd = *reinterpret_cast<const f32x4*>(cstd + n * C + c0);
     const int so = (style_per_n ? n * C : 0) + c0;
     const f32x4 sm = *reinterpret_cast<const f32x4*>(smean + so), ss = *reinterpret_cast<const f32x4*>(sstd + so);
     const bool blend = (alpha != 1.f);
@@ -612,18 +568,20 @@ extern "C" int ccst_adain_tile_sums_f32(const float* x, const float* partials, i
                                         const float* style_std, int style_per_n, float alpha, float* y, int N, int C, int HW, float eps,
                                         float* mean_out, float* std_out, uint32_t* y_absmax, void* stream) {
     CCST_REQUIRE(x && partials && style_mean && style_std && y, "adain_tile_sums: null pointer");
+    CCST_REQUIRE(mean_out && std_out, "adain_tile_sums: mean_out / std_out ([N*C] floats each) carry the folded statistics to the streaming kernel");
     CCST_REQUIRE(partial_floats == 2 || partial_floats == 4, "adain_tile_sums: partials are [..][C][2] (sum, sum^2) or [..][C][4] (sum, M2, count, 0)");
     CCST_REQUIRE(N > 0 && N <= 65535 && C > 0 && C % (4 * TS_CQ) == 0 && HW >= 2 && tiles_per_image > 0, "adain_tile_sums: bad shape (C %% 64 == 0, HW >= 2)");
     CCST_REQUIRE(alpha >= 0.f && alpha <= 1.f, "adain_tile_sums: alpha=%f outside [0,1]", (double)alpha);
-    CCST_REQUIRE((mean_out == nullptr) == (std_out == nullptr), "adain_tile_sums: mean_out and std_out come together");
     const int chunks = (HW + TS_PIX - 1) / TS_PIX;
     CCST_REQUIRE(chunks <= 65535, "adain_tile_sums: plane too large");
+    hipStream_t st = (hipStream_t)stream;
+    const int NC = N * C;
     if (partial_floats == 4)
-        hipLaunchKernelGGL(adain_tile_sums_nhwc_kernel<true>, dim3(C / (4 * TS_CQ), N, chunks), dim3(TPB), 0, (hipStream_t)stream, x, y, partials,
-                           tiles_per_image, style_mean, style_std, style_per_n, alpha, HW, C, eps, mean_out, std_out, y_absmax);
+        hipLaunchKernelGGL(tile_stats_fold_kernel<true>, dim3((NC + TPB - 1) / TPB), dim3(TPB), 0, st, partials, tiles_per_image, HW, C, NC, eps, mean_out, std_out);
     else
-        hipLaunchKernelGGL(adain_tile_sums_nhwc_kernel<false>, dim3(C / (4 * TS_CQ), N, chunks), dim3(TPB), 0, (hipStream_t)stream, x, y, partials,
-                           tiles_per_image, style_mean, style_std, style_per_n, alpha, HW, C, eps, mean_out, std_out, y_absmax);
+        hipLaunchKernelGGL(tile_stats_fold_kernel<false>, dim3((NC + TPB - 1) / TPB), dim3(TPB), 0, st, partials, tiles_per_image, HW, C, NC, eps, mean_out, std_out);
+    hipLaunchKernelGGL(adain_stream_nhwc_kernel, dim3(C / (4 * TS_CQ), N, chunks), dim3(TPB), 0, st, x, y, mean_out, std_out, style_mean, style_std,
+                       style_per_n, alpha, HW, C, y_absmax);
     return ccst_launch_status("adain_tile_sums");
 }
 

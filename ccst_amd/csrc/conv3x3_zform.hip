@@ -152,7 +152,10 @@ __global__ __launch_bounds__(256, Z_WGS) void conv3x3_zform_kernel(const ZArgs p
 #pragma unroll
             for (int h = 0; h < 2; ++h) st[d][2 * ks + h] = *reinterpret_cast<const f32x4*>(p.x + off + ks * 32 + h * 16);
     };
-    int t = tile_of(0);           // >= 0: the grid never exceeds the tile count
+    int t = tile_of(0);
+    // (the per-XCD ranges are ceil(ntiles / 8) long, so the last XCD's workgroups can be left without a tile -- ntiles = 1025 on 256
+    //  CUs: slots 122..127 of XCD 7; nothing below may run on tile -1.  Workgroup-uniform, before any barrier.)
+    if (t < 0) return;
     Tile cur, nxt;
     offsets(t, cur);
 #pragma unroll

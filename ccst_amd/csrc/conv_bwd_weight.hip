@@ -25,6 +25,8 @@ struct BwdWArgs {
     int M, splits, tilesI, tilesJ;
     float invHW, invWo;     // reciprocals for the division-free pixel decode (valid while M < 2^22)
     int fastdiv;
+    const unsigned* xmax;   // (half-piece kernel) |max| words of x and of dy
+    const unsigned* dmax;
 };
 
 // floor(m / d) for 0 <= m < 2^22 via one float multiply + correction (an integer division costs ~40
@@ -301,6 +303,325 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(const BwdWArgs p) 
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The same GEMM on the 16-bit MFMA (round 5): every fp32 product as three products of IEEE-half pieces (v = hi + lo, 22 significant
+// bits, fp32 accumulation: x_lo dy_hi + x_hi dy_lo + x_hi dy_hi), v_mfma_f32_32x32x16_f16 -- 12 MFMAs of K = 16 per 64x64 wave tile
+// and 16 pixels instead of 32 of K = 2, 5.3x the fp32 MFMA's rate.  The reduction runs over PIXELS, so an MFMA operand is eight
+// consecutive pixels of one channel, while memory (NHWC) has the channels of one pixel side by side: the LDS images stay
+// [pixel][channel] (what the loader's 16-byte loads deliver: four channels of a pixel -> two 8-byte stores of half pieces) and the
+// operands are fetched with ds_read_b64_tr_b16, the transposing LDS read of gfx950 (a 16-lane group reads four pixel rows x 16 channels
+// and each lane receives its channel's four pixels).  Rows are padded by 64 bytes: the four pixel rows a 32-lane half reads then
+// fall on the four 64-byte quarters of the 256-byte bank row (conflict-free; 256-byte rows would be four-way).
+// Range: x and dy are scaled by powers of two from their tensors' |max| words (x: left by the BatchNorm apply that produced it; dy:
+// by the BatchNorm-backward apply, ccst_bn_train_bwd_*'s dx_absmax) to max < 2^14 as they are split; the slab is scaled back.  An
+// element 2^-k below its tensor's maximum keeps min(22, 38 - k) bits, an absolute error of 2^-38 of that maximum at worst.
+// Loads run two steps ahead in two register sets (a step of 16 pixels is ~0.3 us: one step would not cover an HBM round trip),
+// unconditionally (past the range: clamped addresses, never stored), so that the compiler's vmcnt counts stay exact.
+// ------------------------------------------------------------------------------------------------------------------------
+typedef _Float16 f16x8w __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2w __attribute__((ext_vector_type(2)));
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+typedef short s16x4w __attribute__((ext_vector_type(4)));
+typedef short s16x8w __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+
+// (as split4h of conv3x3_halo.hip: v_pk_mul_f32 / v_cvt_pk_f16_f32 / v_pk_fma_f32, 12 vector instructions per four values)
+__device__ __forceinline__ void split4w(f32x4 v, float s, u32x2w& hi, u32x2w& lo) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2w q = f32x2w{v[2 * h], v[2 * h + 1]} * s;
+        const f16x2w qh = __builtin_convertvector(q, f16x2w);
+        const f16x2w ql = __builtin_convertvector(q - __builtin_convertvector(qh, f32x2w), f16x2w);
+        hi[h] = __builtin_bit_cast(unsigned, qh);
+        lo[h] = __builtin_bit_cast(unsigned, ql);
+    }
+}
+// eight consecutive pixels (k) of this lane's channel: two transposing reads four pixel rows apart.  EXEC must be all ones.
+__device__ __forceinline__ f16x8w lds_tr8(const unsigned char* p, int row_bytes) {
+    typedef __attribute__((address_space(3))) s16x4w* lp;
+    const s16x4w a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)p);
+    const s16x4w b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(p + 4 * row_bytes));
+    return __builtin_bit_cast(f16x8w, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int MI, int NJ, int PK, bool PW, bool TP2 = false>
+__global__ __launch_bounds__(256, 2) void conv_bwd_weight_split_kernel(const BwdWArgs p) {
+    static_assert(!TP2 || (MI == 1 && !PW), "tap packing is for the 64x64 tile of a multi-tap problem");
+    static_assert(PK % 16 == 0, "a step is whole K = 16 MFMAs");
+    constexpr int BI = 64 * MI, BJ = 64 * NJ;
+    constexpr int SI = 2 * BI + 64, SJ = 2 * BJ + 64;     // bytes per pixel row of a piece image (see the header comment)
+    constexpr int XIMG = PK * SI, DIMG = PK * SJ;         // bytes per piece image
+    constexpr int STAGE = 2 * XIMG + 2 * DIMG;            // x hi | x lo | dy hi | dy lo
+    constexpr int XU = PK * BI / 4, DU = PK * BJ / 4;     // float4 units per step
+    constexpr int XR = XU / 256, DR = DU / 256;
+    static_assert(XU % 256 == 0 && DU % 256 == 0, "tile/thread mismatch");
+    constexpr int NKS = PK / 16;
+
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave >> 1, wj = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const unsigned xword = ccst_absmax_load(p.xmax), dword = ccst_absmax_load(p.dmax);
+
+    // workgroup order: as conv_bwd_weight_kernel (the workgroups of one pixel range side by side behind one L2)
+    int b = ccst_xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int tj = b % p.tilesJ;
+    b /= p.tilesJ;
+    const int ti = b % p.tilesI;
+    b /= p.tilesI;
+    const int ngroups = (int)gridDim.x / (p.splits * p.tilesI * p.tilesJ);
+    const int tapg = b % ngroups;
+    const int split = b / ngroups;
+    const int tap = TP2 ? 2 * tapg : tapg;
+    const int ky = tap / p.nkx, kx = tap - ky * p.nkx;
+    const int ci0 = ti * BI, co0 = tj * BJ;
+    const int ntap = p.nky * p.nkx;
+
+    const int steps_total = (p.M + PK - 1) / PK;
+    const int sps = (steps_total + p.splits - 1) / p.splits;
+    const int s0 = split * sps;
+    const int s1 = min(steps_total, s0 + sps);
+
+    f32x16 acc[MI][NJ];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int c = 0; c < NJ; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+    f32x4 rx[2][XR], rd[2][DR];
+    unsigned okm[2] = {0u, 0u};        // which units of a register set are real data (bit u: x unit u, bit XR + u: dy unit u) -- applied
+                                       // when the set is split, not behind the load: a select on the loaded value would wait for it
+    const int HW = p.Ho * p.Wo;
+    int un = 0, uoy = 0, uox = 0;                       // (n, oy, ox) of the first pixel of the next step to load (!PW), wave-uniform
+    const int stepRows = PK / p.Wo, stepCols = PK - (PK / p.Wo) * p.Wo;
+    const unsigned magicW = (65536u + (unsigned)p.Wo - 1u) / (unsigned)p.Wo, magicH = (65536u + (unsigned)p.Ho - 1u) / (unsigned)p.Ho;
+    const bool wideW = p.Wo > 224, wideH = p.Ho > 224;
+    if (!PW) {
+        const int m0 = min(s0 * PK, p.M - 1);
+        un = m0 / HW;
+        const int rem = m0 - un * HW;
+        uoy = rem / p.Wo;
+        uox = rem - uoy * p.Wo;
+        un = __builtin_amdgcn_readfirstlane(un);
+        uoy = __builtin_amdgcn_readfirstlane(uoy);
+        uox = __builtin_amdgcn_readfirstlane(uox);
+    }
+    auto advance_pixels = [&]() {
+        uox += stepCols;
+        uoy += stepRows;
+        if (uox >= p.Wo) {
+            uox -= p.Wo;
+            ++uoy;
+        }
+        while (uoy >= p.Ho) {
+            uoy -= p.Ho;
+            ++un;
+        }
+    };
+
+    // loads of step st into register set R (steps past the tensor's end read clamped addresses and are zeroed; steps past this
+    // workgroup's range are loaded and never used)
+    auto load_step = [&](int st, f32x4 (&rxs)[XR], f32x4 (&rds)[DR], unsigned& okbits) {
+        const int m0 = st * PK;
+        unsigned bits = 0u;
+#pragma unroll
+        for (int u = 0; u < XR; ++u) {
+            const int unit = tid + 256 * u;
+            const int px = unit / (BI / 4), cp = unit - px * (BI / 4);
+            const int m = m0 + px;
+            const int mc = min(m, p.M - 1);
+            int ci = ci0 + cp * 4, kyu = ky, kxu = kx;
+            bool tap_ok = true;
+            if (TP2) {
+                const int tapu = tap + (cp >> 3);
+                ci = (cp & 7) * 4;
+                kyu = tapu / p.nkx;
+                kxu = tapu - kyu * p.nkx;
+                tap_ok = tapu < ntap;
+            }
+            const int cic = min(ci, p.Cin - 4);
+            bool ok;
+            if (PW) {
+                ok = (m < p.M) & (ci < p.Cin);
+                rxs[u] = *reinterpret_cast<const f32x4*>(p.x + (long long)mc * p.xsW + cic);
+            } else {
+                const unsigned t = (unsigned)(uox + px);
+                const unsigned q = wideW ? (t >= (unsigned)p.Wo ? 1u : 0u) : (__umul24(t, magicW) >> 16);
+                const int ox = (int)(t - __umul24(q, (unsigned)p.Wo));
+                const unsigned ty = (unsigned)uoy + q;
+                const unsigned r = wideH ? (ty >= (unsigned)p.Ho ? 1u : 0u) : (__umul24(ty, magicH) >> 16);
+                const int oy = (int)(ty - __umul24(r, (unsigned)p.Ho));
+                const int n = min(un + (int)r, p.N - 1);
+                int iy = __mul24(oy, p.ay) + kyu * p.by + p.cy, ix = __mul24(ox, p.ax) + kxu * p.bx + p.cx;
+                ok = (m < p.M) & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi) & (ci < p.Cin) & tap_ok;
+                iy = min(max(iy, 0), p.Hi - 1);
+                ix = min(max(ix, 0), p.Wi - 1);
+                rxs[u] = *reinterpret_cast<const f32x4*>(p.x + (long long)n * p.xsN + (unsigned)(__mul24(iy, p.xsH) + __mul24(ix, p.xsW) + cic));
+            }
+            bits |= ok ? (1u << u) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < DR; ++u) {
+            const int unit = tid + 256 * u;
+            const int px = unit / (BJ / 4), cp = unit - px * (BJ / 4);
+            const int m = m0 + px;
+            const int mc = min(m, p.M - 1);
+            const int co = co0 + cp * 4;
+            rds[u] = *reinterpret_cast<const f32x4*>(p.dy + (long long)mc * p.Cout + min(co, p.Cout - 4));
+            bits |= ((m < p.M) & (co < p.Cout)) ? (1u << (XR + u)) : 0u;
+        }
+        okbits = bits;
+        if (!PW) advance_pixels();
+    };
+
+    const int kxs = ccst_scale_exp(ccst_absmax_reduce(xword), CCST_SPLIT_X_TARGET);
+    const int kds = ccst_scale_exp(ccst_absmax_reduce(dword), CCST_SPLIT_X_TARGET);
+    const float xsc = __uint_as_float((unsigned)(127 + kxs) << 23), dsc = __uint_as_float((unsigned)(127 + kds) << 23);
+
+    auto store_step = [&](int buf, const f32x4 (&rxs)[XR], const f32x4 (&rds)[DR], unsigned okbits) {
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        unsigned char* const base = lds + buf * STAGE;
+#pragma unroll
+        for (int u = 0; u < XR; ++u) {
+            const int unit = tid + 256 * u;
+            const int px = unit / (BI / 4), cp = unit - px * (BI / 4);
+            u32x2w hi, lo;
+            split4w(((okbits >> u) & 1u) ? rxs[u] : z4, xsc, hi, lo);
+            *reinterpret_cast<u32x2w*>(base + px * SI + cp * 8) = hi;
+            *reinterpret_cast<u32x2w*>(base + XIMG + px * SI + cp * 8) = lo;
+        }
+#pragma unroll
+        for (int u = 0; u < DR; ++u) {
+            const int unit = tid + 256 * u;
+            const int px = unit / (BJ / 4), cp = unit - px * (BJ / 4);
+            u32x2w hi, lo;
+            split4w(((okbits >> (XR + u)) & 1u) ? rds[u] : z4, dsc, hi, lo);
+            *reinterpret_cast<u32x2w*>(base + 2 * XIMG + px * SJ + cp * 8) = hi;
+            *reinterpret_cast<u32x2w*>(base + 2 * XIMG + DIMG + px * SJ + cp * 8) = lo;
+        }
+    };
+
+    // this lane's share of a transposing read: pixel row 8 lh + (lane & 15) / 4 of the 16-pixel k-step, channels 16 ((lane >> 4) & 1) +
+    // 4 (lane & 3) .. + 3 of the wave's 32-channel block; it receives channel (lane & 31), pixels 8 lh .. 8 lh + 3 (+ 4 by the second read)
+    const int trow = 8 * lh + ((lane & 15) >> 2), tcol = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const int xoff = trow * SI + 2 * (wi * (32 * MI) + tcol), doff = trow * SJ + 2 * (wj * (32 * NJ) + tcol);
+    struct Frags {
+        f16x8w a[2][MI], b[2][NJ];          // [piece][tile]
+    };
+    auto read_frags = [&](int buf, int ks, Frags& f) {
+        const unsigned char* const base = lds + buf * STAGE;
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+#pragma unroll
+            for (int a = 0; a < MI; ++a) f.a[pc][a] = lds_tr8(base + pc * XIMG + ks * 16 * SI + xoff + a * 64, SI);
+#pragma unroll
+            for (int c = 0; c < NJ; ++c) f.b[pc][c] = lds_tr8(base + 2 * XIMG + pc * DIMG + ks * 16 * SJ + doff + c * 64, SJ);
+        }
+    };
+    auto mfmas = [&](const Frags& f) {
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int c = 0; c < NJ; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[1][a], f.b[0][c], acc[a][c], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int c = 0; c < NJ; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[0][a], f.b[1][c], acc[a][c], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int c = 0; c < NJ; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[0][a], f.b[0][c], acc[a][c], 0, 0, 0);
+    };
+    // one step: the MFMAs of LDS stage `buf` (step t); registers of step t + 1 -> the other stage; loads of step t + 3 into the
+    // register set just freed
+    auto step = [&](int buf, int st_load, f32x4 (&rxs)[XR], f32x4 (&rds)[DR], unsigned& okbits) {
+        Frags f[2];
+        read_frags(buf, 0, f[0]);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks + 1 < NKS) read_frags(buf, ks + 1, f[(ks + 1) & 1]);
+            if (ks == NKS - 1) {
+                store_step(buf ^ 1, rxs, rds, okbits);
+                load_step(st_load, rxs, rds, okbits);
+            }
+            mfmas(f[ks & 1]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+
+    if (s0 < s1) {
+        const int T = s1 - s0;
+        load_step(s0, rx[0], rd[0], okm[0]);
+        load_step(s0 + 1, rx[1], rd[1], okm[1]);
+        store_step(0, rx[0], rd[0], okm[0]);
+        load_step(s0 + 2, rx[0], rd[0], okm[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        int t = 0;
+        for (; t + 2 <= T; t += 2) {
+            step(0, s0 + t + 3, rx[1], rd[1], okm[1]);
+            step(1, s0 + t + 4, rx[0], rd[0], okm[0]);
+        }
+        if (t < T) step(0, s0 + t + 3, rx[1], rd[1], okm[1]);
+    }
+
+    // scale back (two exact multiplications: either power of two is a normal float, their product need not be)
+    const float xin = __uint_as_float((unsigned)(127 - kxs) << 23), din = __uint_as_float((unsigned)(127 - kds) << 23);
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int c = 0; c < NJ; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = acc[a][c][r] * xin * din;
+
+    // partial slab store: ws[((split*ntap + tap)*Cin + ci)*Cout + co]
+    float* wsb = p.ws + ((long long)split * ntap + tap) * p.Cin * p.Cout;
+    if (TP2) {
+        if (tap + wi >= ntap) return;
+        wsb += (long long)wi * p.Cin * p.Cout;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int co = co0 + wj * 32 + li;
+            if (ci < p.Cin && co < p.Cout) wsb[(long long)ci * p.Cout + co] = acc[0][0][r];
+        }
+        return;
+    }
+    if (ci0 + BI <= p.Cin && co0 + BJ <= p.Cout) {
+        float* const tile = wsb + (long long)(ci0 + wi * (32 * MI)) * p.Cout + co0 + wj * (32 * NJ);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile, 0, 0x7fffffff, 0x00020000);
+        const unsigned lane_off = (unsigned)(4 * lh * p.Cout + li) * 4u;
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int srow = (a * 32 + (r & 3) + 8 * (r >> 2)) * p.Cout * 4;
+#pragma unroll
+                for (int c = 0; c < NJ; ++c)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[a][c][r]), rsrc, lane_off + c * 128, srow, 0);
+            }
+        return;
+    }
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wi * (32 * MI) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (ci < p.Cin) {
+#pragma unroll
+                for (int c = 0; c < NJ; ++c) {
+                    const int co = co0 + wj * (32 * NJ) + c * 32 + li;
+                    if (co < p.Cout) wsb[(long long)ci * p.Cout + co] = acc[a][c][r];
+                }
+            }
+        }
+}
+
 // dw[co][ci][tap] (+)= sum_s ws[s][tap][ci][co].  The slabs are the bulk of the traffic (splits x the weight tensor: 17-75 MB per
 // ResNet50 layer at B=64) and this kernel is bound by reading them: a thread owns four consecutive co (one 16-byte load per slab) of
 // one ci and sums the slabs l, l + NL, ... of its split-lane l with eight loads in flight; a workgroup = 32 co x (32 / NL) ci x NL
@@ -361,6 +682,20 @@ int launch(BwdWArgs& a, hipStream_t s) {
     return ccst_launch_status("conv_bwd_weight");
 }
 
+template <int MI, int NJ, int PK, bool PW, bool TP2 = false>
+int launch_split(BwdWArgs& a, hipStream_t s) {
+    a.tilesI = (a.Cin + 64 * MI - 1) / (64 * MI);
+    a.tilesJ = (a.Cout + 64 * NJ - 1) / (64 * NJ);
+    const int tapgroups = TP2 ? (a.nky * a.nkx + 1) / 2 : a.nky * a.nkx;
+    const long long grid = (long long)tapgroups * a.tilesI * a.tilesJ * a.splits;
+    if (grid <= 0 || grid > 0x7fffffffLL) {
+        ccst_set_error("bwd_weight_split: bad grid");
+        return CCST_EINVAL;
+    }
+    hipLaunchKernelGGL((conv_bwd_weight_split_kernel<MI, NJ, PK, PW, TP2>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    return ccst_launch_status("conv_bwd_weight_split");
+}
+
 }  // namespace
 
 // Tile (ci x co) per problem: 128x128 when both sides have >= 128 channels, else 64x64.  (64x128 / 128x64 tiles
@@ -385,8 +720,44 @@ extern "C" int ccst_conv2d_bwd_weight_splits(int M, int cin, int cout, int ntap)
     return (int)s;
 }
 
+// the half-piece kernel's tiles: 128 channels on a side that has them, else 64 (its loop is short enough that the 64 <-> 256 layers
+// gain from the rectangular tiles the fp32 kernel measured slower with)
+static void pick_tile_split(int cin, int cout, int* mi, int* nj) {
+    *mi = cin >= 128 ? 2 : 1;
+    *nj = cout >= 128 ? 2 : 1;
+}
+constexpr int SPLIT_PK = 16;
+
+extern "C" int ccst_conv2d_bwd_weight_split_splits(int M, int cin, int cout, int ntap) {
+    int mi, nj;
+    pick_tile_split(cin, cout, &mi, &nj);
+    const int tapgroups = (mi == 1 && ntap > 1 && cin <= 32) ? (ntap + 1) / 2 : ntap;
+    const long long tiles = (long long)tapgroups * ((cin + 64 * mi - 1) / (64 * mi)) * ((cout + 64 * nj - 1) / (64 * nj));
+    long long s = (1024 + tiles - 1) / tiles;
+    const long long smax = (M / SPLIT_PK) / 16 > 0 ? (M / SPLIT_PK) / 16 : 1;     // >= 16 steps per workgroup
+    if (s > smax) s = smax;
+    if (s > 512) s = 512;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+static int bwd_weight_entry(const CcstConvDesc* d, const float* x, const uint32_t* x_absmax, const float* dy, const uint32_t* dy_absmax,
+                            float* dw_oihw, int splits, int accumulate, void* ws, int64_t ws_bytes, void* stream);
+
+extern "C" int ccst_conv2d_bwd_weight_split_f32(const CcstConvDesc* d, const float* x, const uint32_t* x_absmax, const float* dy,
+                                                const uint32_t* dy_absmax, float* dw_oihw, int splits, int accumulate, void* ws,
+                                                int64_t ws_bytes, void* stream) {
+    CCST_REQUIRE(x_absmax && dy_absmax, "bwd_weight_split: the |max| words of x and dy are required");
+    return bwd_weight_entry(d, x, x_absmax, dy, dy_absmax, dw_oihw, splits, accumulate, ws, ws_bytes, stream);
+}
+
 extern "C" int ccst_conv2d_bwd_weight_f32(const CcstConvDesc* d, const float* x, const float* dy, float* dw_oihw, int splits,
                                           int accumulate, void* ws, int64_t ws_bytes, void* stream) {
+    return bwd_weight_entry(d, x, nullptr, dy, nullptr, dw_oihw, splits, accumulate, ws, ws_bytes, stream);
+}
+
+static int bwd_weight_entry(const CcstConvDesc* d, const float* x, const uint32_t* x_absmax, const float* dy, const uint32_t* dy_absmax,
+                            float* dw_oihw, int splits, int accumulate, void* ws, int64_t ws_bytes, void* stream) {
     CCST_REQUIRE(d && x && dy && dw_oihw && ws, "bwd_weight: null pointer");
     CCST_REQUIRE(d->cin > 0 && d->cin % 4 == 0 && d->cout > 0 && d->cout % 4 == 0, "bwd_weight: cin/cout must be multiples of 4");
     CCST_REQUIRE(d->n > 0 && d->ho > 0 && d->wo > 0 && d->nky > 0 && d->nkx > 0 && splits >= 1, "bwd_weight: bad extents");
@@ -414,10 +785,21 @@ extern "C" int ccst_conv2d_bwd_weight_f32(const CcstConvDesc* d, const float* x,
     const bool pw = ntap == 1 && d->ay == 1 && d->ax == 1 && d->cy == 0 && d->cx == 0 && d->hi == d->ho && d->wi == d->wo &&
                     d->xsH == (long long)d->wi * d->xsW && d->xsN == (long long)d->hi * d->wi * d->xsW;
     int mi, nj;
+    a.xmax = x_absmax;
+    a.dmax = dy_absmax;
+    if (x_absmax != nullptr) {          // half pieces on the 16-bit MFMA
+        pick_tile_split(d->cin, d->cout, &mi, &nj);
+        if (!pw && ntap > 1 && d->cin <= 32) rc = launch_split<1, 1, SPLIT_PK, false, true>(a, s);
+        else if (mi == 2 && nj == 2) rc = pw ? launch_split<2, 2, SPLIT_PK, true>(a, s) : launch_split<2, 2, SPLIT_PK, false>(a, s);
+        else if (mi == 2) rc = pw ? launch_split<2, 1, SPLIT_PK, true>(a, s) : launch_split<2, 1, SPLIT_PK, false>(a, s);
+        else if (nj == 2) rc = pw ? launch_split<1, 2, SPLIT_PK, true>(a, s) : launch_split<1, 2, SPLIT_PK, false>(a, s);
+        else rc = pw ? launch_split<1, 1, SPLIT_PK, true>(a, s) : launch_split<1, 1, SPLIT_PK, false>(a, s);
+    } else {
     pick_tile(d->cin, d->cout, &mi, &nj);
     if (mi == 2 && nj == 2) rc = pw ? launch<2, 2, 16, true>(a, s) : launch<2, 2, 16, false>(a, s);
     else if (!pw && ntap > 1 && d->cin <= 32) rc = launch<1, 1, 32, false, true>(a, s);      // two taps per ci tile
     else rc = pw ? launch<1, 1, 32, true>(a, s) : launch<1, 1, 32, false>(a, s);
+    }
     if (rc) return rc;
     // split-lanes of the reduce: the fewest (4, 8, 16, 32) that give >= 1024 workgroups, never more than there are slabs to share
     const long long cols = (long long)((d->cout + 31) / 32) * ntap;

@@ -292,8 +292,10 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ beta, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ sums, int relu,
                                                            float* __restrict__ dx, float* __restrict__ dres, long long total4, int C,
-                                                           float invM, const unsigned char* __restrict__ rmask = nullptr) {
+                                                           float invM, const unsigned char* __restrict__ rmask = nullptr,
+                                                           unsigned* __restrict__ dxmax = nullptr) {
     const int cg = C / 4;
+    float amax = 0.f;          // dxmax: the largest |dx| this thread writes (the half-piece weight-gradient / backward-data kernels scale by it)
     const long long stride = (long long)gridDim.x * TPB;
     const long long i0 = (long long)blockIdx.x * TPB + threadIdx.x;
     struct Chan {
@@ -318,7 +320,9 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
             for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
         }
         if (dres) *reinterpret_cast<f32x4*>(dres + i * 4) = g;
-        *reinterpret_cast<f32x4*>(dx + i * 4) = k.ga * k.is * (g - k.k1 - xh * k.k2);
+        const f32x4 d = k.ga * k.is * (g - k.k1 - xh * k.k2);
+        amax = fmaxf(fmaxf(fmaxf(amax, fabsf(d[0])), fmaxf(fabsf(d[1]), fabsf(d[2]))), fabsf(d[3]));
+        *reinterpret_cast<f32x4*>(dx + i * 4) = d;
     };
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     auto one = [&](long long i, const Chan& k) {
@@ -346,6 +350,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
             one(i, k);
         }
     }
+    if (dxmax != nullptr) ccst_absmax_publish(dxmax, amax, blockIdx.x);
 }
 // grid of the BatchNorm apply kernels: enough workgroups for per_thread elements per thread, at most 2048, and such that grid x 256 is a
 // multiple of the channel-group count (256 is a multiple of every C / 4 <= 256 of the ResNets; an even grid covers C / 4 = 512)
@@ -486,8 +491,9 @@ __global__ __launch_bounds__(TPB) void stem_bwd_apply_kernel(const float* __rest
                                                              const float* __restrict__ beta, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd, const float* __restrict__ sums,
                                                              float* __restrict__ dx, long long total4, int C, float invM, int H, int W, int Ho,
-                                                             int Wo) {
+                                                             int Wo, unsigned* __restrict__ dxmax) {
     const int cg = C / 4;
+    float amax = 0.f;
     for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total4; i += (long long)gridDim.x * TPB) {
         const unsigned iu = (unsigned)i, r = iu / (unsigned)cg, q = r / (unsigned)W, n = q / (unsigned)H;      // (total4 < 2^31: launcher)
         const int cq = (int)(iu - r * (unsigned)cg), c = cq * 4;
@@ -501,8 +507,11 @@ __global__ __launch_bounds__(TPB) void stem_bwd_apply_kernel(const float* __rest
 #pragma unroll
         for (int j = 0; j < 4; ++j) g[j] = o[j] > 0.f ? g[j] : 0.f;
         const f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + c), s2 = *reinterpret_cast<const f32x4*>(sums + C + c);
-        *reinterpret_cast<f32x4*>(dx + i * 4) = ga * is * (g - s1 * invM - xh * (s2 * invM));
+        const f32x4 d = ga * is * (g - s1 * invM - xh * (s2 * invM));
+        amax = fmaxf(fmaxf(fmaxf(amax, fabsf(d[0])), fmaxf(fabsf(d[1]), fabsf(d[2]))), fabsf(d[3]));
+        *reinterpret_cast<f32x4*>(dx + i * 4) = d;
     }
+    if (dxmax != nullptr) ccst_absmax_publish(dxmax, amax, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -818,7 +827,7 @@ extern "C" int ccst_bn_eval_fwd_f32(const float* x, const float* gamma, const fl
 extern "C" int ccst_bn_train_bwd_mask_f32(const float* dy, const float* x, const float* y, const uint8_t* relu_mask, const float* gamma,
                                           const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dx,
                                           float* d_residual, float* dgamma, float* dbeta, int accumulate, int64_t M, int C, void* ws,
-                                          int64_t ws_bytes, void* stream) {
+                                          int64_t ws_bytes, uint32_t* dx_absmax, void* stream) {
     CCST_REQUIRE(dy && x && gamma && save_mean && save_invstd && dx && dgamma && dbeta && ws, "bn_train_bwd: null pointer");
     CCST_REQUIRE(!relu || y || relu_mask || beta, "bn_train_bwd: relu=1 needs the forward's mask, the saved output y, or beta to recompute the mask from x");
     CCST_REQUIRE(!(relu && d_residual && !y && !relu_mask), "bn_train_bwd: with a residual the ReLU mask must come from the forward (mask or saved output y)");
@@ -847,7 +856,7 @@ extern "C" int ccst_bn_train_bwd_mask_f32(const float* dy, const float* x, const
     const long long total4 = (long long)M * (C / 4);
 #define CCST_BWD_APPLY(MK)                                                                                                          \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<MK>), dim3(bn_grid(total4, C, 2)), dim3(TPB), 0, st, dy, x, y, gamma, beta, save_mean, save_invstd, \
-                       sums, relu, dx, d_residual, total4, C, 1.f / (float)M, relu_mask)
+                       sums, relu, dx, d_residual, total4, C, 1.f / (float)M, relu_mask, dx_absmax)
     if (mask == 0) CCST_BWD_APPLY(0);
     else if (mask == 1) CCST_BWD_APPLY(1);
     else if (mask == 2) CCST_BWD_APPLY(2);
@@ -858,7 +867,8 @@ extern "C" int ccst_bn_train_bwd_mask_f32(const float* dy, const float* x, const
 
 extern "C" int ccst_bn_train_bwd_partials_f32(const float* dy, const float* x, const float* gamma, const float* save_mean,
                                               const float* save_invstd, const float* partials, int groups, float* dx, float* dgamma,
-                                              float* dbeta, int accumulate, int64_t M, int C, void* ws, int64_t ws_bytes, void* stream) {
+                                              float* dbeta, int accumulate, int64_t M, int C, void* ws, int64_t ws_bytes,
+                                              uint32_t* dx_absmax, void* stream) {
     CCST_REQUIRE(dy && x && gamma && save_mean && save_invstd && partials && dx && dgamma && dbeta && ws, "bn_train_bwd_partials: null pointer");
     CCST_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && groups > 0, "bn_train_bwd_partials: need M>0, groups>0 and C %% 4 == 0");
     if (ws_bytes < ccst_bn_workspace_bytes(M, C)) {
@@ -873,7 +883,7 @@ extern "C" int ccst_bn_train_bwd_partials_f32(const float* dy, const float* x, c
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<16>, dim3((C + 15) / 16), dim3(256), 0, st, partials, dgamma, dbeta, sums, C, groups, accumulate);
     const long long total4 = (long long)M * (C / 4);
     hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), dim3(bn_grid(total4, C, 2)), dim3(TPB), 0, st, dy, x, nullptr, gamma, nullptr, save_mean, save_invstd,
-                       sums, 0, dx, nullptr, total4, C, 1.f / (float)M, nullptr);
+                       sums, 0, dx, nullptr, total4, C, 1.f / (float)M, nullptr, dx_absmax);
     return ccst_launch_status("bn_train_bwd_partials");
 }
 
@@ -882,7 +892,7 @@ extern "C" int ccst_bn_train_bwd_f32(const float* dy, const float* x, const floa
                                      float* dgamma, float* dbeta, int accumulate, int64_t M, int C, void* ws, int64_t ws_bytes,
                                      void* stream) {
     return ccst_bn_train_bwd_mask_f32(dy, x, y, nullptr, gamma, beta, save_mean, save_invstd, relu, dx, d_residual, dgamma, dbeta, accumulate,
-                                      M, C, ws, ws_bytes, stream);
+                                      M, C, ws, ws_bytes, nullptr, stream);
 }
 
 extern "C" int ccst_bn_relu_maxpool_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
@@ -930,7 +940,7 @@ extern "C" int ccst_bn_relu_maxpool_train_fwd_f32(const float* x, const float* g
 extern "C" int ccst_bn_relu_maxpool_train_bwd_f32(const float* dy_pooled, const uint32_t* idx, const float* x, const float* gamma,
                                                   const float* beta, const float* save_mean, const float* save_invstd, float* dx,
                                                   float* dgamma, float* dbeta, int accumulate, int N, int H, int W, int C, int Ho, int Wo,
-                                                  void* ws, int64_t ws_bytes, void* stream) {
+                                                  void* ws, int64_t ws_bytes, uint32_t* dx_absmax, void* stream) {
     CCST_REQUIRE(dy_pooled && idx && x && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta && ws, "bn_relu_maxpool_bwd: null pointer");
     CCST_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, "bn_relu_maxpool_bwd: bad extents");
     CCST_REQUIRE((long long)N * H * W * (C / 4) < 0x7fffffffLL, "bn_relu_maxpool_bwd: the conv output must have < 2^31 channel quads (32-bit index arithmetic)");
@@ -951,7 +961,7 @@ extern "C" int ccst_bn_relu_maxpool_train_bwd_f32(const float* dy_pooled, const 
         hipLaunchKernelGGL(bn_bwd_finalize_kernel<16>, dim3((C + 15) / 16), dim3(256), 0, st, part, dgamma, dbeta, sums, C, sp.S, accumulate);
     const long long total4 = (long long)M * (C / 4);
     hipLaunchKernelGGL(stem_bwd_apply_kernel, dim3(grid_for(total4)), dim3(TPB), 0, st, x, (const f32x4*)dy_pooled, idx, gamma, beta, save_mean,
-                       save_invstd, sums, dx, total4, C, 1.f / (float)M, H, W, Ho, Wo);
+                       save_invstd, sums, dx, total4, C, 1.f / (float)M, H, W, Ho, Wo, dx_absmax);
     return ccst_launch_status("bn_relu_maxpool_bwd");
 }
 

@@ -406,8 +406,19 @@ class ImageWriterPool(object):
             self.drain()
 
     def drain(self):
+        import multiprocessing as mp
         for f in self.futures:
-            f.get() if self.kind == "processes" else f.result()
+            if self.kind != "processes":
+                f.result()
+                continue
+            # multiprocessing.Pool never completes the AsyncResult of a task whose worker died (OOM kill, signal): poll, and look at the
+            # worker set between polls, so that a dead encoder raises here instead of blocking the run for ever
+            while True:
+                try:
+                    f.get(timeout=0.5)
+                    break
+                except mp.TimeoutError:
+                    self.check_workers()
         self.futures = []
         self.check_workers()
 

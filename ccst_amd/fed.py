@@ -240,6 +240,7 @@ class _GraphedTrainStep(object):
         self.loss_all, self.correct_all = loss_all, correct_all
         self.convs = [m for m in model.modules() if hasattr(m, "prepack")]
         self.graph = torch.cuda.CUDAGraph()
+        ops.reset_absmax_pool()                 # the step's |max| word rows: from a block zero-filled INSIDE the graph
         with torch.cuda.graph(self.graph):
             optimizer.zero_grad()
             loss = loss_fun(model(self.x), self.y)
@@ -248,6 +249,7 @@ class _GraphedTrainStep(object):
             backward(loss)
             optimizer.step()
             nn_ops.join_prepack(dev)            # every forked stream re-joins before the capture ends
+        ops.reset_absmax_pool()
 
     def run(self, img, class_l):
         self.x.copy_(img, non_blocking=True)

@@ -54,7 +54,13 @@ class Conv2d(nn.Conv2d):
 
     def wabsmax(self):
         """|max| words of the weight (ops.absmax); after the first optimiser step the batched side-stream refresh keeps them current."""
-        return self._cached("wmax", lambda w, prev: ops.absmax(w))
+        # (refreshed IN PLACE: a captured graph reads the words at the address it was captured with -- ADVICE r4)
+        def build(w, prev):
+            if prev is None:
+                return ops.absmax(w)
+            nn_ops.fill_(prev.view(torch.float32), 0.0)
+            return ops.absmax(w, out=prev)
+        return self._cached("wmax", build)
 
     def wino_ok(self, H, W):
         return self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and \
@@ -92,6 +98,8 @@ class Conv2d(nn.Conv2d):
                 self.wino4_fwd()
             if "_ccst_w4t" in d:
                 self.wino4_bwd()
+            if "_ccst_wmax" in d:         # the half-piece forward scales the packed weight by these words: as current as the packs
+                self.wabsmax()
 
     def packed_stem(self):
         def build(w, prev):

@@ -71,6 +71,29 @@ _PREPACK_PENDING = set()
 # weight's words (refreshed with the packed weights after each optimiser step) -- range-safe, no host synchronisation.  CCST_CONV_BF=0
 # turns the words off as well (fp32 MFMA everywhere).
 HALF_FWD = _os.environ.get("CCST_CONV_BF", "4") == "4"
+# The weight gradients on two IEEE-half pieces per operand (conv_bwd_weight.hip, ccst_conv2d_bwd_weight_split_f32): x scaled by the |max|
+# words its producing BatchNorm apply left, dy by the words the BatchNorm backward that produced it leaves (dx_absmax).  CCST_BWD_HALF=0:
+# the fp32-MFMA kernel.  (Needs the forward's words, i.e. CCST_CONV_BF=4.)
+HALF_BWD = HALF_FWD and _os.environ.get("CCST_BWD_HALF", "1") != "0"
+# |max| words of gradient tensors, keyed by the tensor's address: autograd hands a backward's result to the next node as a new Python
+# object, so a tag on the tensor would not survive; an entry is consumed by the one conv backward that reads the gradient.
+_GRAD_WORDS = {}
+
+
+def _publish_grad_words(device):
+    return ops.absmax_words(device) if HALF_BWD else None
+
+
+def _note_grad_words(t, words):
+    if words is not None:
+        if len(_GRAD_WORDS) > 1024:         # (gradients nobody consumed: a backward that stopped early)
+            _GRAD_WORDS.clear()
+        _GRAD_WORDS[t.data_ptr()] = (words, tuple(t.shape))
+
+
+def _take_grad_words(t):
+    ent = _GRAD_WORDS.pop(t.data_ptr(), None)
+    return ent[0] if ent is not None and ent[1] == tuple(t.shape) else None
 
 
 def _prepack_jobs(model, convs):
@@ -275,21 +298,27 @@ def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None, relu_mas
     return dx
 
 
-def conv_bwd_weight(d, x, dy, weight_grad_oihw, accumulate=True):
+def conv_bwd_weight(d, x, dy, weight_grad_oihw, accumulate=True, x_absmax=None, dy_absmax=None):
+    """x_absmax + dy_absmax (the |max| words of both operands): half pieces on the 16-bit MFMA; else the fp32-MFMA kernel."""
     lib = _lib.load()
     M = d.n * d.ho * d.wo
     ntap = d.nky * d.nkx
-    splits = lib.ccst_conv2d_bwd_weight_splits(M, d.cin, d.cout, ntap)
+    half = x_absmax is not None and dy_absmax is not None
+    splits = (lib.ccst_conv2d_bwd_weight_split_splits if half else lib.ccst_conv2d_bwd_weight_splits)(M, d.cin, d.cout, ntap)
     need = splits * ntap * d.cin * d.cout * 4
     ws = _workspace(need, x.device)
     if ops.TIMING is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    check(lib.ccst_conv2d_bwd_weight_f32(ctypes.byref(d), ptr(x), ptr(dy), ptr(weight_grad_oihw), splits, int(accumulate),
-                                         ptr(ws), ws.numel(), stream_ptr()), "conv bwd-weight")
+    if half:
+        check(lib.ccst_conv2d_bwd_weight_split_f32(ctypes.byref(d), ptr(x), ptr(x_absmax), ptr(dy), ptr(dy_absmax), ptr(weight_grad_oihw), splits,
+                                                   int(accumulate), ptr(ws), ws.numel(), stream_ptr()), "conv bwd-weight (half pieces)")
+    else:
+        check(lib.ccst_conv2d_bwd_weight_f32(ctypes.byref(d), ptr(x), ptr(dy), ptr(weight_grad_oihw), splits, int(accumulate),
+                                             ptr(ws), ws.numel(), stream_ptr()), "conv bwd-weight")
     if ops.TIMING is not None:
         e1.record()
-        ops.TIMING.append(("bwd_weight", 2.0 * M * d.cin * d.cout * ntap, e0, e1,
+        ops.TIMING.append(("bwd_weight" + ("_h" if half else ""), 2.0 * M * d.cin * d.cout * ntap, e0, e1,
                            "n%d %dx%d cin%d cout%d taps%dx%d splits%d" % (d.n, d.ho, d.wo, d.cin, d.cout, d.nky, d.nkx, splits)))
 
 
@@ -365,6 +394,7 @@ class ConvFn(torch.autograd.Function):
         ctx.sink = sink
         ctx.link = link          # MaskLink of the ReLU that produced x (residual blocks), or None
         ctx.want_stats = bool(want_stats)
+        ctx.xmax = ops.tagged_absmax(x) if HALF_BWD else None      # for the half-piece weight gradient
         ctx.set_materialize_grads(False)       # no zero tensor for the non-differentiable stats output
         ctx.wino4 = mod.wino4_ok(x.shape[1], x.shape[2])       # 64-channel F(4x4): the trunk's 56x56 and 28x28 maps
         ctx.wino = mod.wino_ok(x.shape[1], x.shape[2])
@@ -394,16 +424,18 @@ class ConvFn(torch.autograd.Function):
             return None, None, None, None, None, None
         x, weight = ctx.saved_tensors
         mod = ctx.mod
+        dymax = _take_grad_words(dy) if HALF_BWD else None
         dy = dy.contiguous()
         stride, pad = mod.stride[0], mod.padding[0]
         N, H, W, Cin = x.shape
         if weight.requires_grad:
             d, _, _ = _fwd_desc(N, H, W, Cin, weight.shape[2], weight.shape[3], stride, pad, Cin, weight.shape[0], 0)
             g = _grad_slot(weight)
+            xmax = ctx.xmax if dymax is not None else None
             if SIDE_STREAM:
-                _on_side_stream(x.device, (x, dy), lambda: conv_bwd_weight(d, x, dy, g))
+                _on_side_stream(x.device, (x, dy), lambda: conv_bwd_weight(d, x, dy, g, x_absmax=xmax, dy_absmax=dymax))
             else:
-                conv_bwd_weight(d, x, dy, g)
+                conv_bwd_weight(d, x, dy, g, x_absmax=xmax, dy_absmax=dymax)
         dx = None
         if ctx.needs_input_grad[0]:
             into, deposit = None, False
@@ -478,6 +510,7 @@ class StemConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         xp, weight = ctx.saved_tensors
         N, ho, wo, Hp, Wp, kh, kw, kwp, stride, C = ctx.geom
+        dymax = _take_grad_words(dy) if HALF_BWD else None
         if weight.requires_grad:
             cout = weight.shape[0]
             d = CcstConvDesc()
@@ -488,7 +521,9 @@ class StemConvFn(torch.autograd.Function):
             d.ax, d.bx, d.cx = stride, 0, 0
             d.xsN, d.xsH, d.xsW = Hp * Wp * 4, Wp * 4, 4
             gv = torch.empty((cout, kwp * 4, kh, 1), device=dy.device, dtype=torch.float32)    # virtual-pixel gradient
-            conv_bwd_weight(d, xp, dy.contiguous(), gv, accumulate=False)
+            # (the padded image has no producer kernel that could leave its |max| words: one 53 MB pass, ~15 us, for a 3x shorter GEMM)
+            conv_bwd_weight(d, xp, dy.contiguous(), gv, accumulate=False, x_absmax=ops.absmax(xp) if dymax is not None else None,
+                            dy_absmax=dymax)
             # un-fold (kx, ci) <- virtual channel kx*4+ci : 9.4k floats of glue
             check(_lib.load().ccst_stem_grad_unfold_f32(ptr(gv), ptr(_grad_slot(weight)), cout, kwp, kh, kw, C, 1, stream_ptr()),
                   "stem_grad_unfold")
@@ -550,6 +585,7 @@ class BNFn(torch.autograd.Function):
         M = N * H * W
         dy = dy.contiguous()
         dx = torch.empty_like(x)
+        dxmax = _publish_grad_words(x.device)       # max |dx|: the conv in front of this BatchNorm scales its weight gradient's dy by it
         ws = _workspace(int(lib.ccst_bn_workspace_bytes(M, C)), x.device)
         link = getattr(ctx, "link", None)
         if link is not None and link.premasked:
@@ -561,16 +597,17 @@ class BNFn(torch.autograd.Function):
             if part is not None:        # ... and left this backward's partial sums: finalize + apply only
                 check(lib.ccst_bn_train_bwd_partials_f32(ptr(dy), ptr(x), ptr(gamma), ptr(save[0]), ptr(save[1]), ptr(part), int(part.shape[0]),
                                                          ptr(dx), ptr(_grad_slot(gamma)), ptr(_grad_slot(beta)), 1, M, C, ptr(ws), ws.numel(),
-                                                         stream_ptr()), "bn_train_bwd")
+                                                         ptr(dxmax), stream_ptr()), "bn_train_bwd")
             else:
                 check(lib.ccst_bn_train_bwd_mask_f32(ptr(dy), ptr(x), None, None, ptr(gamma), ptr(beta), ptr(save[0]), ptr(save[1]),
                                                      0, ptr(dx), None, ptr(_grad_slot(gamma)), ptr(_grad_slot(beta)), 1, M, C,
-                                                     ptr(ws), ws.numel(), stream_ptr()), "bn_train_bwd")
+                                                     ptr(ws), ws.numel(), ptr(dxmax), stream_ptr()), "bn_train_bwd")
         else:
             dres = torch.empty_like(x) if ctx.has_res else None
             check(lib.ccst_bn_train_bwd_mask_f32(ptr(dy), ptr(x), ptr(y), ptr(mask), ptr(gamma), ptr(beta), ptr(save[0]), ptr(save[1]),
                                                  int(ctx.relu), ptr(dx), ptr(dres), ptr(_grad_slot(gamma)), ptr(_grad_slot(beta)), 1, M, C,
-                                                 ptr(ws), ws.numel(), stream_ptr()), "bn_train_bwd")
+                                                 ptr(ws), ws.numel(), ptr(dxmax), stream_ptr()), "bn_train_bwd")
+        _note_grad_words(dx, dxmax)
         if ctx.sink is not None and dres is not None:
             ctx.sink.grad, dres = dres, None        # handed to the block's first conv (GradSink), not to autograd
         return dx, None, None, dres, None, None, None, None
@@ -609,10 +646,12 @@ class StemBnReluPoolFn(torch.autograd.Function):
         N, H, W, C = x.shape
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         dx = torch.empty_like(x)
+        dxmax = _publish_grad_words(x.device)
         ws = _workspace(int(lib.ccst_bn_workspace_bytes(N * H * W, C)), x.device)
         check(lib.ccst_bn_relu_maxpool_train_bwd_f32(ptr(dy.contiguous()), ptr(idx), ptr(x), ptr(gamma), ptr(beta), ptr(save[0]), ptr(save[1]),
                                                      ptr(dx), ptr(_grad_slot(gamma)), ptr(_grad_slot(beta)), 1, N, H, W, C, Ho, Wo, ptr(ws),
-                                                     ws.numel(), stream_ptr()), "bn_relu_maxpool_bwd")
+                                                     ws.numel(), ptr(dxmax), stream_ptr()), "bn_relu_maxpool_bwd")
+        _note_grad_words(dx, dxmax)
         return dx, None, None, None, None
 
 

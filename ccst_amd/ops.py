@@ -254,6 +254,30 @@ def from_api(x, cpad=1):
 # ---------------------------------------------------------------------------
 # convolution
 # ---------------------------------------------------------------------------
+class _PackOrder(object):
+    """Cross-stream ordering of lazily packed layouts: a layout is packed by a kernel on the stream that is current at its
+    first use; the Python slot is set at once, so a use on ANOTHER stream (style._style_transfer_two_streams: the side half finds the
+    slot filled by the main half) could launch its conv before that pack kernel has run.  `packed(slot)` records an event behind the
+    pack launch; `use(slot)` makes any other stream wait for it, once per (slot, stream) -- a dictionary lookup per use after that."""
+    __slots__ = ("ev",)
+
+    def __init__(self):
+        self.ev = {}
+
+    def packed(self, slot):
+        e = torch.cuda.Event()
+        e.record()
+        self.ev[slot] = (e, {_lib.raw_stream()})
+
+    def use(self, slot):
+        ent = self.ev.get(slot)
+        if ent is not None:
+            st = _lib.raw_stream()
+            if st not in ent[1]:
+                torch.cuda.current_stream().wait_event(ent[0])
+                ent[1].add(st)
+
+
 class PackedConv(object):
     """A conv weight in the layouts the kernels read (+ optional bias).  `w`: [kh*kw][K/4][n_pad][4] for the implicit-GEMM kernels.
     A weight packed with wino=... (the 3x3 layers of the AdaIN plan) keeps the OIHW source and builds each kernel's layout ON FIRST USE
@@ -268,6 +292,7 @@ class PackedConv(object):
         self.src, self.wino = src, wino          # OIHW source (kept only for lazily packed weights) and the wino= argument
         self.u_pad, self.u4_pad = round_up(cout, 32), round_up(cout, 64)
         self._u = self._u4 = self._u4n = self._wsplit = self._wabsmax = self._uf23 = None
+        self._order = _PackOrder()
 
     # ---- which layouts exist (no packing) ----
     def can_wino2(self):
@@ -292,6 +317,9 @@ class PackedConv(object):
             t = torch.empty(int(nfloats), device=self.src.device, dtype=torch.float32)
             check(fn(ptr(self.src), ptr(t), self.cout, self.cin, *tail, stream_ptr()), what)
             setattr(self, slot, t)
+            self._order.packed(slot)
+        else:
+            self._order.use(slot)
         return t
 
     @property
@@ -300,6 +328,9 @@ class PackedConv(object):
             self._w = torch.empty(self.kh * self.kw * self.k_pad * self.n_pad, device=self.src.device, dtype=torch.float32)
             check(_lib.load().ccst_pack_conv_weight_f32(ptr(self.src), ptr(self._w), self.cout, self.cin, self.kh, self.kw, int(self.transpose),
                                                         self.k_pad, self.n_pad, stream_ptr()), "pack_conv_weight")
+            self._order.packed("_w")
+        elif self.src is not None:          # (eagerly packed weights -- src is None -- were complete before the object existed)
+            self._order.use("_w")
         return self._w
 
     @property
@@ -324,6 +355,9 @@ class PackedConv(object):
     def wabsmax(self):
         if self._wabsmax is None and self.can_split():
             self._wabsmax = absmax(self.src)
+            self._order.packed("_wabsmax")
+        else:
+            self._order.use("_wabsmax")
         return self._wabsmax
 
     @property
@@ -376,6 +410,14 @@ def absmax_words(device):
     row = ent[0][ent[1]]
     ent[1] += 1
     return row
+
+
+def reset_absmax_pool():
+    """Forget the current blocks: the next absmax_words() zero-fills a fresh one.  fed._GraphedTrainStep calls it on both sides of a
+    capture, so that a captured step takes its rows from a block whose zero fill is part of the graph (re-zeroed by every replay:
+    words only grow, and a row zeroed once before the capture would freeze at the largest value any replay ever saw) and eager code
+    never hands out rows of the graph's private block."""
+    _ABSMAX_POOL.clear()
 
 
 def absmax(t, out=None):
@@ -722,9 +764,12 @@ class PackedZform:
     def __init__(self, w_tap_co_ci):
         self.w = w_tap_co_ci
         self._packed = None
+        self._order = _PackOrder()
 
     def get(self):
-        if self._packed is None:
+        if self._packed is not None:
+            self._order.use("packed")
+        else:
             w = self.w
             cout, cin = int(w.shape[2]), int(w.shape[3])
             lib = _lib.load()
@@ -732,6 +777,7 @@ class PackedZform:
             packed = torch.empty(int(lib.ccst_conv3x3_zform_weight_floats(cin)), device=w.device, dtype=torch.float32)
             check(lib.ccst_pack_conv_weight_zform_f32(ptr(w), ptr(words), ptr(packed), cin, cout, stream_ptr()), "pack_conv_weight_zform")
             self._packed = (packed, words)
+            self._order.packed("packed")
         return self._packed
 
 
@@ -987,8 +1033,9 @@ def adain_from_tile_sums(feat, partials, style_mean, style_std, alpha=1.0, eps=1
         raise RuntimeError("ccst_amd: style statistics must have C or N*C elements")
     out = torch.empty_like(buf)
     amax = absmax_words(feat.device)      # the kernel leaves max |out|: the decoder's first half-piece conv scales by it
+    stat = torch.empty((2, N * C), device=feat.device, dtype=torch.float32)      # the folded content statistics (fold kernel -> stream kernel)
     args = (ptr(buf), ptr(partials), int(partials.shape[2]), int(partials.shape[0] // N), ptr(sm), ptr(ss), per_n, float(alpha), ptr(out), N, C, H * W,
-            eps, None, None, ptr(amax), stream_ptr())
+            eps, ptr(stat[0]), ptr(stat[1]), ptr(amax), stream_ptr())
     if TIMING is None:
         check(_lib.load().ccst_adain_tile_sums_f32(*args), "adain_tile_sums")
     else:       # bench.py: the AdaIN step of the path = this one launch; HBM-bound: algorithmic bytes = read x + write y

@@ -323,6 +323,16 @@ int ccst_conv2d_bwd_weight_f32(const CcstConvDesc* d, const float* x, const floa
                                int splits, int accumulate, void* ws, int64_t ws_bytes, void* stream);
 /* Split count that fills the chip for this problem (M = n*ho*wo). */
 int ccst_conv2d_bwd_weight_splits(int M, int cin, int cout, int ntap);
+/* The same weight gradient with every fp32 product as three products of IEEE-half pieces on the 16-bit MFMA (22 significant bits,
+ * fp32 accumulation; the LDS images stay [pixel][channel] and the pixel-major MFMA operands come from the transposing LDS read).
+ * x_absmax / dy_absmax: the |max| words (CCST_ABSMAX_WORDS) of x and dy -- x's from the BatchNorm apply that produced it, dy's from
+ * the BatchNorm backward that produced it (dx_absmax below), or ccst_absmax_f32; any upper bound is valid.  Both tensors are scaled
+ * by powers of two derived from the words on the device and the result is scaled back: any finite fp32 magnitude is safe.  Same
+ * slabs, reduce and determinism as ccst_conv2d_bwd_weight_f32; its own split count (the loop per pixel is ~3x shorter). */
+int ccst_conv2d_bwd_weight_split_f32(const CcstConvDesc* d, const float* x, const uint32_t* x_absmax, const float* dy,
+                                     const uint32_t* dy_absmax, float* dw_oihw, int splits, int accumulate, void* ws,
+                                     int64_t ws_bytes, void* stream);
+int ccst_conv2d_bwd_weight_split_splits(int M, int cin, int cout, int ntap);
 
 /* ------------------------------------------------------------------------
  * AdaIN feature statistics / normalisation.  layout: 0 = NCHW planes, 1 = NHWC.
@@ -338,9 +348,10 @@ int ccst_adain_f32(const float* x, const float* style_mean, const float* style_s
                    void* ws, int64_t ws_bytes, uint32_t* y_absmax /* NULL or zeroed |max| words of y (CCST_ABSMAX_WORDS) */, void* stream);
 /* The same AdaIN (+ alpha blend) for an NHWC x [N][HW][C] whose producer already left the statistics: partials
  * [N * tiles_per_image][C][2] = per-(spatial tile, channel) (sum, sum of squares) of x, the tiles of image n contiguous -- what
- * ccst_conv3x3_wino4w_f32 writes into chan_sum_partials (tiles_per_image = ccst_wino4w_spatial_tiles(1, H, W)).  One launch, x read
- * once, no pass for the statistics: mean = S / HW, unbiased variance = (Q - S mean) / (HW - 1) folded in fp64.  C % 64 == 0.
- * mean_out / std_out: NULL, or [N*C] receiving the content statistics. */
+ * ccst_conv3x3_wino4w_f32 writes into chan_sum_partials (tiles_per_image = ccst_wino4w_spatial_tiles(1, H, W)), or the centred
+ * (sum, M2, count, 0) quadruples of the half-piece kernels.  Two launches: the records folded ONCE in fp64 (a thread per (image,
+ * channel)) into mean_out / std_out, then x streamed once against them; no pass over x for the statistics.  C % 64 == 0.
+ * mean_out / std_out: [N*C] floats each, REQUIRED (caller-owned): the content statistics, handed from the fold to the stream. */
 int ccst_adain_tile_sums_f32(const float* x, const float* partials, int partial_floats /* 2 or 4, as ccst_chan_sums_finalize_f32 */,
                              int tiles_per_image, const float* style_mean,
                              const float* style_std, int style_per_n, float alpha, float* y, int N, int C, int HW, float eps,
@@ -393,12 +404,17 @@ int ccst_bn_train_fwd_mask_f32(const float* x, const float* gamma, const float* 
 int ccst_bn_train_bwd_mask_f32(const float* dy, const float* x, const float* y, const uint8_t* relu_mask,
                                const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                                int relu, float* dx, float* d_residual, float* dgamma, float* dbeta, int accumulate,
-                               int64_t M, int C, void* ws, int64_t ws_bytes, void* stream);
+                               int64_t M, int C, void* ws, int64_t ws_bytes,
+                               uint32_t* dx_absmax /* NULL, or zeroed |max| words (CCST_ABSMAX_WORDS) receiving max |dx|: dx is the
+                                                      output gradient of the conv in front of this BatchNorm, and the half-piece
+                                                      weight-gradient kernel (ccst_conv2d_bwd_weight_split_f32) scales it by them */,
+                               void* stream);
 /* BatchNorm2d backward WITHOUT its reduction pass: the per-channel partial sums [groups][C][2] of (dy, dy*xhat) come from the kernel
  * that produced dy (ccst_conv2d_igemm_accum_masked_f32); dy carries no ReLU to undo and the skip connection's share is dy itself. */
 int ccst_bn_train_bwd_partials_f32(const float* dy, const float* x, const float* gamma, const float* save_mean,
                                    const float* save_invstd, const float* partials, int groups, float* dx, float* dgamma,
-                                   float* dbeta, int accumulate, int64_t M, int C, void* ws, int64_t ws_bytes, void* stream);
+                                   float* dbeta, int accumulate, int64_t M, int C, void* ws, int64_t ws_bytes,
+                                   uint32_t* dx_absmax /* as ccst_bn_train_bwd_mask_f32 */, void* stream);
 int64_t ccst_bn_workspace_bytes(int64_t M, int C);
 
 /* BatchNorm2d (training) -> ReLU -> MaxPool2d(3, 2, 1), the ResNet stem (nets/resnet.py:138-140), without the full-resolution tensors in
@@ -413,7 +429,7 @@ int ccst_bn_relu_maxpool_train_fwd_f32(const float* x, const float* gamma, const
 int ccst_bn_relu_maxpool_train_bwd_f32(const float* dy_pooled, const uint32_t* idx, const float* x, const float* gamma,
                                        const float* beta, const float* save_mean, const float* save_invstd, float* dx,
                                        float* dgamma, float* dbeta, int accumulate, int N, int H, int W, int C, int Ho, int Wo,
-                                       void* ws, int64_t ws_bytes, void* stream);
+                                       void* ws, int64_t ws_bytes, uint32_t* dx_absmax /* as ccst_bn_train_bwd_mask_f32 */, void* stream);
 
 /* MaxPool2d(kernel 3, stride 2, padding 1) nets/resnet.py:140, NHWC, C % 4 == 0.  idx[N,Ho,Wo,C/4]
  * packs, per channel, the window position (0..8) of the first maximum (one byte each); backward

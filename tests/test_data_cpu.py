@@ -150,3 +150,29 @@ def test_adain_loader_shards_are_a_partition(tmp_path):
     assert len(flat) == len(set(flat)) == 23 and set(flat) == set(r.split(" ")[0] for r in rows)
     one = data.get_train_dataloader(args, str(tmp_path))
     assert isinstance(one.loader.sampler, torch.utils.data.RandomSampler) and len(one.dataset) == 23     # the reference's shuffle=True
+
+
+@pytest.mark.timeout(60)
+def test_image_writer_pool_raises_when_an_encoder_dies(tmp_path):
+    """A worker process killed under a task never completes that task's AsyncResult: drain() must notice the changed worker set and
+    raise, not block for ever; an intact pool writes every file."""
+    import os
+    import signal
+    import time
+    import numpy as np
+    from ccst_amd import data
+    pool = data.ImageWriterPool(workers=2)
+    assert pool.kind == "processes"               # (no GPU was touched in this process)
+    img = np.zeros((2, 8, 8, 3), dtype=np.uint8)
+    pool.submit(img, [str(tmp_path / "a.png"), str(tmp_path / "b.png")])
+    pool.drain()
+    assert (tmp_path / "a.png").exists() and (tmp_path / "b.png").exists()
+    pool.futures += [pool.pool.apply_async(time.sleep, (30,)) for _ in range(2)]      # both workers busy ...
+    time.sleep(0.5)
+    for pid in pool.pids:
+        os.kill(pid, signal.SIGKILL)                                                   # ... and killed under their tasks
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="encoder process died"):
+        pool.drain()
+    assert time.time() - t0 < 20
+    pool.pool.terminate()

@@ -228,10 +228,10 @@ def test_pointwise_backward_data_masked_accumulate(dev):
     ws = torch.empty(int(lib.ccst_bn_workspace_bytes(M, C)) // 4, device=dev)
     dx_a, dg_a, db_a = torch.empty_like(bx), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
     check(lib.ccst_bn_train_bwd_partials_f32(ptr(out2), ptr(bx), ptr(gam), ptr(mean), ptr(invstd), ptr(part), int(part.shape[0]), ptr(dx_a),
-                                             ptr(dg_a), ptr(db_a), 0, M, C, ptr(ws), ws.numel() * 4, stream_ptr()), "bn bwd partials")
+                                             ptr(dg_a), ptr(db_a), 0, M, C, ptr(ws), ws.numel() * 4, None, stream_ptr()), "bn bwd partials")
     dx_b, dg_b, db_b = torch.empty_like(bx), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
     check(lib.ccst_bn_train_bwd_mask_f32(ptr(out2), ptr(bx), None, None, ptr(gam), ptr(bet), ptr(mean), ptr(invstd), 0, ptr(dx_b), None,
-                                         ptr(dg_b), ptr(db_b), 0, M, C, ptr(ws), ws.numel() * 4, stream_ptr()), "bn bwd")
+                                         ptr(dg_b), ptr(db_b), 0, M, C, ptr(ws), ws.numel() * 4, None, stream_ptr()), "bn bwd")
     for a, b in ((dx_a, dx_b), (dg_a, dg_b), (db_a, db_b)):
         assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
     # the BatchNorm + ReLU form (bn2 -> conv3): y = (bn(bx) > 0) ? dX : 0 with the mask recomputed from the BatchNorm's input, and the
@@ -245,10 +245,10 @@ def test_pointwise_backward_data_masked_accumulate(dev):
     assert float((got - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max()))
     dx_c, dg_c, db_c = torch.empty_like(bx), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
     check(lib.ccst_bn_train_bwd_partials_f32(ptr(got), ptr(bx), ptr(gam), ptr(mean), ptr(invstd), ptr(part2), int(part2.shape[0]), ptr(dx_c),
-                                             ptr(dg_c), ptr(db_c), 0, M, C, ptr(ws), ws.numel() * 4, stream_ptr()), "bn bwd partials")
+                                             ptr(dg_c), ptr(db_c), 0, M, C, ptr(ws), ws.numel() * 4, None, stream_ptr()), "bn bwd partials")
     dx_d, dg_d, db_d = torch.empty_like(bx), torch.zeros(C, device=dev), torch.zeros(C, device=dev)       # plain: ReLU mask recomputed by the BN kernels
     check(lib.ccst_bn_train_bwd_mask_f32(ptr(dxr.contiguous()), ptr(bx), None, None, ptr(gam), ptr(bet), ptr(mean), ptr(invstd), 1, ptr(dx_d), None,
-                                         ptr(dg_d), ptr(db_d), 0, M, C, ptr(ws), ws.numel() * 4, stream_ptr()), "bn bwd")
+                                         ptr(dg_d), ptr(db_d), 0, M, C, ptr(ws), ws.numel() * 4, None, stream_ptr()), "bn bwd")
     for a, b in ((dx_c, dx_d), (dg_c, dg_d), (db_c, db_d)):
         assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
     # shapes the streaming kernel does not take are refused by the predicate (3x3, stride 2)

@@ -23,10 +23,10 @@ else:
 sm, ss = torch.rand(C).to(dev), (torch.rand(C) + 0.5).to(dev)
 words = None if os.environ.get("NO_WORDS") == "1" else torch.zeros(64, dtype=torch.int32, device=dev)
 lib = _lib.load()
-
+stat = torch.empty(2, N * C, device=dev)
 
 def run():
-    check(lib.ccst_adain_tile_sums_f32(ptr(x), ptr(part), pf, tpi, ptr(sm), ptr(ss), 0, 1.0, ptr(out), N, C, H * W, 1e-5, None, None,
+    check(lib.ccst_adain_tile_sums_f32(ptr(x), ptr(part), pf, tpi, ptr(sm), ptr(ss), 0, 1.0, ptr(out), N, C, H * W, 1e-5, ptr(stat[0]), ptr(stat[1]),
                                        ptr(words), stream_ptr()), "adain_tile_sums")
 
 
