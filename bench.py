@@ -19,7 +19,8 @@ Prints ONE JSON line on rank 0 (see the bench contract) including
   cpu_baseline : the CPU oracle (a port of the reference path) timed on the host cores, rank 0, N=1
   secondary    : a list -- [0] ResNet50 train-step images/sec @222x222 B=64 (second half of the metric) with its MFMA / HBM rooflines;
                  then the other BASELINE configs: stage-1 statistics at B=32 512^2 with the HBM roofline of calc_sum (configs 0/1),
-                 Single-mode style transfer at B=32 (config 3), ResNet18 B=32 classes=2 @222 (config 5)
+                 Single-mode style transfer at B=32 (config 3), ResNet18 B=32 classes=2 @222 (config 5), the eval forward of test()
+                 (a12) and the in-process communication() of K = 3 ResNet50 clients against HBM (a13)
 """
 import argparse
 import gc
@@ -535,6 +536,9 @@ def main():
             sec.append(bench_extra.single_mode(dev, vgg31, dec, A, world, rank))                                   # config 3
             sec.append(bench_resnet.run(dev, world, steps=max(6, args.steps // 2), warmup=5, batch=32, arch="resnet18", classes=2,
                                         graph="auto", cpu_baseline=cpu_legs))                                     # config 5
+            sec.append(bench_extra.eval_forward(dev, world, rank))                                                 # a12: test()
+            if rank == 0:
+                sec.append(bench_extra.communication_inprocess(dev))                                               # a13: communication(), in-process
         result["secondary"] = sec
 
     if rank == 0:

@@ -111,3 +111,75 @@ def single_mode(dev, vgg31, dec, A, world, rank, steps=4, warmup=1, batch=32, si
             "config": {"workload": "CCST_SingleStyleTransfer PACS %dx%d batch=%d: one style image per batch (encode + calc_sum), then "
                                    "encoder -> AdaIN -> decoder over the content batch; source domains shard one per rank" % (size, size, batch)},
             "note": "same kernels as the headline line (its roofline applies); 33 encoder passes + 32 decoder passes per step"}
+
+
+def eval_forward(dev, world, rank, steps=12, warmup=3, batch=64, size=222, arch="resnet50", classes=7):
+    """a12: test() (fed_run.py:214-259) -- the eval-mode forward (BatchNorm on running statistics), cross-entropy and accuracy of one
+    batch, data resident.  MFMA-bound like the train step's forward: 8.17 GFLOP per image, against the fp32
+    MFMA (the eval forward runs on it: the half-piece pointwise form needs the |max| words only the training BatchNorm applies leave)."""
+    import types
+    import torch.distributed as dist
+    from ccst_amd import fed
+    from ccst_amd.nets import models
+    barrier = (lambda: (dist.barrier(), torch.cuda.synchronize())) if world > 1 else (lambda: None)
+    torch.manual_seed(1 + rank)
+    model = models.get_network(arch)(types.SimpleNamespace(dg_method=""), pretrained=False, classes=classes).to(dev)
+    model.eval()
+    loss_fun = fed.CrossEntropyLoss()
+    g = torch.Generator(device="cpu").manual_seed(7 + rank)
+    x = torch.randn(batch, 3, size, size, generator=g).to(dev)
+    y = torch.randint(0, classes, (batch,), generator=g).to(dev)
+
+    def step():
+        with torch.no_grad():
+            return loss_fun(model(x), y)
+    gc.collect()
+    elapsed = _max_over_ranks(_timed(step, steps, warmup, barrier), dev, world)
+    gflop = {"resnet50": 8.170, "resnet18": 3.623}[arch] * batch
+    tf = gflop * steps / elapsed / 1e3
+    return {"metric": "%s eval-forward images/sec @%dx%d B=%d (test() body)" % (arch, size, size, batch),
+            "value": round(world * batch * steps / elapsed, 2), "unit": "images/sec", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 3), "dtype": "f32", "scaling": "weak",
+            "config": {"workload": "fed_run.py test() body: eval-mode forward + CrossEntropy + accuracy, %s classes=%d" % (arch, classes)},
+            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
+                         "gflop_per_step": round(gflop, 1), "traffic": None,
+                         "note": "forward convs + FC on the fp32 MFMA (8.17 GFLOP per image at 222x222); BatchNorm (eval) applies are HBM passes on top"}}
+
+
+def communication_inprocess(dev, K=3, reps=10, arch="resnet50", classes=7):
+    """a13: communication() (fed_run.py:385-455, fedavg branch :400-414) with the server and K clients on ONE GPU -- the in-process form
+    of the reference (its Python loop over 320 keys x K clients on the CPU).  HBM-bound: algorithmic bytes = K arenas read + (K + 1)
+    arenas written (every client is overwritten with the average)."""
+    import types
+    from ccst_amd import fed
+    from ccst_amd.nets import models
+    args = types.SimpleNamespace(mode="fedavg", dg_method="")
+    torch.manual_seed(5)
+    server = models.get_network(arch)(args, pretrained=False, classes=classes).to(dev)
+    clients = []
+    for k in range(K):
+        m = models.get_network(arch)(args, pretrained=False, classes=classes).to(dev)
+        clients.append(m)
+    weights = [1.0 / K] * K
+    fed.communication(args, server, clients, weights)          # builds the flat arenas
+    torch.cuda.synchronize()
+    n = int(fed.FlatParams.of(server).n_total)
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        h0 = time.perf_counter()
+        e0.record()
+        fed.communication(args, server, clients, weights)
+        e1.record()
+        torch.cuda.synchronize()
+        ts.append((e0.elapsed_time(e1) * 1e3, (time.perf_counter() - h0) * 1e6))
+    ts.sort()
+    dev_us, wall_us = ts[len(ts) // 2]
+    nbytes = (2 * K + 1) * n * 4
+    return {"metric": "communication() fedavg, K=%d %s clients on one GPU" % (K, arch), "value": round(dev_us, 1), "unit": "us per call (device)",
+            "higher_is_better": False, "n_gpus": 1, "wall_us_per_call": round(wall_us, 1), "state_floats": n,
+            "config": {"workload": "fed_run.py communication(), --mode fedavg, %d clients + server in one process" % K},
+            "roofline": {"bound": "hbm", "bytes": nbytes, "achieved": round(nbytes / dev_us / 1e3, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                         "frac": round(nbytes / dev_us / 1e3 / PEAK_HBM_GBPS, 4), "traffic": None,
+                         "kernel": "fedavg_kernel (ccst_fedavg_f32): K reads + K + 1 writes per element in one pass; the 53 int64 counters are "
+                                   "copied by the host loop over the state dict (the wall figure includes it)"}}

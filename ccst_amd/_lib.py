@@ -40,7 +40,10 @@ _SIGNATURES = {
     "ccst_conv2d_igemm_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P],
     "ccst_conv2d_igemm_stats_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P, _P],
     "ccst_conv2d_igemm_stats_groups": [c_int, c_int, c_int, c_int],
-    "ccst_conv2d_igemm_stats_scaled_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P, _P, _P, _P],
+    "ccst_conv2d_stream_ok": [POINTER(CcstConvDesc)],
+    "ccst_conv2d_pointwise_half_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "ccst_pack_conv_weight_split_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    "ccst_pack_conv_weights_split_batch_f32": [_P, c_int, _P],
     "ccst_conv2d_pointwise_ok": [POINTER(CcstConvDesc)],
     "ccst_conv2d_igemm_accum_masked_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "ccst_conv2d_igemm_bn_relu_bwd_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -61,10 +64,7 @@ _SIGNATURES = {
     "ccst_conv3x3_halo_narrow": [c_int, c_int, c_int, c_int],
     "ccst_wino_weight_floats": [c_int, c_int],
     "ccst_pack_conv_weight_wino_f32": [_P, _P, c_int, c_int, c_int, _P],
-    "ccst_conv3x3_wino_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_wino4_weight_floats": [c_int, c_int],
-    "ccst_pack_conv_weight_wino4_f32": [_P, _P, c_int, c_int, c_int, _P],
-    "ccst_conv3x3_wino4_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_pack_conv_weight_wino4w_f32": [_P, _P, c_int, c_int, c_int, _P],
     "ccst_conv3x3_wino4w_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P, _P],
     "ccst_wino4w_spatial_tiles": [c_int, c_int, c_int],
@@ -119,6 +119,7 @@ _SIGNATURES = {
     "ccst_softmax_ce_f32": [_P, _P, _P, _P, _P, c_int, c_int, _P],
     "ccst_sgd_f32": [_P, _P, c_float, c_int64, _P],
     "ccst_scale_f32": [_P, c_float, c_int64, _P],
+    "ccst_fedavg_f32": [_P, _P, _P, c_int, c_int64, _P],
     "ccst_fill_f32": [_P, c_float, c_int64, _P],
     "ccst_add_i64": [_P, c_int64, c_int, _P],
     "ccst_mul_scalar_f32": [_P, _P, _P, c_int64, _P],

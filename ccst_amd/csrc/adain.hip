@@ -275,12 +275,8 @@ __global__ __launch_bounds__(TPB) void adain_apply_nchw_kernel(const float* __re
 // wave (xor-shuffles that keep the channel quad), then over the 8 waves through LDS in fixed order (fp64), twice.  The normalise
 // (function.py:31-33, four separately rounded operations) and the alpha blend run on the registers; 64 contiguous bytes per pixel
 // in and out.  Algorithmic traffic = the HBM roofline's 2 * N*C*H*W*4 bytes, in ONE launch.
-#ifndef FP_CQ
 #define FP_CQ 4                      // channel quads per workgroup (16 channels = 64 contiguous bytes per pixel)
-#endif
-#ifndef FP_THREADS
 #define FP_THREADS 512
-#endif
 constexpr int FP_T = FP_THREADS, FP_PL = FP_T / FP_CQ, FP_PPT = 4096 / FP_PL, FP_W = FP_T / 64;
 
 __device__ __forceinline__ f32x4 quad_lane_sum(f32x4 v) {       // sum over the lanes of a wave that share lane % FP_CQ
@@ -416,18 +412,21 @@ int check_common(const void* x, int N, int C, int HW, int layout) {
 //   s = sum of (x - pivot) and q = sum of (x - pivot)^2 about a pivot (the first slab's mean), assembled in fp64 from slab quantities
 //   that carry no cancellation: the variance is sum M2_i + sum n_i (mean_i - mean)^2 up to fp64 rounding however large |mean| / sigma.
 //   Raw (sum, sum of squares) pairs (ccst_conv3x3_wino4w_f32): mean = S / HW, unbiased variance = (Q - S mean) / (HW - 1) in fp64.
+// (a workgroup = 16 channels of one image x 16 record lanes: lane kl folds records kl, kl + 16, ...; the lanes are then summed in
+//  fixed order through LDS -- one memory round trip and one barrier deep, bitwise reproducible)
 template <bool CENTRED>
 __global__ __launch_bounds__(TPB) void tile_stats_fold_kernel(const float* __restrict__ part, int tpi, int HW, int C, int NC, float eps,
                                                               float* __restrict__ mean_out, float* __restrict__ std_out) {
-    const int i = blockIdx.x * TPB + threadIdx.x;          // (image, channel): consecutive threads = consecutive channels
-    if (i >= NC) return;
+    __shared__ double red[2][16][17];
+    const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + cl;                    // (image, channel); C % 16 == 0, so a workgroup stays inside one image
     const int n = i / C, c = i - n * C;
     double s = 0.0, q = 0.0, piv = 0.0;
     if (CENTRED) {
         const f32x4* pp = reinterpret_cast<const f32x4*>(part) + (long long)n * tpi * C + c;
         const f32x4 a0 = pp[0];
         piv = a0[2] > 0.f ? (double)(a0[0] / a0[2]) : 0.0;          // (any pivot near the data will do: fp32 division)
-        for (int k = 0; k < tpi; ++k) {
+        for (int k = kl; k < tpi; k += 16) {
             const f32x4 a = pp[(long long)k * C];
             if (a[2] > 0.f) {
                 // sum of (x - pivot) = S - n pivot, exactly in fp64; sum of (x - pivot)^2 = M2 + (S - n pivot)^2 / n
@@ -438,10 +437,21 @@ __global__ __launch_bounds__(TPB) void tile_stats_fold_kernel(const float* __res
         }
     } else {
         const float* pp = part + ((long long)n * tpi * C + c) * 2;
-        for (int k = 0; k < tpi; ++k) {
+        for (int k = kl; k < tpi; k += 16) {
             s += (double)pp[(long long)k * C * 2];
             q += (double)pp[(long long)k * C * 2 + 1];
         }
+    }
+    red[0][kl][cl] = s;
+    red[1][kl][cl] = q;
+    __syncthreads();
+    if (kl != 0) return;
+    s = red[0][0][cl];
+    q = red[1][0][cl];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        s += red[0][k][cl];
+        q += red[1][k][cl];
     }
     const double m = s / (double)HW;                                            // (CENTRED: of x - pivot)
     const double var = fmax(q - s * m, 0.0) / ((double)HW - 1.0);
@@ -577,9 +587,9 @@ extern "C" int ccst_adain_tile_sums_f32(const float* x, const float* partials, i
     hipStream_t st = (hipStream_t)stream;
     const int NC = N * C;
     if (partial_floats == 4)
-        hipLaunchKernelGGL(tile_stats_fold_kernel<true>, dim3((NC + TPB - 1) / TPB), dim3(TPB), 0, st, partials, tiles_per_image, HW, C, NC, eps, mean_out, std_out);
+        hipLaunchKernelGGL(tile_stats_fold_kernel<true>, dim3(NC / 16), dim3(TPB), 0, st, partials, tiles_per_image, HW, C, NC, eps, mean_out, std_out);
     else
-        hipLaunchKernelGGL(tile_stats_fold_kernel<false>, dim3((NC + TPB - 1) / TPB), dim3(TPB), 0, st, partials, tiles_per_image, HW, C, NC, eps, mean_out, std_out);
+        hipLaunchKernelGGL(tile_stats_fold_kernel<false>, dim3(NC / 16), dim3(TPB), 0, st, partials, tiles_per_image, HW, C, NC, eps, mean_out, std_out);
     hipLaunchKernelGGL(adain_stream_nhwc_kernel, dim3(C / (4 * TS_CQ), N, chunks), dim3(TPB), 0, st, x, y, mean_out, std_out, style_mean, style_std,
                        style_per_n, alpha, HW, C, y_absmax);
     return ccst_launch_status("adain_tile_sums");

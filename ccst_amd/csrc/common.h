@@ -92,9 +92,6 @@ __device__ __forceinline__ unsigned ccst_absmax_peek(const unsigned* slots, unsi
 // every lane passes the largest |value| it holds (>= 0, or NaN).  Called by ALL threads of the workgroup (it contains a barrier -- a raw
 // s_barrier behind lgkmcnt(0) only: __syncthreads() would also wait for the epilogue's stores).
 __device__ __forceinline__ void ccst_absmax_publish(unsigned* slots, float lane_max, unsigned block, unsigned peeked = CCST_NOT_PEEKED) {
-#ifdef CCST_ABSMAX_NOPUBLISH      // timing experiment only (tools): what publishing costs; the consumers then use a fixed scale
-    return;
-#endif
     __shared__ unsigned ccst_amax_wave_[16];
     const unsigned m = ccst_wave_umax(__float_as_uint(lane_max) & 0x7fffffffu);
     if ((threadIdx.x & 63) == 0) ccst_amax_wave_[threadIdx.x >> 6] = m;
@@ -112,9 +109,6 @@ __device__ __forceinline__ void ccst_absmax_publish(unsigned* slots, float lane_
 // the two halves of ccst_absmax_read for kernels that want the load in flight behind other work: every lane loads its word early
 // (ccst_absmax_load), the wave reduces it where the value is first needed (ccst_absmax_reduce)
 __device__ __forceinline__ unsigned ccst_absmax_load(const unsigned* slots) {
-#ifdef CCST_ABSMAX_NOPUBLISH
-    return 0x46000000u;
-#endif
     return slots[threadIdx.x & 63];
 }
 __device__ __forceinline__ unsigned ccst_absmax_reduce(unsigned lane_word) {
@@ -122,9 +116,6 @@ __device__ __forceinline__ unsigned ccst_absmax_reduce(unsigned lane_word) {
 }
 // the tensor's |max| bits, wave-uniform (every wave reads for itself: one 256-byte load, no LDS, no barrier)
 __device__ __forceinline__ unsigned ccst_absmax_read(const unsigned* slots) {
-#ifdef CCST_ABSMAX_NOPUBLISH      // (the timing experiment: a fixed plausible maximum, 8192, so that the operands stay real data)
-    return 0x46000000u;
-#endif
     const unsigned v = slots[threadIdx.x & 63];
     return (unsigned)__builtin_amdgcn_readfirstlane((int)ccst_wave_umax(v));
 }
@@ -139,3 +130,23 @@ __host__ __device__ __forceinline__ int ccst_scale_exp(unsigned absmax_bits, int
 // targets of the half-piece (SPLIT) kernels: activations below 2^14, weights below 2^10 -- hi pieces far inside half's range (65504),
 // lo pieces normal for every element within 2^-17 (2^-13 for weights) of the largest
 constexpr int CCST_SPLIT_X_TARGET = 13, CCST_SPLIT_W_TARGET = 9;
+
+// Four fp32 values scaled by s = 2^k -> two IEEE-half pieces each (hi = half(v s), lo = half(v s - hi): 22 significant bits), two per
+// word.  8 vector instructions per four values: v_pk_mul_f32 + v_cvt_pk_f16_f32 per pair for hi, and ONE v_fma_mix{lo,hi}_f16 per value
+// for lo -- fma(v, s, -hi) with hi read as the half it is, rounded to half.  (hipcc's own rendering of the same arithmetic re-derives hi
+// per value, 14 instructions; the convert-back-and-subtract form takes 12.  Vector instructions are paid on top of the MFMA time.)
+typedef unsigned ccst_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ccst_split4_half(f32x4 v, float s, ccst_u32x2& hi, ccst_u32x2& lo) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f2 q = f2{v[2 * h], v[2 * h + 1]} * s;
+        const unsigned qh = __builtin_bit_cast(unsigned, __builtin_convertvector(q, h2));
+        unsigned ql;
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ql) : "v"(v[2 * h]), "v"(s), "v"(qh));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ql) : "v"(v[2 * h + 1]), "v"(s), "v"(qh));
+        hi[h] = qh;
+        lo[h] = ql;
+    }
+}

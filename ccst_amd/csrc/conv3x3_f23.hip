@@ -90,16 +90,10 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
 }
 // wait until all but the wave's N youngest vector-memory operations (= its LDS-DMA pieces) have landed and its own LDS accesses are
 // done, then the workgroup barrier: what landed before it may be read by every wave after it
-#ifndef F23A_VM_EXTRA
 #define F23A_VM_EXTRA 0        // timing experiments only: let this many more pieces stay in flight than is safe
-#endif
 template <int N>
 __device__ __forceinline__ void dma_barrier() {
-#ifdef F23A_NO_LGKM
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N == 0 ? 0 : N + F23A_VM_EXTRA) : "memory");
-#else
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N == 0 ? 0 : N + F23A_VM_EXTRA) : "memory");
-#endif
 }
 
 template <bool POOL>
@@ -280,13 +274,11 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) acc[q][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[1][mt], cur.b[0], acc[q][mt], 0, 0, 0);   // a_lo b_hi
             __builtin_amdgcn_sched_barrier(0);
-#ifndef F23A_NO_READ
             {   // fragments of the NEXT k-step: its weights landed before the previous barrier; V of this chunk, or of the next one -- complete
                 // since k-step 8's stores
                 const int sn = (s + 1) % 12;
                 read_frags(nxt, s == 11 ? PAR ^ 1 : PAR, sn % F_RING, sn);
             }
-#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) acc[q][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[0][mt], cur.b[1], acc[q][mt], 0, 0, 0);   // a_hi b_lo
@@ -294,34 +286,21 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
             // staging.  The raw buffer holds chunk c + 1 (landed before barrier 3: its pieces are older than the weights issued at k-step
             // 11); it is transformed into V[PAR ^ 1] at k-steps 4-8, one item per thread and k-step, and refilled with chunk c + 2 at
             // 9-11.  Order inside a k-step: raw piece first, weight piece second -- the vmcnt table below counts on it.
-#ifndef F23A_NO_LOADV
             if (s >= 9) dma_raw(c + 2, s - 9);
-#endif
-#ifndef F23A_NO_LOADB
             dma_w(c, s + F_RING);                      // (stage s % 6: its fragments were read during k-step s - 1)
-#endif
-#ifndef F23A_NO_STOREV
             if (s >= 4 && s <= 8) xform(PAR ^ 1, s - 4);
-#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) acc[q][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[0][mt], cur.b[0], acc[q][mt], 0, 0, 0);   // a_hi b_hi
             __builtin_amdgcn_sched_barrier(0);
             // barrier j: the weights of k-step j + 2 (issued at k-step j - 4) must have landed: all but the pieces issued since -- four
             // weight pieces plus the raw pieces of k-steps j - 3 .. j -- may stay in flight
-#if defined(F23A_NO_LOADV) || defined(F23A_NO_LOADB)
-            dma_barrier<0>();
-#else
             switch (s) {          // (folded once the k-step loop is unrolled; the asm operand must be a literal)
                 case 0: case 11: dma_barrier<7>(); break;
                 case 1: case 10: dma_barrier<6>(); break;
                 case 2: case 9: dma_barrier<5>(); break;
                 default: dma_barrier<4>(); break;
             }
-#endif
-#ifdef F23A_NO_READ
-            nxt = cur;
-#endif
             cur = nxt;
         }
     };

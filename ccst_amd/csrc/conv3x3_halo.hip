@@ -48,18 +48,10 @@ struct HaloArgs {
 };
 
 // Positions (in groups of 4 MFMAs, 8 groups per k-step) of the staging inside a step; measured sweep in DESIGN.md 3.0.
-#ifndef LOAD_P
 #define LOAD_P 7       // global loads of the weights of step t+3 / a halo unit of the next chunk
-#endif
-#ifndef STORE_P
 #define STORE_P 6      // LDS writes of what was fetched during the previous step
-#endif
-#ifndef READ1_P
 #define READ1_P 3      // second 8-channel fragment pair of this step
-#endif
-#ifndef PRE_P
 #define PRE_P 5        // first fragment pair of the NEXT step (visible since the previous barrier: 3-deep weight ring)
-#endif
 constexpr int CKH = 16, PITCH = CKH + 4, HW_ = 18;
 constexpr int BPITCH = 20;      // SPLIT: words per output-channel row of the weight image (16 channels hi | lo as half = 16 words, + 4 of pad)
 typedef unsigned u32x2h __attribute__((ext_vector_type(2)));
@@ -332,37 +324,22 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
                 const int q = (tap + P) & 1;
                 mfma_split(cur, 1, 0);                                             // a_lo b_hi
                 __builtin_amdgcn_sched_barrier(0);
-#ifndef SPA_NO_READ
                 {   // first fragments of the NEXT step (visible since the previous barrier: 3-deep weight ring, halo of this chunk)
                     const int tp = (tap + 1) % 9;
                     read_frags_split(nxt, tap == 8 ? (c + 1) & 1 : c & 1, tp % 3, (tp / 3) * HROW + (tp % 3) * PITCH);
                 }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_split(cur, 0, 1);                                             // a_hi b_lo
                 __builtin_amdgcn_sched_barrier(0);
-#ifndef SPA_NO_STOREB
                 store_b_from(rb2[q], (tap + 2) % 3);
-#endif
-#ifndef SPA_NO_STOREH
                 if (tap >= 2 && tap <= HR + 1) store_h_from(rh2[tap & 1], (c + 1) & 1, tap - 2, hok[tap - 2]);
-#endif
-#ifndef SPA_NO_LOADB
                 if (tap + 4 < 9) load_b_to(rb2[q], c, tap + 4);
                 else load_b_to(rb2[q], cn, tap + 4 - 9);
-#endif
-#ifndef SPA_NO_LOADH
                 if (tap < HR) rh2[tap & 1] = *reinterpret_cast<const f32x4*>(p.x + hoff[tap] + cn * CKH);
-#endif
                 __builtin_amdgcn_sched_barrier(0);
                 mfma_split(cur, 0, 0);                                             // a_hi b_hi
                 __builtin_amdgcn_sched_barrier(0);
-#ifndef SPA_NO_BARRIER
                 __syncthreads();
-#endif
-#ifdef SPA_NO_READ
-                nxt = cur;
-#endif
                 cur = nxt;
             }
         };
@@ -383,9 +360,6 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
     } else {
     __syncthreads();
     read_frags(0, 0, 0, 0);
-#ifdef ABLATE_LOOP_REPEAT
-    for (int rep_ = 0; rep_ < ABLATE_LOOP_REPEAT; ++rep_)
-#endif
     for (int c = 0; c < nchunks; ++c) {
         const int cn = min(c + 1, nchunks - 1);
 #pragma unroll
@@ -426,10 +400,6 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
     }
 
     // ---- epilogue ----------------------------------------------------------------------------------------
-#ifdef ABLATE_NO_STORE      // timing experiments only: keep one store so the accumulators stay live
-    if (acc[0][0][0] == 123.456f) p.y[0] = acc[1][NT - 1][15];
-    return;
-#endif
     const bool relu = p.relu != 0;
     // Interior tiles (the common case) store through a buffer resource on the tile origin: the per-lane byte
     // offset is ONE VGPR for the whole epilogue and the row's (dy, dx) -- which depend only on mt and the register

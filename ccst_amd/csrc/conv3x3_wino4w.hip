@@ -29,12 +29,8 @@
 #include "common.h"
 #include <type_traits>
 
-#ifndef W4W_STORE_AUX
 #define W4W_STORE_AUX 0
-#endif
-#ifndef W4W_LOAD_AUX
 #define W4W_LOAD_AUX 0
-#endif
 namespace {
 
 struct W4wArgs {
@@ -163,16 +159,8 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
             r = a - q * d;
             return q;
         };
-#if defined(W4W_MAP) && W4W_MAP == 1
-        int bid = tile, tx, ty;
-#else
         int bid = ccst_xcd_remap(tile, pk.ntiles), tx, ty;
-#endif
-#if defined(W4W_MAP) && W4W_MAP == 2
-        { const int sp = pk.ntiles / p.tilesN; t_tn = bid / sp; bid -= t_tn * sp; }
-#else
         bid = divmod(bid, p.tilesN, p.mN, t_tn);
-#endif
         bid = divmod(bid, p.tilesX, p.mX, tx);
         t_n = divmod(bid, p.tilesY, p.mY, ty);
         t_co0 = t_tn * 64;
@@ -274,16 +262,7 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int li = lane & 31, lh = lane >> 5;
-#if defined(ABLW_STAMPS) || defined(ABLW_GSTAMPS)
-    unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(pk.y) + (long long)tile * 16;
-#ifdef ABLW_GSTAMPS
 #define WW_STAMP(k) do { } while (0)
-#else
-#define WW_STAMP(k) do { if (tid == 0) stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
-#endif
-#else
-#define WW_STAMP(k) do { } while (0)
-#endif
     WW_STAMP(0);
     const int tn = c_tn, n = c_n, co0 = c_co0, oy0 = c_oy0, ox0 = c_ox0;
     const int tile_spatial = STATS ? (n * p.tilesY + oy0 / THW) * p.tilesX + ox0 / TWW : 0;
@@ -295,9 +274,6 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
     // two register sets: a group is stored two pair-steps (~2 us) after its loads were issued -- they come from HBM
     f32x4 rh[2][4];
     auto load_g = [&](int g, int c, int rs) {
-#if defined(ABLW_NO_HALO) || defined(ABLW_NO_HALO_LOAD)
-        if (c > 1 || nchunks_ > 2) return;
-#endif
         const unsigned cs = (unsigned)c * (CKW * 4);
         if (g < 2) {
 #pragma unroll
@@ -311,9 +287,6 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
         }
     };
     auto store_g = [&](int g, float* __restrict__ dst, int rs) {
-#if defined(ABLW_NO_HALO) || defined(ABLW_NO_HALO_STORE)
-        if (dst != nullptr) return;
-#endif
         if (g < 2) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(dst + c_hdst + (4 * g + k) * 2 * ROWPW) = rh[rs][k];
@@ -350,54 +323,32 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
     // AFTER the next one -- two pair-steps (~2 us) of lead.  Vector memory loads return in order: a weight load (L2) younger than a
     // halo load (HBM) cannot return before it, and with one pair-step of lead every halo load stalled the MFMAs behind it.
     auto load_b = [&](int j, int c, int pr) {
-#ifdef ABLW_NO_B
-        if (c != 0 || pr > 1 || nchunks > 1) return;
-#endif
         bq[pr & 1][j] = bufw_load4(urs, uvoff, (unsigned)c * 144u * up_bytes + upos(j) + (unsigned)pr * up_bytes);
     };
     auto read_col = [&](const float* __restrict__ hs, int pr, int cc, int slot) {
-#ifdef ABLW_NO_LDS_READ
-        if (hs != nullptr) return;
-#endif
         const float* hp = hs + abase + col_off(cc) + 2 * pr;
 #pragma unroll
         for (int a = 0; a < 5; ++a) d[slot][a] = *reinterpret_cast<const f32x2*>(hp + a * ROWPW);
     };
     auto row_pass = [&](int cc, int slot) {
-#ifdef ABLW_NO_XFORM
-        w[0][cc] = d[slot][0]; w[1][cc] = d[slot][1]; w[2][cc] = d[slot][2];
-        return;
-#endif
         bt3<RB == 0>(K, d[slot][0], d[slot][1], d[slot][2], d[slot][3], d[slot][4], w[0][cc], w[1][cc], w[2][cc]);
     };
     auto col_pass = [&](int rr) {
-#ifdef ABLW_NO_XFORM
-        v[3 * rr] = w[rr][0]; v[3 * rr + 1] = w[rr][1]; v[3 * rr + 2] = w[rr][2];
-        return;
-#endif
         bt3<CB == 0>(K, w[rr][0], w[rr][1], w[rr][2], w[rr][3], w[rr][4], v[3 * rr], v[3 * rr + 1], v[3 * rr + 2]);
     };
     // The 18 accumulators are 288 registers: 16 of them fill the 256 accumulation registers (AGPRs), position 8's two live in
     // ordinary VGPRs.  Written as assembly because the register class is not expressible through the builtin: left to itself the
     // allocator puts all 18 into AGPRs and then shuttles blocks between the two files inside the loop (496 v_accvgpr_* per chunk).
-#ifdef ABLW_NO_MFMA
-#define WW_M1(j, nb, k) asm volatile("" : "+v"(acc[j][nb][(k) + 2 * (nb)]) : "v"(v[j][k]), "v"(bq[ps][j][2 * (nb) + (k)]))
-#else
 #define WW_M1(j, nb, k)                                                                                                              \
     do {                                                                                                                             \
         if ((j) < 8) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[j][nb]) : "v"(bq[ps][j][2 * (nb) + (k)]), "v"(v[j][k])); \
         else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[j][nb]) : "v"(bq[ps][j][2 * (nb) + (k)]), "v"(v[j][k]));      \
     } while (0)
-#endif
-#ifdef ABLW_NO_MFMA
-#define WW_M1I(j, nb, k) acc[j][nb] = f32x16{} + v[j][k] * bq[ps][j][2 * (nb) + (k)]
-#else
 #define WW_M1I(j, nb, k)                                                                                                             \
     do {                                                                                                                             \
         if ((j) < 8) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(acc[j][nb]) : "v"(bq[ps][j][2 * (nb) + (k)]), "v"(v[j][k])); \
         else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=&v"(acc[j][nb]) : "v"(bq[ps][j][2 * (nb) + (k)]), "v"(v[j][k]));     \
     } while (0)
-#endif
 #define WW_MFMA4(j)                                                                                                                  \
     do {                                                                                                                             \
         if (decltype(init)::value) { WW_M1I(j, 0, 0); WW_M1I(j, 1, 0); } else { WW_M1(j, 0, 0); WW_M1(j, 1, 0); }                     \
@@ -414,13 +365,7 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
                          auto init, auto opts) {
         constexpr int ps = decltype(ps_t)::value & 1;
         constexpr bool LB = (decltype(opts)::value & 1) != 0, XF = (decltype(opts)::value & 2) != 0;
-#ifdef ABLW_GSTAMPS
-        unsigned long long gst[11];
-        const bool gs_on = (decltype(ps_t)::value == 1) && (cb == 2);
-#define WW_GS(k) do { if (gs_on) gst[k] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
 #define WW_GS(k) do { } while (0)
-#endif
         WW_GS(0);
         if (XF) read_col(hs, pn, 0, 0);
         WW_SB;
@@ -478,12 +423,6 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
         }
         WW_SB;
         WW_GS(10);
-#ifdef ABLW_GSTAMPS
-        if (gs_on && tid == 0) {
-#pragma unroll
-            for (int k = 0; k < 11; ++k) stamps[k] = gst[k];
-        }
-#endif
     };
 
     // ---- prologue: chunk 0 -> LDS, weights of (chunk 0, pair 0), the transform of pair 0, group 0 of chunk 1 in flight ---------
@@ -507,11 +446,9 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
     for (int j = 0; j < 9; ++j) load_b(j, 0, 1);
     WW_STAMP(9);
     // chunk 0 was requested a tile ago (rp[]); every wave is past the closing barrier, the exchange area is free
-#if !(defined(ABLW_NO_HALO) || defined(ABLW_NO_HALO_STORE))
 #pragma unroll
     for (int i = 0; i < 9; ++i) *reinterpret_cast<f32x4*>(Hs0 + c_hdst + i * 2 * ROWPW) = rp[i];
     if (has_x) *reinterpret_cast<f32x4*>(Hs0 + c_hdstx) = rp[9];
-#endif
     WW_STAMP(10);
     load_g(0, min(1, last), 0);
     load_g(1, min(1, last), 1);
@@ -560,9 +497,7 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
         pair_step(std::integral_constant<int, 0>{}, cur, 1, c, 2, 0, nxt, 2, c1, first, FULL{});
         pair_step(std::integral_constant<int, 1>{}, cur, 2, c, 3, 1, nxt, -1, 0, std::false_type{}, FULL{});
         pair_step(std::integral_constant<int, 2>{}, cur, 3, c1, 0, 2, nxt, 0, c2, std::false_type{}, FULL{});
-#ifndef ABLW_NO_BARRIER
         __syncthreads();
-#endif
         WW_SB;
         pair_step(std::integral_constant<int, 3>{}, nxt, 0, c1, 1, -1, nullptr, 1, c2, std::false_type{}, FULL{});
     };
@@ -586,15 +521,6 @@ __device__ __forceinline__ void wino4w_body(const W4wArgs& pk, float* __restrict
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // (asm MFMAs: no automatic wait states between the last one and the first read of its result)
     __syncthreads();                // every wave is done with the halo buffers: the exchange area overlays them
 
-#ifdef ABLW_NO_EPILOGUE
-    {
-        float t_ = 0.f;
-        for (int j = 0; j < 9; ++j)
-            for (int nb = 0; nb < 2; ++nb) t_ += acc[j][nb][0] + acc[j][nb][15];
-        if (t_ == 123.456f) p.y[0] = t_;
-        return;
-    }
-#endif
     // ---- epilogue ---------------------------------------------------------------------------------------------------------------
     // exchange area ex[pos][tile 0..31][channel quad ^ (tile & 7)][4 channels]: a lane's accumulator registers 4g..4g+3 are
     // channels 8g + 4 lh .. +3 (of the group) of tile li = one 16-byte slot; the XOR spreads the 8 (16) lanes of a b128 access over
@@ -849,6 +775,9 @@ static int pack_wino4w_impl(const float* w_oihw, float* u, int cout, int cin, in
     hipLaunchKernelGGL(pack_weight_wino4w_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, u, cout, cin, cin_pad, cout_pad, bwd);
     return ccst_launch_status("pack_weight_wino4w");
 }
+
+// floats of a transformed weight: [Cin/16][36][2][cout_pad][8]
+extern "C" int64_t ccst_wino4_weight_floats(int cin, int cout_pad) { return (int64_t)((cin + 15) / 16) * 36 * 2 * cout_pad * 8; }
 
 extern "C" int ccst_pack_conv_weight_wino4w_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, void* stream) {
     return pack_wino4w_impl(w_oihw, u, cout, cin, cout_pad, 0, stream);

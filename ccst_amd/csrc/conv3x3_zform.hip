@@ -32,19 +32,13 @@ typedef _Float16 f16x8z __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2z __attribute__((ext_vector_type(2)));
 typedef float f32x2z __attribute__((ext_vector_type(2)));
 
-#ifndef Z_TH
 #define Z_TH 8
-#endif
-#ifndef Z_WGS
 #define Z_WGS 4                                         // workgroups per CU the launch bounds ask for
-#endif
 constexpr int Z_TW = 32, Z_HH = Z_TH + 2, Z_HW = Z_TW + 2;
 constexpr int Z_PIX = Z_HH * Z_HW;                      // 340 halo pixels (612 for 16 rows)
 constexpr int Z_GROUPS = (Z_PIX + 15) / 16;             // 22 groups of 16 pixels
 constexpr int Z_GPW = (Z_GROUPS + 3) / 4;               // groups per wave (6)
-#ifndef Z_DEPTH
 #define Z_DEPTH 2                                       // groups of loads in flight per wave
-#endif
 constexpr int Z_PLANES = 27;
 constexpr int Z_PITCH = Z_GROUPS * 16 + 4;              // words per z plane: the 16-pixel groups whole (the last one runs past the halo) + 4, so that the pitch is 4 modulo 8
 static_assert(Z_PITCH % 8 == 4 && Z_PITCH - Z_PIX >= 16, "z plane pitch");

@@ -27,6 +27,7 @@ struct BwdWArgs {
     int fastdiv;
     const unsigned* xmax;   // (half-piece kernel) |max| words of x and of dy
     const unsigned* dmax;
+    unsigned xbytes, dbytes; // (half-piece kernel) extents of x and dy in bytes: its buffer loads return zero beyond them
 };
 
 // floor(m / d) for 0 <= m < 2^22 via one float multiply + correction (an integer division costs ~40
@@ -324,19 +325,8 @@ typedef _Float16 f16x2w __attribute__((ext_vector_type(2)));
 typedef float f32x2w __attribute__((ext_vector_type(2)));
 typedef short s16x4w __attribute__((ext_vector_type(4)));
 typedef short s16x8w __attribute__((ext_vector_type(8)));
-typedef unsigned u32x2w __attribute__((ext_vector_type(2)));
+typedef ccst_u32x2 u32x2w;
 
-// (as split4h of conv3x3_halo.hip: v_pk_mul_f32 / v_cvt_pk_f16_f32 / v_pk_fma_f32, 12 vector instructions per four values)
-__device__ __forceinline__ void split4w(f32x4 v, float s, u32x2w& hi, u32x2w& lo) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const f32x2w q = f32x2w{v[2 * h], v[2 * h + 1]} * s;
-        const f16x2w qh = __builtin_convertvector(q, f16x2w);
-        const f16x2w ql = __builtin_convertvector(q - __builtin_convertvector(qh, f32x2w), f16x2w);
-        hi[h] = __builtin_bit_cast(unsigned, qh);
-        lo[h] = __builtin_bit_cast(unsigned, ql);
-    }
-}
 // eight consecutive pixels (k) of this lane's channel: two transposing reads four pixel rows apart.  EXEC must be all ones.
 __device__ __forceinline__ f16x8w lds_tr8(const unsigned char* p, int row_bytes) {
     typedef __attribute__((address_space(3))) s16x4w* lp;
@@ -395,10 +385,44 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_split_kernel(const Bwd
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
     f32x4 rx[2][XR], rd[2][DR];
-    unsigned okm[2] = {0u, 0u};        // which units of a register set are real data (bit u: x unit u, bit XR + u: dy unit u) -- applied
-                                       // when the set is split, not behind the load: a select on the loaded value would wait for it
+    // Loads are buffer loads: whatever is not data -- pixels past M, channels past Cin / Cout, taps that fall into the zero padding --
+    // gets an offset beyond the resource's extent and comes back as ZERO from the memory pipeline: no select on loaded values (which
+    // would wait for them), no clamping, and for the dense operands no address arithmetic beyond one add per unit and step.
+    constexpr unsigned OOB = 0xfffffff0u;                // (>= any extent: the launcher keeps the tensors below 2^31 bytes)
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dbytes, 0x00020000);
+    unsigned xoffs[XR], xinc[XR], doffs[DR], dinc[DR];   // byte offsets of the NEXT step to load, and their advance per step
+    int xtapy[XR], xtapx[XR], xch[XR];                   // (!PW) a unit's tap offsets (by*ky + cy, bx*kx + cx) and channel offset, or -1
+#pragma unroll
+    for (int u = 0; u < XR; ++u) {
+        const int unit = tid + 256 * u;
+        const int px = unit / (BI / 4), cp = unit - px * (BI / 4);
+        int ci = ci0 + cp * 4, kyu = ky, kxu = kx;
+        bool tap_ok = true;
+        if (TP2) {
+            const int tapu = tap + (cp >> 3);
+            ci = (cp & 7) * 4;
+            kyu = tapu / p.nkx;
+            kxu = tapu - kyu * p.nkx;
+            tap_ok = tapu < ntap;
+        }
+        const bool chan_ok = (ci < p.Cin) & tap_ok;
+        xoffs[u] = chan_ok ? (unsigned)((s0 * PK + px) * p.xsW + ci) * 4u : OOB;       // (PW: xsW = Cin, pixel m IS input pixel m)
+        xinc[u] = chan_ok ? (unsigned)(PK * p.xsW) * 4u : 0u;
+        xtapy[u] = kyu * p.by + p.cy;
+        xtapx[u] = kxu * p.bx + p.cx;
+        xch[u] = chan_ok ? ci : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < DR; ++u) {
+        const int unit = tid + 256 * u;
+        const int px = unit / (BJ / 4), cp = unit - px * (BJ / 4);
+        const int co = co0 + cp * 4;
+        doffs[u] = co < p.Cout ? (unsigned)((s0 * PK + px) * p.Cout + co) * 4u : OOB;
+        dinc[u] = co < p.Cout ? (unsigned)(PK * p.Cout) * 4u : 0u;
+    }
+    int un = 0, uoy = 0, uox = 0, um = s0 * PK;          // (!PW) (n, oy, ox) and index of the first pixel of the next step to load, wave-uniform
     const int HW = p.Ho * p.Wo;
-    int un = 0, uoy = 0, uox = 0;                       // (n, oy, ox) of the first pixel of the next step to load (!PW), wave-uniform
     const int stepRows = PK / p.Wo, stepCols = PK - (PK / p.Wo) * p.Wo;
     const unsigned magicW = (65536u + (unsigned)p.Wo - 1u) / (unsigned)p.Wo, magicH = (65536u + (unsigned)p.Ho - 1u) / (unsigned)p.Ho;
     const bool wideW = p.Wo > 224, wideH = p.Ho > 224;
@@ -413,6 +437,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_split_kernel(const Bwd
         uox = __builtin_amdgcn_readfirstlane(uox);
     }
     auto advance_pixels = [&]() {
+        um += PK;
         uox += stepCols;
         uoy += stepRows;
         if (uox >= p.Wo) {
@@ -425,58 +450,37 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_split_kernel(const Bwd
         }
     };
 
-    // loads of step st into register set R (steps past the tensor's end read clamped addresses and are zeroed; steps past this
-    // workgroup's range are loaded and never used)
-    auto load_step = [&](int st, f32x4 (&rxs)[XR], f32x4 (&rds)[DR], unsigned& okbits) {
-        const int m0 = st * PK;
-        unsigned bits = 0u;
+    // loads of the next step into a register set (steps past this workgroup's range are loaded and never used; past the tensor: zeros)
+    auto load_step = [&](f32x4 (&rxs)[XR], f32x4 (&rds)[DR]) {
 #pragma unroll
         for (int u = 0; u < XR; ++u) {
-            const int unit = tid + 256 * u;
-            const int px = unit / (BI / 4), cp = unit - px * (BI / 4);
-            const int m = m0 + px;
-            const int mc = min(m, p.M - 1);
-            int ci = ci0 + cp * 4, kyu = ky, kxu = kx;
-            bool tap_ok = true;
-            if (TP2) {
-                const int tapu = tap + (cp >> 3);
-                ci = (cp & 7) * 4;
-                kyu = tapu / p.nkx;
-                kxu = tapu - kyu * p.nkx;
-                tap_ok = tapu < ntap;
-            }
-            const int cic = min(ci, p.Cin - 4);
-            bool ok;
+            unsigned off;
             if (PW) {
-                ok = (m < p.M) & (ci < p.Cin);
-                rxs[u] = *reinterpret_cast<const f32x4*>(p.x + (long long)mc * p.xsW + cic);
+                off = xoffs[u];
+                xoffs[u] += xinc[u];
             } else {
+                // pixel um + px from the step's uniform (n, oy, ox): px < PK columns further on, at most PK / Wo + 1 row wraps and one
+                // image wrap
+                const int unit = tid + 256 * u;
+                const int px = unit / (BI / 4);
                 const unsigned t = (unsigned)(uox + px);
                 const unsigned q = wideW ? (t >= (unsigned)p.Wo ? 1u : 0u) : (__umul24(t, magicW) >> 16);
                 const int ox = (int)(t - __umul24(q, (unsigned)p.Wo));
                 const unsigned ty = (unsigned)uoy + q;
                 const unsigned r = wideH ? (ty >= (unsigned)p.Ho ? 1u : 0u) : (__umul24(ty, magicH) >> 16);
                 const int oy = (int)(ty - __umul24(r, (unsigned)p.Ho));
-                const int n = min(un + (int)r, p.N - 1);
-                int iy = __mul24(oy, p.ay) + kyu * p.by + p.cy, ix = __mul24(ox, p.ax) + kxu * p.bx + p.cx;
-                ok = (m < p.M) & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi) & (ci < p.Cin) & tap_ok;
-                iy = min(max(iy, 0), p.Hi - 1);
-                ix = min(max(ix, 0), p.Wi - 1);
-                rxs[u] = *reinterpret_cast<const f32x4*>(p.x + (long long)n * p.xsN + (unsigned)(__mul24(iy, p.xsH) + __mul24(ix, p.xsW) + cic));
+                const int n = un + (int)r;
+                const int iy = __mul24(oy, p.ay) + xtapy[u], ix = __mul24(ox, p.ax) + xtapx[u];
+                const bool ok = (um + px < p.M) & (iy >= 0) & (iy < p.Hi) & (ix >= 0) & (ix < p.Wi) & (xch[u] >= 0);
+                off = ok ? ((unsigned)n * (unsigned)p.xsN + (unsigned)(__mul24(iy, p.xsH) + __mul24(ix, p.xsW) + xch[u])) * 4u : OOB;
             }
-            bits |= ok ? (1u << u) : 0u;
+            rxs[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 0, 0));
         }
 #pragma unroll
         for (int u = 0; u < DR; ++u) {
-            const int unit = tid + 256 * u;
-            const int px = unit / (BJ / 4), cp = unit - px * (BJ / 4);
-            const int m = m0 + px;
-            const int mc = min(m, p.M - 1);
-            const int co = co0 + cp * 4;
-            rds[u] = *reinterpret_cast<const f32x4*>(p.dy + (long long)mc * p.Cout + min(co, p.Cout - 4));
-            bits |= ((m < p.M) & (co < p.Cout)) ? (1u << (XR + u)) : 0u;
+            rds[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, (int)doffs[u], 0, 0));
+            doffs[u] += dinc[u];
         }
-        okbits = bits;
         if (!PW) advance_pixels();
     };
 
@@ -484,15 +488,14 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_split_kernel(const Bwd
     const int kds = ccst_scale_exp(ccst_absmax_reduce(dword), CCST_SPLIT_X_TARGET);
     const float xsc = __uint_as_float((unsigned)(127 + kxs) << 23), dsc = __uint_as_float((unsigned)(127 + kds) << 23);
 
-    auto store_step = [&](int buf, const f32x4 (&rxs)[XR], const f32x4 (&rds)[DR], unsigned okbits) {
-        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    auto store_step = [&](int buf, const f32x4 (&rxs)[XR], const f32x4 (&rds)[DR]) {
         unsigned char* const base = lds + buf * STAGE;
 #pragma unroll
         for (int u = 0; u < XR; ++u) {
             const int unit = tid + 256 * u;
             const int px = unit / (BI / 4), cp = unit - px * (BI / 4);
             u32x2w hi, lo;
-            split4w(((okbits >> u) & 1u) ? rxs[u] : z4, xsc, hi, lo);
+            ccst_split4_half(rxs[u], xsc, hi, lo);
             *reinterpret_cast<u32x2w*>(base + px * SI + cp * 8) = hi;
             *reinterpret_cast<u32x2w*>(base + XIMG + px * SI + cp * 8) = lo;
         }
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_split_kernel(const Bwd
             const int unit = tid + 256 * u;
             const int px = unit / (BJ / 4), cp = unit - px * (BJ / 4);
             u32x2w hi, lo;
-            split4w(((okbits >> (XR + u)) & 1u) ? rds[u] : z4, dsc, hi, lo);
+            ccst_split4_half(rds[u], dsc, hi, lo);
             *reinterpret_cast<u32x2w*>(base + 2 * XIMG + px * SJ + cp * 8) = hi;
             *reinterpret_cast<u32x2w*>(base + 2 * XIMG + DIMG + px * SJ + cp * 8) = lo;
         }
@@ -539,16 +542,16 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_split_kernel(const Bwd
             for (int c = 0; c < NJ; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[0][a], f.b[0][c], acc[a][c], 0, 0, 0);
     };
     // one step: the MFMAs of LDS stage `buf` (step t); registers of step t + 1 -> the other stage; loads of step t + 3 into the
-    // register set just freed
-    auto step = [&](int buf, int st_load, f32x4 (&rxs)[XR], f32x4 (&rds)[DR], unsigned& okbits) {
+    // register set just freed (the loader's own state says which step is next)
+    auto step = [&](int buf, f32x4 (&rxs)[XR], f32x4 (&rds)[DR]) {
         Frags f[2];
         read_frags(buf, 0, f[0]);
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             if (ks + 1 < NKS) read_frags(buf, ks + 1, f[(ks + 1) & 1]);
             if (ks == NKS - 1) {
-                store_step(buf ^ 1, rxs, rds, okbits);
-                load_step(st_load, rxs, rds, okbits);
+                store_step(buf ^ 1, rxs, rds);
+                load_step(rxs, rds);
             }
             mfmas(f[ks & 1]);
         }
@@ -557,17 +560,17 @@ __global__ __launch_bounds__(256, 2) void conv_bwd_weight_split_kernel(const Bwd
 
     if (s0 < s1) {
         const int T = s1 - s0;
-        load_step(s0, rx[0], rd[0], okm[0]);
-        load_step(s0 + 1, rx[1], rd[1], okm[1]);
-        store_step(0, rx[0], rd[0], okm[0]);
-        load_step(s0 + 2, rx[0], rd[0], okm[0]);
+        load_step(rx[0], rd[0]);
+        load_step(rx[1], rd[1]);
+        store_step(0, rx[0], rd[0]);
+        load_step(rx[0], rd[0]);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         int t = 0;
         for (; t + 2 <= T; t += 2) {
-            step(0, s0 + t + 3, rx[1], rd[1], okm[1]);
-            step(1, s0 + t + 4, rx[0], rd[0], okm[0]);
+            step(0, rx[1], rd[1]);
+            step(1, rx[0], rd[0]);
         }
-        if (t < T) step(0, s0 + t + 3, rx[1], rd[1], okm[1]);
+        if (t < T) step(0, rx[1], rd[1]);
     }
 
     // scale back (two exact multiplications: either power of two is a normal float, their product need not be)
@@ -726,14 +729,19 @@ static void pick_tile_split(int cin, int cout, int* mi, int* nj) {
     *mi = cin >= 128 ? 2 : 1;
     *nj = cout >= 128 ? 2 : 1;
 }
-constexpr int SPLIT_PK = 16;
+#ifndef BWW_PK
+#define BWW_PK 16
+#endif
+constexpr int SPLIT_PK = BWW_PK;
 
 extern "C" int ccst_conv2d_bwd_weight_split_splits(int M, int cin, int cout, int ntap) {
     int mi, nj;
     pick_tile_split(cin, cout, &mi, &nj);
     const int tapgroups = (mi == 1 && ntap > 1 && cin <= 32) ? (ntap + 1) / 2 : ntap;
     const long long tiles = (long long)tapgroups * ((cin + 64 * mi - 1) / (64 * mi)) * ((cout + 64 * nj - 1) / (64 * nj));
-    long long s = (1024 + tiles - 1) / tiles;
+    // two workgroups per CU, ONE round: measured over the 22 ResNet50 weight-gradient shapes at 256 / 512 / 1024 / 2048 workgroups,
+    // 512 is the fastest or within 3 % of it on 19 (more workgroups = more slabs for the reduce and more prologues: -12 % at 1024)
+    long long s = (512 + tiles - 1) / tiles;
     const long long smax = (M / SPLIT_PK) / 16 > 0 ? (M / SPLIT_PK) / 16 : 1;     // >= 16 steps per workgroup
     if (s > smax) s = smax;
     if (s > 512) s = 512;
@@ -788,6 +796,11 @@ static int bwd_weight_entry(const CcstConvDesc* d, const float* x, const uint32_
     a.xmax = x_absmax;
     a.dmax = dy_absmax;
     if (x_absmax != nullptr) {          // half pieces on the 16-bit MFMA
+        const long long xb = (long long)d->n * d->xsN * 4, db = (long long)a.M * d->cout * 4;
+        CCST_REQUIRE(xb < 0x7fffffffLL && db < 0x7fffffffLL && d->xsN >= (long long)d->hi * d->xsH,
+                     "bwd_weight_split: x and dy must be below 2^31 bytes each (32-bit buffer offsets)");
+        a.xbytes = (unsigned)xb;
+        a.dbytes = (unsigned)db;
         pick_tile_split(d->cin, d->cout, &mi, &nj);
         if (!pw && ntap > 1 && d->cin <= 32) rc = launch_split<1, 1, SPLIT_PK, false, true>(a, s);
         else if (mi == 2 && nj == 2) rc = pw ? launch_split<2, 2, SPLIT_PK, true>(a, s) : launch_split<2, 2, SPLIT_PK, false>(a, s);
@@ -805,9 +818,6 @@ static int bwd_weight_entry(const CcstConvDesc* d, const float* x, const uint32_
     const long long cols = (long long)((d->cout + 31) / 32) * ntap;
     int nl = 4;
     while (nl < 32 && nl < splits && cols * ((d->cin + 32 / nl - 1) / (32 / nl)) < 1024) nl *= 2;
-#ifdef REDUCE_FORCE_NL          // (diagnostic builds: the split-lane count fixes the summation order)
-    nl = REDUCE_FORCE_NL;
-#endif
     dim3 grid((d->cout + 31) / 32, (d->cin + 32 / nl - 1) / (32 / nl), ntap);
 #define CCST_REDUCE(NL_)                                                                                                       \
     hipLaunchKernelGGL(bwd_weight_reduce_kernel<NL_>, grid, dim3(256), 0, s, (const float*)ws, dw_oihw, ntap, d->cin, d->cout, splits, \

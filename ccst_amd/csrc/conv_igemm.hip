@@ -30,8 +30,7 @@
 
 namespace {
 
-typedef unsigned u32x2s __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+typedef ccst_u32x2 u32x2s;
 typedef _Float16 f16x8s __attribute__((ext_vector_type(8)));
 
 
@@ -214,14 +213,8 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
     };
     auto load_step = [&](int ky_, int kx_, int c_) {
         const float* xc = p.x + c_ * CK;                                   // uniform
-#ifndef ABLATE_NO_A_LOAD          // timing experiments only (tools/build_variant.sh): wrong results
 #pragma unroll
         for (int a = 0; a < AR; ++a) ra[a] = *reinterpret_cast<const f32x4*>(xc + aoff[a]);
-#else
-#pragma unroll
-        for (int a = 0; a < AR; ++a) ra[a] = f32x4{1.f, 2.f, 3.f, (float)c_};
-        (void)xc;
-#endif
         const int tap = p.tap_base + ky_ * p.tap_sy + kx_ * p.tap_sx;
         const float* wc = p.w + ((long long)tap * (p.Cin / 4) + c_ * (CK / 4)) * p.CoutPad * 4;   // uniform
 #pragma unroll
@@ -232,14 +225,8 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
         for (int a = 0; a < AR; ++a) {
             const int r = tid / PPR + (256 / PPR) * a;
             f32x4 v = ra[a];
-#ifndef ABLATE_NO_A_MASK
             if (!aok[a]) v = f32x4{0.f, 0.f, 0.f, 0.f};
-#endif
-#ifndef ABLATE_NO_A_STORE
             *reinterpret_cast<f32x4*>(&As[buf][r * A_LD + part * 4]) = v;
-#else
-            if (v[0] == 123.456f) As[buf][r * A_LD + part * 4] = v[1];
-#endif
         }
 #pragma unroll
         for (int b = 0; b < BR; ++b) {
@@ -484,22 +471,21 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
 // wave, 16 MFMAs per step, 4 workgroups per CU).
 // ------------------------------------------------------------------------------------------------------------------------
 // MASKED: 0 none, 1 the forward's byte mask (ACCUM), 2 recomputed from the BatchNorm's own input (bn(x) > 0; needs BSTATS)
-// BF3: the products on the bf16 MFMA, fp32-accurate: x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 significant bits),
-// a b ~ a_lo b_hi + a_hi b_lo + a_hi b_hi accumulated in fp32 -- v_mfma_f32_32x32x16_bf16 does 16x the multiply-adds per cycle of
-// v_mfma_f32_32x32x2_f32, so three products run at 5.3x the fp32 MFMA rate with an error of 5e-7 of sum |a b| (4x the fp32 MFMA's
-// own rounding; tools/micro/bf16x3.hip, profiles/r03_bf16x3_microbench.txt).  Both operands are split where they pass from
-// registers to LDS (the weights too: no second packed format); LDS rows are [32 channels hi | 32 channels lo] as bf16 = the same 128
-// bytes + pad as the fp32 row, both for the pixel rows of A and the output-channel rows of B ([col][k]: a lane's 8 consecutive k).
-// BFP = 3 pieces (hi, mid, lo: 24 bits, every product whose weight is >= 2^-16 of the leading one: six MFMAs per 16 channels, 2.7x the
-// fp32 MFMA rate, the fp32 MFMA's own accuracy) is what the ResNet step needs -- its gradient gates amplify a conv's rounding by ~1e3
-// and two pieces (16 bits, error 5e-6 of max |y|) fail them; BFP = 2 is kept for inference-grade callers.
-template <bool STATS, bool ACCUM, int MASKED = 0, bool BSTATS = false, int BFP = 0>
-__global__ __launch_bounds__(256, BFP == 3 ? 3 : 4) void conv1x1_stream_kernel(const ConvArgs p, int ntiles) {
-    // BFP = 4: TWO IEEE-half pieces (22 bits: 1e-6 of max |y|, the form the AdaIN path's direct kernel uses; the weights are scaled by
-    // 2^8 into half's normal range as they are split and the accumulators scaled back) -- for FORWARD convolutions only: gradients are
-    // outside half's range.
-    constexpr bool BF3 = BFP != 0, HALFP = BFP == 4;
-    constexpr int NPIECE = HALFP ? 2 : BFP;
+// HALFP: the products on the 16-bit MFMA at fp32 accuracy -- every fp32 product as three products of IEEE-half pieces (v = hi + lo, 22
+// significant bits, fp32 accumulation: a_lo b_hi + a_hi b_lo + a_hi b_hi; v_mfma_f32_32x32x16_f16 does 16x the multiply-adds per cycle
+// of v_mfma_f32_32x32x2_f32).  LDS rows are [32 channels hi | 32 channels lo] as half = the same 128 bytes + pad as the fp32 row, both
+// for the pixel rows of A and the output-channel rows of B ([col][k]: a lane's 8 consecutive k).  Round 5: the activations are split
+// where they pass from registers to LDS by ccst_split4_half (8 vector instructions per four values; 14 before), and the WEIGHTS
+// arrive pre-split from ccst_pack_conv_weight_split_f32 (a 16-byte unit of the packed layout = four k of one column as four hi
+// halves | four lo halves, scaled by the power of two of the weight's |max| words): the B side of the loader is two 8-byte LDS stores
+// and no arithmetic.  With both splits in the loader (round 3/4) a k-step carried ~60 vector instructions next to 6 MFMAs and only
+// the training forward gained (1.43x); now it carries ~16, and the backward-data forms run on it too -- their operand is a
+// gradient, scaled by the |max| words its producer (the BatchNorm backward's apply) leaves.
+// (bf16 pieces -- 16 bits with two, 24 with three -- were measured in round 3 and retired: DESIGN / JOURNAL.)
+template <bool STATS, bool ACCUM, int MASKED = 0, bool BSTATS = false, bool HALFP = false>
+__global__ __launch_bounds__(256, 4) void conv1x1_stream_kernel(const ConvArgs p, int ntiles) {
+    constexpr bool BF3 = HALFP;
+    constexpr int NPIECE = 2;
     // HALFP: both operands scaled by powers of two from the tensors' |max| words (activations to < 2^14, weights to < 2^10): no finite
     // fp32 value overflows half, small tensors are lifted out of its subnormals; the accumulators are scaled back exactly (v_ldexp)
     int kxs = 0, kws = 0;
@@ -507,7 +493,7 @@ __global__ __launch_bounds__(256, BFP == 3 ? 3 : 4) void conv1x1_stream_kernel(c
         kxs = ccst_scale_exp(ccst_absmax_read(p.xmax), CCST_SPLIT_X_TARGET);
         kws = ccst_scale_exp(ccst_absmax_read(p.wmax), CCST_SPLIT_W_TARGET);
     }
-    const float xsc = __uint_as_float((unsigned)(127 + kxs) << 23), wsc = __uint_as_float((unsigned)(127 + kws) << 23);
+    const float xsc = __uint_as_float((unsigned)(127 + kxs) << 23);
     constexpr int BM = 64, BN = 64, CK = 32, PPR = CK / 4, AR = BM * PPR / 256, BR = (CK / 4) * BN / 256;
     constexpr int PW = CK / 2;                               // words per piece of a row (32 bf16)
     constexpr int A_LD = BF3 ? NPIECE * PW + 4 : CK + 4;     // BF: a row = [32 channels piece 0 | piece 1 | ...] + 4 words of pad
@@ -578,43 +564,22 @@ __global__ __launch_bounds__(256, BFP == 3 ? 3 : 4) void conv1x1_stream_kernel(c
             loader_tile(++lt);
         }
     };
-    // four fp32 values -> their bf16 pieces (each the round-to-nearest bf16 of what the previous ones left), two bf16 per word
-    auto split4 = [](f32x4 v, u32x2s (&pc)[BF3 ? NPIECE : 1]) {
-#pragma unroll
-        for (int q = 0; q < (BF3 ? NPIECE : 1); ++q)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (HALFP) {
-                    const _Float16 b0 = (_Float16)v[2 * h], b1 = (_Float16)v[2 * h + 1];
-                    pc[q][h] = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
-                    v[2 * h] -= (float)b0;
-                    v[2 * h + 1] -= (float)b1;
-                } else {
-                    const __bf16 b0 = (__bf16)v[2 * h], b1 = (__bf16)v[2 * h + 1];
-                    pc[q][h] = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
-                    v[2 * h] -= (float)b0;
-                    v[2 * h + 1] -= (float)b1;
-                }
-            }
-    };
     auto store_step = [&](int buf) {
-        if (BF3) {
+        if (HALFP) {
 #pragma unroll
-            for (int a = 0; a < AR; ++a) {          // row = pixel
-                u32x2s pc[BF3 ? NPIECE : 1];
-                split4(HALFP ? ra[a] * xsc : ra[a], pc);
+            for (int a = 0; a < AR; ++a) {          // row = pixel: [32 channels hi | 32 channels lo]
+                u32x2s hi, lo;
+                ccst_split4_half(ra[a], xsc, hi, lo);
                 float* row = &As[buf][(tid / PPR + (256 / PPR) * a) * A_LD];
-#pragma unroll
-                for (int q = 0; q < (BF3 ? NPIECE : 1); ++q) *reinterpret_cast<u32x2s*>(row + q * PW + part * 2) = pc[q];
+                *reinterpret_cast<u32x2s*>(row + part * 2) = hi;
+                *reinterpret_cast<u32x2s*>(row + PW + part * 2) = lo;
             }
 #pragma unroll
-            for (int b = 0; b < BR; ++b) {          // unit u = (k quad u / BN, column u % BN): row = output channel
+            for (int b = 0; b < BR; ++b) {          // unit u = (k quad u / BN, column u % BN), pre-split: row = output channel
                 const int u = tid + 256 * b;
-                u32x2s pc[BF3 ? NPIECE : 1];
-                split4(HALFP ? rb[b] * wsc : rb[b], pc);
                 float* row = &Bs[buf][(u % BN) * B_LD];
-#pragma unroll
-                for (int q = 0; q < (BF3 ? NPIECE : 1); ++q) *reinterpret_cast<u32x2s*>(row + q * PW + (u / BN) * 2) = pc[q];
+                *reinterpret_cast<u32x2s*>(row + (u / BN) * 2) = u32x2s{__float_as_uint(rb[b][0]), __float_as_uint(rb[b][1])};
+                *reinterpret_cast<u32x2s*>(row + PW + (u / BN) * 2) = u32x2s{__float_as_uint(rb[b][2]), __float_as_uint(rb[b][3])};
             }
             return;
         }
@@ -641,27 +606,21 @@ __global__ __launch_bounds__(256, BFP == 3 ? 3 : 4) void conv1x1_stream_kernel(c
     auto step_bf3 = [&](int buf, auto do_store, auto do_load) {
         const float* ar = aRdB + buf * (BM * A_LD);
         const float* br = bRdB + buf * (BN * B_LD);
-        constexpr int NPC = BF3 ? NPIECE : 1;
-        bf16x8s af_[2][NPC], bf_[2][NPC];
+        constexpr int NPC = NPIECE;
+        f16x8s af_[2][NPC], bf_[2][NPC];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int q = 0; q < NPC; ++q) {
-                af_[kb][q] = __builtin_bit_cast(bf16x8s, *reinterpret_cast<const f32x4*>(ar + q * PW + 8 * kb));
-                bf_[kb][q] = __builtin_bit_cast(bf16x8s, *reinterpret_cast<const f32x4*>(br + q * PW + 8 * kb));
+                af_[kb][q] = __builtin_bit_cast(f16x8s, *reinterpret_cast<const f32x4*>(ar + q * PW + 8 * kb));
+                bf_[kb][q] = __builtin_bit_cast(f16x8s, *reinterpret_cast<const f32x4*>(br + q * PW + 8 * kb));
             }
         // products of pieces (i, j) with i + j < NPC, the smallest first
         auto block = [&](int kb) {
 #pragma unroll
             for (int sum = NPC - 1; sum >= 0; --sum)
 #pragma unroll
-                for (int i = sum; i >= 0; --i) {
-                    if (HALFP)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8s, af_[kb][i]), __builtin_bit_cast(f16x8s, bf_[kb][sum - i]),
-                                                                     acc, 0, 0, 0);
-                    else
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af_[kb][i], bf_[kb][sum - i], acc, 0, 0, 0);
-                }
+                for (int i = sum; i >= 0; --i) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[kb][i], bf_[kb][sum - i], acc, 0, 0, 0);
         };
         block(0);
         if (decltype(do_store)::value) {
@@ -866,6 +825,39 @@ __global__ void pack_weight_batch_kernel(const long long* __restrict__ jobs) {
     }
 }
 
+// A 1x1 weight in the pointwise kernel's packed layout [K/4][n_pad] of 16-byte units, PRE-SPLIT for its half-piece form: unit (kg, col)
+// = the four k = 4 kg .. 4 kg + 3 of column col as four hi halves | four lo halves of w * 2^kw (kw from the weight's |max| words, the
+// exponent the conv kernel derives from the same words: CCST_SPLIT_W_TARGET).  The same 16 bytes per unit as the fp32 layout.
+__device__ __forceinline__ void pack_split_units(const float* __restrict__ w, const unsigned* __restrict__ wmax, float* __restrict__ out, int cout,
+                                                 int cin, int transpose, int k_pad, int n_pad) {
+    const int kw = ccst_scale_exp(ccst_absmax_read(wmax), CCST_SPLIT_W_TARGET);
+    const float wsc = __uint_as_float((unsigned)(127 + kw) << 23);
+    const long long units = (long long)(k_pad / 4) * n_pad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (long long)gridDim.x * blockDim.x) {
+        const int ncol = (int)(i % n_pad), kg = (int)(i / n_pad);
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = kg * 4 + j;
+            const int ci = transpose ? ncol : k, co = transpose ? k : ncol;
+            v[j] = (ci < cin && co < cout) ? w[(long long)co * cin + ci] : 0.f;
+        }
+        ccst_u32x2 hi, lo;
+        ccst_split4_half(v, wsc, hi, lo);
+        *reinterpret_cast<f32x4*>(out + i * 4) = f32x4{__uint_as_float(hi[0]), __uint_as_float(hi[1]), __uint_as_float(lo[0]), __uint_as_float(lo[1])};
+    }
+}
+__global__ __launch_bounds__(256) void pack_weight_split_kernel(const float* __restrict__ w, const unsigned* __restrict__ wmax, float* __restrict__ out,
+                                                                int cout, int cin, int transpose, int k_pad, int n_pad) {
+    pack_split_units(w, wmax, out, cout, cin, transpose, k_pad, n_pad);
+}
+// ... for a whole model in one launch: jobs[j] = {src, dst, cout, cin, |max| words, transpose, k_pad, n_pad} (int64 each), blockIdx.y = job
+__global__ __launch_bounds__(256) void pack_weight_split_batch_kernel(const long long* __restrict__ jobs) {
+    const long long* jb = jobs + (long long)blockIdx.y * 8;
+    pack_split_units(reinterpret_cast<const float*>(jb[0]), reinterpret_cast<const unsigned*>(jb[4]), reinterpret_cast<float*>(jb[1]), (int)jb[2],
+                     (int)jb[3], (int)jb[5], (int)jb[6], (int)jb[7]);
+}
+
 // NCHW (C<=4) -> padded NHWC4
 __global__ void nchw_to_nhwc4_pad_kernel(const float* __restrict__ x, f32x4* __restrict__ y, int N, int C, int H, int W,
                                          int pad, int Wp, int reflect) {
@@ -1029,16 +1021,49 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
                            void* stream, const unsigned char* relu_mask, const BnLink* bn, const uint32_t* xmax = nullptr,
                            const uint32_t* wmax = nullptr);
 
-// ccst_conv2d_igemm_stats_f32 with the |max| words of x and of the OIHW weight (include/ccst_hip.h, CCST_ABSMAX_WORDS): where the problem
-// runs on the streaming pointwise kernel, its products are formed from two IEEE-half pieces per operand on the 16-bit MFMA (1.43x the fp32
-// MFMA on the ResNet50 pointwise shapes at its accuracy), both operands scaled by powers of two derived from the words on the device --
-// range-safe at any fp32 magnitude.  Without the words (ccst_conv2d_igemm_stats_f32) the fp32 MFMA runs.  CCST_CONV_BF=0: fp32 always.
-extern "C" int ccst_conv2d_igemm_stats_scaled_f32(const CcstConvDesc* d, const float* x, const uint32_t* x_absmax, const float* w_packed,
-                                                  const uint32_t* w_absmax, const float* bias, float* y, float* stats, void* stream) {
-    CCST_REQUIRE(stats != nullptr, "conv_stats_scaled: null stats buffer");
-    CCST_REQUIRE(x_absmax && w_absmax, "conv_stats_scaled: the |max| words of x and w");
-    CCST_REQUIRE(d && !(d->flags & (CCST_CONV_POOL2 | CCST_CONV_RELU)), "conv_stats_scaled: statistics are of the raw conv output (no ReLU / pool)");
-    return conv_igemm_impl(d, x, w_packed, bias, y, stats, stream, nullptr, nullptr, x_absmax, w_absmax);
+// 1 when this problem runs on the persistent pointwise kernel at all (dense or strided 1x1 input, dense output, no bias / ReLU / pool):
+// the shapes ccst_conv2d_pointwise_half_f32 takes.
+static bool stream_problem(const CcstConvDesc* d) {
+    if (!d || (d->flags & (CCST_CONV_POOL2 | CCST_CONV_RELU | CCST_CONV_UPS2 | CCST_CONV_REFLECT))) return false;
+    const bool dense_out = d->ysC == 1 && d->ysW == d->cout && d->ysH == (long long)d->wo * d->ysW && d->ysN == (long long)d->ho * d->wo * d->ysW;
+    const bool pw_in = d->nky == 1 && d->nkx == 1 && d->cy == 0 && d->cx == 0 && d->ay >= 1 && d->ax >= 1 &&
+                       (long long)(d->ho - 1) * d->ay < d->hi && (long long)(d->wo - 1) * d->ax < d->wi;
+    return pw_in && dense_out && stream_shape_ok(d->n * d->ho * d->wo, d->cout, d->cin, 1);
+}
+extern "C" int ccst_conv2d_stream_ok(const CcstConvDesc* d) { return stream_problem(d) ? 1 : 0; }
+
+// Every form of the streaming pointwise kernel on half pieces (16-bit MFMA, fp32 accuracy; see conv1x1_stream_kernel): x scaled by its
+// |max| words, the weight PRE-SPLIT by ccst_pack_conv_weight_split_f32 with the same w_absmax words.  The form follows from the
+// arguments, as in the fp32 entries: stats (training forward), CCST_CONV_ACCUM (+ relu_mask (+ the BatchNorm link bn_x / bn_mean /
+// bn_invstd / bn_partials)), the BatchNorm + ReLU backward link (bn_gamma / bn_beta too, no ACCUM), or plain.  Requires
+// ccst_conv2d_stream_ok(d) (and ccst_conv2d_pointwise_ok(d) for the masked / linked forms).
+extern "C" int ccst_conv2d_pointwise_half_f32(const CcstConvDesc* d, const float* x, const uint32_t* x_absmax, const float* w_split,
+                                              const uint32_t* w_absmax, float* y, float* stats, const uint8_t* relu_mask, const float* bn_x,
+                                              const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                                              float* bn_partials, void* stream) {
+    CCST_REQUIRE(x_absmax && w_absmax, "conv_pointwise_half: the |max| words of x and w");
+    CCST_REQUIRE(stream_problem(d), "conv_pointwise_half: not a problem of the streaming pointwise kernel (ccst_conv2d_stream_ok)");
+    CCST_REQUIRE((relu_mask == nullptr && bn_x == nullptr) || ccst_conv2d_pointwise_ok(d), "conv_pointwise_half: the masked / linked forms need a dense input");
+    CCST_REQUIRE((bn_x != nullptr) == (bn_partials != nullptr) && (bn_x == nullptr || (bn_mean && bn_invstd)) && ((bn_gamma != nullptr) == (bn_beta != nullptr)),
+                 "conv_pointwise_half: incomplete BatchNorm link");
+    CCST_REQUIRE(stream_bfp() == 4, "conv_pointwise_half: CCST_CONV_BF=0 turns the half-piece kernels off");
+    const BnLink bn = {bn_x, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_partials};
+    return conv_igemm_impl(d, x, w_split, nullptr, y, stats, stream, relu_mask, bn_x ? &bn : nullptr, x_absmax, w_absmax);
+}
+
+extern "C" int ccst_pack_conv_weight_split_f32(const float* w_oihw, const uint32_t* w_absmax, float* packed, int cout, int cin, int transpose,
+                                               int k_pad, int n_pad, void* stream) {
+    CCST_REQUIRE(w_oihw && w_absmax && packed && cout > 0 && cin > 0, "pack_conv_weight_split: bad args");
+    CCST_REQUIRE(k_pad % 4 == 0 && k_pad >= (transpose ? cout : cin) && n_pad >= (transpose ? cin : cout), "pack_conv_weight_split: padding");
+    const long long units = (long long)(k_pad / 4) * n_pad;
+    hipLaunchKernelGGL(pack_weight_split_kernel, dim3((unsigned)((units + 255) / 256 < 2048 ? (units + 255) / 256 : 2048)), dim3(256), 0, (hipStream_t)stream,
+                       w_oihw, w_absmax, packed, cout, cin, transpose, k_pad, n_pad);
+    return ccst_launch_status("pack_weight_split");
+}
+extern "C" int ccst_pack_conv_weights_split_batch_f32(const int64_t* jobs_device, int njobs, void* stream) {
+    CCST_REQUIRE(jobs_device && njobs > 0, "pack_conv_weights_split_batch: bad args");
+    hipLaunchKernelGGL(pack_weight_split_batch_kernel, dim3(32, njobs), dim3(256), 0, (hipStream_t)stream, (const long long*)jobs_device);
+    return ccst_launch_status("pack_weight_split_batch");
 }
 
 extern "C" int ccst_conv2d_igemm_accum_masked_f32(const CcstConvDesc* d, const float* x, const float* w_packed, float* y,
@@ -1114,13 +1139,13 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
         const bool acc = (a.flags & CCST_CONV_ACCUM) != 0;
         if (relu_mask) CCST_REQUIRE(acc && !stats, "conv: the ReLU mask goes with CCST_CONV_ACCUM (the sum is masked)");
         if (bn) CCST_REQUIRE(!stats && ((acc && relu_mask) || (!acc && bn->gamma)), "conv: BatchNorm link without its masked form");
-        // half pieces: the training forward (the form with the statistics epilogue) and only where the caller passed the |max| words of
-        // both operands -- without them nothing bounds the operands, and the fp32 MFMA runs
-        const bool halfp = stream_bfp() == 4 && stats != nullptr && xmax != nullptr && wmax != nullptr;
+        // half pieces only where the caller passed the |max| words of both operands -- without them nothing bounds the operands, and
+        // the fp32 MFMA runs
+        const bool halfp = xmax != nullptr && wmax != nullptr;      // (ccst_conv2d_pointwise_half_f32: w_packed is the pre-split layout)
 #define CCST_STREAM(...)                                                                                                     \
     do {                                                                                                                     \
-        if (halfp) hipLaunchKernelGGL((conv1x1_stream_kernel<__VA_ARGS__, 4>), dim3(grid), dim3(256), 0, s, a, ntiles);      \
-        else hipLaunchKernelGGL((conv1x1_stream_kernel<__VA_ARGS__, 0>), dim3(grid), dim3(256), 0, s, a, ntiles);            \
+        if (halfp) hipLaunchKernelGGL((conv1x1_stream_kernel<__VA_ARGS__, true>), dim3(grid), dim3(256), 0, s, a, ntiles);   \
+        else hipLaunchKernelGGL((conv1x1_stream_kernel<__VA_ARGS__, false>), dim3(grid), dim3(256), 0, s, a, ntiles);        \
     } while (0)
         if (stats) CCST_STREAM(true, false, 0, false);
         else if (acc && relu_mask && bn) CCST_STREAM(false, true, 1, true);
@@ -1132,6 +1157,7 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
         return ccst_launch_status("conv1x1_stream");
     }
     CCST_REQUIRE(relu_mask == nullptr && bn == nullptr, "conv: the masked / BatchNorm-linked forms exist only where ccst_conv2d_pointwise_ok() says so");
+    CCST_REQUIRE(xmax == nullptr && wmax == nullptr, "conv: the half-piece form exists only on the streaming pointwise kernel (ccst_conv2d_stream_ok)");
     const int tile = choose_tile(a.M, d->cout, d->cin, d->nky * d->nkx, pool);
     // ccst_conv2d_igemm_stats_groups() counted the streaming kernel's slabs for every 1x1 problem of its shape class
     CCST_REQUIRE(!(stats && stream_shape_ok(a.M, d->cout, d->cin, d->nky * d->nkx)),

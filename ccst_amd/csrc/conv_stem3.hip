@@ -60,9 +60,7 @@ __host__ __device__ __forceinline__ void stem3_k(int ks, int lh, int i, int& c, 
     }
 }
 
-#ifndef STEM_WAVES
 #define STEM_WAVES 3
-#endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STEM_WAVES, STEM_WAVES))) void conv_stem3_kernel(const Stem3Args p) {
     __shared__ __attribute__((aligned(16))) char tr[4][32 * 256];             // per wave: 32 pixels x 64 channels
     const int tid = threadIdx.x, lane = tid & 63;

@@ -698,6 +698,31 @@ __global__ __launch_bounds__(TPB) void sgd_kernel(float* __restrict__ p, const f
     }
     for (long long i = (n4 << 2) + (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) p[i] -= lr * g[i];
 }
+// communication()'s fedavg branch (fed_run.py:400-414) over K flat arenas in ONE pass: server = sum_k w_k client_k accumulated from zero in
+// client order with the arithmetic of the K sgd_kernel launches it replaces (t = t - (-w_k) c_k, one rounding sequence: bit-identical),
+// and every client overwritten with it -- K reads + K + 1 writes per element instead of 3 K + K reads and 1 + 2 K writes.
+constexpr int FEDAVG_MAXK = 16;
+struct FedAvgArgs {
+    float* client[FEDAVG_MAXK];
+    float negw[FEDAVG_MAXK];
+    float* server;
+    int K;
+};
+__global__ __launch_bounds__(TPB) void fedavg_kernel(const FedAvgArgs a, long long n) {
+    const long long n4 = n >> 2;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long long)gridDim.x * TPB) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < a.K; ++k) t = t - reinterpret_cast<const f32x4*>(a.client[k])[i] * a.negw[k];
+        reinterpret_cast<f32x4*>(a.server)[i] = t;
+        for (int k = 0; k < a.K; ++k) reinterpret_cast<f32x4*>(a.client[k])[i] = t;
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) {
+        float t = 0.f;
+        for (int k = 0; k < a.K; ++k) t -= a.negw[k] * a.client[k][i];
+        a.server[i] = t;
+        for (int k = 0; k < a.K; ++k) a.client[k][i] = t;
+    }
+}
 __global__ __launch_bounds__(TPB) void scale_kernel(float* __restrict__ p, float s, long long n) {
     const long long n4 = n >> 2;
     for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n4; i += (long long)gridDim.x * TPB) {
@@ -1025,6 +1050,21 @@ extern "C" int ccst_sgd_f32(float* p, const float* g, float lr, int64_t n, void*
     CCST_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0), "sgd: arenas must be 16-byte aligned");
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4 + 1)), dim3(TPB), 0, (hipStream_t)stream, p, g, lr, (long long)n);
     return ccst_launch_status("sgd");
+}
+extern "C" int ccst_fedavg_f32(float* server, float* const* clients_host, const float* weights_host, int K, int64_t n, void* stream) {
+    CCST_REQUIRE(server && clients_host && weights_host && n > 0, "fedavg: bad args");
+    CCST_REQUIRE(K >= 1 && K <= FEDAVG_MAXK, "fedavg: 1..16 clients per launch");
+    FedAvgArgs a;
+    a.server = server;
+    a.K = K;
+    CCST_REQUIRE((uintptr_t)server % 16 == 0, "fedavg: arenas must be 16-byte aligned");
+    for (int k = 0; k < K; ++k) {
+        CCST_REQUIRE(clients_host[k] != nullptr && (uintptr_t)clients_host[k] % 16 == 0 && clients_host[k] != server, "fedavg: arenas must be distinct and 16-byte aligned");
+        a.client[k] = clients_host[k];
+        a.negw[k] = -weights_host[k];
+    }
+    hipLaunchKernelGGL(fedavg_kernel, dim3(grid_for(n / 4 + 1)), dim3(TPB), 0, (hipStream_t)stream, a, (long long)n);
+    return ccst_launch_status("fedavg");
 }
 extern "C" int ccst_fill_f32(float* p, float value, int64_t n, void* stream) {
     CCST_REQUIRE(p && n > 0 && ((uintptr_t)p % 4 == 0), "fill: bad args");

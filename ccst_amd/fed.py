@@ -392,10 +392,21 @@ def communication(args, server_model, models, client_weights):
         srv, clients = arenas[0], arenas[1:]
         if any(c.n_total != srv.n_total for c in clients):
             raise ValueError("communication: client and server models differ in size")
-        srv.flat.zero_()
-        for ci in range(len(client_weights)):
-            _axpy(srv.flat, clients[ci].flat, client_weights[ci])
-        if mode == "fedbn":
+        K = len(client_weights)
+        fused = mode != "fedbn" and 1 <= K <= 16 and len({c.flat.data_ptr() for c in clients[:K]} | {srv.flat.data_ptr()}) == K + 1
+        if fused:
+            # one pass: K reads, K + 1 writes per element (ccst_fedavg_f32; the same rounding sequence as the loop below)
+            import ctypes
+            cl = (ctypes.c_void_p * K)(*[c.flat.data_ptr() for c in clients[:K]])
+            cw = (ctypes.c_float * K)(*[float(w) for w in client_weights])
+            check(_lib.load().ccst_fedavg_f32(ptr(srv.flat), cl, cw, K, srv.flat.numel(), stream_ptr()), "fedavg")
+        else:
+            nn_ops.fill_(srv.flat, 0.0)
+            for ci in range(K):
+                _axpy(srv.flat, clients[ci].flat, client_weights[ci])
+        if fused:
+            pass
+        elif mode == "fedbn":
             # fed_run.py:388-399: the server averages everything, clients keep every key whose name contains 'bn'
             shared = srv.key_ranges(lambda k: 'bn' not in k)
             for ci in range(len(client_weights)):

@@ -62,6 +62,13 @@ class Conv2d(nn.Conv2d):
             return ops.absmax(w, out=prev)
         return self._cached("wmax", build)
 
+    def packed_h(self):
+        """The pointwise kernel's pre-split half-piece pack of a 1x1 weight (scaled by the words of wabsmax())."""
+        return self._cached("pkh", lambda w, prev: ops.pack_conv_weight_split(w, self.wabsmax(), out=prev))
+
+    def packed_th(self):
+        return self._cached("pkht", lambda w, prev: ops.pack_conv_weight_split(w, self.wabsmax(), transpose=True, out=prev))
+
     def wino_ok(self, H, W):
         return self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and \
             ops.wino_train_ok(H, W, self.in_channels, self.out_channels)
@@ -98,8 +105,12 @@ class Conv2d(nn.Conv2d):
                 self.wino4_fwd()
             if "_ccst_w4t" in d:
                 self.wino4_bwd()
-            if "_ccst_wmax" in d:         # the half-piece forward scales the packed weight by these words: as current as the packs
+            if "_ccst_wmax" in d:         # the half-piece kernels scale the weight by these words: as current as the packs
                 self.wabsmax()
+            if "_ccst_pkh" in d:          # (after the words: the pre-split packs are scaled by them)
+                self.packed_h()
+            if "_ccst_pkht" in d:
+                self.packed_th()
 
     def packed_stem(self):
         def build(w, prev):

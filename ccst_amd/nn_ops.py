@@ -97,14 +97,15 @@ def _take_grad_words(t):
 
 
 def _prepack_jobs(model, convs):
-    """Device tables for the batched re-pack launches covering every packed copy the model's convs hold: the direct
-    layouts (ccst_pack_conv_weights_batch_f32) and the Winograd transforms (ccst_pack_conv_weights_wino_batch_f32).  Rebuilt
-    only if a weight or a packed buffer moved (the key is the tuple of their addresses)."""
-    slots, wslots, w4slots, mslots = [], [], [], []
+    """Device tables for the batched re-pack launches covering every packed copy the model's convs hold: the direct layouts
+    (ccst_pack_conv_weights_batch_f32), the Winograd transforms (ccst_pack_conv_weights_wino_batch_f32), the weights' |max| words
+    (ccst_absmax_batch_f32) and the pre-split half-piece packs scaled by them (ccst_pack_conv_weights_split_batch_f32).  Rebuilt only
+    if a weight or a packed buffer moved (the key is the tuple of their addresses)."""
+    slots, wslots, w4slots, mslots, hslots = [], [], [], [], []
     for m in convs:
         if m.in_channels <= 4:
             continue
-        if m.__dict__.get("_ccst_wmax") is not None:          # the weight's |max| words (pointwise convs that ran the half-piece forward)
+        if m.__dict__.get("_ccst_wmax") is not None:          # the weight's |max| words (pointwise convs that ran a half-piece kernel)
             mslots.append(m)
         for name, transpose in (("_ccst_pk", 0), ("_ccst_pkt", 1)):
             slot = m.__dict__.get(name)
@@ -118,37 +119,45 @@ def _prepack_jobs(model, convs):
             slot = m.__dict__.get(name)
             if slot is not None:
                 w4slots.append((m, name, slot[1], bwd))
+        for name, transpose in (("_ccst_pkh", 0), ("_ccst_pkht", 1)):
+            slot = m.__dict__.get(name)
+            if slot is not None:
+                hslots.append((m, name, slot[1], transpose))
     sig = tuple((m.weight.data_ptr(), pc.w.data_ptr()) for m, _n, pc, _t in slots) + \
-        tuple((m.weight.data_ptr(), pk[0].data_ptr()) for m, _n, pk, _b in wslots + w4slots) + tuple(("wmax", m.weight.data_ptr()) for m in mslots)
-    cached = model.__dict__.get("_ccst_prepack_jobs")
+        tuple((m.weight.data_ptr(), pk[0].data_ptr()) for m, _n, pk, _b in wslots + w4slots) + tuple(("wmax", m.weight.data_ptr()) for m in mslots) + \
+        tuple((m.weight.data_ptr(), t.data_ptr()) for m, _n, t, _t in hslots)
+    jobs = {"sig": sig, "table": None, "slots": slots, "wtable": None, "wslots": wslots, "w4table": None, "w4slots": w4slots, "mtable": None,
+            "mwords": None, "mslots": mslots, "htable": None, "hslots": hslots}
     if not slots and not wslots and not w4slots:
-        return (sig, None, slots, None, wslots, None, w4slots, None, None, mslots)
-    if cached is None or cached[0] != sig:
-        dev = (slots or wslots or w4slots)[0][0].weight.device
-        table = wtable = w4table = None
-        if slots:
-            rows = [[m.weight.data_ptr(), pc.w.data_ptr(), m.out_channels, m.in_channels, pc.kh * pc.kw, t, pc.k_pad, pc.n_pad]
-                    for m, _n, pc, t in slots]
-            table = torch.tensor(rows, dtype=torch.int64).to(dev)
-        if wslots:
+        return jobs
+    cached = model.__dict__.get("_ccst_prepack_jobs")
+    if cached is not None and cached["sig"] == sig:
+        return cached
+    dev = (slots or wslots or w4slots)[0][0].weight.device
+    if slots:
+        rows = [[m.weight.data_ptr(), pc.w.data_ptr(), m.out_channels, m.in_channels, pc.kh * pc.kw, t, pc.k_pad, pc.n_pad]
+                for m, _n, pc, t in slots]
+        jobs["table"] = torch.tensor(rows, dtype=torch.int64).to(dev)
+    for key, sl in (("wtable", wslots), ("w4table", w4slots)):
+        if sl:
             rows = []
-            for m, _n, (u, pad, n_out), bwd in wslots:
+            for m, _n, (u, pad, n_out), bwd in sl:
                 n_in = m.out_channels if bwd else m.in_channels
                 rows.append([m.weight.data_ptr(), u.data_ptr(), n_out, n_in, (n_in + 15) // 16 * 16, pad, bwd, 0])
-            wtable = torch.tensor(rows, dtype=torch.int64).to(dev)
-        if w4slots:
-            rows = []
-            for m, _n, (u, pad, n_out), bwd in w4slots:
-                n_in = m.out_channels if bwd else m.in_channels
-                rows.append([m.weight.data_ptr(), u.data_ptr(), n_out, n_in, (n_in + 15) // 16 * 16, pad, bwd, 0])
-            w4table = torch.tensor(rows, dtype=torch.int64).to(dev)
-        mtable = mwords = None
-        if mslots:      # one batched |max| launch over the pointwise weights, into one [n, ABSMAX_WORDS] block (zeroed per step)
-            mtable = torch.tensor([[m.weight.data_ptr(), m.weight.numel()] for m in mslots], dtype=torch.int64).to(dev)
-            mwords = torch.zeros((len(mslots), ops.ABSMAX_WORDS), device=dev, dtype=torch.int32)
-        cached = (sig, table, slots, wtable, wslots, w4table, w4slots, mtable, mwords, mslots)
-        model.__dict__["_ccst_prepack_jobs"] = cached
-    return cached
+            jobs[key] = torch.tensor(rows, dtype=torch.int64).to(dev)
+    if mslots:      # one batched |max| launch over the pointwise weights, into one [n, ABSMAX_WORDS] block (zeroed per step)
+        jobs["mtable"] = torch.tensor([[m.weight.data_ptr(), m.weight.numel()] for m in mslots], dtype=torch.int64).to(dev)
+        jobs["mwords"] = torch.zeros((len(mslots), ops.ABSMAX_WORDS), device=dev, dtype=torch.int32)
+    if hslots:      # ... and the pre-split packs, scaled by those words (every conv that holds one also holds words: packed_h() asks for them)
+        row_of = {id(m): i for i, m in enumerate(mslots)}
+        rows = []
+        for m, _n, t, transpose in hslots:
+            kdim, ndim = (m.out_channels, m.in_channels) if transpose else (m.in_channels, m.out_channels)
+            rows.append([m.weight.data_ptr(), t.data_ptr(), m.out_channels, m.in_channels, jobs["mwords"][row_of[id(m)]].data_ptr(), transpose,
+                         ops.round_up(kdim, 16), ops.round_up(ndim, 128)])
+        jobs["htable"] = torch.tensor(rows, dtype=torch.int64).to(dev)
+    model.__dict__["_ccst_prepack_jobs"] = jobs
+    return jobs
 
 
 def prepack_on_side(model):
@@ -160,21 +169,23 @@ def prepack_on_side(model):
     if not convs:
         return
     device = convs[0].weight.device
-    _sig, table, slots, wtable, wslots, w4table, w4slots, mtable, mwords, mslots = _prepack_jobs(model, convs)
-    if table is None and wtable is None and w4table is None:
+    j = _prepack_jobs(model, convs)
+    if j["table"] is None and j["wtable"] is None and j["w4table"] is None:
         return
 
     def launch():
         lib = _lib.load()
-        if table is not None:
-            check(lib.ccst_pack_conv_weights_batch_f32(ptr(table), len(slots), stream_ptr()), "pack_weights_batch")
-        if wtable is not None:
-            check(lib.ccst_pack_conv_weights_wino_batch_f32(ptr(wtable), len(wslots), stream_ptr()), "pack_weights_wino_batch")
-        if w4table is not None:
-            check(lib.ccst_pack_conv_weights_wino4w_batch_f32(ptr(w4table), len(w4slots), stream_ptr()), "pack_weights_wino4w_batch")
-        if mtable is not None:
-            check(lib.ccst_fill_f32(ptr(mwords), 0.0, mwords.numel(), stream_ptr()), "zero weight |max| words")
-            check(lib.ccst_absmax_batch_f32(ptr(mtable), len(mslots), ptr(mwords), stream_ptr()), "absmax_batch")
+        if j["table"] is not None:
+            check(lib.ccst_pack_conv_weights_batch_f32(ptr(j["table"]), len(j["slots"]), stream_ptr()), "pack_weights_batch")
+        if j["wtable"] is not None:
+            check(lib.ccst_pack_conv_weights_wino_batch_f32(ptr(j["wtable"]), len(j["wslots"]), stream_ptr()), "pack_weights_wino_batch")
+        if j["w4table"] is not None:
+            check(lib.ccst_pack_conv_weights_wino4w_batch_f32(ptr(j["w4table"]), len(j["w4slots"]), stream_ptr()), "pack_weights_wino4w_batch")
+        if j["mtable"] is not None:
+            check(lib.ccst_fill_f32(ptr(j["mwords"]), 0.0, j["mwords"].numel(), stream_ptr()), "zero weight |max| words")
+            check(lib.ccst_absmax_batch_f32(ptr(j["mtable"]), len(j["mslots"]), ptr(j["mwords"]), stream_ptr()), "absmax_batch")
+        if j["htable"] is not None:         # (after the words: the packs are scaled by them)
+            check(lib.ccst_pack_conv_weights_split_batch_f32(ptr(j["htable"]), len(j["hslots"]), stream_ptr()), "pack_weights_split_batch")
     if SIDE_STREAM:
         side = _side_stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
@@ -183,12 +194,12 @@ def prepack_on_side(model):
         _PREPACK_PENDING.add(device.index)
     else:
         launch()
-    for m, name, pk, _t in slots + wslots + w4slots:           # the packed copies now match the weights of this epoch
+    for m, name, pk, _t in j["slots"] + j["wslots"] + j["w4slots"] + j["hslots"]:       # the packed copies now match the weights of this epoch
         w = m.weight
         m.__dict__[name] = ((w._version, w.data_ptr(), ops.WEIGHTS_EPOCH), pk)
-    for i, m in enumerate(mslots):
+    for i, m in enumerate(j["mslots"]):
         w = m.weight
-        m.__dict__["_ccst_wmax"] = ((w._version, w.data_ptr(), ops.WEIGHTS_EPOCH), mwords[i])
+        m.__dict__["_ccst_wmax"] = ((w._version, w.data_ptr(), ops.WEIGHTS_EPOCH), j["mwords"][i])
 
 
 def join_prepack(device):
@@ -227,11 +238,13 @@ def _fwd_desc(N, Hs, Ws, Cx, kh, kw, stride, pad, cin_k, cout, n_pad):
     return d, ho, wo
 
 
-def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None, relu_mask=None, bn_link=None, bn_relu=None):
+def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None, relu_mask=None, bn_link=None, bn_relu=None, half=None):
     """dX of a zero-padded conv: an implicit GEMM over dY with the transposed packed weight.
     Stride 1: one launch (iy = oy + pad - ky).  Stride s: one launch per output parity class.
     accumulate_into (stride 1 only): a tensor of x's shape that already holds another gradient contribution (the
-    identity branch of a residual block); the epilogue adds to it in place (CCST_CONV_ACCUM) and it is returned."""
+    identity branch of a residual block); the epilogue adds to it in place (CCST_CONV_ACCUM) and it is returned.
+    half = (dy |max| words, weight |max| words, pre-split transposed pack): pointwise problems of the streaming kernel run on half
+    pieces (ccst_conv2d_pointwise_half_f32); everything else, and half=None, on the fp32 MFMA."""
     N, H, W, Cin = x_shape
     _, Ho, Wo, Cout = dy.shape
     kh, kw = pc_t.kh, pc_t.kw
@@ -274,7 +287,21 @@ def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None, relu_mas
         d.xsN, d.xsH, d.xsW = Ho * Wo * Cout, Wo * Cout, Cout
         d.y_off, d.ysN, d.ysH, d.ysW, d.ysC = (py * W + px) * Cin, H * W * Cin, stride * W * Cin, stride * Cin, 1
         d.flags = _lib.CONV_ACCUM if accumulate_into is not None else 0
-        if relu_mask is not None:       # masked accumulate (see MaskLink); the caller checked masked_accum_ok()
+        use_half = half is not None and bool(lib.ccst_conv2d_stream_ok(ctypes.byref(d)))
+        if use_half:
+            dmax, wmax, wsp = half
+            bx, bm, bi, bg, bb, bp = (None,) * 6
+            if relu_mask is not None:
+                assert accumulate_into is not None and stride == 1
+                if bn_link is not None:
+                    bx, bm, bi, bp = bn_link
+            elif bn_relu is not None:
+                assert accumulate_into is None and stride == 1
+                bx, bm, bi, bg, bb, bp = bn_relu
+            launch = lambda: check(lib.ccst_conv2d_pointwise_half_f32(ctypes.byref(d), ptr(dy), ptr(dmax), ptr(wsp), ptr(wmax), ptr(dx), None,
+                                                                      ptr(relu_mask), ptr(bx), ptr(bm), ptr(bi), ptr(bg), ptr(bb), ptr(bp), stream_ptr()),
+                                   "conv bwd-data (half pieces)")
+        elif relu_mask is not None:       # masked accumulate (see MaskLink); the caller checked masked_accum_ok()
             assert accumulate_into is not None and stride == 1
             bx, bm, bi, bp = bn_link if bn_link is not None else (None, None, None, None)     # (bn input, mean, invstd, partials out)
             launch = lambda: check(lib.ccst_conv2d_igemm_accum_masked_f32(ctypes.byref(d), ptr(dy), ptr(pc_t.w), ptr(dx), ptr(relu_mask),
@@ -293,7 +320,7 @@ def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None, relu_mas
             e0.record()
             launch()
             e1.record()
-            ops.TIMING.append(("bwd_data:" + ops._conv_kernel_name(Cin, False, N * Hc * Wc, pc_t.k_pad, nky * nkx), 2.0 * N * Hc * Wc * Cin * Cout * nky * nkx,
+            ops.TIMING.append(("bwd_data:" + ops._conv_kernel_name(Cin, False, N * Hc * Wc, pc_t.k_pad, nky * nkx) + ("_h" if use_half else ""), 2.0 * N * Hc * Wc * Cin * Cout * nky * nkx,
                                e0, e1, "n%d %dx%d cin%d cout%d taps%dx%d s%d" % (N, Hc, Wc, Cout, Cin, nky, nkx, stride)))
     return dx
 
@@ -409,7 +436,8 @@ class ConvFn(torch.autograd.Function):
                 # the weight's are at hand (refreshed with the packed weights after every optimiser step) -- else the fp32 MFMA
                 xmax = ops.tagged_absmax(x) if (HALF_FWD and mod.kernel_size == (1, 1)) else None
                 y, stats = ops.conv2d_nhwc(x, pc, stride=mod.stride[0], pad=mod.padding[0], want_stats=True, x_absmax=xmax,
-                                           w_absmax=mod.wabsmax() if xmax is not None else None)
+                                           w_absmax=mod.wabsmax() if xmax is not None else None,
+                                           w_split=mod.packed_h() if xmax is not None else None)
             ctx.mark_non_differentiable(stats)
             return y, stats
         if ctx.wino4:
@@ -465,8 +493,11 @@ class ConvFn(torch.autograd.Function):
                         MASK_LINK_STATS and masked_accum_ok(dy, mod.packed_t(), tuple(x.shape), stride, pad):
                     link.partials = torch.empty((lib_groups(M, Cin, dy.shape[3]), Cin, 2), device=x.device, dtype=torch.float32)
                     bn_relu = (link.bn_x, link.bn_save[0], link.bn_save[1], link.gamma, link.beta, link.partials)
+                half = None
+                if dymax is not None and mod.kernel_size == (1, 1):      # the gradient's words are at hand: half pieces where the streaming kernel runs
+                    half = (dymax, mod.wabsmax(), mod.packed_th())
                 dx = conv_bwd_data(dy, mod.packed_t(), tuple(x.shape), stride, pad, accumulate_into=into, relu_mask=mask, bn_link=bn_link,
-                                   bn_relu=bn_relu)
+                                   bn_relu=bn_relu, half=half)
                 if mask is not None or bn_relu is not None:
                     link.premasked = True
             if deposit:

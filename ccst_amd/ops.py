@@ -190,15 +190,17 @@ def _conv_kernel_name(cout, pool, M, cin, taps=1):
     return "conv_igemm_kernel<%s,%s,%s%s%s>" % (t[0], t[1], t[2], small, ",pool" if pool else "")
 
 
-def _launch_conv(d, x, pc, out, flops, pool, what, stats=None, x_absmax=None, w_absmax=None):
+def _launch_conv(d, x, pc, out, flops, pool, what, stats=None, x_absmax=None, w_absmax=None, w_split=None):
     lib = _lib.load()
+    half = x_absmax is not None and w_absmax is not None and w_split is not None and pc.bias is None and \
+        bool(lib.ccst_conv2d_stream_ok(ctypes.byref(d)))
 
     def call():
-        if stats is None:
+        if half:        # (pointwise problems: half pieces on the 16-bit MFMA, x scaled by its words, the weight pre-split)
+            check(lib.ccst_conv2d_pointwise_half_f32(ctypes.byref(d), ptr(x), ptr(x_absmax), ptr(w_split), ptr(w_absmax), ptr(out), ptr(stats),
+                                                     None, None, None, None, None, None, None, stream_ptr()), what)
+        elif stats is None:
             check(lib.ccst_conv2d_igemm_f32(ctypes.byref(d), ptr(x), ptr(pc.w), ptr(pc.bias), ptr(out), stream_ptr()), what)
-        elif x_absmax is not None and w_absmax is not None:      # (pointwise problems: half pieces on the 16-bit MFMA, scaled by the words)
-            check(lib.ccst_conv2d_igemm_stats_scaled_f32(ctypes.byref(d), ptr(x), ptr(x_absmax), ptr(pc.w), ptr(w_absmax), ptr(pc.bias),
-                                                         ptr(out), ptr(stats), stream_ptr()), what)
         else:
             check(lib.ccst_conv2d_igemm_stats_f32(ctypes.byref(d), ptr(x), ptr(pc.w), ptr(pc.bias), ptr(out), ptr(stats),
                                                   stream_ptr()), what)
@@ -209,7 +211,7 @@ def _launch_conv(d, x, pc, out, flops, pool, what, stats=None, x_absmax=None, w_
     e0.record()
     call()
     e1.record()
-    TIMING.append((_conv_kernel_name(pc.cout, pool, d.n * d.ho * d.wo, d.cin, d.nky * d.nkx), flops, e0, e1,
+    TIMING.append((_conv_kernel_name(pc.cout, pool, d.n * d.ho * d.wo, d.cin, d.nky * d.nkx) + ("_h" if half else ""), flops, e0, e1,
                    "n%d %dx%d cin%d cout%d taps%dx%d flags%d" % (d.n, d.ho, d.wo, d.cin, d.cout, d.nky, d.nkx, d.flags)))
 
 
@@ -281,8 +283,7 @@ class _PackOrder(object):
 class PackedConv(object):
     """A conv weight in the layouts the kernels read (+ optional bias).  `w`: [kh*kw][K/4][n_pad][4] for the implicit-GEMM kernels.
     A weight packed with wino=... (the 3x3 layers of the AdaIN plan) keeps the OIHW source and builds each kernel's layout ON FIRST USE
-    -- `u` (F(2x2)), `u4` / `u4n` (F(4x4), 64- / 32-channel workgroups), `wsplit` (direct kernel on half pieces), `uf23` (F(2,3) on half
-    pieces), `wabsmax` (the weight's |max| words: the half-piece kernels derive their power-of-two weight scale from them on the
+    -- `u4` (F(4x4), 64-channel workgroups), `wsplit` (direct kernel on half pieces), `uf23` (F(2,3) on half pieces), `wabsmax` (the weight's |max| words: the half-piece kernels derive their power-of-two weight scale from them on the
     device) -- so a plan holds ONE packed copy per layer, that of the kernel it runs (all four were built before).
     The can_* predicates say which layouts exist for this weight without building anything."""
 
@@ -290,22 +291,19 @@ class PackedConv(object):
         self._w, self.bias, self.cin, self.cout, self.kh, self.kw = w, bias, cin, cout, kh, kw
         self.k_pad, self.n_pad, self.transpose = k_pad, n_pad, transpose
         self.src, self.wino = src, wino          # OIHW source (kept only for lazily packed weights) and the wino= argument
-        self.u_pad, self.u4_pad = round_up(cout, 32), round_up(cout, 64)
-        self._u = self._u4 = self._u4n = self._wsplit = self._wabsmax = self._uf23 = None
+        self.u4_pad = round_up(cout, 64)
+        self._u4 = self._wsplit = self._wabsmax = self._uf23 = None
         self._order = _PackOrder()
 
     # ---- which layouts exist (no packing) ----
-    def can_wino2(self):
+    def lazy3x3(self):             # a 3x3 forward weight packed with wino=...: its kernel's layout is built on first use
         return self.src is not None and bool(self.wino) and self.kh == 3 and self.kw == 3 and not self.transpose
 
     def can_wino4(self):
-        return self.can_wino2() and (self.wino in (4, "4n") or (WINO_F4 and self.cin >= WINO_F4_MIN_CIN))
+        return self.lazy3x3() and (self.wino == 4 or (WINO_F4 and self.cin >= WINO_F4_MIN_CIN))
 
     def can_wino4w(self):          # the 64-channel kernel peels a first and a last 16-channel chunk
         return self.can_wino4() and self.cin >= 32
-
-    def can_wino4n(self):
-        return self.can_wino4() and (WINO_F4_NARROW or self.wino == "4n" or self.cin < 32)
 
     def can_split(self):
         return self.can_wino4() and HALO_SPLIT != "0" and self.cin % 16 == 0
@@ -334,22 +332,10 @@ class PackedConv(object):
         return self._w
 
     @property
-    def u(self):
-        lib = _lib.load()
-        return self._lazy("_u", lib.ccst_wino_weight_floats(self.cin, self.u_pad), lib.ccst_pack_conv_weight_wino_f32, "pack_conv_weight_wino",
-                          self.u_pad) if self.can_wino2() else None
-
-    @property
     def u4(self):
         lib = _lib.load()
         return self._lazy("_u4", lib.ccst_wino4_weight_floats(self.cin, self.u4_pad), lib.ccst_pack_conv_weight_wino4w_f32,
                           "pack_conv_weight_wino4w", self.u4_pad) if self.can_wino4w() else None
-
-    @property
-    def u4n(self):
-        lib = _lib.load()
-        return self._lazy("_u4n", lib.ccst_wino4_weight_floats(self.cin, self.u4_pad), lib.ccst_pack_conv_weight_wino4_f32,
-                          "pack_conv_weight_wino4", self.u4_pad) if self.can_wino4n() else None
 
     @property
     def wabsmax(self):
@@ -371,16 +357,14 @@ class PackedConv(object):
                           self.n_pad, ptr(self.wabsmax)) if self.can_split() else None
 
 
-# Fused Winograd for the 3x3 stride-1 layers of the AdaIN encoder / decoder.  CCST_CONV_WINO = 4 (default): F(4x4,3x3)
-# (conv3x3_wino4.hip, 2.25 multiplies per output); 2 (or 1): F(2x2,3x3) (conv3x3_wino.hip, 4 per output: 549 -> 880 images/s over
-# the direct form); 0: the direct halo kernel (9 per output).
+# The 3x3 stride-1 layers of the AdaIN encoder / decoder keep their OIHW weight and pack the layout of the kernel they run on first
+# use (PackedConv).  CCST_CONV_WINO = 4 (default): the half-piece kernels (CCST_HALO_SPLIT / CCST_CONV_F23 below), or with
+# CCST_HALO_SPLIT=0 the fp32-MFMA F(4x4,3x3) kernel (conv3x3_wino4w.hip, 2.25 multiplies per output); 0: the direct fp32-MFMA halo
+# kernel everywhere (9 per output).  (The F(2x2) AdaIN form and the 32-channel F(4x4) kernel of rounds 1-2 were retired in round 5.)
 _WINO_MODE = os.environ.get("CCST_CONV_WINO", "4")
 USE_WINO = _WINO_MODE != "0"
 WINO_F4 = _WINO_MODE == "4"
-WINO_F4_MIN_CIN = int(os.environ.get("CCST_WINO4_MIN_CIN", "16"))
-# the F(4x4) kernel runs 64 output channels per workgroup (conv3x3_wino4w.hip); CCST_WINO4_NARROW=1 keeps the 32-channel workgroups
-# of conv3x3_wino4.hip (A/B runs).  The two kernels read differently ordered transformed weights.
-WINO_F4_NARROW = os.environ.get("CCST_WINO4_NARROW", "0") == "1"
+WINO_F4_MIN_CIN = 16
 # The direct 3x3 kernel with every fp32 product as three products of IEEE-half pieces on the 16-bit MFMA (conv3x3_halo.hip SPLIT form:
 # x = hi + lo, 22 significant bits, fp32 accumulation; 5.3x the fp32 MFMA's rate at about its accuracy -- 1e-6 of max |y| per layer, 5x
 # tighter than F(4x4) Winograd in fp32) runs every 3x3 layer of the AdaIN plan by default (CCST_HALO_SPLIT=2).  Measured per layer at B=6
@@ -550,7 +534,7 @@ def wino4_ok(cin, cout, H, W):
 
 
 def pack_conv_weight(w_oihw, bias=None, transpose=False, out=None, wino=False):
-    """OIHW checkpoint tensor -> PackedConv.  transpose=True builds the backward-data operand.  wino (True, 4 or "4n"; 3x3 weights):
+    """OIHW checkpoint tensor -> PackedConv.  transpose=True builds the backward-data operand.  wino (True or 4; 3x3 weights):
     nothing is packed here -- the PackedConv keeps the source and builds the layout of whichever kernel ends up running the layer
     (the implicit-GEMM one, F(2x2), F(4x4), the half-piece direct kernel, F(2,3) on half pieces) on first use."""
     _require_cuda(w_oihw, "weight")
@@ -571,28 +555,41 @@ def pack_conv_weight(w_oihw, bias=None, transpose=False, out=None, wino=False):
     return PackedConv(out, b, cin, cout, kh, kw, k_pad, n_pad, transpose)
 
 
-def conv3x3_wino4(x, pc, flags=0, narrow=None, sums=False):
-    """3x3 stride-1 pad-1 conv on the F(4x4,3x3) kernels; x NHWC [N,Hs,Ws,Cin], pc packed with wino=4.  flags: CONV_* bits.
-    narrow: the 32-output-channel workgroups of conv3x3_wino4.hip (pc packed with wino="4n") instead of the 64-channel ones.
-    sums=True (64-channel kernel, no pool): also returns the per-tile (sum, sum of squares) partials [tiles, Cout, 2] of the
-    output from the conv epilogue -- fold them with chan_sums_finalize()."""
+def pack_conv_weight_split(w_oihw, w_absmax, transpose=False, out=None):
+    """A 1x1 OIHW weight in the pointwise kernel's packed layout, PRE-SPLIT into half pieces scaled by the power of two of its |max|
+    words (ccst_pack_conv_weight_split_f32): the `w_split` of conv2d_nhwc / nn_ops.conv_bwd_data (transpose=True)."""
+    _require_cuda(w_oihw, "weight")
+    w = w_oihw.contiguous()
+    cout, cin, kh, kw = w.shape
+    assert kh == 1 and kw == 1, "pre-split packs are for pointwise convs"
+    kdim, ndim = (cout, cin) if transpose else (cin, cout)
+    k_pad, n_pad = round_up(kdim, 16), round_up(ndim, 128)
+    if out is None or out.numel() != k_pad * n_pad:
+        out = torch.empty(k_pad * n_pad, device=w.device, dtype=torch.float32)
+    check(_lib.load().ccst_pack_conv_weight_split_f32(ptr(w), ptr(w_absmax), ptr(out), cout, cin, int(transpose), k_pad, n_pad, stream_ptr()),
+          "pack_conv_weight_split")
+    return out
+
+
+def conv3x3_wino4(x, pc, flags=0, sums=False):
+    """3x3 stride-1 pad-1 conv on the F(4x4,3x3) kernel (64 output channels per workgroup); x NHWC [N,Hs,Ws,Cin], pc packed with
+    wino=4, Cin >= 32.  flags: CONV_* bits.  sums=True (no pool): also returns the per-tile (sum, sum of squares) partials
+    [tiles, Cout, 2] of the output from the conv epilogue -- fold them with chan_sums_finalize()."""
     N, Hs, Ws, Cx = x.shape
     ups, pool = bool(flags & CONV_UPS2), bool(flags & CONV_POOL2)
     Hi, Wi = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
     oh, ow = ((Hi + 1) // 2, (Wi + 1) // 2) if pool else (Hi, Wi)
     out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
-    narrow = (not pc.can_wino4w() or (WINO_F4_NARROW and pc.can_wino4n())) if narrow is None else (narrow or not pc.can_wino4w())
+    if not pc.can_wino4w():
+        raise ValueError("ccst_amd.ops: the F(4x4) kernel needs a 3x3 weight packed with wino=4 and Cin >= 32")
     lib = _lib.load()
     part = None
     if sums:
-        if narrow or pool:
-            raise ValueError("ccst_amd.ops: the statistics epilogue belongs to the 64-channel F(4x4) kernel without pooling")
+        if pool:
+            raise ValueError("ccst_amd.ops: the statistics epilogue is that of the un-pooled output")
         part = torch.empty((int(lib.ccst_wino4w_spatial_tiles(N, Hi, Wi)), pc.cout, 2), device=x.device, dtype=torch.float32)
-    if narrow:
-        fn, args = lib.ccst_conv3x3_wino4_f32, (ptr(x), ptr(pc.u4n), ptr(pc.bias), ptr(out), N, Hi, Wi, Cx, pc.cout, pc.u4_pad, flags, stream_ptr())
-    else:
-        fn, args = lib.ccst_conv3x3_wino4w_f32, (ptr(x), ptr(pc.u4), ptr(pc.bias), ptr(out), N, Hi, Wi, Cx, pc.cout, pc.u4_pad, flags, ptr(part),
-                                                 stream_ptr())
+    fn, args = lib.ccst_conv3x3_wino4w_f32, (ptr(x), ptr(pc.u4), ptr(pc.bias), ptr(out), N, Hi, Wi, Cx, pc.cout, pc.u4_pad, flags, ptr(part),
+                                             stream_ptr())
     if TIMING is None:
         check(fn(*args), "conv3x3_wino4")
     else:
@@ -600,7 +597,7 @@ def conv3x3_wino4(x, pc, flags=0, narrow=None, sums=False):
         e0.record()
         check(fn(*args), "conv3x3_wino4")
         e1.record()
-        TIMING.append(("conv3x3_wino4%s_kernel<%s>" % ("" if narrow else "w", "pool" if pool else "nopool"), 2.0 * N * Hi * Wi * pc.cout * pc.cin * 9, e0, e1,
+        TIMING.append(("conv3x3_wino4w_kernel<%s>" % ("pool" if pool else "nopool"), 2.0 * N * Hi * Wi * pc.cout * pc.cin * 9, e0, e1,
                        "n%d %dx%d cin%d cout%d taps3x3 flags%d" % (N, Hi, Wi, pc.cin, pc.cout, flags)))
     return (out, part) if sums else out
 
@@ -626,11 +623,11 @@ def wino4w_sums_ok(pc, stride, pad, pool, out_nchw):
     SPLIT form, un-pooled)?"""
     if stride != 1 or pad != 1 or pool or out_nchw or pc.kh != 3 or pc.kw != 3:
         return False
-    return halo_split_wanted(pc) or (pc.can_wino4w() and not WINO_F4_NARROW and wino4_ok(pc.cin, pc.cout, 0, 0))
+    return halo_split_wanted(pc) or (pc.can_wino4w() and wino4_ok(pc.cin, pc.cout, 0, 0))
 
 
 def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, ups=False, out_nchw=False, out=None,
-                want_stats=False, chan_sums=False, x_absmax=None, y_absmax=None, w_absmax=None):
+                want_stats=False, chan_sums=False, x_absmax=None, y_absmax=None, w_absmax=None, w_split=None):
     """Forward convolution of an NHWC tensor x [N,Hs,Ws,Cin_pad] with PackedConv pc.
 
     ups:  x is read through a nearest x2 upsample (logical input is [2Hs,2Ws]).
@@ -640,8 +637,8 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
                 conv epilogue for the following BatchNorm2d (returns (out, stats)).
     x_absmax / y_absmax: |max| words of x (from its producer) / zeroed words for max |out| -- used by the half-piece (SPLIT) kernel only;
                 a caller that passes y_absmax must check halo_split_wanted(pc) (other kernels leave the words untouched).
-    w_absmax (with want_stats and x_absmax): the |max| words of the OIHW weight -- a pointwise problem then runs on half pieces
-                (ccst_conv2d_igemm_stats_scaled_f32); without both word sets the fp32 MFMA runs.
+    w_absmax + w_split (with x_absmax): the |max| words of the OIHW weight and its pre-split pack (pack_conv_weight_split) -- a
+                pointwise problem then runs on half pieces (ccst_conv2d_pointwise_half_f32); without them the fp32 MFMA runs.
     """
     _require_cuda(x, "activation")
     assert x.is_contiguous() and x.dim() == 4 and not pc.transpose
@@ -676,23 +673,9 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
         if f23_wanted(pc, N, Hi, Wi, x.device):
             return conv3x3_f23(x, pc, flags, x_absmax=x_absmax, y_absmax=y_absmax)
         return conv3x3_halo_split(x, pc, flags, x_absmax=x_absmax, y_absmax=y_absmax)
-    if (pc.can_wino4w() or pc.can_wino4n()) and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats \
+    if pc.can_wino4w() and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats \
             and wino4_ok(pc.cin, pc.cout, Hi, Wi):
         return conv3x3_wino4(x, pc, flags)
-    if USE_WINO and pc.can_wino2() and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats:
-        out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
-        lib = _lib.load()
-        args = (ptr(x), ptr(pc.u), ptr(pc.bias), ptr(out), N, Hi, Wi, Cx, pc.cout, pc.u_pad, flags, stream_ptr())
-        if TIMING is None:
-            check(lib.ccst_conv3x3_wino_f32(*args), "conv3x3_wino")
-        else:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            check(lib.ccst_conv3x3_wino_f32(*args), "conv3x3_wino")
-            e1.record()
-            TIMING.append(("conv3x3_wino_kernel<%s>" % ("pool" if pool else "nopool"), 2.0 * N * ho * wo * pc.cout * pc.cin * 9, e0, e1,
-                           "n%d %dx%d cin%d cout%d taps3x3 flags%d" % (N, ho, wo, pc.cin, pc.cout, flags)))
-        return out
     if USE_HALO and reflect and pc.kh == 3 and pc.kw == 3 and stride == 1 and pad == 1 and not out_nchw \
             and out is None and not want_stats:
         out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
@@ -725,7 +708,7 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
         groups = _lib.load().ccst_conv2d_igemm_stats_groups(N * ho * wo, pc.cout, pc.k_pad, pc.kh * pc.kw)
         stats = torch.empty((groups, pc.cout, 2), device=x.device, dtype=torch.float32)
     _launch_conv(d, x, pc, out, 2.0 * N * ho * wo * pc.cout * pc.cin * pc.kh * pc.kw, pool, "conv2d_igemm", stats,
-                 x_absmax if want_stats else None, w_absmax if want_stats else None)
+                 x_absmax, w_absmax, w_split)
     return (out, stats) if want_stats else out
 
 

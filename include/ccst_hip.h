@@ -85,12 +85,26 @@ int ccst_conv2d_igemm_f32(const CcstConvDesc* d, const float* x, const float* w_
 int ccst_conv2d_igemm_stats_f32(const CcstConvDesc* d, const float* x, const float* w_packed,
                                 const float* bias, float* y, float* stats, void* stream);
 int ccst_conv2d_igemm_stats_groups(int M, int cout, int cin /* padded, d->cin */, int taps /* nky*nkx */);
-/* The same call with the |max| words (CCST_ABSMAX_WORDS, below) of x and of the OIHW weight: where the problem runs on the streaming
- * pointwise kernel its products are formed from two IEEE-half pieces per operand on the 16-bit MFMA (22 significant bits; 1.43x the
- * fp32 MFMA on the ResNet50 pointwise shapes), both operands scaled by powers of two derived from the words on the device -- safe at
- * any fp32 magnitude; ccst_conv2d_igemm_stats_f32 (no words) runs the fp32 MFMA.  The training forward of nets/resnet.py's 1x1 convs. */
-int ccst_conv2d_igemm_stats_scaled_f32(const CcstConvDesc* d, const float* x, const uint32_t* x_absmax, const float* w_packed,
-                                       const uint32_t* w_absmax, const float* bias, float* y, float* stats, void* stream);
+/* The streaming pointwise kernel on half pieces (round 5: every form, forward and backward-data): 1x1 convs of nets/resnet.py between
+ * dense NHWC tensors (or a strided 1x1 read: the downsample branches) with every fp32 product formed from two IEEE-half pieces per
+ * operand on the 16-bit MFMA (22 significant bits, fp32 accumulation).  x is scaled by the power of two of its |max| words (x_absmax:
+ * CCST_ABSMAX_WORDS, below -- activations: left by the BatchNorm apply that produced them; gradients: by the BatchNorm backward's
+ * dx_absmax) as it is split on its way into LDS; the weight arrives PRE-SPLIT and scaled from ccst_pack_conv_weight_split_f32 (same
+ * [K/4][n_pad] units as ccst_pack_conv_weight_f32's 1x1 layout, each 16-byte unit = four hi halves | four lo halves; transpose = 1
+ * for backward-data), packed with the SAME w_absmax words the call passes.  Safe at any finite fp32 magnitude, no host
+ * synchronisation.  The form follows from the arguments exactly as in the fp32 entries: stats != NULL (training forward, BatchNorm
+ * statistics epilogue: ccst_conv2d_igemm_stats_f32), CCST_CONV_ACCUM in d->flags with relu_mask and optionally the BatchNorm link
+ * (ccst_conv2d_igemm_accum_masked_f32), the BatchNorm + ReLU link with bn_gamma / bn_beta (ccst_conv2d_igemm_bn_relu_bwd_f32), or
+ * none of them (plain / y += conv).  Needs ccst_conv2d_stream_ok(d) -- and ccst_conv2d_pointwise_ok(d) for the masked / linked forms. */
+int ccst_conv2d_stream_ok(const CcstConvDesc* d);
+int ccst_conv2d_pointwise_half_f32(const CcstConvDesc* d, const float* x, const uint32_t* x_absmax, const float* w_split,
+                                   const uint32_t* w_absmax, float* y, float* stats, const uint8_t* relu_mask, const float* bn_x,
+                                   const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                                   float* bn_partials, void* stream);
+int ccst_pack_conv_weight_split_f32(const float* w_oihw, const uint32_t* w_absmax, float* packed, int cout, int cin, int transpose,
+                                    int k_pad, int n_pad, void* stream);
+/* ... of n weights in one launch: jobs [n][8] int64 on the device = (w_oihw, packed, cout, cin, w_absmax, transpose, k_pad, n_pad). */
+int ccst_pack_conv_weights_split_batch_f32(const int64_t* jobs_device, int njobs, void* stream);
 
 /* 3x3 stride-1 "same" conv (reflection or zero padding) with the input halo staged once per 16-channel
  * chunk in LDS (A-side loads / LDS writes 9x fewer than the gather form): the AdaIN encoder/decoder
@@ -149,22 +163,15 @@ int ccst_conv3x3_f23_tiles(int N, int H, int W);
  * ccst_chan_sums_finalize_f32 (partial_floats = 4) take instead of a pass over the tensor.  ccst_conv3x3_f23_f32 writes the same
  * quadruples; ccst_conv3x3_wino4w_f32 writes (sum, sum of squares) pairs (partial_floats = 2). */
 int ccst_conv3x3_halo_split_tiles(int N, int H, int W);
-/* The same convolution as fused Winograd F(2x2,3x3) (16 multiplies per 2x2 output tile and input channel instead of
- * 36): transformed weights from ccst_pack_conv_weight_wino_f32 (ccst_wino_weight_floats(cin, cout_pad) floats,
- * cout_pad a multiple of 32), same x / y / flags contract as ccst_conv3x3_halo_f32.  fp32 throughout; differs from the
- * direct form by Winograd's rounding (~1e-6 relative). */
+/* Fused Winograd F(2x2,3x3) (16 multiplies per 2x2 output tile and input channel instead of 36) for the ResNet trunk's 3x3 stride-1
+ * layers (ccst_conv3x3_wino_train_f32 below): transformed weights from ccst_pack_conv_weight_wino_f32 (ccst_wino_weight_floats(cin,
+ * cout_pad) floats, cout_pad a multiple of 32).  fp32 throughout; differs from the direct form by Winograd's rounding (~1e-6
+ * relative).  (Its AdaIN entry -- bias / ReLU / pool / upsample flags -- was retired in round 5: no default path selected it.) */
 int64_t ccst_wino_weight_floats(int cin, int cout_pad);
 int ccst_pack_conv_weight_wino_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, void* stream);
-int ccst_conv3x3_wino_f32(const float* x, const float* u_packed, const float* bias, float* y, int N, int H, int W,
-                          int Cin, int Cout, int cout_pad, uint32_t flags, void* stream);
 
-/* Fused Winograd F(4x4,3x3): same contract as ccst_conv3x3_wino_f32 (3x3 stride-1 "same" conv of net.py:6-36,38-69: reflection or
- * zero padding, fused bias / ReLU / nearest-x2 upsample on read / 2x2 ceil max-pool), 2.25 multiplies per output instead of 4.
- * u_packed from ccst_pack_conv_weight_wino4_f32 ([Cin/16][36][2][cout_pad][8] floats = ccst_wino4_weight_floats). */
+/* Floats of a Winograd F(4x4,3x3) transformed weight ([Cin/16][36][2][cout_pad][8]) for ccst_pack_conv_weight_wino4w_f32. */
 int64_t ccst_wino4_weight_floats(int cin, int cout_pad);
-int ccst_pack_conv_weight_wino4_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, void* stream);
-int ccst_conv3x3_wino4_f32(const float* x, const float* u_packed, const float* bias, float* y, int N, int H, int W, int Cin,
-                           int Cout, int cout_pad, uint32_t flags, void* stream);
 /* The AdaIN encoder's first layer (net.py:39-42: the 1x1 colour conv folded into ReflectionPad2d(1) + Conv2d(3,64,3x3) + ReLU) from the
  * contiguous NCHW image [N,3,H,W] to the NHWC map [N,H,W,64]; wa = ccst_pack_stem3_weight_f32(w [64,3,3,3], bias [64] or null)
  * (18*2*64 floats: a header with the weights' power-of-two scale, the half-piece fragments of the 16-bit MFMA's A operand and the bias;
@@ -172,7 +179,9 @@ int ccst_conv3x3_wino4_f32(const float* x, const float* u_packed, const float* b
 int ccst_pack_stem3_weight_f32(const float* w_oihw, const float* bias, float* wa, int cout, void* stream);
 int ccst_conv3x3_stem3_f32(const float* x_nchw, const float* wa, float* y_nhwc, int N, int H, int W, int relu,
                            uint32_t* y_absmax /* NULL or zeroed |max| words of y, see CCST_ABSMAX_WORDS */, void* stream);
-/* F(4x4,3x3) with 64 output channels per workgroup (conv3x3_wino4w.hip): the same convolution and flags as ccst_conv3x3_wino4_f32;
+/* Fused Winograd F(4x4,3x3) with 64 output channels per workgroup (conv3x3_wino4w.hip): the 3x3 stride-1 "same" conv of net.py:6-36,38-69
+ * (reflection or zero padding, fused bias / ReLU / nearest-x2 upsample on read / 2x2 ceil max-pool; flags as ccst_conv3x3_halo_f32), 2.25
+ * multiplies per output;
  * every transformed input value feeds two MFMAs and the halo is fetched once per 64 output channels.  cout_pad a multiple of 64, Cin >= 32;
  * u_packed from ccst_pack_conv_weight_wino4w_f32 ([Cin/16][36][4 channel pairs][2][cout_pad/64][32][2][2] floats: a lane's weights
  * of one position and channel pair for both 32-channel groups are one 16-byte load, a wave's load 2 x 512 contiguous bytes;
@@ -452,6 +461,10 @@ int ccst_softmax_ce_f32(const float* logits, const int64_t* labels, float* loss,
 /* SGD p -= lr*g over a flat arena (fed_run.py:657,80), and the FedAvg pre-scale p *= s. */
 int ccst_sgd_f32(float* p, const float* g, float lr, int64_t n, void* stream);
 int ccst_scale_f32(float* p, float s, int64_t n, void* stream);
+/* communication()'s fedavg branch (fed_run.py:400-414) over K <= 16 flat fp32 arenas of n floats on ONE GPU, in one pass: server[i] =
+ * sum_k weights[k] * clients[k][i] (accumulated from zero in client order, the arithmetic of K ccst_sgd_f32 calls: bit-identical) and
+ * every client overwritten with the result.  clients_host / weights_host: HOST arrays of K device pointers / K floats. */
+int ccst_fedavg_f32(float* server, float* const* clients_host, const float* weights_host, int K, int64_t n, void* stream);
 /* Glue the reference gets from ATen, as HIP launches so that no framework kernel runs inside a train step:
  * optimizer.zero_grad() (fed_run.py:58) as one fill of the flat gradient arena; BatchNorm2d's num_batches_tracked += 1
  * over the re-homed int64 counters; the chain-rule scale of CrossEntropyLoss's saved dlogits by the incoming gradient

@@ -98,7 +98,7 @@ def test_pointwise_conv_statistics(dev, cfg):
 @pytest.mark.parametrize("xscale,wscale", [(1.0, 1.0), (1e-6, 1.0), (3e4, 1.0), (1e5, 1000.0), (1e20, 1e-10), (1.0, 1e4)])
 def test_pointwise_conv_half_pieces_any_magnitude(dev, xscale, wscale):
     """the pointwise training forward multiplies IEEE-half pieces; with round 3's fixed 2^8 weight scale and unscaled
-    activations |w| >= 256 or |x| >= 65504 became inf / NaN.  ccst_conv2d_igemm_stats_scaled_f32 scales both operands by powers of two
+    activations |w| >= 256 or |x| >= 65504 became inf / NaN.  ccst_conv2d_pointwise_half_f32 scales both operands by powers of two
     derived on the device from their |max| words: the result must be at the fp32 level at any magnitude (incl. weights of 1e4 and
     activations of 1e5), and the BatchNorm statistics of its epilogue must be those of its output."""
     from ccst_amd import ops
@@ -108,7 +108,8 @@ def test_pointwise_conv_half_pieces_any_magnitude(dev, xscale, wscale):
     w = (torch.randn(Cout, Cin, 1, 1, generator=g) * (1.0 / Cin) ** 0.5 * wscale).to(dev)
     pc = ops.pack_conv_weight(w)
     ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu()).permute(0, 2, 3, 1)
-    y, st = ops.conv2d_nhwc(x, pc, want_stats=True, x_absmax=ops.absmax(x), w_absmax=ops.absmax(w))
+    wmax = ops.absmax(w)
+    y, st = ops.conv2d_nhwc(x, pc, want_stats=True, x_absmax=ops.absmax(x), w_absmax=wmax, w_split=ops.pack_conv_weight_split(w, wmax))
     y32, _ = ops.conv2d_nhwc(x, pc, want_stats=True)                       # (no words: the fp32 MFMA)
     assert bool(torch.isfinite(y).all())
     scale = float(ref.abs().max())
@@ -958,37 +959,118 @@ def test_wino4w_train_form_vs_gather(dev, shape):
     assert torch.equal(uf, pf[0]) and torch.equal(ub, pb[0])
 
 
-@pytest.mark.parametrize("pieces,tol", [(2, 3e-5), (3, 4e-6), (4, 4e-6), (0, 4e-6)])
-def test_pointwise_conv_on_the_bf16_mfma(dev, pieces, tol):
-    """CCST_CONV_BF: the streaming pointwise kernel's training forward with every fp32 product as three products of IEEE-half pieces
-    (4, the default), as three / six products of bf16 pieces (2 / 3, experiments) or on the fp32 MFMA (0): against an fp64
-    convolution, in a child process (the mode is read once per process).  bf16 x 2 carries 16 significant bits (error ~5e-6 of max
-    |y|); half x 2 (22 bits) and bf16 x 3 (24) are at the fp32 MFMA's own accuracy."""
-    import os
-    import subprocess
-    import sys
-    code = r'''
-import torch
-from ccst_amd import ops
-dev = torch.device("cuda:0")
-g = torch.Generator().manual_seed(5)
-worst = 0.0
-for (N, H, cin, cout, stride) in ((8, 56, 64, 128, 2), (8, 56, 64, 256, 1), (8, 14, 256, 512, 2), (4, 28, 128, 512, 1), (3, 7, 2048, 512, 1)):
-    x = torch.randn(N, H, H, cin, generator=g).to(dev)
-    w = (torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5).to(dev)
-    y, st = ops.conv2d_nhwc(x, ops.pack_conv_weight(w, None), stride=stride, pad=0, want_stats=True)
-    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), stride=stride).permute(0, 2, 3, 1)
-    worst = max(worst, float((y - ref).abs().max() / ref.abs().max()))
-    s_ref = torch.stack([ref.sum(dim=(0, 1, 2)), (ref * ref).sum(dim=(0, 1, 2))], dim=1)
-    worst = max(worst, float((st.double().sum(0) - s_ref).abs().max() / s_ref.abs().max()))
-print("WORST %.3e" % worst)
-'''
-    env = dict(os.environ, CCST_CONV_BF=str(pieces))
-    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
-                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert out.returncode == 0, out.stderr[-2000:]
-    worst = float(out.stdout.strip().split("WORST")[-1])
-    assert worst < tol, worst
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Cin, Cout, k, stride          (tiles: 128x128, 64x128, 128x64, 64x64; ragged M, Cin / Cout that do not fill a tile)
+    (3, 14, 14, 256, 128, 3, 1), (2, 28, 28, 64, 256, 1, 1), (2, 28, 28, 256, 64, 1, 1), (2, 30, 26, 64, 64, 3, 1),
+    (2, 29, 27, 128, 128, 3, 2), (5, 7, 7, 512, 192, 1, 1), (1, 9, 11, 96, 160, 3, 1), (2, 28, 28, 128, 256, 1, 2),
+])
+@pytest.mark.parametrize("gscale", [1.0, 1e-8, 1e6])
+def test_conv_bwd_weight_half_pieces_vs_fp64(dev, cfg, gscale):
+    """ccst_conv2d_bwd_weight_split_f32 (three half-piece products per fp32 product on the 16-bit MFMA, operands scaled by their |max|
+    words) against an fp64 weight gradient: every tile shape, the gathered (3x3, strided) and the pointwise loader, zero padding
+    through the buffer bounds, pixel counts and channel counts that leave tiles partly empty, gradients from 1e-8 to 1e6; and the
+    fp32-MFMA kernel on the same operands for scale.  Bitwise reproducible."""
+    import ctypes
+    from ccst_amd import _lib, nn_ops, ops
+    from ccst_amd._lib import check, ptr, stream_ptr
+    N, H, W, Cin, Cout, k, stride = cfg
+    pad = k // 2
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(N, H, W, Cin, generator=g).to(dev)
+    d, ho, wo = nn_ops._fwd_desc(N, H, W, Cin, k, k, stride, pad, Cin, Cout, 0)
+    dy = (torch.randn(N, ho, wo, Cout, generator=g) * gscale).to(dev)
+    xp = torch.zeros(N, H + 2 * pad, W + 2 * pad, Cin, device=dev, dtype=torch.float64)
+    xp[:, pad:pad + H, pad:pad + W] = x.double()
+    d2 = dy.double().reshape(-1, Cout)
+    ref = torch.empty(Cout, Cin, k, k, device=dev, dtype=torch.float64)
+    for ky in range(k):
+        for kx in range(k):
+            xs = xp[:, ky:ky + (ho - 1) * stride + 1:stride, kx:kx + (wo - 1) * stride + 1:stride].reshape(-1, Cin)
+            ref[:, :, ky, kx] = d2.t() @ xs
+    lib = _lib.load()
+    M = N * ho * wo
+    out = []
+    for rep in range(2):
+        dw = torch.full((Cout, Cin, k, k), 7.0, device=dev)
+        splits = lib.ccst_conv2d_bwd_weight_split_splits(M, Cin, Cout, k * k)
+        ws = torch.empty(splits * k * k * Cin * Cout, device=dev)
+        check(lib.ccst_conv2d_bwd_weight_split_f32(ctypes.byref(d), ptr(x), ptr(ops.absmax(x)), ptr(dy), ptr(ops.absmax(dy)), ptr(dw), splits, rep,
+                                                   ptr(ws), ws.numel() * 4, stream_ptr()), "bwd_weight_split")
+        out.append(dw)
+    scale = float(ref.abs().max())
+    err = float((out[0].double() - ref).abs().max()) / scale
+    assert err < 2e-6, err
+    assert float((out[1].double() - (ref + 7.0)).abs().max()) < 2e-6 * scale + 1e-5         # accumulate = 1 adds to what was there
+    dw32 = torch.empty((Cout, Cin, k, k), device=dev)
+    nn_ops.conv_bwd_weight(d, x, dy, dw32, accumulate=False)
+    err32 = float((dw32.double() - ref).abs().max()) / scale
+    assert err < 4 * err32 + 1e-7, (err, err32)
+
+
+@pytest.mark.parametrize("half", [True, False])
+def test_pointwise_conv_forward_vs_fp64(dev, half):
+    """The streaming pointwise kernel's training forward -- every fp32 product as three products of IEEE-half pieces on the 16-bit MFMA
+    (the default where the |max| words are at hand: activations split in the loader, weights pre-split by pack_conv_weight_split) or
+    on the fp32 MFMA -- against an fp64 convolution, dense and strided (the downsample branches), with the statistics epilogue."""
+    from ccst_amd import ops
+    g = torch.Generator().manual_seed(5)
+    worst = 0.0
+    for (N, H, cin, cout, stride) in ((8, 56, 64, 128, 2), (8, 56, 64, 256, 1), (8, 14, 256, 512, 2), (4, 28, 128, 512, 1), (3, 7, 2048, 512, 1)):
+        x = torch.randn(N, H, H, cin, generator=g).to(dev)
+        w = (torch.randn(cout, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5).to(dev)
+        kw = {}
+        if half:
+            wmax = ops.absmax(w)
+            kw = dict(x_absmax=ops.absmax(x), w_absmax=wmax, w_split=ops.pack_conv_weight_split(w, wmax))
+        y, st = ops.conv2d_nhwc(x, ops.pack_conv_weight(w, None), stride=stride, pad=0, want_stats=True, **kw)
+        ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), stride=stride).permute(0, 2, 3, 1)
+        worst = max(worst, float((y - ref).abs().max() / ref.abs().max()))
+        s_ref = torch.stack([ref.sum(dim=(0, 1, 2)), (ref * ref).sum(dim=(0, 1, 2))], dim=1)
+        worst = max(worst, float((st.double().sum(0) - s_ref).abs().max() / s_ref.abs().max()))
+    assert worst < 4e-6, worst
+
+
+@pytest.mark.parametrize("gscale", [1.0, 1e-7, 3e5])
+def test_pointwise_backward_data_half_pieces_match_fp32_forms(dev, gscale):
+    """Backward-data of a pointwise conv on half pieces (ccst_conv2d_pointwise_half_f32: the gradient scaled by its |max| words, the
+    transposed weight pre-split) in all four forms -- plain, y +=, masked accumulate with the BatchNorm link, BatchNorm + ReLU link --
+    against the fp32-MFMA forms on the same operands, at gradient magnitudes from 1e-7 to 3e5."""
+    from ccst_amd import nn_ops, ops
+    g = torch.Generator().manual_seed(17)
+    N, H, W, Cin, Cout = 4, 28, 28, 128, 256                # forward conv Cin -> Cout; dX [N,H,W,Cin]
+    M = N * H * W
+    dy = (torch.randn(N, H, W, Cout, generator=g) * gscale).to(dev)
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5).to(dev)
+    pct = ops.pack_conv_weight(w, transpose=True)
+    wmax = ops.absmax(w)
+    half = (ops.absmax(dy), wmax, ops.pack_conv_weight_split(w, wmax, transpose=True))
+    ref = (dy.double().reshape(M, Cout) @ w.double().reshape(Cout, Cin)).reshape(N, H, W, Cin)
+    scale = float(ref.abs().max())
+    tol = 4e-6 * scale
+    # plain
+    a = nn_ops.conv_bwd_data(dy, pct, (N, H, W, Cin), 1, 0, half=half)
+    b = nn_ops.conv_bwd_data(dy, pct, (N, H, W, Cin), 1, 0)
+    assert float((a.double() - ref).abs().max()) < tol and float((b.double() - ref).abs().max()) < tol
+    # y +=
+    base = (torch.randn(N, H, W, Cin, generator=g) * gscale).to(dev)
+    a = nn_ops.conv_bwd_data(dy, pct, (N, H, W, Cin), 1, 0, accumulate_into=base.clone(), half=half)
+    assert float((a.double() - (ref + base.double())).abs().max()) < tol
+    # masked accumulate + BatchNorm link
+    mask = (torch.rand(M * Cin // 4, generator=g) * 16).to(torch.uint8).to(dev)
+    bx = torch.randn(N, H, W, Cin, generator=g).to(dev)
+    mean, invstd = torch.randn(Cin, generator=g).to(dev) * 0.1, (torch.rand(Cin, generator=g) + 0.5).to(dev)
+    groups = nn_ops.lib_groups(M, Cin, Cout)
+    pa, pb = torch.empty((groups, Cin, 2), device=dev), torch.empty((groups, Cin, 2), device=dev)
+    a = nn_ops.conv_bwd_data(dy, pct, (N, H, W, Cin), 1, 0, accumulate_into=base.clone(), relu_mask=mask, bn_link=(bx, mean, invstd, pa), half=half)
+    b = nn_ops.conv_bwd_data(dy, pct, (N, H, W, Cin), 1, 0, accumulate_into=base.clone(), relu_mask=mask, bn_link=(bx, mean, invstd, pb))
+    assert float((a - b).abs().max()) < 2 * tol
+    assert float((pa.double().sum(0) - pb.double().sum(0)).abs().max()) < 1e-4 * max(float(pb.double().sum(0).abs().max()), 1e-30)
+    # BatchNorm + ReLU link
+    gam, bet = (torch.rand(Cin, generator=g) + 0.5).to(dev), (torch.randn(Cin, generator=g) * 0.3).to(dev)
+    a = nn_ops.conv_bwd_data(dy, pct, (N, H, W, Cin), 1, 0, bn_relu=(bx, mean, invstd, gam, bet, pa), half=half)
+    b = nn_ops.conv_bwd_data(dy, pct, (N, H, W, Cin), 1, 0, bn_relu=(bx, mean, invstd, gam, bet, pb))
+    assert float((a - b).abs().max()) < 2 * tol
+    assert float((pa.double().sum(0) - pb.double().sum(0)).abs().max()) < 1e-4 * max(float(pb.double().sum(0).abs().max()), 1e-30)
 
 
 @pytest.mark.parametrize("arch", ["resnet18", "resnet50"])

@@ -3,7 +3,8 @@
 python tools/bwdw_time.py [reps]   -> per shape and kernel (fp32 MFMA / half pieces on the 16-bit MFMA): splits, us (kernel + slab
 reduce), TFLOP/s, and the error against an fp64 reference (max |dw - ref| / max |ref|).
 BWDW_SPLITS=<n> overrides the split count (workspace sized accordingly); BWDW_SHAPES=i,j,.. picks rows; BWDW_SCALE=<f> multiplies dy
-(gradient-sized operands: 1e-6)."""
+(gradient-sized operands: 1e-6); BWDW_SWEEP=a,b,.. times the half-piece kernel at those workgroup targets (splits = target / tiles)
+instead of the library's choice."""
 import ctypes
 import os
 import sys
@@ -55,8 +56,14 @@ for (H, cin, cout, k, stride) in SHAPES:
     ref = ref64(x, dy, cin, cout, k, stride, pad)
     xmax, dmax = ops.absmax(x), ops.absmax(dy)
     line = "%3dx%-3d %4d->%-4d k%d s%d " % (H, H, cin, cout, k, stride)
-    for kind in ("f32", "half"):
+    kinds = [("f32", None), ("half", None)]
+    if os.environ.get("BWDW_SWEEP"):
+        ti, tj = (cin + 127) // 128 if cin >= 128 else 1, (cout + 127) // 128 if cout >= 128 else 1
+        kinds = [("half", max(1, int(t) // (ti * tj * k * k))) for t in os.environ["BWDW_SWEEP"].split(",")]
+    for kind, forced in kinds:
         splits = (lib.ccst_conv2d_bwd_weight_split_splits if kind == "half" else lib.ccst_conv2d_bwd_weight_splits)(M, cin, cout, k * k)
+        if forced is not None:
+            splits = max(1, min(forced, M // 64))
         if os.environ.get("BWDW_SPLITS"):
             splits = max(1, min(int(os.environ["BWDW_SPLITS"]), M // 128))
         ws = torch.empty(splits * k * k * cin * cout, device=dev)
