@@ -136,6 +136,17 @@ constexpr int CCST_SPLIT_X_TARGET = 13, CCST_SPLIT_W_TARGET = 9;
 // for lo -- fma(v, s, -hi) with hi read as the half it is, rounded to half.  (hipcc's own rendering of the same arithmetic re-derives hi
 // per value, 14 instructions; the convert-back-and-subtract form takes 12.  Vector instructions are paid on top of the MFMA time.)
 typedef unsigned ccst_u32x2 __attribute__((ext_vector_type(2)));
+// ... of a pair that is already scaled: (hi word, lo word) = 1 v_cvt_pk_f16_f32 + 2 v_fma_mix (lo = half(q - hi), q * 1.0 - hi in one rounding)
+__device__ __forceinline__ void ccst_split2_half(float q0, float q1, unsigned& hi, unsigned& lo) {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const unsigned qh = __builtin_bit_cast(unsigned, __builtin_convertvector(f2{q0, q1}, h2));
+    unsigned ql;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(ql) : "v"(q0), "v"(qh));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(ql) : "v"(q1), "v"(qh));
+    hi = qh;
+    lo = ql;
+}
 __device__ __forceinline__ void ccst_split4_half(f32x4 v, float s, ccst_u32x2& hi, ccst_u32x2& lo) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     typedef float f2 __attribute__((ext_vector_type(2)));

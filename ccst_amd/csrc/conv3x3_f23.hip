@@ -43,7 +43,7 @@ struct F23Args {
     int tilesX, tilesY, tilesN;
 };
 
-typedef unsigned u32x2f __attribute__((ext_vector_type(2)));
+typedef ccst_u32x2 u32x2f;
 typedef _Float16 f16x8f __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2f __attribute__((ext_vector_type(2)));
 typedef float f32x2f __attribute__((ext_vector_type(2)));
@@ -68,14 +68,10 @@ __device__ __forceinline__ int reflect_f(int i, int n) {
 
 // four fp32 values scaled by s -> (hi, lo) half pieces, two per word (see split4h in conv3x3_halo.hip)
 __device__ __forceinline__ void split4f(f32x4 v, float s, u32x2f& hi, u32x2f& lo) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const f32x2f p = f32x2f{v[2 * h], v[2 * h + 1]} * s;
-        const f16x2f ph = __builtin_convertvector(p, f16x2f);
-        const f16x2f pl = __builtin_convertvector(p - __builtin_convertvector(ph, f32x2f), f16x2f);
-        hi[h] = __builtin_bit_cast(unsigned, ph);
-        lo[h] = __builtin_bit_cast(unsigned, pl);
-    }
+    ccst_u32x2 h2, l2;          // (round 5: 8 vector instructions per four values, common.h)
+    ccst_split4_half(v, s, h2, l2);
+    hi = h2;
+    lo = l2;
 }
 
 // One LDS-DMA piece: 64 lanes x 16 bytes from (uniform base + per-lane byte offset) to 1 KiB of LDS at the wave-uniform byte address
@@ -206,10 +202,10 @@ __global__ __launch_bounds__(F_NT, 2) void conv3x3_f23_kernel(const F23Args p) {
         for (int h = 0; h < 2; ++h) {          // (d_a + sgn d_b) * 2^kx as d_a * s + d_b * (sgn s): exact scaling, one rounding (the add's)
             const f32x2f pa = f32x2f{da[2 * h], da[2 * h + 1]} * xs;
             const f32x2f pv = f32x2f{db[2 * h], db[2 * h + 1]} * xsb + pa;
-            const f16x2f ph = __builtin_convertvector(pv, f16x2f);
-            const f16x2f pl = __builtin_convertvector(pv - __builtin_convertvector(ph, f32x2f), f16x2f);
-            hi[h] = __builtin_bit_cast(unsigned, ph);
-            lo[h] = __builtin_bit_cast(unsigned, pl);
+            unsigned wh, wl;
+            ccst_split2_half(pv[0], pv[1], wh, wl);         // (1 + 2 vector instructions per pair; the convert-back-and-subtract form took 5)
+            hi[h] = wh;
+            lo[h] = wl;
         }
         float* o = &Vs[buf * F_VW + tdst + i * (2 * F_ROWW)];
         *reinterpret_cast<u32x2f*>(o) = hi;

@@ -54,7 +54,7 @@ struct HaloArgs {
 #define PRE_P 5        // first fragment pair of the NEXT step (visible since the previous barrier: 3-deep weight ring)
 constexpr int CKH = 16, PITCH = CKH + 4, HW_ = 18;
 constexpr int BPITCH = 20;      // SPLIT: words per output-channel row of the weight image (16 channels hi | lo as half = 16 words, + 4 of pad)
-typedef unsigned u32x2h __attribute__((ext_vector_type(2)));
+typedef ccst_u32x2 u32x2h;
 typedef _Float16 f16x8h __attribute__((ext_vector_type(8)));      // the 16-bit pieces are IEEE half: 11 significant bits each
 typedef _Float16 f16x2h __attribute__((ext_vector_type(2)));
 typedef float f32x2h __attribute__((ext_vector_type(2)));
@@ -64,14 +64,10 @@ typedef float f32x2h __attribute__((ext_vector_type(2)));
 // within 2^-17 of the tensor's largest, an absolute error of 2^-38 of that largest below), two per word.  Written on 2-vectors so that
 // hipcc emits v_pk_mul_f32 / v_cvt_pk_f16_f32 / v_pk_fma_f32: 12 vector instructions per four values (the scalar form took 21).
 __device__ __forceinline__ void split4h(f32x4 v, float s, u32x2h& hi, u32x2h& lo) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const f32x2h p = f32x2h{v[2 * h], v[2 * h + 1]} * s;
-        const f16x2h ph = __builtin_convertvector(p, f16x2h);
-        const f16x2h pl = __builtin_convertvector(p - __builtin_convertvector(ph, f32x2h), f16x2h);
-        hi[h] = __builtin_bit_cast(unsigned, ph);
-        lo[h] = __builtin_bit_cast(unsigned, pl);
-    }
+    ccst_u32x2 h2, l2;          // (round 5: 8 vector instructions per four values, common.h)
+    ccst_split4_half(v, s, h2, l2);
+    hi = h2;
+    lo = l2;
 }
 
 __device__ __forceinline__ int reflect_h(int i, int n) {
@@ -95,7 +91,6 @@ __device__ __forceinline__ int reflect_h(int i, int n) {
 // that puts the tensor's largest |value| (p.xmax, left by the producing kernel's epilogue) below 2^14 -- any finite fp32 input is safe.
 template <int WM, int WN, int NT, bool POOL, bool TRAIN = false, bool SPLIT = false>
 __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_kernel(const HaloArgs p) {
-    static_assert(!(SPLIT && TRAIN), "the train form stays on the fp32 MFMA");
     static_assert(!(TRAIN && POOL), "the train form has no pooled epilogue");
     constexpr int MT = 2;
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
@@ -422,7 +417,7 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int co = co0 + cw + nt * 32 + li;
-                if (!SPLIT) {
+                if (!SPLIT || TRAIN) {
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
@@ -579,8 +574,11 @@ int launch_halo(HaloArgs& a, hipStream_t s) {
 
 // OIHW 3x3 -> the pre-split weight image of the SPLIT kernels: [tap][Cin/16][cout_pad][16 words] with words 0..7 = the 16 input
 // channels of the chunk as half(w * scale) (two per word, even channel in the low half), words 8..15 = half(w * scale - hi)
-__global__ void pack_weight_halo_split_kernel(const float* __restrict__ w, unsigned* __restrict__ out, int cout, int cin, int cout_pad,
-                                              const unsigned* __restrict__ wmax) {
+// transpose: the weight of the backward-data conv dY -> dX of the same layer -- rows = the forward conv's INPUT channels, k = its output
+// channels (cout / cin name the GEMM's sides then: n = `cout` rows, k = `cin`); the taps stay in forward order (the kernel's flip
+// reverses them).
+__device__ __forceinline__ void pack_halo_split_words(const float* __restrict__ w, unsigned* __restrict__ out, int cout, int cin, int cout_pad,
+                                                      const unsigned* __restrict__ wmax, int transpose) {
     const int kw = ccst_scale_exp(ccst_absmax_read(wmax), CCST_SPLIT_W_TARGET);      // the conv kernel derives the same exponent
     const int nch = cin / 16;
     const long long total = 9LL * nch * cout_pad * 16;
@@ -594,13 +592,24 @@ __global__ void pack_weight_halo_split_kernel(const float* __restrict__ w, unsig
         unsigned r = 0;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const float v = (co < cout) ? __builtin_ldexpf(w[((long long)co * cin + k0 + e) * 9 + tap], kw) : 0.f;
+            const long long src = transpose ? ((long long)(k0 + e) * cout + co) * 9 + tap : ((long long)co * cin + k0 + e) * 9 + tap;
+            const float v = (co < cout) ? __builtin_ldexpf(w[src], kw) : 0.f;
             const _Float16 h = (_Float16)v;
             const _Float16 q = piece ? (_Float16)(v - (float)h) : h;
             r |= (unsigned)__builtin_bit_cast(unsigned short, q) << (16 * e);
         }
         out[i] = r;
     }
+}
+__global__ void pack_weight_halo_split_kernel(const float* __restrict__ w, unsigned* __restrict__ out, int cout, int cin, int cout_pad,
+                                              const unsigned* __restrict__ wmax, int transpose) {
+    pack_halo_split_words(w, out, cout, cin, cout_pad, wmax, transpose);
+}
+// ... of a whole model in one launch: jobs[j] = {src, dst, n rows, k, cout_pad, |max| words, transpose, 0} (int64 each), blockIdx.y = job
+__global__ void pack_weight_halo_split_batch_kernel(const long long* __restrict__ jobs) {
+    const long long* jb = jobs + (long long)blockIdx.y * 8;
+    pack_halo_split_words(reinterpret_cast<const float*>(jb[0]), reinterpret_cast<unsigned*>(jb[1]), (int)jb[2], (int)jb[3], (int)jb[4],
+                          reinterpret_cast<const unsigned*>(jb[5]), (int)jb[6]);
 }
 
 }  // namespace
@@ -610,15 +619,25 @@ extern "C" int ccst_conv3x3_halo_narrow(int N, int H, int W, int Cout);
 // Weights of ccst_conv3x3_halo_split_f32: 9 * cin * cout_pad floats (the same size as the fp32 packed form); cin a multiple of 16,
 // cout_pad a multiple of 128.
 extern "C" int ccst_pack_conv_weight_halo_split_f32(const float* w_oihw, float* out, int cout, int cin, int cout_pad, const uint32_t* w_absmax,
-                                                    void* stream) {
-    CCST_REQUIRE(w_oihw && out && cout > 0 && cin > 0 && cin % 16 == 0, "pack_halo_split: bad args (cin a multiple of 16)");
+                                                    int transpose, void* stream) {
+    if (transpose) {          // (the GEMM's sides: rows = the forward conv's input channels, k = its output channels)
+        const int t = cout;
+        cout = cin;
+        cin = t;
+    }
+    CCST_REQUIRE(w_oihw && out && cout > 0 && cin > 0 && cin % 16 == 0, "pack_halo_split: bad args (the k side a multiple of 16)");
     CCST_REQUIRE(w_absmax, "pack_halo_split: the |max| words of the weight (ccst_absmax_f32)");
     CCST_REQUIRE(cout_pad >= cout && cout_pad % 128 == 0, "pack_halo_split: cout_pad must be a multiple of 128 >= cout");
     const long long total = 9LL * cin * cout_pad;
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(pack_weight_halo_split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w_oihw, reinterpret_cast<unsigned*>(out), cout, cin,
-                       cout_pad, w_absmax);
+                       cout_pad, w_absmax, transpose);
     return ccst_launch_status("pack_weight_halo_split");
+}
+extern "C" int ccst_pack_conv_weights_halo_split_batch_f32(const int64_t* jobs_device, int njobs, void* stream) {
+    CCST_REQUIRE(jobs_device && njobs > 0, "pack_halo_split_batch: bad args");
+    hipLaunchKernelGGL(pack_weight_halo_split_batch_kernel, dim3(64, njobs), dim3(256), 0, (hipStream_t)stream, (const long long*)jobs_device);
+    return ccst_launch_status("pack_weight_halo_split_batch");
 }
 
 // x: NHWC source [N,Hs,Ws,Cin] (Hs = H/2 if CCST_CONV_UPS2), w: packed [9][Cin/4][cout_pad][4], y: NHWC
@@ -707,6 +726,29 @@ extern "C" int ccst_conv3x3_halo_train_f32(const float* x, const float* w_packed
     hipStream_t s = (hipStream_t)stream;
     if (ccst_conv3x3_halo_narrow(N, H, W, Cout)) return launch_halo<2, 2, 1, false, true>(a, s);
     return launch_halo<2, 2, 2, false, true>(a, s);
+}
+
+// The ResNet-trunk form on half pieces (round 5): as ccst_conv3x3_halo_train_f32 with every fp32 product as three half-piece products
+// on the 16-bit MFMA -- x scaled by its |max| words (an activation: left by the BatchNorm apply; a gradient: by the BatchNorm backward),
+// w_split from ccst_pack_conv_weight_halo_split_f32 (transpose = 1 + CCST_CONV_FLIP: backward-data).  Same flags, same statistics.
+extern "C" int ccst_conv3x3_halo_train_split_f32(const float* x, const uint32_t* x_absmax, const float* w_split, const uint32_t* w_absmax, float* y,
+                                                 float* stats, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags, void* stream) {
+    CCST_REQUIRE(x && w_split && y && x_absmax && w_absmax, "conv3x3_halo_train_split: null pointer");
+    CCST_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0, "conv3x3_halo_train_split: bad shape");
+    CCST_REQUIRE(cout_pad >= Cout && cout_pad % 128 == 0, "conv3x3_halo_train_split: cout_pad must be a multiple of 128 >= cout");
+    CCST_REQUIRE(!(flags & ~(CCST_CONV_FLIP | CCST_CONV_ACCUM)), "conv3x3_halo_train_split: only CCST_CONV_FLIP | CCST_CONV_ACCUM");
+    CCST_REQUIRE(!(stats && (flags & CCST_CONV_ACCUM)), "conv3x3_halo_train_split: statistics are of the conv output, not of y += conv");
+    CCST_REQUIRE((long long)N * H * W * Cin < 0x7fffffffLL, "conv3x3_halo_train_split: input must have < 2^31 elements");
+    HaloArgs a;
+    a.x = x; a.w = w_split; a.bias = nullptr; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.Hs = H; a.Ws = W; a.Cin = Cin; a.Cout = Cout; a.CoutPad = cout_pad;
+    a.reflect = 0; a.ups = 0; a.relu = 0;
+    a.stats = stats; a.flip = (flags & CCST_CONV_FLIP) ? 1 : 0; a.accum = (flags & CCST_CONV_ACCUM) ? 1 : 0;
+    a.xmax = x_absmax; a.wmax = w_absmax; a.ymax = nullptr;
+    a.ysW = Cout; a.ysH = W * Cout; a.ysN = (long long)H * W * Cout;
+    hipStream_t s = (hipStream_t)stream;
+    if (ccst_conv3x3_halo_narrow(N, H, W, Cout)) return launch_halo<2, 2, 1, false, true, true>(a, s);
+    return launch_halo<2, 2, 2, false, true, true>(a, s);
 }
 
 // Row groups ccst_conv3x3_halo_train_f32 writes statistics for: two wave rows per 8x16-pixel tile.

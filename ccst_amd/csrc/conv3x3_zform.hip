@@ -71,8 +71,9 @@ __device__ __forceinline__ void split8z(const f32x4 a, const f32x4 b, float s, f
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
         const f32x2z v = (h < 2 ? f32x2z{a[2 * h], a[2 * h + 1]} : f32x2z{b[2 * h - 4], b[2 * h - 3]}) * s;
-        const f16x2z ph = __builtin_convertvector(v, f16x2z);
-        const f16x2z pl = __builtin_convertvector(v - __builtin_convertvector(ph, f32x2z), f16x2z);
+        unsigned wh, wl;
+        ccst_split2_half(v[0], v[1], wh, wl);
+        const f16x2z ph = __builtin_bit_cast(f16x2z, wh), pl = __builtin_bit_cast(f16x2z, wl);
         hi[2 * h] = ph[0];
         hi[2 * h + 1] = ph[1];
         lo[2 * h] = pl[0];

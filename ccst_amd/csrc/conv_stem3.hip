@@ -133,8 +133,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STEM_WAVES,
 #pragma unroll
             for (int h = 0; h < 4; ++h) {
                 const f32x2s v = f32x2s{bv[8 * ks + 2 * h], bv[8 * ks + 2 * h + 1]} * xs;
-                const f16x2s ph = __builtin_convertvector(v, f16x2s);
-                const f16x2s pl = __builtin_convertvector(v - __builtin_convertvector(ph, f32x2s), f16x2s);
+                unsigned wh, wl;
+                ccst_split2_half(v[0], v[1], wh, wl);
+                const f16x2s ph = __builtin_bit_cast(f16x2s, wh), pl = __builtin_bit_cast(f16x2s, wl);
                 bhi[ks][2 * h] = ph[0];
                 bhi[ks][2 * h + 1] = ph[1];
                 blo[ks][2 * h] = pl[0];

@@ -69,6 +69,17 @@ class Conv2d(nn.Conv2d):
     def packed_th(self):
         return self._cached("pkht", lambda w, prev: ops.pack_conv_weight_split(w, self.wabsmax(), transpose=True, out=prev))
 
+    def halo_h(self):
+        """Half-piece weight image of a 3x3 weight for the halo kernel's train form (scaled by the words of wabsmax())."""
+        return self._cached("hh", lambda w, prev: ops.pack_halo_split(w, self.wabsmax(), out=None if prev is None else prev[0]))
+
+    def halo_ht(self):
+        return self._cached("hht", lambda w, prev: ops.pack_halo_split(w, self.wabsmax(), bwd=True, out=None if prev is None else prev[0]))
+
+    def halo_split_ok(self):
+        return self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and \
+            ops.halo_train_split_ok(0, 0, self.in_channels, self.out_channels)
+
     def wino_ok(self, H, W):
         return self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and \
             ops.wino_train_ok(H, W, self.in_channels, self.out_channels)
@@ -111,6 +122,10 @@ class Conv2d(nn.Conv2d):
                 self.packed_h()
             if "_ccst_pkht" in d:
                 self.packed_th()
+            if "_ccst_hh" in d:
+                self.halo_h()
+            if "_ccst_hht" in d:
+                self.halo_ht()
 
     def packed_stem(self):
         def build(w, prev):

@@ -78,6 +78,10 @@ HALF_BWD = HALF_FWD and _os.environ.get("CCST_BWD_HALF", "1") != "0"
 # |max| words of gradient tensors, keyed by the tensor's address: autograd hands a backward's result to the next node as a new Python
 # object, so a tag on the tensor would not survive; an entry is consumed by the one conv backward that reads the gradient.
 _GRAD_WORDS = {}
+# The 3x3 stride-1 trunk layers on the half-piece halo kernel (conv3x3_halo.hip, TRAIN + SPLIT form): backward-data by default (its
+# operand is a gradient with words at hand; rounding there moves no ReLU mask); CCST_RESNET_HALF3X3 = 2 also runs the FORWARD on it
+# (0: neither -- the fp32 F(2x2) Winograd kernel).
+HALF3X3 = int(_os.environ.get("CCST_RESNET_HALF3X3", "1")) if HALF_BWD else 0
 
 
 def _publish_grad_words(device):
@@ -101,7 +105,7 @@ def _prepack_jobs(model, convs):
     (ccst_pack_conv_weights_batch_f32), the Winograd transforms (ccst_pack_conv_weights_wino_batch_f32), the weights' |max| words
     (ccst_absmax_batch_f32) and the pre-split half-piece packs scaled by them (ccst_pack_conv_weights_split_batch_f32).  Rebuilt only
     if a weight or a packed buffer moved (the key is the tuple of their addresses)."""
-    slots, wslots, w4slots, mslots, hslots = [], [], [], [], []
+    slots, wslots, w4slots, mslots, hslots, h3slots = [], [], [], [], [], []
     for m in convs:
         if m.in_channels <= 4:
             continue
@@ -123,11 +127,15 @@ def _prepack_jobs(model, convs):
             slot = m.__dict__.get(name)
             if slot is not None:
                 hslots.append((m, name, slot[1], transpose))
+        for name, transpose in (("_ccst_hh", 0), ("_ccst_hht", 1)):
+            slot = m.__dict__.get(name)
+            if slot is not None:
+                h3slots.append((m, name, slot[1], transpose))
     sig = tuple((m.weight.data_ptr(), pc.w.data_ptr()) for m, _n, pc, _t in slots) + \
         tuple((m.weight.data_ptr(), pk[0].data_ptr()) for m, _n, pk, _b in wslots + w4slots) + tuple(("wmax", m.weight.data_ptr()) for m in mslots) + \
-        tuple((m.weight.data_ptr(), t.data_ptr()) for m, _n, t, _t in hslots)
+        tuple((m.weight.data_ptr(), t.data_ptr()) for m, _n, t, _t in hslots) + tuple((m.weight.data_ptr(), pk[0].data_ptr()) for m, _n, pk, _t in h3slots)
     jobs = {"sig": sig, "table": None, "slots": slots, "wtable": None, "wslots": wslots, "w4table": None, "w4slots": w4slots, "mtable": None,
-            "mwords": None, "mslots": mslots, "htable": None, "hslots": hslots}
+            "mwords": None, "mslots": mslots, "htable": None, "hslots": hslots, "h3table": None, "h3slots": h3slots}
     if not slots and not wslots and not w4slots:
         return jobs
     cached = model.__dict__.get("_ccst_prepack_jobs")
@@ -156,6 +164,13 @@ def _prepack_jobs(model, convs):
             rows.append([m.weight.data_ptr(), t.data_ptr(), m.out_channels, m.in_channels, jobs["mwords"][row_of[id(m)]].data_ptr(), transpose,
                          ops.round_up(kdim, 16), ops.round_up(ndim, 128)])
         jobs["htable"] = torch.tensor(rows, dtype=torch.int64).to(dev)
+    if h3slots:     # ... and the 3x3 layers' half-piece weight images
+        row_of = {id(m): i for i, m in enumerate(mslots)}
+        rows = []
+        for m, _n, (u, pad, n_out), transpose in h3slots:
+            n_in = m.out_channels if transpose else m.in_channels
+            rows.append([m.weight.data_ptr(), u.data_ptr(), n_out, n_in, pad, jobs["mwords"][row_of[id(m)]].data_ptr(), transpose, 0])
+        jobs["h3table"] = torch.tensor(rows, dtype=torch.int64).to(dev)
     model.__dict__["_ccst_prepack_jobs"] = jobs
     return jobs
 
@@ -186,6 +201,8 @@ def prepack_on_side(model):
             check(lib.ccst_absmax_batch_f32(ptr(j["mtable"]), len(j["mslots"]), ptr(j["mwords"]), stream_ptr()), "absmax_batch")
         if j["htable"] is not None:         # (after the words: the packs are scaled by them)
             check(lib.ccst_pack_conv_weights_split_batch_f32(ptr(j["htable"]), len(j["hslots"]), stream_ptr()), "pack_weights_split_batch")
+        if j["h3table"] is not None:
+            check(lib.ccst_pack_conv_weights_halo_split_batch_f32(ptr(j["h3table"]), len(j["h3slots"]), stream_ptr()), "pack_weights_halo_split_batch")
     if SIDE_STREAM:
         side = _side_stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
@@ -194,7 +211,7 @@ def prepack_on_side(model):
         _PREPACK_PENDING.add(device.index)
     else:
         launch()
-    for m, name, pk, _t in j["slots"] + j["wslots"] + j["w4slots"] + j["hslots"]:       # the packed copies now match the weights of this epoch
+    for m, name, pk, _t in j["slots"] + j["wslots"] + j["w4slots"] + j["hslots"] + j["h3slots"]:       # the packed copies now match the weights of this epoch
         w = m.weight
         m.__dict__[name] = ((w._version, w.data_ptr(), ops.WEIGHTS_EPOCH), pk)
     for i, m in enumerate(j["mslots"]):
@@ -425,7 +442,14 @@ class ConvFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)       # no zero tensor for the non-differentiable stats output
         ctx.wino4 = mod.wino4_ok(x.shape[1], x.shape[2])       # 64-channel F(4x4): the trunk's 56x56 and 28x28 maps
         ctx.wino = mod.wino_ok(x.shape[1], x.shape[2])
-        pc = None if (ctx.wino4 or ctx.wino) else mod.packed()      # (the direct layout is packed only where it is used)
+        ctx.half3 = HALF3X3 >= 1 and mod.halo_split_ok()         # 3x3 stride 1: backward-data (and with 2 the forward) on half pieces
+        fwd_half3 = ctx.half3 and HALF3X3 >= 2 and ctx.xmax is not None
+        pc = None if (ctx.wino4 or ctx.wino or fwd_half3) else mod.packed()      # (the direct layout is packed only where it is used)
+        if fwd_half3:
+            out = ops.conv3x3_halo_train_split(x, ctx.xmax, mod.halo_h(), mod.wabsmax(), want_stats=bool(want_stats))
+            if want_stats:
+                ctx.mark_non_differentiable(out[1])
+            return out
         if want_stats:      # BN batch statistics from the conv epilogue (non-differentiable side output)
             if ctx.wino4:
                 y, stats = ops.conv3x3_wino4w_train(x, mod.wino4_fwd(), want_stats=True)
@@ -472,7 +496,9 @@ class ConvFn(torch.autograd.Function):
                     into, ctx.sink.grad = ctx.sink.grad, None
                 elif ctx.sink.pair:
                     deposit = True
-            if ctx.wino4 and into is None:          # (y += lives in the F(2x2) kernel only)
+            if ctx.half3 and dymax is not None:     # 3x3 stride 1: the half-piece halo kernel with the transposed image, taps flipped
+                dx = ops.conv3x3_halo_train_split(dy, dymax, mod.halo_ht(), mod.wabsmax(), flip=True, accumulate_into=into)
+            elif ctx.wino4 and into is None:          # (y += lives in the F(2x2) kernel only)
                 dx = ops.conv3x3_wino4w_train(dy, mod.wino4_bwd(), tag="bwd_data:")
             elif ctx.wino:
                 dx = ops.conv3x3_wino_train(dy, mod.wino_bwd(), accumulate_into=into, tag="bwd_data:")

@@ -177,6 +177,53 @@ def conv3x3_halo_train(x, pc, want_stats=False, flip=False, accumulate_into=None
                        2.0 * N * H * W * cout * Cx * 9, e0, e1, "n%d %dx%d cin%d cout%d taps3x3 s1" % (N, H, W, Cx, cout)))
     return (y, stats) if want_stats else y
 
+def pack_halo_split(w_oihw, w_absmax, bwd=False, out=None):
+    """The half-piece weight image of a 3x3 OIHW weight for conv3x3_halo_train_split: (w_split, cout_pad, cout) of the forward conv, or
+    with bwd=True of the backward-data conv dY -> dX (its `cout` is the forward Cin; run it with flip=True)."""
+    cout, cin = w_oihw.shape[0], w_oihw.shape[1]
+    n_out, n_in = (cin, cout) if bwd else (cout, cin)
+    pad = round_up(n_out, 128)
+    nfl = 9 * n_in * pad
+    u = out if out is not None and out.numel() == nfl else torch.empty(nfl, device=w_oihw.device, dtype=torch.float32)
+    check(_lib.load().ccst_pack_conv_weight_halo_split_f32(ptr(w_oihw.contiguous()), ptr(u), cout, cin, pad, ptr(w_absmax), int(bwd), stream_ptr()),
+          "pack_conv_weight_halo_split")
+    return u, pad, n_out
+
+
+def halo_train_split_ok(H, W, cin, cout):
+    """3x3 stride-1 trunk layers the half-piece halo kernel takes: its k side a multiple of 16 (its 8x16-pixel tiles cover a 7x7 map by
+    38 %, and it is still ahead of the fp32 gather kernel there)."""
+    return cin % 16 == 0 and cout % 16 == 0
+
+
+def conv3x3_halo_train_split(x, x_absmax, packed, w_absmax, want_stats=False, flip=False, accumulate_into=None):
+    """3x3 stride-1 zero-padded bias-free conv on the half-piece halo kernel (ResNet trunk).  packed = pack_halo_split(...); the words of x
+    and of the OIHW weight scale the operands.  flip=True with the bwd pack: backward-data.  Returns y or (y, stats)."""
+    u, pad, cout = packed
+    N, H, W, Cx = x.shape
+    lib = _lib.load()
+    if accumulate_into is not None:
+        assert tuple(accumulate_into.shape) == (N, H, W, cout) and accumulate_into.is_contiguous() and not want_stats
+        y = accumulate_into
+    else:
+        y = torch.empty((N, H, W, cout), device=x.device, dtype=torch.float32)
+    stats = None
+    if want_stats:
+        stats = torch.empty((lib.ccst_conv3x3_halo_stats_groups(N, H, W), cout, 2), device=x.device, dtype=torch.float32)
+    flags = (_lib.CONV_FLIP if flip else 0) | (_lib.CONV_ACCUM if accumulate_into is not None else 0)
+    args = (ptr(x), ptr(x_absmax), ptr(u), ptr(w_absmax), ptr(y), ptr(stats), N, H, W, Cx, cout, pad, flags, stream_ptr())
+    if TIMING is None:
+        check(lib.ccst_conv3x3_halo_train_split_f32(*args), "conv3x3_halo_train_split")
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.ccst_conv3x3_halo_train_split_f32(*args), "conv3x3_halo_train_split")
+        e1.record()
+        TIMING.append((("bwd_data:" if flip else "") + "conv3x3_halo_kernel<%s,train,split>" % ("2,2,1" if lib.ccst_conv3x3_halo_narrow(N, H, W, cout) else "2,2,2"),
+                       2.0 * N * H * W * cout * Cx * 9, e0, e1, "n%d %dx%d cin%d cout%d taps3x3 s1" % (N, H, W, Cx, cout)))
+    return (y, stats) if want_stats else y
+
+
 # bench.py sets TIMING = [] to collect (kernel name, algorithmic flops, start event, end event) per conv launch.
 TIMING = None
 
@@ -349,7 +396,7 @@ class PackedConv(object):
     @property
     def wsplit(self):
         return self._lazy("_wsplit", 9 * self.cin * self.n_pad, _lib.load().ccst_pack_conv_weight_halo_split_f32, "pack_conv_weight_halo_split",
-                          self.n_pad, ptr(self.wabsmax)) if self.can_split() else None
+                          self.n_pad, ptr(self.wabsmax), 0) if self.can_split() else None
 
     @property
     def uf23(self):

@@ -138,7 +138,10 @@ int ccst_absmax_batch_f32(const int64_t* table, int n, uint32_t* absmax, void* s
  *   y_absmax: NULL, or zeroed words receiving max |y| (of the stored, i.e. ReLU'd / pooled, output);
  * otherwise the x / y / flags contract of ccst_conv3x3_halo_f32. */
 int ccst_pack_conv_weight_halo_split_f32(const float* w_oihw, float* w_split, int cout, int cin, int cout_pad, const uint32_t* w_absmax,
-                                         void* stream);
+                                         int transpose /* 1: the backward-data weight (rows = cin, k = cout; cout_pad >= cin then) */, void* stream);
+/* ... of n weights in one launch: jobs [n][8] int64 = (w_oihw, w_split, rows, k, cout_pad, w_absmax, transpose, 0), rows / k = the
+ * GEMM's sides (cout, cin -- swapped when transpose). */
+int ccst_pack_conv_weights_halo_split_batch_f32(const int64_t* jobs_device, int njobs, void* stream);
 int ccst_conv3x3_halo_split_f32(const float* x, const uint32_t* x_absmax, const float* w_split, const uint32_t* w_absmax, const float* bias,
                                 float* y, uint32_t* y_absmax, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags,
                                 float* chan_sum_partials, void* stream);
@@ -222,6 +225,11 @@ int ccst_pack_conv_weights_wino_batch_f32(const int64_t* jobs_device, int njobs,
 int ccst_conv3x3_halo_train_f32(const float* x, const float* w_packed, float* y, float* stats, int N, int H, int W,
                                 int Cin, int Cout, int cout_pad, uint32_t flags, void* stream);
 int ccst_conv3x3_halo_stats_groups(int N, int H, int W);
+/* ... on half pieces (16-bit MFMA, fp32 accuracy; as ccst_conv3x3_halo_split_f32): x scaled by its |max| words -- an activation's from
+ * the BatchNorm apply that produced it, a gradient's from the BatchNorm backward (dx_absmax) --, w_split from
+ * ccst_pack_conv_weight_halo_split_f32 (transpose = 1 together with CCST_CONV_FLIP: backward-data).  Same flags and statistics. */
+int ccst_conv3x3_halo_train_split_f32(const float* x, const uint32_t* x_absmax, const float* w_split, const uint32_t* w_absmax, float* y,
+                                      float* stats, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags, void* stream);
 
 /* The tile code (WM WN NT as decimal digits: 222 = 128x128, 221 = 128x64, 412 = 256x64, 411 = 256x32; 1221 / 1222 =
  * 64x64 with a 16- / 32-channel k-step for grids that cannot fill the chip) ccst_conv2d_igemm_f32 dispatches for

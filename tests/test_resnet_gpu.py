@@ -190,6 +190,37 @@ def test_halo_train_form_vs_gather(dev, shape):
     assert float((acc2 - (base + dx_ref)).abs().max()) < 1e-5 * max(1.0, float(dx_ref.abs().max()))
 
 
+@pytest.mark.parametrize("shape", [(3, 28, 28, 128, 128), (2, 56, 56, 64, 64), (2, 14, 14, 256, 192), (1, 13, 19, 32, 48), (5, 7, 7, 512, 512)])
+@pytest.mark.parametrize("gscale", [1.0, 1e-7])
+def test_halo_train_form_on_half_pieces_vs_fp64(dev, shape, gscale):
+    """ccst_conv3x3_halo_train_split_f32 (the trunk's 3x3 stride-1 layers on the 16-bit MFMA): forward + BatchNorm statistics,
+    backward-data by flipped taps with the transposed half-piece image, and y += conv, against fp64 convolutions; the gradient
+    operand at 1 and at 1e-7 of the activations' magnitude."""
+    from ccst_amd import ops
+    N, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, H, W, Cin, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(dev)
+    dy = (torch.randn(N, H, W, Cout, generator=g) * gscale).to(dev)
+    base = (torch.randn(N, H, W, Cin, generator=g) * gscale).to(dev)
+    wmax = ops.absmax(w)
+    ph, pht = ops.pack_halo_split(w, wmax), ops.pack_halo_split(w, wmax, bwd=True)
+    y_ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
+    dx_ref = torch.nn.grad.conv2d_input((N, Cin, H, W), w.double(), dy.permute(0, 3, 1, 2).double(), padding=1).permute(0, 2, 3, 1)
+    y, st = ops.conv3x3_halo_train_split(x, ops.absmax(x), ph, wmax, want_stats=True)
+    assert float((y.double() - y_ref).abs().max()) < 4e-6 * float(y_ref.abs().max())
+    tot = st.double().sum(0)
+    ref_tot = torch.stack([y_ref.sum(dim=(0, 1, 2)), (y_ref * y_ref).sum(dim=(0, 1, 2))], dim=1)
+    assert float((tot - ref_tot).abs().max()) < 1e-4 * float(ref_tot.abs().max())
+    dmax = ops.absmax(dy)
+    dx = ops.conv3x3_halo_train_split(dy, dmax, pht, wmax, flip=True)
+    assert float((dx.double() - dx_ref).abs().max()) < 4e-6 * float(dx_ref.abs().max())
+    acc = base.clone()
+    out = ops.conv3x3_halo_train_split(dy, dmax, pht, wmax, flip=True, accumulate_into=acc)
+    assert out.data_ptr() == acc.data_ptr()
+    assert float((acc.double() - (base.double() + dx_ref)).abs().max()) < 4e-6 * float(dx_ref.abs().max()) + 1e-6 * float(base.abs().max())
+
+
 def test_pointwise_backward_data_masked_accumulate(dev):
     """ccst_conv2d_igemm_accum_masked_f32: y = mask ? y + dX : 0 (the residual-block input gradient, masked by the previous block's
     ReLU in the conv's own epilogue) against torch; the byte mask has the layout ccst_bn_train_fwd_mask_f32 writes."""
