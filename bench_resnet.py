@@ -135,9 +135,6 @@ def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False
     sync = sync or torch.cuda.synchronize
     auto_graph = graph == "auto"
     graph = False if auto_graph else bool(graph)
-    if graph and os.environ.get("CCST_GRAPH_SIDE", "1") == "0":       # single-stream capture
-        from ccst_amd import nn_ops
-        nn_ops.SIDE_STREAM = False
     distributed = world > 1 and dist.is_available() and dist.is_initialized()
     rank = dist.get_rank() if distributed else 0
     n_ranks_seen = dist.get_world_size() if distributed else 1

@@ -77,8 +77,6 @@ _SIGNATURES = {
     "ccst_conv3x3_wino_train_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_conv3x3_wino_stats_groups": [c_int, c_int, c_int],
     "ccst_pack_conv_weights_wino_batch_f32": [_P, c_int, _P],
-    "ccst_pack_conv_weight_wino4w_bwd_f32": [_P, _P, c_int, c_int, c_int, _P],
-    "ccst_pack_conv_weights_wino4w_batch_f32": [_P, c_int, _P],
     "ccst_conv3x3_halo_train_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_conv3x3_halo_stats_groups": [c_int, c_int, c_int],
     "ccst_conv2d_igemm_tile": [c_int, c_int, c_int, c_int, c_int],

@@ -695,8 +695,7 @@ static int halo_impl(const float* x, const float* w_packed, const float* bias, f
         // Cout <= 64 (the 512 x 512 layers): 256 pixels (16 x 16) x 64 channels per workgroup, a wave 64 pixels x 64 channels -- the same 12
         // MFMAs per wave and k-step as the 128x128 tile for a halo of 1.27 instead of 1.41 pixels per output pixel (the 128x64 tile has 6
         // MFMAs per wave for the same halo conversion work: 3.2 other vector instructions per MFMA, 0.50 MFMA-busy)
-        static const bool tall_ok = !(getenv("CCST_HALO_TALL") && getenv("CCST_HALO_TALL")[0] == '0');
-        if (tall_ok && Cout <= 64 && sums == nullptr && H >= 16)
+        if (Cout <= 64 && sums == nullptr && H >= 16)
             return pool ? launch_halo<4, 1, 2, true, false, true>(a, s) : launch_halo<4, 1, 2, false, false, true>(a, s);
         if (narrow) return pool ? launch_halo<2, 2, 1, true, false, true>(a, s) : launch_halo<2, 2, 1, false, false, true>(a, s);
         return pool ? launch_halo<2, 2, 2, true, false, true>(a, s) : launch_halo<2, 2, 2, false, false, true>(a, s);

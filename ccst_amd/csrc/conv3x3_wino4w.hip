@@ -757,13 +757,6 @@ __global__ void pack_weight_wino4w_kernel(const float* __restrict__ w, float* __
     pack_weight_wino4w_body(w, u, cout, cin, cin_pad, cout_pad, bwd);
 }
 
-// the same for many weight tensors in one launch: jobs[j] = {src, dst, n_out, n_in, n_in_pad16, n_out_pad64, bwd, 0} (int64, device)
-__global__ void pack_weight_wino4w_batch_kernel(const long long* __restrict__ jobs) {
-    const long long* jb = jobs + (long long)blockIdx.y * 8;
-    pack_weight_wino4w_body(reinterpret_cast<const float*>(jb[0]), reinterpret_cast<float*>(jb[1]), (int)jb[2], (int)jb[3], (int)jb[4],
-                            (int)jb[5], (int)jb[6]);
-}
-
 }  // namespace
 
 static int pack_wino4w_impl(const float* w_oihw, float* u, int cout, int cin, int cout_pad, int bwd, void* stream) {
@@ -783,22 +776,6 @@ extern "C" int ccst_pack_conv_weight_wino4w_f32(const float* w_oihw, float* u, i
     return pack_wino4w_impl(w_oihw, u, cout, cin, cout_pad, 0, stream);
 }
 
-// The backward-data operand of a stride-1 3x3 conv with forward weight w_oihw [cout][cin][3][3]: the transformed weights of the conv
-// dY -> dX (output channels = cin, input channels = cout; cin_pad a multiple of 64 >= cin).
-extern "C" int ccst_pack_conv_weight_wino4w_bwd_f32(const float* w_oihw, float* u, int cout, int cin, int cin_pad, void* stream) {
-    return pack_wino4w_impl(w_oihw, u, cin, cout, cin_pad, 1, stream);
-}
-
-// Many transforms in one launch (the per-step refresh after ccst_sgd_f32): jobs_device [njobs][8] int64 {src OIHW, dst, n_out, n_in,
-// n_in rounded up to 16, n_out rounded up to 64, bwd, 0}, (n_out, n_in) = channels of the conv the transform serves.
-extern "C" int ccst_pack_conv_weights_wino4w_batch_f32(const int64_t* jobs_device, int njobs, void* stream) {
-    CCST_REQUIRE(jobs_device && njobs > 0 && njobs <= 65535, "pack_wino4w_batch: bad job table");
-    hipLaunchKernelGGL(pack_weight_wino4w_batch_kernel, dim3(64, njobs), dim3(256), 0, (hipStream_t)stream, (const long long*)jobs_device);
-    return ccst_launch_status("pack_weight_wino4w_batch");
-}
-
-// x: NHWC source [N,Hs,Ws,Cin] (Hs = H/2 if CCST_CONV_UPS2), u: ccst_pack_conv_weight_wino4w_f32 output, y: NHWC [N,H,W,Cout] or
-// its 2x2 ceil-pooled form.  flags: CCST_CONV_RELU | POOL2 | UPS2 | REFLECT.
 extern "C" int ccst_wino4w_spatial_tiles(int N, int H, int W) { return N * ((H + THW - 1) / THW) * ((W + TWW - 1) / TWW); }
 
 extern "C" int ccst_conv3x3_wino4w_f32(const float* x, const float* u_packed, const float* bias, float* y, int N, int H, int W, int Cin,

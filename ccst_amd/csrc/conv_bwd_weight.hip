@@ -729,10 +729,7 @@ static void pick_tile_split(int cin, int cout, int* mi, int* nj) {
     *mi = cin >= 128 ? 2 : 1;
     *nj = cout >= 128 ? 2 : 1;
 }
-#ifndef BWW_PK
-#define BWW_PK 16
-#endif
-constexpr int SPLIT_PK = BWW_PK;
+constexpr int SPLIT_PK = 16;      // pixels per step (32 -- two K = 16 MFMA steps per barrier, 80 KB of LDS -- measured 10-25 % slower on the pointwise shapes)
 
 extern "C" int ccst_conv2d_bwd_weight_split_splits(int M, int cin, int cout, int ntap) {
     int mi, nj;

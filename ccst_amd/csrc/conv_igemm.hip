@@ -915,8 +915,7 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
 // Tile choice.  128x128 (222) is the most efficient tile (measured 129 TF vs 116 for 256x64 and 114 for
 // 128x64) but a launch only runs at that rate while every CU holds ~3 workgroups: with 768 resident
 // slots a grid of 784 workgroups costs two rounds.  Cost model: rounds(grid / 768 slots) x tile area /
-// relative tile efficiency; the cheapest candidate wins.  CCST_CONV_TILE=222|221|412|411 overrides
-// (tuning experiments only).  A 256x128 tile (MT=4, 2 waves/SIMD) and a 32-channel k-step (CK=32, 2
+// relative tile efficiency; the cheapest candidate wins.  A 256x128 tile (MT=4, 2 waves/SIMD) and a 32-channel k-step (CK=32, 2
 // workgroups/CU) were measured slower (92-115 / 112 TF) and are not dispatched.
 // Small problems (the 14x14 and 7x7 ResNet stages at B=64: M = 12544 / 3136) cannot fill 768 slots even with
 // 128x64 tiles; they run on 64x64 tiles (one MFMA tile per wave, code 1221) with a 32-channel k-step (1222) so a
@@ -939,11 +938,6 @@ static int choose_tile(int M, int cout, int cin, int taps, bool pool) {
         const double c222 = ceil(g222 / slots) * (128.0 * 128.0) / 1.00;
         const double c221 = ceil(g221 / slots) * (128.0 * 64.0) / 0.88;
         tile = (c221 < c222) ? 221 : 222;
-    }
-    if (const char* e = getenv("CCST_CONV_TILE")) {
-        const int t = atoi(e);
-        if (t == 222 || t == 221 || t == 412 || (t == 411 && !pool)) tile = t;
-        if ((t == 1221 || (t == 1222 && cin % 32 == 0)) && !pool) tile = t;
     }
     return tile;
 }
@@ -1167,12 +1161,11 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
         if (tile == 221) return launch_conv<2, 2, 1, true>(a, s);
         return launch_conv<2, 2, 2, true>(a, s);
     }
-    if (tile == 1221) return launch_conv<2, 2, 1, false, 1, 16>(a, s);      // 64x64, experiments (CCST_CONV_TILE)
+    if (tile == 1221) return launch_conv<2, 2, 1, false, 1, 16>(a, s);      // 64x64 (Cin not a multiple of 32)
     if (tile == 1222) return launch_conv<2, 2, 1, false, 1, 32>(a, s);      // 64x64, 32-channel k-step
     if (tile == 411) return launch_conv<4, 1, 1, false>(a, s);
     if (tile == 412) return launch_conv<4, 1, 2, false>(a, s);
     if (tile == 221) return launch_conv<2, 2, 1, false>(a, s);
-    if (getenv("CCST_CONV_CK32") && d->cin % 32 == 0) return launch_conv<2, 2, 2, false, 2, 32>(a, s);
     return launch_conv<2, 2, 2, false>(a, s);
 }
 

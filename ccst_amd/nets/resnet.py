@@ -84,16 +84,6 @@ class Conv2d(nn.Conv2d):
         return self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and \
             ops.wino_train_ok(H, W, self.in_channels, self.out_channels)
 
-    def wino4_ok(self, H, W):
-        return self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1) and \
-            ops.wino4w_train_ok(H, W, self.in_channels, self.out_channels)
-
-    def wino4_fwd(self):
-        return self._cached("w4", lambda w, prev: ops.pack_wino4w(w, out=None if prev is None else prev[0]))
-
-    def wino4_bwd(self):
-        return self._cached("w4t", lambda w, prev: ops.pack_wino4w(w, bwd=True, out=None if prev is None else prev[0]))
-
     def wino_fwd(self):
         return self._cached("wu", lambda w, prev: ops.pack_wino(w, out=None if prev is None else prev[0]))
 
@@ -112,10 +102,6 @@ class Conv2d(nn.Conv2d):
                 self.wino_fwd()
             if "_ccst_wut" in d:
                 self.wino_bwd()
-            if "_ccst_w4" in d:
-                self.wino4_fwd()
-            if "_ccst_w4t" in d:
-                self.wino4_bwd()
             if "_ccst_wmax" in d:         # the half-piece kernels scale the weight by these words: as current as the packs
                 self.wabsmax()
             if "_ccst_pkh" in d:          # (after the words: the pre-split packs are scaled by them)

@@ -14,9 +14,7 @@ from . import _lib, ops
 from ._lib import CcstConvDesc, check, ptr, stream_ptr
 
 _WS = {}
-# ReLU mask of BN backward: from the saved output (1) or recomputed from x when no residual was added (0)
 import os as _os
-BN_MASK_FROM_Y = _os.environ.get("CCST_BN_MASK_FROM_Y", "0") != "0"
 BN_BYTE_MASK = _os.environ.get("CCST_BN_BYTE_MASK", "1") != "0"      # ReLU mask of the residual BNs as bytes (0: read the saved output)
 
 
@@ -105,7 +103,7 @@ def _prepack_jobs(model, convs):
     (ccst_pack_conv_weights_batch_f32), the Winograd transforms (ccst_pack_conv_weights_wino_batch_f32), the weights' |max| words
     (ccst_absmax_batch_f32) and the pre-split half-piece packs scaled by them (ccst_pack_conv_weights_split_batch_f32).  Rebuilt only
     if a weight or a packed buffer moved (the key is the tuple of their addresses)."""
-    slots, wslots, w4slots, mslots, hslots, h3slots = [], [], [], [], [], []
+    slots, wslots, mslots, hslots, h3slots = [], [], [], [], []
     for m in convs:
         if m.in_channels <= 4:
             continue
@@ -119,10 +117,6 @@ def _prepack_jobs(model, convs):
             slot = m.__dict__.get(name)
             if slot is not None:
                 wslots.append((m, name, slot[1], bwd))
-        for name, bwd in (("_ccst_w4", 0), ("_ccst_w4t", 1)):
-            slot = m.__dict__.get(name)
-            if slot is not None:
-                w4slots.append((m, name, slot[1], bwd))
         for name, transpose in (("_ccst_pkh", 0), ("_ccst_pkht", 1)):
             slot = m.__dict__.get(name)
             if slot is not None:
@@ -132,27 +126,26 @@ def _prepack_jobs(model, convs):
             if slot is not None:
                 h3slots.append((m, name, slot[1], transpose))
     sig = tuple((m.weight.data_ptr(), pc.w.data_ptr()) for m, _n, pc, _t in slots) + \
-        tuple((m.weight.data_ptr(), pk[0].data_ptr()) for m, _n, pk, _b in wslots + w4slots) + tuple(("wmax", m.weight.data_ptr()) for m in mslots) + \
+        tuple((m.weight.data_ptr(), pk[0].data_ptr()) for m, _n, pk, _b in wslots) + tuple(("wmax", m.weight.data_ptr()) for m in mslots) + \
         tuple((m.weight.data_ptr(), t.data_ptr()) for m, _n, t, _t in hslots) + tuple((m.weight.data_ptr(), pk[0].data_ptr()) for m, _n, pk, _t in h3slots)
-    jobs = {"sig": sig, "table": None, "slots": slots, "wtable": None, "wslots": wslots, "w4table": None, "w4slots": w4slots, "mtable": None,
+    jobs = {"sig": sig, "table": None, "slots": slots, "wtable": None, "wslots": wslots, "mtable": None,
             "mwords": None, "mslots": mslots, "htable": None, "hslots": hslots, "h3table": None, "h3slots": h3slots}
-    if not slots and not wslots and not w4slots:
+    if not slots and not wslots:
         return jobs
     cached = model.__dict__.get("_ccst_prepack_jobs")
     if cached is not None and cached["sig"] == sig:
         return cached
-    dev = (slots or wslots or w4slots)[0][0].weight.device
+    dev = (slots or wslots)[0][0].weight.device
     if slots:
         rows = [[m.weight.data_ptr(), pc.w.data_ptr(), m.out_channels, m.in_channels, pc.kh * pc.kw, t, pc.k_pad, pc.n_pad]
                 for m, _n, pc, t in slots]
         jobs["table"] = torch.tensor(rows, dtype=torch.int64).to(dev)
-    for key, sl in (("wtable", wslots), ("w4table", w4slots)):
-        if sl:
-            rows = []
-            for m, _n, (u, pad, n_out), bwd in sl:
-                n_in = m.out_channels if bwd else m.in_channels
-                rows.append([m.weight.data_ptr(), u.data_ptr(), n_out, n_in, (n_in + 15) // 16 * 16, pad, bwd, 0])
-            jobs[key] = torch.tensor(rows, dtype=torch.int64).to(dev)
+    if wslots:
+        rows = []
+        for m, _n, (u, pad, n_out), bwd in wslots:
+            n_in = m.out_channels if bwd else m.in_channels
+            rows.append([m.weight.data_ptr(), u.data_ptr(), n_out, n_in, (n_in + 15) // 16 * 16, pad, bwd, 0])
+        jobs["wtable"] = torch.tensor(rows, dtype=torch.int64).to(dev)
     if mslots:      # one batched |max| launch over the pointwise weights, into one [n, ABSMAX_WORDS] block (zeroed per step)
         jobs["mtable"] = torch.tensor([[m.weight.data_ptr(), m.weight.numel()] for m in mslots], dtype=torch.int64).to(dev)
         jobs["mwords"] = torch.zeros((len(mslots), ops.ABSMAX_WORDS), device=dev, dtype=torch.int32)
@@ -185,7 +178,7 @@ def prepack_on_side(model):
         return
     device = convs[0].weight.device
     j = _prepack_jobs(model, convs)
-    if j["table"] is None and j["wtable"] is None and j["w4table"] is None:
+    if j["table"] is None and j["wtable"] is None:
         return
 
     def launch():
@@ -194,8 +187,6 @@ def prepack_on_side(model):
             check(lib.ccst_pack_conv_weights_batch_f32(ptr(j["table"]), len(j["slots"]), stream_ptr()), "pack_weights_batch")
         if j["wtable"] is not None:
             check(lib.ccst_pack_conv_weights_wino_batch_f32(ptr(j["wtable"]), len(j["wslots"]), stream_ptr()), "pack_weights_wino_batch")
-        if j["w4table"] is not None:
-            check(lib.ccst_pack_conv_weights_wino4w_batch_f32(ptr(j["w4table"]), len(j["w4slots"]), stream_ptr()), "pack_weights_wino4w_batch")
         if j["mtable"] is not None:
             check(lib.ccst_fill_f32(ptr(j["mwords"]), 0.0, j["mwords"].numel(), stream_ptr()), "zero weight |max| words")
             check(lib.ccst_absmax_batch_f32(ptr(j["mtable"]), len(j["mslots"]), ptr(j["mwords"]), stream_ptr()), "absmax_batch")
@@ -211,7 +202,7 @@ def prepack_on_side(model):
         _PREPACK_PENDING.add(device.index)
     else:
         launch()
-    for m, name, pk, _t in j["slots"] + j["wslots"] + j["w4slots"] + j["hslots"] + j["h3slots"]:       # the packed copies now match the weights of this epoch
+    for m, name, pk, _t in j["slots"] + j["wslots"] + j["hslots"] + j["h3slots"]:       # the packed copies now match the weights of this epoch
         w = m.weight
         m.__dict__[name] = ((w._version, w.data_ptr(), ops.WEIGHTS_EPOCH), pk)
     for i, m in enumerate(j["mslots"]):
@@ -440,20 +431,17 @@ class ConvFn(torch.autograd.Function):
         ctx.want_stats = bool(want_stats)
         ctx.xmax = ops.tagged_absmax(x) if HALF_BWD else None      # for the half-piece weight gradient
         ctx.set_materialize_grads(False)       # no zero tensor for the non-differentiable stats output
-        ctx.wino4 = mod.wino4_ok(x.shape[1], x.shape[2])       # 64-channel F(4x4): the trunk's 56x56 and 28x28 maps
         ctx.wino = mod.wino_ok(x.shape[1], x.shape[2])
         ctx.half3 = HALF3X3 >= 1 and mod.halo_split_ok()         # 3x3 stride 1: backward-data (and with 2 the forward) on half pieces
         fwd_half3 = ctx.half3 and HALF3X3 >= 2 and ctx.xmax is not None
-        pc = None if (ctx.wino4 or ctx.wino or fwd_half3) else mod.packed()      # (the direct layout is packed only where it is used)
+        pc = None if (ctx.wino or fwd_half3) else mod.packed()      # (the direct layout is packed only where it is used)
         if fwd_half3:
             out = ops.conv3x3_halo_train_split(x, ctx.xmax, mod.halo_h(), mod.wabsmax(), want_stats=bool(want_stats))
             if want_stats:
                 ctx.mark_non_differentiable(out[1])
             return out
         if want_stats:      # BN batch statistics from the conv epilogue (non-differentiable side output)
-            if ctx.wino4:
-                y, stats = ops.conv3x3_wino4w_train(x, mod.wino4_fwd(), want_stats=True)
-            elif ctx.wino:
+            if ctx.wino:
                 y, stats = ops.conv3x3_wino_train(x, mod.wino_fwd(), want_stats=True)
             else:
                 # pointwise convs: half pieces on the 16-bit MFMA where the producer of x (a BatchNorm apply) left its |max| words and
@@ -464,8 +452,6 @@ class ConvFn(torch.autograd.Function):
                                            w_split=mod.packed_h() if xmax is not None else None)
             ctx.mark_non_differentiable(stats)
             return y, stats
-        if ctx.wino4:
-            return ops.conv3x3_wino4w_train(x, mod.wino4_fwd())
         if ctx.wino:
             return ops.conv3x3_wino_train(x, mod.wino_fwd())
         return ops.conv2d_nhwc(x, pc, stride=mod.stride[0], pad=mod.padding[0])
@@ -498,8 +484,6 @@ class ConvFn(torch.autograd.Function):
                     deposit = True
             if ctx.half3 and dymax is not None:     # 3x3 stride 1: the half-piece halo kernel with the transposed image, taps flipped
                 dx = ops.conv3x3_halo_train_split(dy, dymax, mod.halo_ht(), mod.wabsmax(), flip=True, accumulate_into=into)
-            elif ctx.wino4 and into is None:          # (y += lives in the F(2x2) kernel only)
-                dx = ops.conv3x3_wino4w_train(dy, mod.wino4_bwd(), tag="bwd_data:")
             elif ctx.wino:
                 dx = ops.conv3x3_wino_train(dy, mod.wino_bwd(), accumulate_into=into, tag="bwd_data:")
             else:
@@ -617,11 +601,11 @@ class BNFn(torch.autograd.Function):
                   "bn_train_fwd")
             if ymax is not None:
                 ops.tag_absmax(y, ymax)
-            keep_y = ctx.relu and mask is None and (ctx.has_res or BN_MASK_FROM_Y)
+            keep_y = ctx.relu and mask is None and ctx.has_res
             ctx.save_for_backward(x, y if keep_y else None, mask, gamma, beta, save)
             if mask is not None and MASK_LINK:
                 ctx.link = mod._ccst_mask_link = MaskLink(mask, x, save)
-            elif ctx.relu and not ctx.has_res and MASK_LINK and not BN_MASK_FROM_Y:
+            elif ctx.relu and not ctx.has_res and MASK_LINK:
                 ctx.link = mod._ccst_mask_link = MaskLink(None, x, save, gamma, beta)
             else:
                 ctx.link = mod._ccst_mask_link = None

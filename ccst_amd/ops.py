@@ -34,7 +34,7 @@ USE_HALO = os.environ.get("CCST_CONV_HALO", "1") != "0"
 # the same step time (ResNet50 2837 vs 2839 img/s, ResNet18 within noise) -- short K loops and tile waste eat the
 # advantage -- so the gather kernel stays the default; CCST_CONV_HALO_ZERO=1 switches.
 HALO_ZERO_PAD = os.environ.get("CCST_CONV_HALO_ZERO", "0") != "0"
-HALO_MIN_COVER = float(os.environ.get("CCST_CONV_HALO_COVER", "0.7"))
+HALO_MIN_COVER = 0.7
 
 
 def halo_train_ok(H, W, cin, cout):
@@ -46,7 +46,7 @@ def halo_train_ok(H, W, cin, cout):
 # ResNet trunk: 3x3 stride-1 convs (forward with BN statistics, backward-data) on the Winograd kernel when its 8x16-pixel tiles
 # cover the map well enough; CCST_RESNET_WINO=0 keeps the gather kernel.
 RESNET_WINO = os.environ.get("CCST_RESNET_WINO", "1") != "0"
-RESNET_WINO_COVER = float(os.environ.get("CCST_RESNET_WINO_COVER", "0.7"))
+RESNET_WINO_COVER = 0.7
 
 
 def wino_train_ok(H, W, cin, cout):
@@ -93,58 +93,6 @@ def conv3x3_wino_train(x, packed, want_stats=False, accumulate_into=None, tag=""
         check(lib.ccst_conv3x3_wino_train_f32(*args), "conv3x3_wino_train")
         e1.record()
         TIMING.append((tag + "conv3x3_wino_kernel<train>", 2.0 * N * H * W * cout * Cx * 9, e0, e1,
-                       "n%d %dx%d cin%d cout%d taps3x3 s1" % (N, H, W, Cx, cout)))
-    return (y, stats) if want_stats else y
-
-
-# F(4x4) with 64 output channels per workgroup under the ResNet trunk's large maps: OPT-IN.  Alone it beats the F(2x2) kernel on the
-# 56x56 and 28x28 layers (115 -> 90 us, 111 -> 72 us per B=64 layer; from 14x14 down its 16x32-pixel tiles are mostly padding and too
-# few to fill the chip), but in the train step it gains 0.7 % (19.12 vs 19.25 ms on one box): its one workgroup per CU holds 148 KB of LDS,
-# so the weight-gradient stream's kernels cannot share those CUs while it runs; and F(4x4)'s rounding (~20x that of F(2x2)) carried
-# through eight layers puts the ResNet18 fixture's gradient probes at 1.2e-3 of the tensor's largest gradient, outside the 1e-3 gate.
-RESNET_WINO4 = os.environ.get("CCST_RESNET_WINO4", "0") == "1"
-
-
-def wino4w_train_ok(H, W, cin, cout):
-    return RESNET_WINO4 and cin % 16 == 0 and cin >= 32 and cout % 16 == 0 and cout >= 32 and H >= 28 and W >= 28
-
-
-def pack_wino4w(w_oihw, bwd=False, out=None):
-    """F(4x4) transformed copy of a 3x3 OIHW weight for conv3x3_wino4w.hip: (u, cout_pad, cout) of the forward conv, or with bwd=True
-    of the backward-data conv dY -> dX (its `cout` is the forward Cin)."""
-    cout, cin = w_oihw.shape[0], w_oihw.shape[1]
-    lib = _lib.load()
-    n_out, n_in = (cin, cout) if bwd else (cout, cin)
-    pad = round_up(n_out, 64)
-    nfl = int(lib.ccst_wino4_weight_floats(n_in, pad))
-    u = out if out is not None and out.numel() == nfl else torch.empty(nfl, device=w_oihw.device, dtype=torch.float32)
-    w = w_oihw.contiguous()
-    if bwd:
-        check(lib.ccst_pack_conv_weight_wino4w_bwd_f32(ptr(w), ptr(u), cout, cin, pad, stream_ptr()), "pack_wino4w_bwd")
-    else:
-        check(lib.ccst_pack_conv_weight_wino4w_f32(ptr(w), ptr(u), cout, cin, pad, stream_ptr()), "pack_wino4w")
-    return u, pad, n_out
-
-
-def conv3x3_wino4w_train(x, packed, want_stats=False, tag=""):
-    """3x3 stride-1 zero-padded bias-free conv on the 64-channel F(4x4) kernel (ResNet trunk, large maps).  packed = pack_wino4w(...);
-    the statistics are per-tile (sum, sum^2) partials [tiles, cout, 2] like every other producer of BatchNorm statistics."""
-    u, pad, cout = packed
-    N, H, W, Cx = x.shape
-    lib = _lib.load()
-    y = torch.empty((N, H, W, cout), device=x.device, dtype=torch.float32)
-    stats = None
-    if want_stats:
-        stats = torch.empty((int(lib.ccst_wino4w_spatial_tiles(N, H, W)), cout, 2), device=x.device, dtype=torch.float32)
-    args = (ptr(x), ptr(u), None, ptr(y), N, H, W, Cx, cout, pad, 0, ptr(stats), stream_ptr())
-    if TIMING is None:
-        check(lib.ccst_conv3x3_wino4w_f32(*args), "conv3x3_wino4w_train")
-    else:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(lib.ccst_conv3x3_wino4w_f32(*args), "conv3x3_wino4w_train")
-        e1.record()
-        TIMING.append((tag + "conv3x3_wino4w_kernel<train>", 2.0 * N * H * W * cout * Cx * 9, e0, e1,
                        "n%d %dx%d cin%d cout%d taps3x3 s1" % (N, H, W, Cx, cout)))
     return (y, stats) if want_stats else y
 
@@ -492,7 +440,7 @@ def halo_split_wanted(pc):
 # of the chip; the others stay on the direct kernel.  CCST_CONV_F23=0: direct everywhere.
 F23 = os.environ.get("CCST_CONV_F23", "1") != "0"
 F23_MIN_FILL = float(os.environ.get("CCST_F23_MIN_FILL", "0.5"))
-F23_MIN_COUT = int(os.environ.get("CCST_F23_MIN_COUT", "128"))
+F23_MIN_COUT = 128      # (the Cout = 64 layers padded to its 128-channel tile measured slower than the direct half-piece kernel)
 F23_FORCE = os.environ.get("CCST_CONV_F23", "1") == "2"       # every Cout >= 128 layer whatever its grid (tests: small images)
 _N_CU = {}
 

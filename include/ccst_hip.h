@@ -197,14 +197,6 @@ int ccst_conv3x3_wino4w_f32(const float* x, const float* u_packed, const float* 
  * mean_std_computation_effcientMem.py:103-115, without a pass over the tensor; ccst_chan_sums_finalize_f32 folds K such pairs
  * [K][C][2] into the [C] totals in fp64 (fixed order: bitwise reproducible). */
 int ccst_wino4w_spatial_tiles(int N, int H, int W);
-/* The same kernel under the ResNet trunk's 3x3 stride-1 zero-padded bias-free convs where the feature map is at least 28x28
- * (nets/resnet.py:160-161 via the torchvision blocks): forward = ccst_conv3x3_wino4w_f32 with flags 0, bias NULL and the partials as
- * the following BatchNorm2d's statistics; backward-data = the same call on dY with the weights of ccst_pack_conv_weight_wino4w_bwd_f32
- * (channels swapped, taps reversed; cin_pad a multiple of 64).  ccst_pack_conv_weights_wino4w_batch_f32 refreshes many transforms in
- * one launch after an optimiser step: jobs_device [njobs][8] int64 {src OIHW, dst, n_out, n_in, n_in rounded up to 16, n_out rounded
- * up to 64, bwd, 0}. */
-int ccst_pack_conv_weight_wino4w_bwd_f32(const float* w_oihw, float* u, int cout, int cin, int cin_pad, void* stream);
-int ccst_pack_conv_weights_wino4w_batch_f32(const int64_t* jobs_device, int njobs, void* stream);
 int ccst_chan_sums_finalize_f32(const float* partials, int partial_floats /* 2: (sum, sum^2) pairs; 4: (sum, M2, count, 0), see
                                 ccst_conv3x3_halo_split_f32 */, int K, int C, float* sum, float* sqsum, void* stream);
 /* The Winograd kernel for the ResNet trunk's 3x3 stride-1 zero-padded bias-free convs (forward with the BatchNorm statistics

@@ -9,8 +9,28 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def host_cores():
+    """CPU cores this process may actually use: min(affinity, cgroup quota).  The GPU boxes expose 256 logical CPUs under a 16-core
+    quota; torch CPU threads sized by the affinity alone (the oracle legs of the GPU tests) run ~5x slower there than 16 threads do."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_threads_match_the_cpu_quota():
+    import torch
+    torch.set_num_threads(host_cores())
 
 
 @pytest.fixture(scope="session")

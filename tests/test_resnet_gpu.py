@@ -489,7 +489,7 @@ def test_resnet50_full_size_step_vs_oracle(dev):
     from ccst_amd import fed
     from ccst_amd.nets import models
     from oracle import resnet_ref as R
-    torch.set_num_threads(max(1, len(__import__("os").sched_getaffinity(0))))
+    torch.set_num_threads(__import__("conftest").host_cores())
     classes, nb, lr = 7, 64, 0.001
     oracle = R.resnet50(classes)
     sd = R.seeded_state_dict(oracle, 77, residual_gamma=0.25, fc_gain=8.0)
@@ -957,39 +957,6 @@ def test_wino_train_form_vs_gather(dev, shape):
     assert float((acc - (base + dx_ref)).abs().max()) < 3e-5 * max(1.0, float(dx_ref.abs().max()))
 
 
-@pytest.mark.parametrize("shape", [(3, 28, 28, 128, 128), (2, 56, 56, 64, 64), (2, 30, 45, 64, 192), (1, 33, 19, 32, 48)])
-def test_wino4w_train_form_vs_gather(dev, shape):
-    """The 64-channel F(4x4) kernel under the trunk's large maps (ops.conv3x3_wino4w_train): forward + BatchNorm statistics partials,
-    backward-data through the swapped / reversed weight transform, against the gather kernel; and the batched re-pack of both
-    transforms (ccst_pack_conv_weights_wino4w_batch_f32) against the single packs, bit for bit."""
-    from ccst_amd import _lib, nn_ops, ops
-    from ccst_amd._lib import check, ptr, stream_ptr
-    N, H, W, Cin, Cout = shape
-    g = torch.Generator().manual_seed(16)
-    x = torch.randn(N, H, W, Cin, generator=g).to(dev)
-    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(dev)
-    dy = torch.randn(N, H, W, Cout, generator=g).to(dev)
-    pc, pct = ops.pack_conv_weight(w), ops.pack_conv_weight(w, transpose=True)
-    y_ref, st_ref = ops.conv2d_nhwc(x, pc, stride=1, pad=1, want_stats=True)
-    dx_ref = nn_ops.conv_bwd_data(dy, pct, (N, H, W, Cin), 1, 1)
-    pf, pb = ops.pack_wino4w(w), ops.pack_wino4w(w, bwd=True)
-    y, st = ops.conv3x3_wino4w_train(x, pf, want_stats=True)
-    assert tuple(y.shape) == (N, H, W, Cout)
-    assert float((y - y_ref).abs().max()) < 2e-4 * max(1.0, float(y_ref.abs().max()))     # F(4x4): ~20x the rounding of F(2x2)
-    tot, tot_ref = st.double().sum(0), st_ref.double().sum(0)
-    assert float((tot - tot_ref).abs().max()) < 1e-4 * float(tot_ref.abs().max())
-    assert torch.equal(ops.conv3x3_wino4w_train(x, pf), y)                                  # the same numbers without the statistics
-    dx = ops.conv3x3_wino4w_train(dy, pb)
-    assert tuple(dx.shape) == (N, H, W, Cin)
-    assert float((dx - dx_ref).abs().max()) < 2e-4 * max(1.0, float(dx_ref.abs().max()))
-    uf, ub = torch.zeros_like(pf[0]), torch.zeros_like(pb[0])
-    rows = [[w.data_ptr(), uf.data_ptr(), Cout, Cin, (Cin + 15) // 16 * 16, pf[1], 0, 0],
-            [w.data_ptr(), ub.data_ptr(), Cin, Cout, (Cout + 15) // 16 * 16, pb[1], 1, 0]]
-    table = torch.tensor(rows, dtype=torch.int64).to(dev)
-    check(_lib.load().ccst_pack_conv_weights_wino4w_batch_f32(ptr(table), 2, stream_ptr()), "batch")
-    assert torch.equal(uf, pf[0]) and torch.equal(ub, pb[0])
-
-
 @pytest.mark.parametrize("cfg", [
     # N, H, W, Cin, Cout, k, stride          (tiles: 128x128, 64x128, 128x64, 64x64; ragged M, Cin / Cout that do not fill a tile)
     (3, 14, 14, 256, 128, 3, 1), (2, 28, 28, 64, 256, 1, 1), (2, 28, 28, 256, 64, 1, 1), (2, 30, 26, 64, 64, 3, 1),
@@ -1115,7 +1082,7 @@ def test_reference_initialisation_within_twice_the_references_own_rounding(dev, 
     from ccst_amd import fed
     from ccst_amd.nets import models
     from oracle import resnet_ref as R
-    torch.set_num_threads(max(1, len(__import__("os").sched_getaffinity(0))))
+    torch.set_num_threads(__import__("conftest").host_cores())
     classes, nb = 7, 8
     torch.manual_seed(5)
     oracle = R.resnet18(classes) if arch == "resnet18" else R.resnet50(classes)      # the reference's initialisation

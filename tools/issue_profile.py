@@ -1,4 +1,4 @@
-"""Host-side cost of issuing the ResNet train step: cProfile over 10 steps (no sync inside).  python tools/issue_profile.py"""
+"""Where the HOST time of a ResNet train step goes: cProfile over a few eager steps (python tools/issue_profile.py [arch] [batch])."""
 import cProfile
 import os
 import pstats
@@ -11,12 +11,12 @@ arch = sys.argv[1] if len(sys.argv) > 1 else "resnet50"
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 model, opt, loss_fun, x, y = B.build(dev, arch=arch, batch=batch, seed=1)
 step = B.make_step(model, opt, loss_fun, x, y)
-for _ in range(3):
+for _ in range(4):
     step()
 torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
-for _ in range(10):
+for _ in range(8):
     step()
 pr.disable()
 torch.cuda.synchronize()
