@@ -375,6 +375,20 @@ def _axpy(dst, src, w):
     check(_lib.load().ccst_sgd_f32(ptr(dst), ptr(src), -float(w), dst.numel(), stream_ptr()), "axpy")
 
 
+def _copy_counters(server_model, client0):
+    """server.num_batches_tracked <- client 0's, for every BatchNorm (fed_run.py:404-405): one copy of the int64 counter arena where both
+    models keep one (nets/resnet.ResNet.counter_arena), else key by key."""
+    sa = server_model.counter_arena() if hasattr(server_model, "counter_arena") else None
+    ca = client0.counter_arena() if hasattr(client0, "counter_arena") else None
+    if sa is not None and ca is not None and sa.numel() == ca.numel() and sa.device == ca.device:
+        sa.copy_(ca)
+        return
+    ssd, c0 = server_model.state_dict(), client0.state_dict()
+    for key in ssd.keys():
+        if 'num_batches_tracked' in key:
+            ssd[key].data.copy_(c0[key])
+
+
 def communication(args, server_model, models, client_weights):
     """fed_run.py:385-455, the branch every non-'fedbn' mode takes (:400-414): for each state key,
     'num_batches_tracked' -> server takes client 0's value (clients keep theirs); otherwise
@@ -416,10 +430,7 @@ def communication(args, server_model, models, client_weights):
             for ci in range(len(client_weights)):
                 clients[ci].flat.copy_(srv.flat)                  # device-to-device memcpy
         ops.bump_weights_epoch()
-        ssd, c0 = server_model.state_dict(), models[0].state_dict()
-        for key in ssd.keys():
-            if 'num_batches_tracked' in key:
-                ssd[key].data.copy_(c0[key])
+        _copy_counters(server_model, models[0])
     return server_model, models
 
 

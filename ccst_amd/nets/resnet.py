@@ -337,18 +337,25 @@ class ResNet(nn.Module):
     def is_patch_based(self):
         return False
 
-    def _bump_counters(self):
-        # BatchNorm2d.num_batches_tracked += 1 for every BN: the int64 counters are re-homed into one small arena (as FlatParams
-        # does for the fp32 state) and bumped by ONE HIP launch
+    def counter_arena(self):
+        """Every BatchNorm2d.num_batches_tracked of the model as ONE int64 tensor (module order): the counters are re-homed into a small
+        arena (as FlatParams does for the fp32 state), so that a train step bumps them with one launch and communication() copies
+        them with one.  None if the model tracks none."""
         arena = self.__dict__.get("_ccst_nbt")
         cs = [m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None]
         if not cs:
-            return
+            return None
         if arena is None or arena.device != cs[0].device or any(c.data_ptr() != arena.data_ptr() + 8 * i for i, c in enumerate(cs)):
             arena = torch.stack([c.detach().reshape(()) for c in cs]).to(torch.int64).contiguous()
             for i, c in enumerate(cs):
                 c.data = arena[i]
             self.__dict__["_ccst_nbt"] = arena
+        return arena
+
+    def _bump_counters(self):
+        arena = self.counter_arena()
+        if arena is None:
+            return
         from .._lib import check, load, ptr, stream_ptr
         check(load().ccst_add_i64(ptr(arena), 1, arena.numel(), stream_ptr()), "bump num_batches_tracked")
 
