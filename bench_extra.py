@@ -115,8 +115,7 @@ def single_mode(dev, vgg31, dec, A, world, rank, steps=4, warmup=1, batch=32, si
 
 def eval_forward(dev, world, rank, steps=12, warmup=3, batch=64, size=222, arch="resnet50", classes=7):
     """a12: test() (fed_run.py:214-259) -- the eval-mode forward (BatchNorm on running statistics), cross-entropy and accuracy of one
-    batch, data resident.  MFMA-bound like the train step's forward: 8.17 GFLOP per image, against the fp32
-    MFMA (the eval forward runs on it: the half-piece pointwise form needs the |max| words only the training BatchNorm applies leave)."""
+    batch, data resident.  MFMA-bound like the train step's forward: 8.17 GFLOP per image."""
     import types
     import torch.distributed as dist
     from ccst_amd import fed
@@ -143,7 +142,9 @@ def eval_forward(dev, world, rank, steps=12, warmup=3, batch=64, size=222, arch=
             "config": {"workload": "fed_run.py test() body: eval-mode forward + CrossEntropy + accuracy, %s classes=%d" % (arch, classes)},
             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
                          "gflop_per_step": round(gflop, 1), "traffic": None,
-                         "note": "forward convs + FC on the fp32 MFMA (8.17 GFLOP per image at 222x222); BatchNorm (eval) applies are HBM passes on top"}}
+                         "note": "8.17 GFLOP per image at 222x222 against the fp32-MFMA peak (SURVEY 8d's bound); the pointwise convs run on half "
+                                 "pieces on the 16-bit MFMA (the eval BatchNorm applies leave the |max| words too), the 3x3 convs on fp32 F(2x2) "
+                                 "Winograd; BatchNorm (eval) applies are HBM passes on top"}}
 
 
 def communication_inprocess(dev, K=3, reps=10, arch="resnet50", classes=7):
@@ -164,22 +165,38 @@ def communication_inprocess(dev, K=3, reps=10, arch="resnet50", classes=7):
     fed.communication(args, server, clients, weights)          # builds the flat arenas
     torch.cuda.synchronize()
     n = int(fed.FlatParams.of(server).n_total)
-    ts = []
+    walls = []
     for _ in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         h0 = time.perf_counter()
-        e0.record()
         fed.communication(args, server, clients, weights)
+        torch.cuda.synchronize()
+        walls.append((time.perf_counter() - h0) * 1e6)
+    walls.sort()
+    # the pass over the arenas alone (what communication() launches), HIP events around the launch
+    import ctypes
+    from ccst_amd import _lib
+    from ccst_amd._lib import check, ptr, stream_ptr
+    srv = fed.FlatParams.of(server)
+    arenas = [fed.FlatParams.of(m) for m in clients]
+    cl = (ctypes.c_void_p * K)(*[a.flat.data_ptr() for a in arenas])
+    cw = (ctypes.c_float * K)(*weights)
+    ts = []
+    for _ in range(reps + 2):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().ccst_fedavg_f32(ptr(srv.flat), cl, cw, K, n, stream_ptr()), "fedavg")
         e1.record()
         torch.cuda.synchronize()
-        ts.append((e0.elapsed_time(e1) * 1e3, (time.perf_counter() - h0) * 1e6))
-    ts.sort()
-    dev_us, wall_us = ts[len(ts) // 2]
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts = sorted(ts[2:])
+    dev_us, wall_us = ts[len(ts) // 2], walls[len(walls) // 2]
     nbytes = (2 * K + 1) * n * 4
-    return {"metric": "communication() fedavg, K=%d %s clients on one GPU" % (K, arch), "value": round(dev_us, 1), "unit": "us per call (device)",
-            "higher_is_better": False, "n_gpus": 1, "wall_us_per_call": round(wall_us, 1), "state_floats": n,
+    return {"metric": "communication() fedavg, K=%d %s clients on one GPU" % (K, arch), "value": round(wall_us, 1), "unit": "us per call (wall)",
+            "higher_is_better": False, "n_gpus": 1, "kernel_us": round(dev_us, 1), "state_floats": n,
             "config": {"workload": "fed_run.py communication(), --mode fedavg, %d clients + server in one process" % K},
+            "note": "the wall figure is host work: four arena validity checks (every tensor's address), the side-stream join, one int64 "
+                    "counter-arena copy -- once per federated round, next to an epoch of training",
             "roofline": {"bound": "hbm", "bytes": nbytes, "achieved": round(nbytes / dev_us / 1e3, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                          "frac": round(nbytes / dev_us / 1e3 / PEAK_HBM_GBPS, 4), "traffic": None,
-                         "kernel": "fedavg_kernel (ccst_fedavg_f32): K reads + K + 1 writes per element in one pass; the 53 int64 counters are "
-                                   "copied by the host loop over the state dict (the wall figure includes it)"}}
+                         "kernel": "fedavg_kernel (ccst_fedavg_f32): K reads + K + 1 writes per element in one pass (the reference: a Python "
+                                   "loop over 320 keys x K clients on the CPU)"}}

@@ -105,7 +105,7 @@ _SIGNATURES = {
     "ccst_chan_sums_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _P],
     "ccst_stats_workspace_bytes": [c_int, c_int, c_int],
     "ccst_bn_train_fwd_f32": [_P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P, _P, _P, c_int64, c_int, _P, c_int, _P, c_int64, _P],
-    "ccst_bn_eval_fwd_f32": [_P, _P, _P, _P, _P, c_float, _P, c_int, _P, c_int64, c_int, _P],
+    "ccst_bn_eval_fwd_f32": [_P, _P, _P, _P, _P, c_float, _P, c_int, _P, c_int64, c_int, _P, _P],
     "ccst_bn_train_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int64, c_int, _P, c_int64, _P],
     "ccst_bn_train_fwd_mask_f32": [_P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P, c_int64, _P, _P],
     "ccst_bn_train_bwd_mask_f32": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int64, c_int, _P, c_int64, _P, _P],

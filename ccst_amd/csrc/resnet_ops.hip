@@ -840,12 +840,12 @@ extern "C" int ccst_bn_train_fwd_f32(const float* x, const float* gamma, const f
 
 extern "C" int ccst_bn_eval_fwd_f32(const float* x, const float* gamma, const float* beta, const float* running_mean,
                                     const float* running_var, float eps, const float* residual, int relu, float* y, int64_t M, int C,
-                                    void* stream) {
+                                    uint32_t* y_absmax, void* stream) {
     CCST_REQUIRE(x && gamma && beta && running_mean && running_var && y, "bn_eval_fwd: null pointer");
     CCST_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_eval_fwd: need M>0 and C %% 4 == 0");
     const long long total4 = (long long)M * (C / 4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_grid(total4, C, BN_UNROLL)), dim3(TPB), 0, (hipStream_t)stream, x, nullptr, nullptr, gamma, beta,
-                       running_mean, running_var, eps, residual, relu, y, total4, C);
+                       running_mean, running_var, eps, residual, relu, y, total4, C, nullptr, y_absmax);
     return ccst_launch_status("bn_eval_fwd");
 }
 

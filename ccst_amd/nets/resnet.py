@@ -143,7 +143,7 @@ class Conv2d(nn.Conv2d):
             # (the |max| words a BatchNorm apply left for x travel with the NHWC view: the half-piece pointwise forward scales by them)
             y, stats = nn_ops.ConvFn.apply(ops.carry_absmax(x, _to_nhwc(x)), self.weight, self, True, sink, link)
             return ops.to_api(y), stats
-        return ops.to_api(nn_ops.ConvFn.apply(_to_nhwc(x), self.weight, self, False, sink, link))
+        return ops.to_api(nn_ops.ConvFn.apply(ops.carry_absmax(x, _to_nhwc(x)), self.weight, self, False, sink, link))
 
 
 class BatchNorm2d(nn.BatchNorm2d):
@@ -217,7 +217,8 @@ class MaxPool2d(nn.MaxPool2d):
     def forward(self, x):
         if (self.kernel_size, self.stride, self.padding, self.ceil_mode) != (3, 2, 1, False):
             raise NotImplementedError("ccst_amd.nets: only MaxPool2d(3, 2, 1) (nets/resnet.py:140)")
-        return ops.to_api(nn_ops.MaxPool3s2Fn.apply(_to_nhwc(x)))
+        y = nn_ops.MaxPool3s2Fn.apply(ops.carry_absmax(x, _to_nhwc(x)))
+        return ops.carry_absmax(y, ops.to_api(y))
 
 
 class AvgPool2d(nn.AvgPool2d):

@@ -454,7 +454,9 @@ class ConvFn(torch.autograd.Function):
             return y, stats
         if ctx.wino:
             return ops.conv3x3_wino_train(x, mod.wino_fwd())
-        return ops.conv2d_nhwc(x, pc, stride=mod.stride[0], pad=mod.padding[0])
+        xmax = ops.tagged_absmax(x) if (HALF_FWD and mod.kernel_size == (1, 1)) else None      # (the eval forward: same half-piece form, no statistics)
+        return ops.conv2d_nhwc(x, pc, stride=mod.stride[0], pad=mod.padding[0], x_absmax=xmax,
+                               w_absmax=mod.wabsmax() if xmax is not None else None, w_split=mod.packed_h() if xmax is not None else None)
 
     @staticmethod
     def backward(ctx, dy, *unused):
@@ -610,8 +612,11 @@ class BNFn(torch.autograd.Function):
             else:
                 ctx.link = mod._ccst_mask_link = None
         else:
+            ymax = ops.absmax_words(x.device) if HALF_FWD else None       # (the eval forward's pointwise convs run on half pieces too)
             check(lib.ccst_bn_eval_fwd_f32(ptr(x), ptr(gamma), ptr(beta), ptr(mod.running_mean), ptr(mod.running_var),
-                                           float(mod.eps), ptr(residual), int(relu), ptr(y), M, C, stream_ptr()), "bn_eval_fwd")
+                                           float(mod.eps), ptr(residual), int(relu), ptr(y), M, C, ptr(ymax), stream_ptr()), "bn_eval_fwd")
+            if ymax is not None:
+                ops.tag_absmax(y, ymax)
             ctx.save_for_backward()
             ctx.eval_mode = True
         return y
@@ -709,6 +714,7 @@ class MaxPool3s2Fn(torch.autograd.Function):
         check(_lib.load().ccst_maxpool3s2_fwd_f32(ptr(x), ptr(y), ptr(idx), N, H, W, C, Ho, Wo, stream_ptr()), "maxpool_fwd")
         ctx.save_for_backward(idx)
         ctx.shape = (N, H, W, C, Ho, Wo)
+        ops.carry_absmax(x, y)              # max |pooled| <= max |x|: the producer's words stay a valid bound
         return y
 
     @staticmethod

@@ -391,7 +391,8 @@ int ccst_bn_train_fwd_f32(const float* x, const float* gamma, const float* beta,
 /* BatchNorm2d eval forward with running stats (fed_run.py:216). */
 int ccst_bn_eval_fwd_f32(const float* x, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, const float* residual, int relu, float* y,
-                         int64_t M, int C, void* stream);
+                         int64_t M, int C, uint32_t* y_absmax /* NULL or zeroed |max| words of y: the eval forward's pointwise convs then run on half pieces too */,
+                        void* stream);
 /* BatchNorm2d backward: dx, dgamma, dbeta (accumulate=1 adds into dgamma/dbeta).  With relu=1 the ReLU mask
  * comes from the saved output y (y > 0), or -- when y == NULL, allowed only if no residual was added in
  * the forward -- is recomputed from x as (x-mean)*invstd*gamma+beta > 0 (one tensor read less per pass).
