@@ -42,7 +42,8 @@ _SIGNATURES = {
     "ccst_conv2d_igemm_stats_groups": [c_int, c_int, c_int, c_int],
     "ccst_conv2d_stream_ok": [POINTER(CcstConvDesc)],
     "ccst_conv2d_pointwise_half_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "ccst_pack_conv_weight_split_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P],
+    "ccst_pack_conv_weight_split_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P],
+    "ccst_conv2d_igemm_half_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P, _P],
     "ccst_pack_conv_weights_split_batch_f32": [_P, c_int, _P],
     "ccst_conv2d_pointwise_ok": [POINTER(CcstConvDesc)],
     "ccst_conv2d_igemm_accum_masked_f32": [POINTER(CcstConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -87,8 +87,14 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return min(max(i, 0), n - 1);
 }
 
-template <int WM, int WN, int NT, bool POOL, int MT = 2, int CK = 16>
+// HALFP (round 5; the 64x64 tile with a 32-channel k-step only): the products on the 16-bit MFMA from two IEEE-half pieces per operand, as
+// conv1x1_stream_kernel's HALFP form -- the gathered A rows are split where they pass from registers to LDS (rows [32 channels hi | 32
+// channels lo], the fp32 row's 128 bytes), the weights arrive pre-split (ccst_pack_conv_weight_split_f32 with all taps), x scaled by
+// its |max| words.  Used for BACKWARD-DATA only (the strided 3x3 layers' parity classes, the strided 1x1 downsample branches): the
+// operand is a gradient with words at hand, and rounding there moves no ReLU mask.
+template <int WM, int WN, int NT, bool POOL, int MT = 2, int CK = 16, bool HALFP = false>
 __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2)) void conv_igemm_kernel(const ConvArgs p) {
+    static_assert(!HALFP || (CK == 32 && MT == 1 && NT == 1 && !POOL), "the half-piece form exists for the 64x64x32 step");
     constexpr int BM = 32 * MT * WM;
     constexpr int BN = 32 * NT * WN;
     constexpr int A_LD = CK + 4;                   // floats per LDS A row (+16 B: conflict-free ds_read_b128)
@@ -98,7 +104,15 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
     constexpr int BR = (BUNITS + 255) / 256;
 
     __shared__ __attribute__((aligned(16))) float As[2][BM * A_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][CK * BN];
+    constexpr int B_LD = A_LD;                     // HALFP: B rows are output channels, [32 k hi | 32 k lo] as half + pad, like the A rows
+    constexpr int PWH = CK / 2;                    // HALFP: words per piece of a row
+    __shared__ __attribute__((aligned(16))) float Bs[2][HALFP ? BN * B_LD : CK * BN];
+    int kxs = 0, kws = 0;
+    if (HALFP) {
+        kxs = ccst_scale_exp(ccst_absmax_read(p.xmax), CCST_SPLIT_X_TARGET);
+        kws = ccst_scale_exp(ccst_absmax_read(p.wmax), CCST_SPLIT_W_TARGET);
+    }
+    const float xsc = __uint_as_float((unsigned)(127 + kxs) << 23);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -226,11 +240,24 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
             const int r = tid / PPR + (256 / PPR) * a;
             f32x4 v = ra[a];
             if (!aok[a]) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(&As[buf][r * A_LD + part * 4]) = v;
+            if (HALFP) {
+                u32x2s hi, lo;
+                ccst_split4_half(v, xsc, hi, lo);
+                *reinterpret_cast<u32x2s*>(&As[buf][r * A_LD + part * 2]) = hi;
+                *reinterpret_cast<u32x2s*>(&As[buf][r * A_LD + PWH + part * 2]) = lo;
+            } else {
+                *reinterpret_cast<f32x4*>(&As[buf][r * A_LD + part * 4]) = v;
+            }
         }
 #pragma unroll
         for (int b = 0; b < BR; ++b) {
             const int u = tid + 256 * b;
+            if (HALFP) {          // unit u = (k quad u / BN, column u % BN), pre-split: four hi halves | four lo halves
+                float* row = &Bs[buf][(u % BN) * B_LD];
+                *reinterpret_cast<u32x2s*>(row + (u / BN) * 2) = u32x2s{__float_as_uint(rb[b][0]), __float_as_uint(rb[b][1])};
+                *reinterpret_cast<u32x2s*>(row + PWH + (u / BN) * 2) = u32x2s{__float_as_uint(rb[b][2]), __float_as_uint(rb[b][3])};
+                continue;
+            }
             if (BUNITS % 256 == 0 || u < BUNITS) *reinterpret_cast<f32x4*>(&Bs[buf][u * 4]) = rb[b];
         }
     };
@@ -273,7 +300,46 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
     // groups, the fetch for step t+2 is issued in front of the last group, and each later 8-channel fragment
     // pair is read one group ahead of its first use.  STORE/LOAD are compile-time so that the peeled last two
     // steps stay branch-free (hipcc hoists conservative vmcnt waits above the MFMAs otherwise).
+    // HALFP step: a lane's 8 consecutive channels of k-block kb (16 channels) = words 8 kb + 4 lh of the hi piece, + PWH for lo
+    const float* aRdH = &As[0][(wm * 32 + li) * A_LD + lh * 4];
+    const float* bRdH = &Bs[0][(wn * 32 + li) * B_LD + lh * 4];
+    auto step_half = [&](int t, auto do_store, auto do_load) {
+        const int buf = t & 1;
+        const float* ar = aRdH + buf * (BM * A_LD);
+        const float* br = bRdH + buf * (BN * B_LD);
+        f16x8s af_[2][2], bf_[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                af_[kb][q] = __builtin_bit_cast(f16x8s, *reinterpret_cast<const f32x4*>(ar + q * PWH + 8 * kb));
+                bf_[kb][q] = __builtin_bit_cast(f16x8s, *reinterpret_cast<const f32x4*>(br + q * PWH + 8 * kb));
+            }
+        auto block = [&](int kb) {      // a_lo b_hi + a_hi b_lo + a_hi b_hi, the smallest first
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[kb][1], bf_[kb][0], acc[0][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[kb][0], bf_[kb][1], acc[0][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af_[kb][0], bf_[kb][0], acc[0][0], 0, 0, 0);
+        };
+        block(0);
+        if (decltype(do_store)::value) {
+            __builtin_amdgcn_sched_barrier(0);
+            store_step(buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (decltype(do_load)::value) {
+            __builtin_amdgcn_sched_barrier(0);
+            advance();
+            load_step(ky, kx, c);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        block(1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto step = [&](int t, auto do_store, auto do_load) {
+        if (HALFP) {
+            step_half(t, do_store, do_load);
+            return;
+        }
         const int buf = t & 1;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -320,6 +386,10 @@ __global__ __launch_bounds__(256, (MT == 1 ? 4 : (MT == 2 && CK == 16) ? 3 : 2))
     step(T - 1, No{}, No{});
 
     // ---- epilogue ------------------------------------------------------------------------
+    if (HALFP) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] = __builtin_ldexpf(acc[0][0][r], -(kxs + kws));      // (exact)
+    }
     const bool relu = (p.flags & CCST_CONV_RELU) != 0;
     float* yb = p.y + p.y_off;
     if (!POOL && p.stats != nullptr) {
@@ -829,18 +899,20 @@ __global__ void pack_weight_batch_kernel(const long long* __restrict__ jobs) {
 // = the four k = 4 kg .. 4 kg + 3 of column col as four hi halves | four lo halves of w * 2^kw (kw from the weight's |max| words, the
 // exponent the conv kernel derives from the same words: CCST_SPLIT_W_TARGET).  The same 16 bytes per unit as the fp32 layout.
 __device__ __forceinline__ void pack_split_units(const float* __restrict__ w, const unsigned* __restrict__ wmax, float* __restrict__ out, int cout,
-                                                 int cin, int transpose, int k_pad, int n_pad) {
+                                                 int cin, int ntap, int transpose, int k_pad, int n_pad) {
     const int kw = ccst_scale_exp(ccst_absmax_read(wmax), CCST_SPLIT_W_TARGET);
     const float wsc = __uint_as_float((unsigned)(127 + kw) << 23);
-    const long long units = (long long)(k_pad / 4) * n_pad;
+    const long long units = (long long)ntap * (k_pad / 4) * n_pad;          // [tap][K/4][n_pad], as ccst_pack_conv_weight_f32
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < units; i += (long long)gridDim.x * blockDim.x) {
-        const int ncol = (int)(i % n_pad), kg = (int)(i / n_pad);
+        const int ncol = (int)(i % n_pad);
+        const long long t = i / n_pad;
+        const int kg = (int)(t % (k_pad / 4)), tap = (int)(t / (k_pad / 4));
         f32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = kg * 4 + j;
             const int ci = transpose ? ncol : k, co = transpose ? k : ncol;
-            v[j] = (ci < cin && co < cout) ? w[(long long)co * cin + ci] : 0.f;
+            v[j] = (ci < cin && co < cout) ? w[((long long)co * cin + ci) * ntap + tap] : 0.f;
         }
         ccst_u32x2 hi, lo;
         ccst_split4_half(v, wsc, hi, lo);
@@ -848,14 +920,15 @@ __device__ __forceinline__ void pack_split_units(const float* __restrict__ w, co
     }
 }
 __global__ __launch_bounds__(256) void pack_weight_split_kernel(const float* __restrict__ w, const unsigned* __restrict__ wmax, float* __restrict__ out,
-                                                                int cout, int cin, int transpose, int k_pad, int n_pad) {
-    pack_split_units(w, wmax, out, cout, cin, transpose, k_pad, n_pad);
+                                                                int cout, int cin, int ntap, int transpose, int k_pad, int n_pad) {
+    pack_split_units(w, wmax, out, cout, cin, ntap, transpose, k_pad, n_pad);
 }
-// ... for a whole model in one launch: jobs[j] = {src, dst, cout, cin, |max| words, transpose, k_pad, n_pad} (int64 each), blockIdx.y = job
+// ... for a whole model in one launch: jobs[j] = {src, dst, cout, cin, |max| words, transpose + 2 * ntap, k_pad, n_pad} (int64 each),
+// blockIdx.y = job
 __global__ __launch_bounds__(256) void pack_weight_split_batch_kernel(const long long* __restrict__ jobs) {
     const long long* jb = jobs + (long long)blockIdx.y * 8;
     pack_split_units(reinterpret_cast<const float*>(jb[0]), reinterpret_cast<const unsigned*>(jb[4]), reinterpret_cast<float*>(jb[1]), (int)jb[2],
-                     (int)jb[3], (int)jb[5], (int)jb[6], (int)jb[7]);
+                     (int)jb[3], (int)(jb[5] >> 1), (int)(jb[5] & 1), (int)jb[6], (int)jb[7]);
 }
 
 // NCHW (C<=4) -> padded NHWC4
@@ -888,7 +961,7 @@ __global__ void nchw_to_nhwc4_pad_kernel(const float* __restrict__ x, f32x4* __r
     }
 }
 
-template <int WM, int WN, int NT, bool POOL, int MT = 2, int CK = 16>
+template <int WM, int WN, int NT, bool POOL, int MT = 2, int CK = 16, bool HALFP = false>
 int launch_conv(ConvArgs& a, hipStream_t s) {
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     a.tilesN = (a.Cout + BN - 1) / BN;
@@ -906,7 +979,7 @@ int launch_conv(ConvArgs& a, hipStream_t s) {
         ccst_set_error("conv: bad grid %lld", grid);
         return CCST_EINVAL;
     }
-    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, NT, POOL, MT, CK>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, NT, POOL, MT, CK, HALFP>), dim3((unsigned)grid), dim3(256), 0, s, a);
     return ccst_launch_status("conv_igemm");
 }
 
@@ -1013,7 +1086,7 @@ struct BnLink {
 }  // namespace
 static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w_packed, const float* bias, float* y, float* stats,
                            void* stream, const unsigned char* relu_mask, const BnLink* bn, const uint32_t* xmax = nullptr,
-                           const uint32_t* wmax = nullptr);
+                           const uint32_t* wmax = nullptr, bool gather_half = false);
 
 // 1 when this problem runs on the persistent pointwise kernel at all (dense or strided 1x1 input, dense output, no bias / ReLU / pool):
 // the shapes ccst_conv2d_pointwise_half_f32 takes.
@@ -1045,14 +1118,27 @@ extern "C" int ccst_conv2d_pointwise_half_f32(const CcstConvDesc* d, const float
     return conv_igemm_impl(d, x, w_split, nullptr, y, stats, stream, relu_mask, bn_x ? &bn : nullptr, x_absmax, w_absmax);
 }
 
-extern "C" int ccst_pack_conv_weight_split_f32(const float* w_oihw, const uint32_t* w_absmax, float* packed, int cout, int cin, int transpose,
-                                               int k_pad, int n_pad, void* stream) {
-    CCST_REQUIRE(w_oihw && w_absmax && packed && cout > 0 && cin > 0, "pack_conv_weight_split: bad args");
+extern "C" int ccst_pack_conv_weight_split_f32(const float* w_oihw, const uint32_t* w_absmax, float* packed, int cout, int cin, int ntap,
+                                               int transpose, int k_pad, int n_pad, void* stream) {
+    CCST_REQUIRE(w_oihw && w_absmax && packed && cout > 0 && cin > 0 && ntap > 0, "pack_conv_weight_split: bad args");
     CCST_REQUIRE(k_pad % 4 == 0 && k_pad >= (transpose ? cout : cin) && n_pad >= (transpose ? cin : cout), "pack_conv_weight_split: padding");
-    const long long units = (long long)(k_pad / 4) * n_pad;
+    const long long units = (long long)ntap * (k_pad / 4) * n_pad;
     hipLaunchKernelGGL(pack_weight_split_kernel, dim3((unsigned)((units + 255) / 256 < 2048 ? (units + 255) / 256 : 2048)), dim3(256), 0, (hipStream_t)stream,
-                       w_oihw, w_absmax, packed, cout, cin, transpose, k_pad, n_pad);
+                       w_oihw, w_absmax, packed, cout, cin, ntap, transpose, k_pad, n_pad);
     return ccst_launch_status("pack_weight_split");
+}
+
+// The gather GEMM on half pieces (conv_igemm_kernel's HALFP form: 64x64 tiles, 32-channel k-steps): any taps / strides / zero padding, dense
+// or strided output, CCST_CONV_ACCUM -- the backward-data launches that are not problems of the streaming pointwise or the halo kernel
+// (the parity classes of a stride-2 3x3 conv, the strided 1x1 downsample branches).  x scaled by its |max| words, w_split =
+// ccst_pack_conv_weight_split_f32 of all taps with the same w_absmax words.  cin % 32 == 0; no bias / ReLU / pool / reflection / upsample.
+extern "C" int ccst_conv2d_igemm_half_f32(const CcstConvDesc* d, const float* x, const uint32_t* x_absmax, const float* w_split,
+                                          const uint32_t* w_absmax, float* y, void* stream) {
+    CCST_REQUIRE(x_absmax && w_absmax, "conv_igemm_half: the |max| words of x and w");
+    CCST_REQUIRE(d && d->cin % 32 == 0 && !(d->flags & (CCST_CONV_POOL2 | CCST_CONV_RELU | CCST_CONV_UPS2 | CCST_CONV_REFLECT)),
+                 "conv_igemm_half: cin a multiple of 32, no ReLU / pool / upsample / reflection");
+    CCST_REQUIRE(stream_bfp() == 4, "conv_igemm_half: CCST_CONV_BF=0 turns the half-piece kernels off");
+    return conv_igemm_impl(d, x, w_split, nullptr, y, nullptr, stream, nullptr, nullptr, x_absmax, w_absmax, true);
 }
 extern "C" int ccst_pack_conv_weights_split_batch_f32(const int64_t* jobs_device, int njobs, void* stream) {
     CCST_REQUIRE(jobs_device && njobs > 0, "pack_conv_weights_split_batch: bad args");
@@ -1087,7 +1173,8 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
 }
 
 static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w_packed, const float* bias, float* y, float* stats,
-                           void* stream, const unsigned char* relu_mask, const BnLink* bn, const uint32_t* xmax, const uint32_t* wmax) {
+                           void* stream, const unsigned char* relu_mask, const BnLink* bn, const uint32_t* xmax, const uint32_t* wmax,
+                           bool gather_half) {
     CCST_REQUIRE(d && x && w_packed && y, "conv: null pointer");
     CCST_REQUIRE(d->cin > 0 && d->cin % CK_MIN == 0, "conv: cin=%d must be a positive multiple of 16", d->cin);
     CCST_REQUIRE(d->cout > 0 && d->cout_pad >= d->cout && d->cout_pad % 128 == 0, "conv: cout=%d cout_pad=%d (need multiple of 128)",
@@ -1125,6 +1212,7 @@ static int conv_igemm_impl(const CcstConvDesc* d, const float* x, const float* w
     const bool pw_in = (a.flags & CONV_DENSE_IN) ||
                        (d->nky == 1 && d->nkx == 1 && d->cy == 0 && d->cx == 0 && d->ay >= 1 && d->ax >= 1 && !(d->flags & (CCST_CONV_UPS2 | CCST_CONV_REFLECT)) &&
                         (long long)(d->ho - 1) * d->ay < d->hi && (long long)(d->wo - 1) * d->ax < d->wi);
+    if (gather_half) return launch_conv<2, 2, 1, false, 1, 32, true>(a, s);      // (ccst_conv2d_igemm_half_f32: the caller asked for this kernel)
     if (pw_in && (a.flags & CONV_DENSE_OUT) && a.ysC == 1 && a.ysW == d->cout && bias == nullptr && !pool &&
         !(a.flags & CCST_CONV_RELU) && stream_shape_ok(a.M, d->cout, d->cin, d->nky * d->nkx)) {
         a.tilesN = d->cout / 64;

@@ -154,8 +154,9 @@ def _prepack_jobs(model, convs):
         rows = []
         for m, _n, t, transpose in hslots:
             kdim, ndim = (m.out_channels, m.in_channels) if transpose else (m.in_channels, m.out_channels)
-            rows.append([m.weight.data_ptr(), t.data_ptr(), m.out_channels, m.in_channels, jobs["mwords"][row_of[id(m)]].data_ptr(), transpose,
-                         ops.round_up(kdim, 16), ops.round_up(ndim, 128)])
+            ntap = m.kernel_size[0] * m.kernel_size[1]
+            rows.append([m.weight.data_ptr(), t.data_ptr(), m.out_channels, m.in_channels, jobs["mwords"][row_of[id(m)]].data_ptr(),
+                         transpose + 2 * ntap, ops.round_up(kdim, 16), ops.round_up(ndim, 128)])
         jobs["htable"] = torch.tensor(rows, dtype=torch.int64).to(dev)
     if h3slots:     # ... and the 3x3 layers' half-piece weight images
         row_of = {id(m): i for i, m in enumerate(mslots)}
@@ -296,7 +297,12 @@ def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None, relu_mas
         d.y_off, d.ysN, d.ysH, d.ysW, d.ysC = (py * W + px) * Cin, H * W * Cin, stride * W * Cin, stride * Cin, 1
         d.flags = _lib.CONV_ACCUM if accumulate_into is not None else 0
         use_half = half is not None and bool(lib.ccst_conv2d_stream_ok(ctypes.byref(d)))
-        if use_half:
+        gather_half = half is not None and not use_half and relu_mask is None and bn_relu is None and d.cin % 32 == 0
+        if gather_half:             # the gather GEMM on half pieces: parity classes of a strided 3x3 conv, strided 1x1 downsample branches
+            dmax, wmax, wsp = half
+            launch = lambda: check(lib.ccst_conv2d_igemm_half_f32(ctypes.byref(d), ptr(dy), ptr(dmax), ptr(wsp), ptr(wmax), ptr(dx), stream_ptr()),
+                                   "conv bwd-data (gather, half pieces)")
+        elif use_half:
             dmax, wmax, wsp = half
             bx, bm, bi, bg, bb, bp = (None,) * 6
             if relu_mask is not None:
@@ -328,7 +334,7 @@ def conv_bwd_data(dy, pc_t, x_shape, stride, pad, accumulate_into=None, relu_mas
             e0.record()
             launch()
             e1.record()
-            ops.TIMING.append(("bwd_data:" + ops._conv_kernel_name(Cin, False, N * Hc * Wc, pc_t.k_pad, nky * nkx) + ("_h" if use_half else ""), 2.0 * N * Hc * Wc * Cin * Cout * nky * nkx,
+            ops.TIMING.append(("bwd_data:" + ops._conv_kernel_name(Cin, False, N * Hc * Wc, pc_t.k_pad, nky * nkx) + ("_h" if (use_half or gather_half) else ""), 2.0 * N * Hc * Wc * Cin * Cout * nky * nkx,
                                e0, e1, "n%d %dx%d cin%d cout%d taps%dx%d s%d" % (N, Hc, Wc, Cout, Cin, nky, nkx, stride)))
     return dx
 
@@ -506,7 +512,7 @@ class ConvFn(torch.autograd.Function):
                     link.partials = torch.empty((lib_groups(M, Cin, dy.shape[3]), Cin, 2), device=x.device, dtype=torch.float32)
                     bn_relu = (link.bn_x, link.bn_save[0], link.bn_save[1], link.gamma, link.beta, link.partials)
                 half = None
-                if dymax is not None and mod.kernel_size == (1, 1):      # the gradient's words are at hand: half pieces where the streaming kernel runs
+                if dymax is not None and mod.out_channels % 32 == 0:      # the gradient's words are at hand: half pieces (streaming or gather kernel)
                     half = (dymax, mod.wabsmax(), mod.packed_th())
                 dx = conv_bwd_data(dy, mod.packed_t(), tuple(x.shape), stride, pad, accumulate_into=into, relu_mask=mask, bn_link=bn_link,
                                    bn_relu=bn_relu, half=half)

@@ -551,18 +551,17 @@ def pack_conv_weight(w_oihw, bias=None, transpose=False, out=None, wino=False):
 
 
 def pack_conv_weight_split(w_oihw, w_absmax, transpose=False, out=None):
-    """A 1x1 OIHW weight in the pointwise kernel's packed layout, PRE-SPLIT into half pieces scaled by the power of two of its |max|
-    words (ccst_pack_conv_weight_split_f32): the `w_split` of conv2d_nhwc / nn_ops.conv_bwd_data (transpose=True)."""
+    """An OIHW weight in the implicit-GEMM kernels' packed layout [tap][K/4][n_pad], PRE-SPLIT into half pieces scaled by the power of two
+    of its |max| words (ccst_pack_conv_weight_split_f32): the `w_split` of conv2d_nhwc / nn_ops.conv_bwd_data (transpose=True)."""
     _require_cuda(w_oihw, "weight")
     w = w_oihw.contiguous()
     cout, cin, kh, kw = w.shape
-    assert kh == 1 and kw == 1, "pre-split packs are for pointwise convs"
     kdim, ndim = (cout, cin) if transpose else (cin, cout)
     k_pad, n_pad = round_up(kdim, 16), round_up(ndim, 128)
-    if out is None or out.numel() != k_pad * n_pad:
-        out = torch.empty(k_pad * n_pad, device=w.device, dtype=torch.float32)
-    check(_lib.load().ccst_pack_conv_weight_split_f32(ptr(w), ptr(w_absmax), ptr(out), cout, cin, int(transpose), k_pad, n_pad, stream_ptr()),
-          "pack_conv_weight_split")
+    if out is None or out.numel() != kh * kw * k_pad * n_pad:
+        out = torch.empty(kh * kw * k_pad * n_pad, device=w.device, dtype=torch.float32)
+    check(_lib.load().ccst_pack_conv_weight_split_f32(ptr(w), ptr(w_absmax), ptr(out), cout, cin, kh * kw, int(transpose), k_pad, n_pad,
+                                                      stream_ptr()), "pack_conv_weight_split")
     return out
 
 

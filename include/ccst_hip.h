@@ -96,14 +96,19 @@ int ccst_conv2d_igemm_stats_groups(int M, int cout, int cin /* padded, d->cin */
  * statistics epilogue: ccst_conv2d_igemm_stats_f32), CCST_CONV_ACCUM in d->flags with relu_mask and optionally the BatchNorm link
  * (ccst_conv2d_igemm_accum_masked_f32), the BatchNorm + ReLU link with bn_gamma / bn_beta (ccst_conv2d_igemm_bn_relu_bwd_f32), or
  * none of them (plain / y += conv).  Needs ccst_conv2d_stream_ok(d) -- and ccst_conv2d_pointwise_ok(d) for the masked / linked forms. */
+/* The gather GEMM (ccst_conv2d_igemm_f32's kernel, 64x64 tiles) on half pieces, for the backward-data launches that are problems of
+ * neither the streaming pointwise nor the halo kernel: the parity classes of a stride-2 3x3 conv, the strided 1x1 downsample branches
+ * (any taps / strides / zero padding / strided output, CCST_CONV_ACCUM).  w_split = ccst_pack_conv_weight_split_f32 over all taps. */
+int ccst_conv2d_igemm_half_f32(const CcstConvDesc* d, const float* x, const uint32_t* x_absmax, const float* w_split,
+                               const uint32_t* w_absmax, float* y, void* stream);
 int ccst_conv2d_stream_ok(const CcstConvDesc* d);
 int ccst_conv2d_pointwise_half_f32(const CcstConvDesc* d, const float* x, const uint32_t* x_absmax, const float* w_split,
                                    const uint32_t* w_absmax, float* y, float* stats, const uint8_t* relu_mask, const float* bn_x,
                                    const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
                                    float* bn_partials, void* stream);
-int ccst_pack_conv_weight_split_f32(const float* w_oihw, const uint32_t* w_absmax, float* packed, int cout, int cin, int transpose,
-                                    int k_pad, int n_pad, void* stream);
-/* ... of n weights in one launch: jobs [n][8] int64 on the device = (w_oihw, packed, cout, cin, w_absmax, transpose, k_pad, n_pad). */
+int ccst_pack_conv_weight_split_f32(const float* w_oihw, const uint32_t* w_absmax, float* packed, int cout, int cin, int ntap /* kh * kw */,
+                                    int transpose, int k_pad, int n_pad, void* stream);
+/* ... of n weights in one launch: jobs [n][8] int64 on the device = (w_oihw, packed, cout, cin, w_absmax, transpose + 2 * ntap, k_pad, n_pad). */
 int ccst_pack_conv_weights_split_batch_f32(const int64_t* jobs_device, int njobs, void* stream);
 
 /* 3x3 stride-1 "same" conv (reflection or zero padding) with the input halo staged once per 16-channel

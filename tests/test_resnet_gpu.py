@@ -1071,6 +1071,33 @@ def test_pointwise_backward_data_half_pieces_match_fp32_forms(dev, gscale):
     assert float((pa.double().sum(0) - pb.double().sum(0)).abs().max()) < 1e-4 * max(float(pb.double().sum(0).abs().max()), 1e-30)
 
 
+@pytest.mark.parametrize("cfg", [
+    # N, H, W, Cin, Cout, k, stride, pad            (forward conv; dX [N,H,W,Cin])
+    (3, 28, 28, 128, 128, 3, 2, 1), (2, 15, 13, 64, 128, 3, 2, 1), (4, 28, 28, 256, 512, 1, 2, 0), (2, 14, 14, 96, 160, 3, 1, 1), (2, 9, 9, 64, 32, 3, 1, 1),
+])
+@pytest.mark.parametrize("gscale", [1.0, 1e-7])
+def test_gather_backward_data_on_half_pieces_vs_fp64(dev, cfg, gscale):
+    """ccst_conv2d_igemm_half_f32: backward-data through the gather GEMM on half pieces -- the parity classes of a stride-2 3x3 conv, a
+    strided 1x1 downsample branch, stride-1 3x3 shapes no other half-piece kernel takes -- plain and accumulating, against fp64."""
+    from ccst_amd import nn_ops, ops
+    N, H, W, Cin, Cout, k, stride, pad = cfg
+    g = torch.Generator().manual_seed(23)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5).to(dev)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    dy = (torch.randn(N, Ho, Wo, Cout, generator=g) * gscale).to(dev)
+    ref = torch.nn.grad.conv2d_input((N, Cin, H, W), w.double(), dy.permute(0, 3, 1, 2).double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    pct = ops.pack_conv_weight(w, transpose=True)
+    wmax = ops.absmax(w)
+    half = (ops.absmax(dy), wmax, ops.pack_conv_weight_split(w, wmax, transpose=True))
+    tol = 4e-6 * float(ref.abs().max())
+    a = nn_ops.conv_bwd_data(dy, pct, (N, H, W, Cin), stride, pad, half=half)
+    b = nn_ops.conv_bwd_data(dy, pct, (N, H, W, Cin), stride, pad)
+    assert float((a.double() - ref).abs().max()) < tol and float((b.double() - ref).abs().max()) < tol
+    base = (torch.randn(N, H, W, Cin, generator=g) * gscale).to(dev)
+    acc = nn_ops.conv_bwd_data(dy, pct, (N, H, W, Cin), stride, pad, accumulate_into=base.clone(), half=half)
+    assert float((acc.double() - (ref + base.double())).abs().max()) < tol + 1e-6 * float(base.abs().max())
+
+
 @pytest.mark.parametrize("arch", ["resnet18", "resnet50"])
 def test_reference_initialisation_within_twice_the_references_own_rounding(dev, arch):
     """every other fixture conditions the weights like a trained net (closing-BN gammas x 0.25, classifier x 8).  This
