@@ -63,7 +63,7 @@ _SIGNATURES = {
     "ccst_conv3x3_halo_split_tiles": [c_int, c_int, c_int],
     "ccst_pack_conv_weight_halo_split_f32": [_P, _P, c_int, c_int, c_int, _P, c_int, _P],
     "ccst_pack_conv_weights_halo_split_batch_f32": [_P, c_int, _P],
-    "ccst_conv3x3_halo_train_split_f32": [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
+    "ccst_conv3x3_halo_train_split_f32": [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P, _P, _P, _P, _P, _P, _P],
     "ccst_conv3x3_halo_narrow": [c_int, c_int, c_int, c_int],
     "ccst_wino_weight_floats": [c_int, c_int],
     "ccst_pack_conv_weight_wino_f32": [_P, _P, c_int, c_int, c_int, _P],

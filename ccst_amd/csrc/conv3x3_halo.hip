@@ -45,6 +45,11 @@ struct HaloArgs {
     unsigned* ymax;         // SPLIT: nullptr, or zeroed |max| words receiving max |y| of what this launch stores
     float* stats;        // TRAIN: per-(spatial tile, wave row) (sum, sum^2) partials of the output, or nullptr; SPLIT: (sum, M2 about the slab's own mean, count, 0)
     int flip, accum;     // TRAIN: taps read in reverse order (backward-data); y += conv
+    // TRAIN + SPLIT, backward-data whose result is the output gradient of a BatchNorm + ReLU that only this conv reads (bn1 -> conv2):
+    // the epilogue recomputes that ReLU's mask from the BatchNorm's input, stores the MASKED gradient and leaves the BatchNorm
+    // backward's per-channel partial sums (sum g, sum g xhat) per (tile, wave row) -- as conv1x1_stream_kernel's MASKED = 2 form
+    const float *bn_x, *bn_mean, *bn_invstd, *bn_gamma, *bn_beta;
+    float* bn_part;
 };
 
 // Positions (in groups of 4 MFMAs, 8 groups per k-step) of the staging inside a step; measured sweep in DESIGN.md 3.0.
@@ -468,6 +473,45 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
                 }
             }
         }
+        if (TRAIN && SPLIT && p.bn_x != nullptr) {
+            const float* const xtile = p.bn_x + (long long)n * p.ysN + (long long)oy0 * p.ysH + (long long)ox0 * p.ysW + co0 + cw;
+            const int slab = ((n * p.tilesY + ty) * p.tilesX + tx) * WM + wm;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int co = co0 + cw + nt * 32 + li;
+                const bool cok = co < p.Cout;
+                const float mu = cok ? p.bn_mean[co] : 0.f, is = cok ? p.bn_invstd[co] : 0.f;
+                const float ga = cok ? p.bn_gamma[co] : 0.f, be = cok ? p.bn_beta[co] : 0.f;
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    float xv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dy = 2 * (wm * MT + mt) + ((r & 3) >> 1), dx = 4 * (r >> 2) + (r & 1) + 2 * lh;
+                        const bool inside = cok && (interior || (oy0 + dy < p.H && ox0 + dx < p.W));
+                        xv[r] = inside ? xtile[(long long)dy * p.ysH + (long long)dx * p.ysW + nt * 32 + li] : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int dy = 2 * (wm * MT + mt) + ((r & 3) >> 1), dx = 4 * (r >> 2) + (r & 1) + 2 * lh;
+                        const bool inside = cok && (interior || (oy0 + dy < p.H && ox0 + dx < p.W));
+                        const float xh = (xv[r] - mu) * is;
+                        const float g = (inside && xh * ga + be > 0.f) ? acc[mt][nt][r] : 0.f;
+                        acc[mt][nt][r] = g;
+                        s1 += g;
+                        s2 += g * xh;
+                    }
+                }
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (lh == 0 && cok) {
+                    float* o = p.bn_part + ((long long)slab * p.Cout + co) * 2;
+                    o[0] = s1;
+                    o[1] = s2;
+                }
+            }
+        }
         if (TRAIN && p.accum && interior) {          // y += acc: the loads of the wave tile first, then adds + stores
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -678,6 +722,7 @@ static int halo_impl(const float* x, const float* w_packed, const float* bias, f
     a.N = N; a.H = H; a.W = W; a.Hs = ups ? H / 2 : H; a.Ws = ups ? W / 2 : W; a.Cin = Cin; a.Cout = Cout; a.CoutPad = cout_pad;
     a.reflect = (flags & CCST_CONV_REFLECT) ? 1 : 0; a.ups = ups ? 1 : 0; a.relu = (flags & CCST_CONV_RELU) ? 1 : 0;
     a.stats = sums; a.flip = 0; a.accum = 0; a.xmax = xmax; a.wmax = wmax; a.ymax = ymax;
+    a.bn_x = a.bn_mean = a.bn_invstd = a.bn_gamma = a.bn_beta = nullptr; a.bn_part = nullptr;
     CCST_REQUIRE((long long)N * a.Hs * a.Ws * Cin < 0x7fffffffLL, "conv3x3_halo: input must have < 2^31 elements");
     const int oh = pool ? (H + 1) / 2 : H, ow = pool ? (W + 1) / 2 : W;
     a.ysW = Cout; a.ysH = ow * Cout; a.ysN = (long long)oh * ow * Cout;
@@ -721,6 +766,7 @@ extern "C" int ccst_conv3x3_halo_train_f32(const float* x, const float* w_packed
     a.reflect = 0; a.ups = 0; a.relu = 0;
     a.stats = stats; a.flip = (flags & CCST_CONV_FLIP) ? 1 : 0; a.accum = (flags & CCST_CONV_ACCUM) ? 1 : 0;
     a.xmax = a.wmax = nullptr; a.ymax = nullptr;
+    a.bn_x = a.bn_mean = a.bn_invstd = a.bn_gamma = a.bn_beta = nullptr; a.bn_part = nullptr;
     a.ysW = Cout; a.ysH = W * Cout; a.ysN = (long long)H * W * Cout;
     hipStream_t s = (hipStream_t)stream;
     if (ccst_conv3x3_halo_narrow(N, H, W, Cout)) return launch_halo<2, 2, 1, false, true>(a, s);
@@ -731,7 +777,12 @@ extern "C" int ccst_conv3x3_halo_train_f32(const float* x, const float* w_packed
 // on the 16-bit MFMA -- x scaled by its |max| words (an activation: left by the BatchNorm apply; a gradient: by the BatchNorm backward),
 // w_split from ccst_pack_conv_weight_halo_split_f32 (transpose = 1 + CCST_CONV_FLIP: backward-data).  Same flags, same statistics.
 extern "C" int ccst_conv3x3_halo_train_split_f32(const float* x, const uint32_t* x_absmax, const float* w_split, const uint32_t* w_absmax, float* y,
-                                                 float* stats, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags, void* stream) {
+                                                 float* stats, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags, const float* bn_x,
+                                                 const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                                                 float* bn_partials, void* stream) {
+    CCST_REQUIRE((bn_x == nullptr) == (bn_partials == nullptr) && (bn_x == nullptr || (bn_mean && bn_invstd && bn_gamma && bn_beta)),
+                 "conv3x3_halo_train_split: the BatchNorm + ReLU link needs its input, mean, invstd, gamma, beta and the partials buffer together");
+    CCST_REQUIRE(!(bn_x && ((flags & CCST_CONV_ACCUM) || stats)), "conv3x3_halo_train_split: the BatchNorm + ReLU link goes with the plain backward-data form");
     CCST_REQUIRE(x && w_split && y && x_absmax && w_absmax, "conv3x3_halo_train_split: null pointer");
     CCST_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0, "conv3x3_halo_train_split: bad shape");
     CCST_REQUIRE(cout_pad >= Cout && cout_pad % 128 == 0, "conv3x3_halo_train_split: cout_pad must be a multiple of 128 >= cout");
@@ -744,6 +795,7 @@ extern "C" int ccst_conv3x3_halo_train_split_f32(const float* x, const uint32_t*
     a.reflect = 0; a.ups = 0; a.relu = 0;
     a.stats = stats; a.flip = (flags & CCST_CONV_FLIP) ? 1 : 0; a.accum = (flags & CCST_CONV_ACCUM) ? 1 : 0;
     a.xmax = x_absmax; a.wmax = w_absmax; a.ymax = nullptr;
+    a.bn_x = bn_x; a.bn_mean = bn_mean; a.bn_invstd = bn_invstd; a.bn_gamma = bn_gamma; a.bn_beta = bn_beta; a.bn_part = bn_partials;
     a.ysW = Cout; a.ysH = W * Cout; a.ysN = (long long)H * W * Cout;
     hipStream_t s = (hipStream_t)stream;
     if (ccst_conv3x3_halo_narrow(N, H, W, Cout)) return launch_halo<2, 2, 1, false, true, true>(a, s);

@@ -269,7 +269,7 @@ class BasicBlock(nn.Module):
             # deposited in `pair`, and the strided downsample conv adds its (sparser) dX to it in place -- no zero-filled temporary
             identity = conv_bn(self.downsample[0], self.downsample[1], x, sink_in=pair)
         out = conv_bn(self.conv1, self.bn1, x, relu=True, sink_in=sink if sink is not None else pair)
-        return conv_bn(self.conv2, self.bn2, out, residual=identity, relu=True, sink_out=sink)
+        return conv_bn(self.conv2, self.bn2, out, residual=identity, relu=True, sink_out=sink, sole_reader=True)     # out = relu(bn1(..)): read here only
 
 
 class Bottleneck(nn.Module):
@@ -294,7 +294,7 @@ class Bottleneck(nn.Module):
         if self.downsample is not None:         # first, so that its backward runs last and adds to the main branch's dX (BasicBlock)
             identity = conv_bn(self.downsample[0], self.downsample[1], x, sink_in=pair)
         out = conv_bn(self.conv1, self.bn1, x, relu=True, sink_in=sink if sink is not None else pair)
-        out = conv_bn(self.conv2, self.bn2, out, relu=True)
+        out = conv_bn(self.conv2, self.bn2, out, relu=True, sole_reader=True)       # (its input relu(bn1(..)) is read here only)
         return conv_bn(self.conv3, self.bn3, out, residual=identity, relu=True, sink_out=sink, sole_reader=True)     # out = relu(bn2(..)): read here only
 
 

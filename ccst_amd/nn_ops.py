@@ -498,7 +498,14 @@ class ConvFn(torch.autograd.Function):
                 elif ctx.sink.pair:
                     deposit = True
             if ctx.half3 and dymax is not None:     # 3x3 stride 1: the half-piece halo kernel with the transposed image, taps flipped
-                dx = ops.conv3x3_halo_train_split(dy, dymax, mod.halo_ht(), mod.wabsmax(), flip=True, accumulate_into=into)
+                link, bn_relu = ctx.link, None
+                # x is the output of a BatchNorm + ReLU that only this conv reads (bn1 -> conv2): mask and partial sums from the epilogue
+                if link is not None and link.mask is None and link.gamma is not None and into is None and ctx.sink is None and MASK_LINK_STATS:
+                    link.partials = torch.empty((ops.halo_stats_groups(N, H, W), Cin, 2), device=x.device, dtype=torch.float32)
+                    bn_relu = (link.bn_x, link.bn_save[0], link.bn_save[1], link.gamma, link.beta, link.partials)
+                dx = ops.conv3x3_halo_train_split(dy, dymax, mod.halo_ht(), mod.wabsmax(), flip=True, accumulate_into=into, bn_relu=bn_relu)
+                if bn_relu is not None:
+                    link.premasked = True
             elif ctx.wino:
                 dx = ops.conv3x3_wino_train(dy, mod.wino_bwd(), accumulate_into=into, tag="bwd_data:")
             else:

@@ -138,15 +138,22 @@ def pack_halo_split(w_oihw, w_absmax, bwd=False, out=None):
     return u, pad, n_out
 
 
+def halo_stats_groups(N, H, W):
+    """Slabs the halo kernel's train forms leave per channel: one per (8x16-pixel tile, wave row)."""
+    return int(_lib.load().ccst_conv3x3_halo_stats_groups(N, H, W))
+
+
 def halo_train_split_ok(H, W, cin, cout):
     """3x3 stride-1 trunk layers the half-piece halo kernel takes: its k side a multiple of 16 (its 8x16-pixel tiles cover a 7x7 map by
     38 %, and it is still ahead of the fp32 gather kernel there)."""
     return cin % 16 == 0 and cout % 16 == 0
 
 
-def conv3x3_halo_train_split(x, x_absmax, packed, w_absmax, want_stats=False, flip=False, accumulate_into=None):
+def conv3x3_halo_train_split(x, x_absmax, packed, w_absmax, want_stats=False, flip=False, accumulate_into=None, bn_relu=None):
     """3x3 stride-1 zero-padded bias-free conv on the half-piece halo kernel (ResNet trunk).  packed = pack_halo_split(...); the words of x
-    and of the OIHW weight scale the operands.  flip=True with the bwd pack: backward-data.  Returns y or (y, stats)."""
+    and of the OIHW weight scale the operands.  flip=True with the bwd pack: backward-data.  Returns y or (y, stats).
+    bn_relu = (bn input, mean, invstd, gamma, beta, partials out [halo_stats_groups(N, H, W), cout, 2]): y is the output gradient of that
+    BatchNorm + ReLU -- stored masked, with the BatchNorm backward's partial sums."""
     u, pad, cout = packed
     N, H, W, Cx = x.shape
     lib = _lib.load()
@@ -159,7 +166,8 @@ def conv3x3_halo_train_split(x, x_absmax, packed, w_absmax, want_stats=False, fl
     if want_stats:
         stats = torch.empty((lib.ccst_conv3x3_halo_stats_groups(N, H, W), cout, 2), device=x.device, dtype=torch.float32)
     flags = (_lib.CONV_FLIP if flip else 0) | (_lib.CONV_ACCUM if accumulate_into is not None else 0)
-    args = (ptr(x), ptr(x_absmax), ptr(u), ptr(w_absmax), ptr(y), ptr(stats), N, H, W, Cx, cout, pad, flags, stream_ptr())
+    bn = tuple(ptr(t) for t in bn_relu) if bn_relu is not None else (None,) * 6
+    args = (ptr(x), ptr(x_absmax), ptr(u), ptr(w_absmax), ptr(y), ptr(stats), N, H, W, Cx, cout, pad, flags) + bn + (stream_ptr(),)
     if TIMING is None:
         check(lib.ccst_conv3x3_halo_train_split_f32(*args), "conv3x3_halo_train_split")
     else:

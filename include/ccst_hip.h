@@ -226,7 +226,13 @@ int ccst_conv3x3_halo_stats_groups(int N, int H, int W);
  * the BatchNorm apply that produced it, a gradient's from the BatchNorm backward (dx_absmax) --, w_split from
  * ccst_pack_conv_weight_halo_split_f32 (transpose = 1 together with CCST_CONV_FLIP: backward-data).  Same flags and statistics. */
 int ccst_conv3x3_halo_train_split_f32(const float* x, const uint32_t* x_absmax, const float* w_split, const uint32_t* w_absmax, float* y,
-                                      float* stats, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags, void* stream);
+                                      float* stats, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags,
+                                      const float* bn_x, const float* bn_mean, const float* bn_invstd, const float* bn_gamma,
+                                      const float* bn_beta, float* bn_partials, void* stream);
+/* bn_x .. bn_partials (all or none; plain backward-data only): y is the output gradient of a BatchNorm + ReLU with input bn_x
+ * [N,H,W,Cout] that only this conv reads (bn1 -> conv2): the epilogue recomputes the ReLU mask (bn(bn_x) > 0), stores the MASKED
+ * gradient and leaves that BatchNorm's backward partial sums (sum g, sum g*xhat) in bn_partials
+ * [ccst_conv3x3_halo_stats_groups(N,H,W)][Cout][2] for ccst_bn_train_bwd_partials_f32 -- one pass over (x, g) less. */
 
 /* The tile code (WM WN NT as decimal digits: 222 = 128x128, 221 = 128x64, 412 = 256x64, 411 = 256x32; 1221 / 1222 =
  * 64x64 with a 16- / 32-channel k-step for grids that cannot fill the chip) ccst_conv2d_igemm_f32 dispatches for

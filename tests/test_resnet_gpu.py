@@ -221,6 +221,45 @@ def test_halo_train_form_on_half_pieces_vs_fp64(dev, shape, gscale):
     assert float((acc.double() - (base.double() + dx_ref)).abs().max()) < 4e-6 * float(dx_ref.abs().max()) + 1e-6 * float(base.abs().max())
 
 
+@pytest.mark.parametrize("shape", [(3, 28, 28, 128, 128), (2, 56, 56, 64, 64), (1, 13, 19, 32, 48), (5, 7, 7, 512, 512)])
+def test_halo_backward_data_with_the_batchnorm_relu_link(dev, shape):
+    """The bn1 -> conv2 link of the half-piece halo kernel: its backward-data epilogue recomputes the ReLU mask of the BatchNorm whose
+    output the conv read (bn(bn_x) > 0), stores the masked gradient and leaves that BatchNorm's backward partial sums -- against the
+    un-linked launch masked and summed on the host side of the test; then ccst_bn_train_bwd_partials_f32 on those sums against the
+    ordinary BatchNorm backward."""
+    from ccst_amd import _lib, ops
+    from ccst_amd._lib import check, ptr, stream_ptr
+    N, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(29)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(dev)
+    dy = torch.randn(N, H, W, Cout, generator=g).to(dev)
+    bx = torch.randn(N, H, W, Cin, generator=g).to(dev)
+    mean, invstd = (torch.randn(Cin, generator=g) * 0.1).to(dev), (torch.rand(Cin, generator=g) + 0.5).to(dev)
+    gam, bet = (torch.rand(Cin, generator=g) + 0.5).to(dev), (torch.randn(Cin, generator=g) * 0.3).to(dev)
+    wmax, dmax = ops.absmax(w), ops.absmax(dy)
+    pht = ops.pack_halo_split(w, wmax, bwd=True)
+    plain = ops.conv3x3_halo_train_split(dy, dmax, pht, wmax, flip=True)
+    part = torch.zeros((ops.halo_stats_groups(N, H, W), Cin, 2), device=dev)
+    got = ops.conv3x3_halo_train_split(dy, dmax, pht, wmax, flip=True, bn_relu=(bx, mean, invstd, gam, bet, part))
+    xh = (bx - mean) * invstd
+    want = torch.where(xh * gam + bet > 0, plain, torch.zeros((), device=dev))
+    assert torch.equal(got, want)
+    tot = part.double().sum(0)
+    ref = torch.stack([want.double().sum(dim=(0, 1, 2)), (want.double() * xh.double()).sum(dim=(0, 1, 2))], dim=1)
+    assert float((tot - ref).abs().max()) < 1e-4 * max(float(ref.abs().max()), 1e-30)
+    lib = _lib.load()
+    M = N * H * W
+    ws = torch.empty(int(lib.ccst_bn_workspace_bytes(M, Cin)) // 4, device=dev)
+    dx_a, dg_a, db_a = torch.empty_like(bx), torch.zeros(Cin, device=dev), torch.zeros(Cin, device=dev)
+    check(lib.ccst_bn_train_bwd_partials_f32(ptr(got), ptr(bx), ptr(gam), ptr(mean), ptr(invstd), ptr(part), int(part.shape[0]), ptr(dx_a),
+                                             ptr(dg_a), ptr(db_a), 0, M, Cin, ptr(ws), ws.numel() * 4, None, stream_ptr()), "bn bwd partials")
+    dx_b, dg_b, db_b = torch.empty_like(bx), torch.zeros(Cin, device=dev), torch.zeros(Cin, device=dev)
+    check(lib.ccst_bn_train_bwd_mask_f32(ptr(plain), ptr(bx), None, None, ptr(gam), ptr(bet), ptr(mean), ptr(invstd), 1, ptr(dx_b), None,
+                                         ptr(dg_b), ptr(db_b), 0, M, Cin, ptr(ws), ws.numel() * 4, None, stream_ptr()), "bn bwd")
+    for a, b in ((dx_a, dx_b), (dg_a, dg_b), (db_a, db_b)):
+        assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
+
+
 def test_pointwise_backward_data_masked_accumulate(dev):
     """ccst_conv2d_igemm_accum_masked_f32: y = mask ? y + dX : 0 (the residual-block input gradient, masked by the previous block's
     ReLU in the conv's own epilogue) against torch; the byte mask has the layout ccst_bn_train_fwd_mask_f32 writes."""
