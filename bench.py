@@ -462,9 +462,10 @@ def main():
         us = sorted(adain_us)[len(adain_us) // 2]
         adain_step = {"bound": "hbm", "bytes": nbytes, "median_us": round(us, 2), "achieved": round(nbytes / us / 1e3, 1),
                       "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(nbytes / us / 1e3 / PEAK_HBM_GBPS, 4),
-                      "kernels": "adain_tile_sums_nhwc_kernel: content statistics folded from the per-tile channel sums that conv4_1's epilogue left "
-                                 "(no statistics pass), normalise + blend streamed once: one read, one write, ONE launch (HIP events around "
-                                 "ccst_adain_tile_sums_f32; CCST_ADAIN_TILE_SUMS=0: the two-pass register-resident kernel of ccst_adain_f32)"}
+                      "kernels": "tile_stats_fold_kernel + adain_stream_nhwc_kernel: content statistics folded ONCE from the per-tile centred records "
+                                 "that conv4_1's epilogue left (no statistics pass), then normalise + blend streamed once: one read, one write (HIP "
+                                 "events around both launches of ccst_adain_tile_sums_f32; the streaming launch alone is ~22 us; "
+                                 "CCST_ADAIN_TILE_SUMS=0: the two-pass register-resident kernel of ccst_adain_f32)"}
 
     # ---- the same step with the two halves of the batch on two HIP streams (CCST_ADAIN_STREAMS=2, style._style_transfer_two_streams):
     # one half's tails, partly filled rounds and HBM-bound edge layers run under the other half's MFMA work.  Reported beside `value`,
