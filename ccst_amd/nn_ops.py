@@ -73,9 +73,6 @@ HALF_FWD = _os.environ.get("CCST_CONV_BF", "4") == "4"
 # words its producing BatchNorm apply left, dy by the words the BatchNorm backward that produced it leaves (dx_absmax).  CCST_BWD_HALF=0:
 # the fp32-MFMA kernel.  (Needs the forward's words, i.e. CCST_CONV_BF=4.)
 HALF_BWD = HALF_FWD and _os.environ.get("CCST_BWD_HALF", "1") != "0"
-# |max| words of gradient tensors, keyed by the tensor's address: autograd hands a backward's result to the next node as a new Python
-# object, so a tag on the tensor would not survive; an entry is consumed by the one conv backward that reads the gradient.
-_GRAD_WORDS = {}
 # The 3x3 stride-1 trunk layers on the half-piece halo kernel (conv3x3_halo.hip, TRAIN + SPLIT form).  CCST_RESNET_HALF3X3:
 #   1: backward-data (its operand is a gradient with words at hand; rounding there moves no ReLU mask);
 #   2 (default): ... and the FORWARD of the layers on maps up to 28 x 28 (ResNet50 layers 2-4: ten of its thirteen stride-1 3x3 convs;
@@ -89,20 +86,28 @@ HALF3X3 = int(_os.environ.get("CCST_RESNET_HALF3X3", "2")) if HALF_BWD else 0
 HALF3X3_FWD_MAX_HW = 28
 
 
-def _publish_grad_words(device):
-    return ops.absmax_words(device) if HALF_BWD else None
+class GradWords(object):
+    """Carries the |max| words of a conv-output gradient from the backward of the BatchNorm that produces it to the backward of the conv
+    that consumes it.  One holder per (conv, BatchNorm) pair and forward pass: Conv2d.forward creates it, hangs it on its output and
+    gives it to its ConvFn; the BatchNorm that reads that output gives it to its own Function, whose backward fills it (`put`); the
+    conv's backward `take`s it -- only for the very tensor it was filled for (autograd may hand over a different one: a hook, an
+    accumulation of several consumers' gradients)."""
+    __slots__ = ("words", "ptr", "shape")
+
+    def __init__(self):
+        self.words = self.ptr = self.shape = None
+
+    def put(self, t, words):
+        self.words, self.ptr, self.shape = words, t.data_ptr(), tuple(t.shape)
+
+    def take(self, t):
+        words, ok = self.words, self.words is not None and self.ptr == t.data_ptr() and self.shape == tuple(t.shape)
+        self.words = self.ptr = self.shape = None
+        return words if ok else None
 
 
-def _note_grad_words(t, words):
-    if words is not None:
-        if len(_GRAD_WORDS) > 1024:         # (gradients nobody consumed: a backward that stopped early)
-            _GRAD_WORDS.clear()
-        _GRAD_WORDS[t.data_ptr()] = (words, tuple(t.shape))
-
-
-def _take_grad_words(t):
-    ent = _GRAD_WORDS.pop(t.data_ptr(), None)
-    return ent[0] if ent is not None and ent[1] == tuple(t.shape) else None
+def _publish_grad_words(device, gw):
+    return ops.absmax_words(device) if (HALF_BWD and gw is not None) else None
 
 
 def _prepack_jobs(model, convs):
@@ -436,8 +441,9 @@ class ConvFn(torch.autograd.Function):
     """Bias-free zero-padded Conv2d on NHWC (nets/resnet.py:160-161 + torchvision blocks)."""
 
     @staticmethod
-    def forward(ctx, x, weight, mod, want_stats=False, sink=None, link=None):
+    def forward(ctx, x, weight, mod, want_stats=False, sink=None, link=None, gw=None):
         ctx.save_for_backward(x, weight)
+        ctx.gw = gw                # GradWords of this conv's output gradient (filled by the following BatchNorm's backward)
         ctx.mod = mod
         ctx.sink = sink
         ctx.link = link          # MaskLink of the ReLU that produced x (residual blocks), or None
@@ -474,10 +480,10 @@ class ConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, *unused):
         if dy is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         x, weight = ctx.saved_tensors
         mod = ctx.mod
-        dymax = _take_grad_words(dy) if HALF_BWD else None
+        dymax = ctx.gw.take(dy) if (HALF_BWD and ctx.gw is not None) else None
         dy = dy.contiguous()
         stride, pad = mod.stride[0], mod.padding[0]
         N, H, W, Cin = x.shape
@@ -534,14 +540,15 @@ class ConvFn(torch.autograd.Function):
                     link.premasked = True
             if deposit:
                 ctx.sink.grad, dx = dx, None
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 class StemConvFn(torch.autograd.Function):
     """Conv2d with <= 4 input channels on the NCHW image (nets/resnet.py:136): no input gradient."""
 
     @staticmethod
-    def forward(ctx, x_nchw, weight, mod):
+    def forward(ctx, x_nchw, weight, mod, gw=None):
+        ctx.gw = gw
         pc, kwp = mod.packed_stem()
         stride, pad, kw = mod.stride[0], mod.padding[0], weight.shape[3]
         x = ops.as_nchw_contiguous(x_nchw)
@@ -573,7 +580,7 @@ class StemConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         xp, weight = ctx.saved_tensors
         N, ho, wo, Hp, Wp, kh, kw, kwp, stride, C = ctx.geom
-        dymax = _take_grad_words(dy) if HALF_BWD else None
+        dymax = ctx.gw.take(dy) if (HALF_BWD and ctx.gw is not None) else None
         if weight.requires_grad:
             cout = weight.shape[0]
             d = CcstConvDesc()
@@ -590,7 +597,7 @@ class StemConvFn(torch.autograd.Function):
             # un-fold (kx, ci) <- virtual channel kx*4+ci : 9.4k floats of glue
             check(_lib.load().ccst_stem_grad_unfold_f32(ptr(gv), ptr(_grad_slot(weight)), cout, kwp, kh, kw, C, 1, stream_ptr()),
                   "stem_grad_unfold")
-        return None, None, None
+        return None, None, None, None
 
 
 # ---------------------------------------------------------------------------
@@ -598,9 +605,10 @@ class StemConvFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------
 class BNFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, mod, relu, stats=None, sink=None):
+    def forward(ctx, x, gamma, beta, residual, mod, relu, stats=None, sink=None, gw=None):
         lib = _lib.load()
         ctx.sink = sink
+        ctx.gw = gw
         N, H, W, C = x.shape
         M = N * H * W
         y = torch.empty_like(x)
@@ -651,7 +659,7 @@ class BNFn(torch.autograd.Function):
         M = N * H * W
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dxmax = _publish_grad_words(x.device)       # max |dx|: the conv in front of this BatchNorm scales its weight gradient's dy by it
+        dxmax = _publish_grad_words(x.device, ctx.gw)       # max |dx|: the conv in front of this BatchNorm scales its backward's dy by it
         ws = _workspace(int(lib.ccst_bn_workspace_bytes(M, C)), x.device)
         link = getattr(ctx, "link", None)
         if link is not None and link.premasked:
@@ -673,10 +681,11 @@ class BNFn(torch.autograd.Function):
             check(lib.ccst_bn_train_bwd_mask_f32(ptr(dy), ptr(x), ptr(y), ptr(mask), ptr(gamma), ptr(beta), ptr(save[0]), ptr(save[1]),
                                                  int(ctx.relu), ptr(dx), ptr(dres), ptr(_grad_slot(gamma)), ptr(_grad_slot(beta)), 1, M, C,
                                                  ptr(ws), ws.numel(), ptr(dxmax), stream_ptr()), "bn_train_bwd")
-        _note_grad_words(dx, dxmax)
+        if dxmax is not None:
+            ctx.gw.put(dx, dxmax)
         if ctx.sink is not None and dres is not None:
             ctx.sink.grad, dres = dres, None        # handed to the block's first conv (GradSink), not to autograd
-        return dx, None, None, dres, None, None, None, None
+        return dx, None, None, dres, None, None, None, None, None
 
 
 class StemBnReluPoolFn(torch.autograd.Function):
@@ -684,8 +693,9 @@ class StemBnReluPoolFn(torch.autograd.Function):
     normalised full-resolution map nor its gradient is ever stored (see ccst_bn_relu_maxpool_train_fwd_f32)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, mod, stats=None):
+    def forward(ctx, x, gamma, beta, mod, stats=None, gw=None):
         lib = _lib.load()
+        ctx.gw = gw
         N, H, W, C = x.shape
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         M = N * H * W
@@ -712,13 +722,14 @@ class StemBnReluPoolFn(torch.autograd.Function):
         N, H, W, C = x.shape
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         dx = torch.empty_like(x)
-        dxmax = _publish_grad_words(x.device)
+        dxmax = _publish_grad_words(x.device, ctx.gw)
         ws = _workspace(int(lib.ccst_bn_workspace_bytes(N * H * W, C)), x.device)
         check(lib.ccst_bn_relu_maxpool_train_bwd_f32(ptr(dy.contiguous()), ptr(idx), ptr(x), ptr(gamma), ptr(beta), ptr(save[0]), ptr(save[1]),
                                                      ptr(dx), ptr(_grad_slot(gamma)), ptr(_grad_slot(beta)), 1, N, H, W, C, Ho, Wo, ptr(ws),
                                                      ws.numel(), ptr(dxmax), stream_ptr()), "bn_relu_maxpool_bwd")
-        _note_grad_words(dx, dxmax)
-        return dx, None, None, None, None
+        if dxmax is not None:
+            ctx.gw.put(dx, dxmax)
+        return dx, None, None, None, None, None
 
 
 # ---------------------------------------------------------------------------
