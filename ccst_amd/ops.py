@@ -295,7 +295,7 @@ class PackedConv(object):
         self.k_pad, self.n_pad, self.transpose = k_pad, n_pad, transpose
         self.src, self.wino = src, wino          # OIHW source (kept only for lazily packed weights) and the wino= argument
         self.u4_pad = round_up(cout, 64)
-        self._u4 = self._wsplit = self._wabsmax = self._uf23 = None
+        self._u4 = self._wsplit = self._wabsmax = self._uf23 = self._uf43 = None
         self._order = _PackOrder()
 
     # ---- which layouts exist (no packing) ----
@@ -357,6 +357,11 @@ class PackedConv(object):
     @property
     def uf23(self):
         return self._lazy("_uf23", 12 * self.cin * self.n_pad, _lib.load().ccst_pack_conv_weight_f23_f32, "pack_conv_weight_f23",
+                          self.n_pad, ptr(self.wabsmax)) if self.can_split() else None
+
+    @property
+    def uf43(self):
+        return self._lazy("_uf43", 18 * self.cin * self.n_pad, _lib.load().ccst_pack_conv_weight_f43_f32, "pack_conv_weight_f43",
                           self.n_pad, ptr(self.wabsmax)) if self.can_split() else None
 
 
@@ -450,6 +455,8 @@ F23 = os.environ.get("CCST_CONV_F23", "1") != "0"
 F23_MIN_FILL = float(os.environ.get("CCST_F23_MIN_FILL", "0.5"))
 F23_MIN_COUT = 128      # (the Cout = 64 layers padded to its 128-channel tile measured slower than the direct half-piece kernel)
 F23_FORCE = os.environ.get("CCST_CONV_F23", "1") == "2"       # every Cout >= 128 layer whatever its grid (tests: small images)
+# ... and F(4,3) along x (conv3x3_f43.hip: 1.5 executed FLOPs per algorithmic one) in the F(2,3) kernel's place.  CCST_CONV_F43=0: F(2,3).
+F43 = os.environ.get("CCST_CONV_F43", "1") != "0"
 _N_CU = {}
 
 
@@ -471,8 +478,13 @@ def f23_wanted(pc, N, H, W, device):
     return wgs >= F23_MIN_FILL * num_cus(device)
 
 
-def conv3x3_f23(x, pc, flags, sums=False, x_absmax=None, y_absmax=None):
-    """3x3 stride-1 pad-1 conv as Winograd F(2,3) along x on half pieces; same arguments and results as conv3x3_halo_split."""
+def conv3x3_f43(x, pc, flags, sums=False, x_absmax=None, y_absmax=None):
+    """3x3 stride-1 pad-1 conv as Winograd F(4,3) along x on half pieces (conv3x3_f43.hip); same arguments and results as conv3x3_f23."""
+    return conv3x3_f23(x, pc, flags, sums=sums, x_absmax=x_absmax, y_absmax=y_absmax, form=4)
+
+
+def conv3x3_f23(x, pc, flags, sums=False, x_absmax=None, y_absmax=None, form=2):
+    """3x3 stride-1 pad-1 conv as Winograd F(2,3) (form=4: F(4,3)) along x on half pieces; same arguments and results as conv3x3_halo_split."""
     N, Hs, Ws, Cx = x.shape
     if x_absmax is None:
         x_absmax = absmax(x)
@@ -486,16 +498,17 @@ def conv3x3_f23(x, pc, flags, sums=False, x_absmax=None, y_absmax=None):
         if pool:
             raise ValueError("ccst_amd.ops: the statistics epilogue is of the un-pooled output")
         part = torch.empty((int(lib.ccst_conv3x3_f23_tiles(N, Hi, Wi)), pc.cout, 4), device=x.device, dtype=torch.float32)
-    args = (ptr(x), ptr(x_absmax), ptr(pc.uf23), ptr(pc.wabsmax), ptr(pc.bias), ptr(out), ptr(y_absmax), N, Hi, Wi, Cx, pc.cout, pc.n_pad, flags,
-            ptr(part), stream_ptr())
+    fn, name = (lib.ccst_conv3x3_f43_f32, "conv3x3_f43") if form == 4 else (lib.ccst_conv3x3_f23_f32, "conv3x3_f23")
+    args = (ptr(x), ptr(x_absmax), ptr(pc.uf43 if form == 4 else pc.uf23), ptr(pc.wabsmax), ptr(pc.bias), ptr(out), ptr(y_absmax), N, Hi, Wi, Cx,
+            pc.cout, pc.n_pad, flags, ptr(part), stream_ptr())
     if TIMING is None:
-        check(lib.ccst_conv3x3_f23_f32(*args), "conv3x3_f23")
+        check(fn(*args), name)
     else:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(lib.ccst_conv3x3_f23_f32(*args), "conv3x3_f23")
+        check(fn(*args), name)
         e1.record()
-        TIMING.append(("conv3x3_f23_kernel<%s>" % ("pool" if pool else "nopool"), 2.0 * N * Hi * Wi * pc.cout * pc.cin * 9, e0, e1,
+        TIMING.append(("%s_kernel<%s>" % (name, "pool" if pool else "nopool"), 2.0 * N * Hi * Wi * pc.cout * pc.cin * 9, e0, e1,
                        "n%d %dx%d cin%d cout%d taps3x3 flags%d" % (N, Hi, Wi, pc.cin, pc.cout, flags)))
     return (out, part) if sums else out
 
@@ -668,12 +681,12 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
     if chan_sums:       # (the caller checked wino4w_sums_ok)
         if halo_split_wanted(pc) and Cx == pc.cin and not pool:
             if f23_wanted(pc, N, Hi, Wi, x.device):
-                return conv3x3_f23(x, pc, flags, sums=True, x_absmax=x_absmax, y_absmax=y_absmax)
+                return conv3x3_f23(x, pc, flags, sums=True, x_absmax=x_absmax, y_absmax=y_absmax, form=4 if F43 else 2)
             return conv3x3_halo_split(x, pc, flags, sums=True, x_absmax=x_absmax, y_absmax=y_absmax)
         return conv3x3_wino4(x, pc, flags, sums=True)
     if halo_split_wanted(pc) and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats and Cx == pc.cin:
         if f23_wanted(pc, N, Hi, Wi, x.device):
-            return conv3x3_f23(x, pc, flags, x_absmax=x_absmax, y_absmax=y_absmax)
+            return conv3x3_f23(x, pc, flags, x_absmax=x_absmax, y_absmax=y_absmax, form=4 if F43 else 2)
         return conv3x3_halo_split(x, pc, flags, x_absmax=x_absmax, y_absmax=y_absmax)
     if pc.can_wino4w() and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats \
             and wino4_ok(pc.cin, pc.cout, Hi, Wi):

@@ -165,6 +165,16 @@ int ccst_conv3x3_f23_f32(const float* x, const uint32_t* x_absmax, const float* 
                          void* stream);
 int ccst_conv3x3_f23_workgroups(int N, int H, int W, int Cout);
 int ccst_conv3x3_f23_tiles(int N, int H, int W);
+/* The same convolution once more (same contract, tile, grid and statistics rows as ccst_conv3x3_f23_f32) as Winograd F(4,3) along x on the
+ * half pieces: SIX transform positions per QUAD of output pixels -- 18 instead of 24 k-steps per pixel quad, 1.5 executed 16-bit MFMA
+ * FLOPs per algorithmic FLOP (conv3x3_f43.hip); ~3x the rounding of F(2,3) (1-2e-6 of max |y| per layer).  u from
+ * ccst_pack_conv_weight_f43_f32: 18 * cin * cout_pad floats' worth of [2 (ky * 3 + j) + group][cin/16][cout_pad][16 k hi | lo] rows of G g
+ * (position q = 3 group + j), scaled by the power of two derived from w_absmax.  Replaces nn.Conv2d(.., (3, 3)) after ReflectionPad2d in
+ * style_transfer/AdaIN/net.py:6-36 (decoder) and :38-69 (vgg) for the layers with Cout >= 128. */
+int ccst_pack_conv_weight_f43_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, const uint32_t* w_absmax, void* stream);
+int ccst_conv3x3_f43_f32(const float* x, const uint32_t* x_absmax, const float* u, const uint32_t* w_absmax, const float* bias, float* y,
+                         uint32_t* y_absmax, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags, float* chan_sum_partials,
+                         void* stream);
 /* chan_sum_partials (may be NULL; not with POOL2): [ccst_conv3x3_halo_split_tiles(N,H,W)][Cout][4] per-(8x16-pixel tile, wave row)
  * (sum, M2, count, 0) of the output after bias / ReLU, M2 = the sum of squares about the slab's OWN mean (no E[x^2] - mean^2
  * cancellation however large |mean| / sigma is), an image's rows contiguous -- the statistics ccst_adain_tile_sums_f32 and
