@@ -8,19 +8,22 @@
 //     G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
 //     A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
 // i.e. 18 k-steps per 16-channel chunk and pixel quad instead of F(2,3)'s 24 (direct: 36): 1.5 executed MFMA FLOPs per algorithmic FLOP.
-// The price is rounding (interpolation points +-2: ~3x F(2,3)'s error per layer, 1-2e-6 of max |y|; test) and six accumulator sets.
+// The price is rounding (interpolation points +-2: ~3x F(2,3)'s error per layer, 1-5e-6 of max |y|; test) and six accumulator sets.
 //
-//   * workgroup = 8 rows x 32 pixels (= 64 GEMM rows: (row, pixel quad)) x 128 output channels, EIGHT waves = 2 POSITION GROUPS (q = 0..2,
-//     q = 3..5) x 4 channel quarters: a wave holds 64 rows x 32 channels x 3 positions = 6 accumulators of 16 registers (all six
-//     positions in one wave would be 192 registers) and runs 9 k-steps of 6 MFMAs per chunk (F(2,3): 12).  The two groups run the same
-//     k-step schedule on different positions (the group is a template parameter of the main loop: every LDS offset is an immediate);
+// Version 1 of this kernel kept the F(2,3) kernel's structure (eight waves, weights through an LDS ring) and was bound by LDS bandwidth:
+// 755 KB per chunk through a 128 B/clock port = 5900 clocks next to 6912 clocks of MFMA, overlapping badly under a barrier per k-step
+// (timing ablation: everything but the MFMAs took 152 of the 217 us of a 256 -> 256 layer).  This version moves two thirds of it away:
+//   * workgroup = 8 rows x 32 pixels (= 64 GEMM rows: (row, pixel quad)) x 128 output channels, FOUR waves of up to 512 registers (one
+//     per SIMD) = 2 POSITION GROUPS (q = 0..2, q = 3..5) x 2 channel halves: a wave holds 64 rows x 64 channels x 3 positions = 12
+//     accumulators (192 registers) and runs 9 k-steps of 12 MFMAs per chunk on 4 A fragments (LDS) and 4 B fragments;
+//   * the WEIGHTS NEVER TOUCH LDS: every wave loads its own B fragments (64 channels x 16 k x hi | lo = 4 KB per k-step, packed in
+//     fragment order) straight into a ring of NINE register sets, one per k-step of a chunk, each refilled for the next chunk right
+//     after its last MFMA: a whole chunk (~2.5 us) of prefetch distance, no barrier for the weights;
+//   * LDS holds the transformed halo (double buffered) and the raw fp32 halo of the next chunk (LDS-DMA): two barriers per chunk;
+//   * the transform works on PAIRS of positions that share their pixels -- (1,2) and (3,4): four 16-byte reads for two positions,
+//     (0,5): six -- 960 items per chunk, four per thread; the scale 2^kx rides in the coefficients;
 //   * the output transform needs all six positions: after the last chunk the groups exchange two partial sums per accumulator
-//     element through LDS (the operand images are dead by then) -- group 0 finishes pixels 4p, 4p + 1, group 1 pixels 4p + 2, 4p + 3;
-//   * the loader is the F(2,3) kernel's: raw fp32 halo pixels and pre-transformed, scaled, split weights by LDS-DMA with hand-counted
-//     vmcnt; 480 threads transform one (halo row, quad, position, 4-channel part) item at each of four k-steps (3-6) per chunk: four 16-byte
-//     LDS reads, c0 d_a + c1 d_b + c2 d_c + c3 d_d with the power-of-two scale folded into the coefficients, split, two 8-byte stores;
-//   * weights: 18 slabs of 8 KB per chunk in the order the two groups consume them, a 9-stage LDS ring: at k-step t every wave refills
-//     the two stages of k-step t (read one k-step earlier) with the slabs of k-steps t + 4 / t + 5.
+//     element through LDS -- group 0 finishes pixels 4p, 4p + 1, group 1 pixels 4p + 2, 4p + 3;
 //   * epilogue as in conv3x3_f23.hip: scale back, A^T, bias, ReLU, the 2x2 ceil max-pool, NHWC stores, max |y|, per-tile statistics.
 #include "common.h"
 
@@ -40,23 +43,27 @@ struct F43Args {
     long long ysN;
     int ysH, ysW;
     int tilesX, tilesY, tilesN;
+    int ubytes;
 };
 
 typedef ccst_u32x2 u32x2g;
 typedef _Float16 f16x8g __attribute__((ext_vector_type(8)));
 typedef float f32x2g __attribute__((ext_vector_type(2)));
 
-constexpr int G_TH = 8, G_TW = 32, G_XQ = G_TW / 4, G_HH = G_TH + 2, G_BN = 128, G_NT = 512;
+constexpr int G_TH = 8, G_TW = 32, G_XQ = G_TW / 4, G_HH = G_TH + 2, G_BN = 128, G_NT = 256;
 constexpr int G_QW = 16;                          // words per (quad, position): 16 channels hi (8 words) | 16 channels lo (8 words)
 constexpr int G_XQW = 6 * G_QW + 4;               // 100 words = 25 sixteen-byte units per quad (9 modulo 16)
 constexpr int G_ROWW = G_XQ * G_XQW + 16;         // 816 words = 204 units per halo row (12 modulo 16): the 16 lanes of a fragment read pass
                                                   // -- rows 0..3 x quads 0..3 -- land on 16 different 16-byte bank groups
 constexpr int G_VW = G_HH * G_ROWW;               // words per V buffer (32.6 KB)
 constexpr int G_RW = G_TW + 2;                    // raw halo pixels per row (34)
-constexpr int G_RAW_PIECES = 22;                  // 1 KiB LDS-DMA pieces of the raw halo image: 10 x 34 pixels x 64 B = 21.25
-constexpr int G_RING = 9;                         // weight stages of 8 KB (128 output channels x 64 B, XOR-swizzled parts)
-constexpr int G_RAW0 = 2 * G_VW, G_WS0 = G_RAW0 + G_RAW_PIECES * 256;
-constexpr int G_LDS_BYTES = (G_WS0 + G_RING * 2048) * 4;        // 161 536 B of the CU's 163 840: one workgroup per CU
+// raw halo image: 64 B per pixel, ONE PAD SLOT after every four pixels -- pixel hx sits in slot hx + (hx >> 2), a quad's six pixels at
+// slots 5 xq + {0, 1, 2, 3, 5, 6}: constant offsets, and four consecutive quads 320 B apart = on four different 64-byte bank groups
+constexpr int G_RSLOTS = 42;                      // slots per raw row (34 pixels + 8 pads)
+constexpr int G_RAW_PIECES = 27;                  // 1 KiB LDS-DMA pieces (16 slots each): 10 x 42 slots = 26.25
+constexpr int G_RAW0 = 2 * G_VW;
+constexpr int G_LDS_BYTES = 131072;               // operand images: 92 928 B; the epilogue's exchange: 4 waves x 32 KB
+static_assert((G_RAW0 + G_RAW_PIECES * 256) * 4 <= G_LDS_BYTES, "LDS layout");
 // operand scale targets (common.h): a position is up to 10 x the largest pixel (|4| + |-5| + |1|); a transformed weight at most 1 x
 constexpr int F43_X_TARGET = CCST_SPLIT_X_TARGET - 4, F43_W_TARGET = CCST_SPLIT_W_TARGET - 1;
 
@@ -66,7 +73,8 @@ __device__ __forceinline__ int reflect_g(int i, int n) {
     return min(max(i, 0), n - 1);
 }
 
-// One LDS-DMA piece (see conv3x3_f23.hip): 64 lanes x 16 bytes -> 1 KiB of LDS at the wave-uniform byte address lds_addr
+// One LDS-DMA piece (see conv3x3_f23.hip): 64 lanes x 16 bytes -> 1 KiB of LDS at the wave-uniform byte address lds_addr.  hipcc neither
+// counts it in its s_waitcnt bookkeeping nor waits for it: the loop's barrier at k-step 2 carries a hand-counted vmcnt.
 __device__ __forceinline__ void glds16g(const void* sbase, unsigned voff, unsigned lds_addr) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -74,26 +82,22 @@ __device__ __forceinline__ void glds16g(const void* sbase, unsigned voff, unsign
                  : "v"(voff), "s"(sbase), "s"(lds_addr)
                  : "memory");
 }
+// (compile-time integers handed to generic lambdas)
 template <int V>
 struct GroupTag {
     static constexpr int value = V;
 };
-template <int N>
-__device__ __forceinline__ void dma_barrier_g() {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
-}
 
 template <bool POOL>
-__global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
+__global__ __launch_bounds__(G_NT, 1) void conv3x3_f43_kernel(const F43Args p) {
     extern __shared__ __attribute__((aligned(16))) float f43_lds[];
     float* const Vs = f43_lds;                     // [2][G_VW]             transformed halo, double buffered
-    float* const Raw = f43_lds + G_RAW0;           // [G_RAW_PIECES * 256]  raw fp32 halo pixels of the NEXT chunk, 64 B per pixel
-    float* const Ws = f43_lds + G_WS0;             // [G_RING][2048]        weight stages, 64 B per output channel, 16-byte parts XOR-swizzled
+    float* const Raw = f43_lds + G_RAW0;           // [G_RAW_PIECES * 256]  raw fp32 halo pixels of the NEXT chunk
     const unsigned lds0 = (unsigned)(size_t)f43_lds;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, wn = wave & 3;
+    const int grp = wave >> 1, wh = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
 
     int bid = ccst_xcd_remap(blockIdx.x, gridDim.x);
@@ -110,21 +114,16 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
     const int nchunks = p.Cin / 16;
 
     const float* const ximg = p.x + (long long)n * p.Hs * p.Ws * p.Cin;
-    // weight piece `wave` of a slab: lane -> row r = 16 wave + (lane >> 2), LDS slot k = lane & 3 holds part k ^ f(r), f(r) = (r >> 2) & 3
-    unsigned wsrc;
-    {
-        const int r = wave * 16 + (lane >> 2), k = lane & 3;
-        wsrc = (unsigned)(((co0 + r) * 16 + ((k ^ ((r >> 2) & 3)) * 4)) * 4);
-    }
-    // raw pieces g = wave + 8 i (i = 0..2) of the 10 x 34-pixel halo (pieces 22, 23 do not exist: waves 6, 7 fetch piece 21 a second time so
-    // that every wave issues the same number of pieces -- the vmcnt table below counts on it)
-    unsigned rsrc_[3];
-    int rpiece[3];
+    // raw pieces g = wave + 4 i (i = 0..6) of the 10 x 42-slot halo image (piece 27 does not exist: wave 3 fetches piece 26 a second time
+    // so that every wave issues the same number of pieces -- the vmcnt at k-step 2 counts on it); lane -> slot 16 g + (lane >> 2), part
+    // lane & 3; reflection / zero padding (the value is zeroed at the transform) / nearest-x2 upsample on the address
+    unsigned rsrc_[7];
+    int rpiece[7];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        rpiece[i] = min(wave + 8 * i, G_RAW_PIECES - 1);
-        const int P = min(rpiece[i] * 16 + (lane >> 2), G_HH * G_RW - 1);
-        const int hy = P / G_RW, hx = P - hy * G_RW;
+    for (int i = 0; i < 7; ++i) {
+        rpiece[i] = min(wave + 4 * i, G_RAW_PIECES - 1);
+        const int S = min(rpiece[i] * 16 + (lane >> 2), G_HH * G_RSLOTS - 1);
+        const int hy = S / G_RSLOTS, sx = S - hy * G_RSLOTS, hx = min(sx - sx / 5, G_RW - 1);
         int gy = oy0 + hy - 1, gx = ox0 + hx - 1;
         if (p.reflect) {
             gy = reflect_g(gy, p.H);
@@ -135,187 +134,201 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
         }
         rsrc_[i] = (unsigned)((((gy >> p.ups) * p.Ws + (gx >> p.ups)) * p.Cin + (lane & 3) * 4) * 4);
     }
-    // transform items: 10 halo rows x 8 quads x 6 positions x 4 channel parts = 1920 = FOUR per thread for 480 threads: thread ->
-    // (position q = (tid >> 2) % 6, part tid & 3), item i -> (row, quad) number (tid >> 2) / 6 + 20 i of the 80.  A position is
-    // c0 d_a + c1 d_b + c2 d_c + c3 d_d of four of the quad's six raw pixels (the rows of B^T; q = 0, 5 have three terms: c3 = 0).
-    int tsrc[4], tdst[4], td1, td2, td3;
-    float tc0, tc1, tc2, tc3;
-    unsigned tok = 0xffffu;          // zero padding: validity of (d_a .. d_d) of item i in bits 4 i .. 4 i + 3
-    const bool titem = tid < 480;
-    {
-        const int u = tid >> 2, part = tid & 3, q = u % 6, v = u / 6;
-        const int da = q == 0 ? 0 : 1, db = (q == 5) ? 3 : 2, dc = q == 0 ? 4 : (q == 5 ? 5 : 3), dd = q == 5 ? 5 : 4;
-        tc0 = q == 0 ? 4.f : q == 1 ? -4.f : q == 2 ? 4.f : q == 3 ? -2.f : q == 4 ? 2.f : 4.f;
-        tc1 = (q == 0 || q == 5) ? -5.f : (q == 1 || q == 2) ? -4.f : -1.f;
-        tc2 = (q == 0 || q == 5) ? 1.f : q == 1 ? 1.f : q == 2 ? -1.f : q == 3 ? 2.f : -2.f;
-        tc3 = (q == 0 || q == 5) ? 0.f : 1.f;
-        td1 = (db - da) * 16;
-        td2 = (dc - da) * 16;
-        td3 = (dd - da) * 16;
-        if (!p.reflect) tok = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int combo = min(v + 20 * i, 79), hy = combo >> 3, xq = combo & 7;
-            tsrc[i] = (hy * G_RW + 4 * xq + da) * 16 + part * 4;
-            tdst[i] = hy * G_ROWW + xq * G_XQW + q * G_QW + part * 2;
-            if (!p.reflect) {
-                const int gy = oy0 + hy - 1, gx = ox0 + 4 * xq - 1;
-                const bool oky = (gy >= 0) & (gy < p.H);
-                const int xs4[4] = {gx + da, gx + db, gx + dc, gx + dd};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) tok |= ((oky & (xs4[j] >= 0) & (xs4[j] < p.W)) ? 1u : 0u) << (4 * i + j);
-            }
-        }
-    }
-
-    auto dma_w = [&](int c_, int m_) {          // slab m_ (>= 18: of the next chunk; clamped at the end) -> ring stage m_ % 9
-        const int cc = min(c_ + m_ / 18, nchunks - 1), mm = m_ % 18;
-        const float* wc = p.u + ((long long)mm * nchunks + cc) * p.CoutPad * 16;         // uniform
-        glds16g(wc, wsrc, (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)((G_WS0 + (m_ % G_RING) * 2048) * 4 + wave * 1024))));
-    };
-    auto dma_raw = [&](int c_, int i) {         // raw piece wave + 8 i of chunk c_
+    auto dma_raw = [&](int c_, int i) {         // raw piece wave + 4 i of chunk c_
         const int cc = min(c_, nchunks - 1);
         glds16g(ximg + cc * 16, rsrc_[i], (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(G_RAW0 * 4 + rpiece[i] * 1024))));
     };
-    // item i of this thread: raw -> position -> (hi, lo) -> V[buf]
-    auto xform = [&](int buf, int i) {
-        if (!titem) return;
-        const float* r0 = &Raw[tsrc[i]];
-        f32x4 da = *reinterpret_cast<const f32x4*>(r0);
-        f32x4 db = *reinterpret_cast<const f32x4*>(r0 + td1);
-        f32x4 dc = *reinterpret_cast<const f32x4*>(r0 + td2);
-        f32x4 dd = *reinterpret_cast<const f32x4*>(r0 + td3);
-        if (!p.reflect) {
-            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (!((tok >> (4 * i)) & 1u)) da = z;
-            if (!((tok >> (4 * i + 1)) & 1u)) db = z;
-            if (!((tok >> (4 * i + 2)) & 1u)) dc = z;
-            if (!((tok >> (4 * i + 3)) & 1u)) dd = z;
+
+    // ---- transform items: 3 position pairs x 10 halo rows x 8 quads x 4 channel parts = 960 = (up to) FOUR per thread: inside an item
+    // lane -> (row + (lane >> 5), quad (lane >> 2) & 7, part lane & 3); items 0..2: pair i of rows 2 wave, 2 wave + 1 (the pair is a compile-
+    // time constant and the row sits in the thread's base address: every LDS offset of the loop is an instruction immediate -- with
+    // run-time rows hipcc hoisted a vector add per access out of the loop and spilled 340 registers); item 3: pair `wave` of rows 8, 9
+    // (wave 3 idle).
+    const int xq_t = (lane >> 2) & 7, part_t = lane & 3;
+    const int tsrcW = ((2 * wave + lh) * G_RSLOTS + 5 * xq_t) * 16 + part_t * 4, tsrc8 = ((8 + lh) * G_RSLOTS + 5 * xq_t) * 16 + part_t * 4;
+    const int tdstW = (2 * wave + lh) * G_ROWW + xq_t * G_XQW + part_t * 2, tdst8 = (8 + lh) * G_ROWW + xq_t * G_XQW + part_t * 2;
+    unsigned tokx = 0x3fu;       // zero padding: validity of the quad's six pixels;
+    bool okyW = true, oky8 = true;   // ... of the rows of items 0..2, of item 3
+    if (!p.reflect) {
+        tokx = 0;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {
+            const int gx = ox0 + 4 * xq_t - 1 + d;
+            tokx |= (((gx >= 0) & (gx < p.W)) ? 1u : 0u) << d;
         }
+        const int gyW = oy0 + 2 * wave + lh - 1, gy8 = oy0 + 8 + lh - 1;
+        okyW = (gyW >= 0) & (gyW < p.H);
+        oky8 = (gy8 >= 0) & (gy8 < p.H);
+    }
+    float xs = 1.f;          // 2^kx (set in the prologue)
+    auto put = [&](float* o, f32x4 v) {          // four scaled fp32 values -> (hi, lo) half pieces -> V
         u32x2g hi, lo;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {          // the scale 2^kx rides in the coefficients (exact): three roundings, those of the fmas
-            f32x2g pv = f32x2g{da[2 * h], da[2 * h + 1]} * tc0;
-            pv = f32x2g{db[2 * h], db[2 * h + 1]} * tc1 + pv;
-            pv = f32x2g{dc[2 * h], dc[2 * h + 1]} * tc2 + pv;
-            pv = f32x2g{dd[2 * h], dd[2 * h + 1]} * tc3 + pv;
-            unsigned wh, wl;
-            ccst_split2_half(pv[0], pv[1], wh, wl);
-            hi[h] = wh;
-            lo[h] = wl;
+        for (int h = 0; h < 2; ++h) {
+            unsigned a, b;
+            ccst_split2_half(v[2 * h], v[2 * h + 1], a, b);
+            hi[h] = a;
+            lo[h] = b;
         }
-        float* o = &Vs[buf * G_VW + tdst[i]];
         *reinterpret_cast<u32x2g*>(o) = hi;
         *reinterpret_cast<u32x2g*>(o + 8) = lo;
     };
+    // one item: raw -> the two positions of pair PAIR -> (hi, lo) -> V.  (The scale rides in the coefficients: c * 2^kx is exact, every
+    // position costs the roundings of its fused multiply-adds only.)
+    auto xpair = [&](auto ptag, const float* r0, float* o, bool oky) __attribute__((always_inline)) {
+        constexpr int PAIR = decltype(ptag)::value;
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool zp = !p.reflect;
+        auto px = [&](int d) {                   // pixel d of the quad (0..5)
+            f32x4 v = *reinterpret_cast<const f32x4*>(r0 + (d < 4 ? d : d + 1) * 16);
+            if (zp && !(oky && ((tokx >> d) & 1u))) v = z;
+            return v;
+        };
+        if (PAIR < 2) {
+            // positions (1, 2): c1 = -4, c2 = 4, c3 = 1;   (3, 4): c1 = -1, c2 = 2, c3 = 2:
+            //   s = c1 d2 + d4,   V_a = -c2 d1 + (c3 d3 + s),   V_b = c2 d1 + (-c3 d3 + s)
+            const float c1 = PAIR == 0 ? -4.f * xs : -xs, c2 = PAIR == 0 ? 4.f * xs : 2.f * xs, c3 = PAIR == 0 ? xs : 2.f * xs;
+            const f32x4 d2 = px(2), d4 = px(4);
+            const f32x4 sc = d2 * c1 + d4 * xs;
+            const f32x4 d1 = px(1), d3 = px(3);
+            const f32x4 va = d1 * (-c2) + (d3 * c3 + sc), vb = d1 * c2 + (sc - d3 * c3);
+            put(o + (PAIR == 0 ? 1 : 3) * G_QW, va);
+            put(o + (PAIR == 0 ? 2 : 4) * G_QW, vb);
+        } else {
+            // positions 0: 4 d0 - 5 d2 + d4;   5: 4 d1 - 5 d3 + d5
+            const float c4 = 4.f * xs, c5 = -5.f * xs;
+            const f32x4 d0 = px(0), d2 = px(2), d4 = px(4);
+            put(o, d0 * c4 + (d2 * c5 + d4 * xs));
+            const f32x4 d1 = px(1), d3 = px(3), d5 = px(5);
+            put(o + 5 * G_QW, d1 * c4 + (d3 * c5 + d5 * xs));
+        }
+    };
+    // (dW, d8: the thread's destination in the V buffer being filled -- tdstW / tdst8 of buffer 0 or 1; the loop swaps them per chunk)
+    auto xform = [&](int dW, int d8, int i) __attribute__((always_inline)) {
+        if (i == 0) xpair(GroupTag<0>{}, &Raw[tsrcW], &Vs[dW], okyW);
+        if (i == 1) xpair(GroupTag<1>{}, &Raw[tsrcW], &Vs[dW], okyW);
+        if (i == 2) xpair(GroupTag<2>{}, &Raw[tsrcW], &Vs[dW], okyW);
+        if (i == 3) {
+            if (wave == 0) xpair(GroupTag<0>{}, &Raw[tsrc8], &Vs[d8], oky8);
+            else if (wave == 1) xpair(GroupTag<1>{}, &Raw[tsrc8], &Vs[d8], oky8);
+            else if (wave == 2) xpair(GroupTag<2>{}, &Raw[tsrc8], &Vs[d8], oky8);
+        }
+    };
 
-    f32x16 acc[3][2];
+    // ---- B fragments straight from memory: packed [m = 2 t + group][chunk][cout_pad / 32][piece][32 channels][16 k as 8 words] -- one
+    // buffer load per (piece, 32-channel tile) reads 1 KiB contiguous; beyond the array (the prefetch of the chunk after the last) it returns 0
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.ubytes, 0x00020000);
+    const int bvoff = li * 32 + lh * 16;
+    const int wgroups = p.CoutPad >> 5, wg0 = (co0 >> 5) + 2 * wh;
+
+    f32x16 acc[3][2][2];         // [position of the group][M tile][N tile]
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[q][mt][r] = 0.f;
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][mt][nt][r] = 0.f;
 
-    // fragment bases: GEMM row li of M tile mt is (row 4 mt + (li & 3), quad li >> 2); weight row wn * 32 + li, piece pc = parts
-    // 2 pc + lh -> slot (2 pc + lh) ^ f(row)
-    int aBase[2], bBase[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) aBase[mt] = (4 * mt + (li & 3)) * G_ROWW + (li >> 2) * G_XQW + lh * 4;
-#pragma unroll
-    for (int pc = 0; pc < 2; ++pc) bBase[pc] = (wn * 32 + li) * 16 + (((2 * pc + lh) ^ ((li >> 2) & 3)) * 4);
+    // A fragment base: GEMM row li of M tile mt is (row 4 mt + (li & 3), quad li >> 2)
+    const int aBase = (li & 3) * G_ROWW + (li >> 2) * G_XQW + lh * 4;
 
-    struct Frags {
-        f16x8g a[2][2], b[2];         // [piece][M tile], [piece]
-    };
-
-    // ---- prologue: raw pixels of chunk 0 and the weight slabs 0..8, transform chunk 0, then the raw pixels of chunk 1 ---------------
+    // ---- prologue: raw pixels of chunk 0, transform, raw pixels of chunk 1 ------------------------------------------------------------
 #pragma unroll
-    for (int i = 0; i < 3; ++i) dma_raw(0, i);
-#pragma unroll
-    for (int m = 0; m < G_RING; ++m) dma_w(0, m);
-    dma_barrier_g<0>();
+    for (int i = 0; i < 7; ++i) dma_raw(0, i);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     asm volatile("" : "+v"(xword), "+v"(wword));
     const int kx = ccst_scale_exp(ccst_absmax_reduce(xword), F43_X_TARGET);
     const int kw = ccst_scale_exp(ccst_absmax_reduce(wword), F43_W_TARGET);
-    {
-        const float xs = __uint_as_float((unsigned)(127 + kx) << 23);
-        tc0 *= xs;
-        tc1 *= xs;
-        tc2 *= xs;
-        tc3 *= xs;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) xform(0, i);
-    dma_barrier_g<0>();
-#pragma unroll
-    for (int i = 0; i < 3; ++i) dma_raw(1, i);
+    xs = __uint_as_float((unsigned)(127 + kx) << 23);
 
-    // The main loop of position group G_ (a compile-time constant: positions, ring stages and V offsets are instruction immediates).
-    // k-step t = ky * 3 + j of a chunk: group G_ multiplies position q = 3 G_ + j of halo rows ky .. ky + 7 by slab m = 2 t + G_.
+    // The main loop of position group G_ (a compile-time constant: positions are instruction immediates).  k-step t = ky * 3 + j of a
+    // chunk: group G_ multiplies position q = 3 G_ + j of halo rows ky .. ky + 7 by slab m = 2 t + G_.  The two V buffers alternate per
+    // chunk: the thread's bases into "this chunk's" and "the next chunk's" buffer are swapped at the end of a chunk (ONE loop body).
     auto run = [&](auto gtag) __attribute__((always_inline)) {
         constexpr int G_ = decltype(gtag)::value;
-        auto read_frags = [&](Frags& f, int vbuf, int t_) {
-            const float* vb = &Vs[vbuf * G_VW + (t_ / 3) * G_ROWW + (3 * G_ + t_ % 3) * G_QW];
-            const float* bb = &Ws[((2 * t_ + G_) % G_RING) * 2048];
+        f16x8g bq[9][2][2];          // [k-step][piece][N tile]: the weight ring
+        const int tstride = 2 * nchunks * wgroups * 2048, cstride = wgroups * 2048;
+        int sbase = (G_ * nchunks * wgroups + wg0) * 2048;          // slab (t = 0, group G_) of the chunk being LOADED
+        auto load_b = [&](int t_) {
+            const int soff = sbase + t_ * tstride;        // uniform
 #pragma unroll
-            for (int pc = 0; pc < 2; ++pc) {
+            for (int pc = 0; pc < 2; ++pc)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) f.a[pc][mt] = __builtin_bit_cast(f16x8g, *reinterpret_cast<const f32x4*>(vb + aBase[mt] + 8 * pc));
-                f.b[pc] = __builtin_bit_cast(f16x8g, *reinterpret_cast<const f32x4*>(bb + bBase[pc]));
-            }
+                for (int nt = 0; nt < 2; ++nt)
+                    bq[t_][pc][nt] = __builtin_bit_cast(f16x8g, __builtin_amdgcn_raw_buffer_load_b128(wrs, bvoff + nt * 2048 + pc * 1024, soff, 0));
         };
-        Frags cur, nxt;
-        read_frags(cur, 0, 0);
-        auto chunk = [&](const int c, const int PAR) __attribute__((always_inline)) {
+        f16x8g a[2][2];              // [piece][M tile]: ONE set -- the lo pieces of the next k-step are read as soon as this k-step's first
+                                     // MFMA group (their only reader) is issued, the hi pieces after its last group
+        auto read_a = [&](int pc, int vbase, int t_) {
+            const float* vb = &Vs[vbase + (t_ / 3) * G_ROWW + (3 * G_ + t_ % 3) * G_QW + 8 * pc];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) a[pc][mt] = __builtin_bit_cast(f16x8g, *reinterpret_cast<const f32x4*>(vb + mt * 4 * G_ROWW));
+        };
+#pragma unroll
+        for (int t = 0; t < 9; ++t) load_b(t);
+        sbase += cstride;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xform(tdstW, tdst8, i);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 7; ++i) dma_raw(1, i);
+        int aCur = aBase, aNxt = aBase + G_VW, dWn = tdstW + G_VW, d8n = tdst8 + G_VW, dWc = tdstW, d8c = tdst8;
+        read_a(1, aCur, 0);
+        read_a(0, aCur, 0);
+
+        for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int j = t % 3;
+                const int nbase = t == 8 ? aNxt : aCur, nt_ = (t + 1) % 9;          // the next k-step's V buffer (of the next chunk: complete since the barrier of k-step 6)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[1][mt], cur.b[0], acc[j][mt], 0, 0, 0);   // a_lo b_hi
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[j][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][mt], bq[t][0][nt], acc[j][mt][nt], 0, 0, 0);   // a_lo b_hi
                 __builtin_amdgcn_sched_barrier(0);
-                {   // fragments of the NEXT k-step: its slabs landed before the previous barrier; V of this chunk, or of the next one -- complete
-                    // since k-step 6's stores
-                    const int tn_ = (t + 1) % 9;
-                    read_frags(nxt, t == 8 ? PAR ^ 1 : PAR, tn_);
-                }
+                read_a(1, nbase, nt_);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[0][mt], cur.b[1], acc[j][mt], 0, 0, 0);   // a_hi b_lo
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[j][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mt], bq[t][1][nt], acc[j][mt][nt], 0, 0, 0);   // a_hi b_lo
                 __builtin_amdgcn_sched_barrier(0);
-                // staging.  The raw buffer holds chunk c + 1 (landed before barrier 1: its pieces are older than the second slab issued at
-                // k-step 8; the prologue's: before barrier 2); it is transformed into V[PAR ^ 1] at k-steps 3-6, one item per thread and
-                // k-step, and refilled with chunk c + 2 at k-steps 7 (two pieces) and 8.  Order inside a k-step: raw pieces, slab
-                // 2 t + 9, slab 2 t + 10 -- the vmcnt table below counts on it.
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[j][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mt], bq[t][0][nt], acc[j][mt][nt], 0, 0, 0);   // a_hi b_hi
+                __builtin_amdgcn_sched_barrier(0);
+                read_a(0, nbase, nt_);
+                // staging.  The raw buffer holds chunk c + 1 (every wave waits for its own pieces, then the barrier, at k-step 2); it is
+                // transformed into the other V buffer at k-steps 3-6, one item per thread and k-step, and after the barrier of k-step 6
+                // refilled with chunk c + 2 (k-steps 7, 8).  The weights of k-step t of the NEXT chunk replace this k-step's.
                 if (t == 7) {
-                    dma_raw(c + 2, 0);
-                    dma_raw(c + 2, 1);
-                }
-                if (t == 8) dma_raw(c + 2, 2);
-                dma_w(c, 2 * t + 9);                   // (stages (2 t) % 9, (2 t + 1) % 9: this k-step's own, read during k-step t - 1)
-                dma_w(c, 2 * t + 10);
-                if (t >= 3 && t <= 6) xform(PAR ^ 1, t - 3);
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[0][mt], cur.b[0], acc[j][mt], 0, 0, 0);   // a_hi b_hi
-                __builtin_amdgcn_sched_barrier(0);
-                // barrier t: the slabs of k-step t + 2 (2 t + 4, issued at k-step t - 3, and 2 t + 5, issued FIRST at k-step t - 2) must have
-                // landed: the five slab pieces issued since, plus the raw pieces of k-steps t - 1 and t, may stay in flight
-                switch (t) {
-                    case 0: dma_barrier_g<6>(); break;
-                    case 7: dma_barrier_g<7>(); break;
-                    case 8: dma_barrier_g<8>(); break;
-                    default: dma_barrier_g<5>(); break;
+                    for (int i = 0; i < 4; ++i) dma_raw(c + 2, i);
                 }
-                cur = nxt;
+                if (t == 8) {
+#pragma unroll
+                    for (int i = 4; i < 7; ++i) dma_raw(c + 2, i);
+                }
+                load_b(t);
+                if (t >= 3 && t <= 6) xform(dWn, d8n, t - 3);
+                __builtin_amdgcn_sched_barrier(0);
+                // k-step 2: the raw pieces (issued before the weights of k-step 8: the 16 loads issued since -- 12 after the prologue's --
+                // may stay in flight) have landed, and every wave is done with the fragments of the previous chunk's V;  k-step 6: the
+                // other V buffer is complete and the raw buffer is free
+                if (t == 2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (t == 6) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
-        };
-        int c = 0;
-        for (; c + 1 < nchunks; c += 2) {
-            chunk(c, 0);
-            chunk(c + 1, 1);
+            sbase += cstride;
+            int tmp = aCur; aCur = aNxt; aNxt = tmp;
+            tmp = dWc; dWc = dWn; dWn = tmp;
+            tmp = d8c; d8c = d8n; d8n = tmp;
         }
-        if (c < nchunks) chunk(c, 0);
     };
     if (grp == 0) run(GroupTag<0>{});
     else run(GroupTag<1>{});
@@ -326,137 +339,150 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
     // ---- epilogue: scale back, the groups' halves of A^T, exchange, bias ---------------------------------------------------------
     //   group 0 (m0 m1 m2): a0 = m0 + m1 + m2, a1 = m1 - m2, a2 = m1 + m2;     group 1 (m3 m4 m5): b0 = m3 + m4, b1 = 2 (m3 - m4), b2 = 4 b0, b3 = 4 b1 + m5
     //   Y0 = a0 + b0, Y1 = a1 + b1 (finished by group 0: it receives b0, b1);   Y2 = a2 + b2, Y3 = a1 + b3 (group 1: receives a2, a1)
-    const int co = co0 + wn * 32 + li;
-    const float bias = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+    // (in two phases over the accumulators, which stay where they are: nothing but one 32-channel tile of results is live beside them)
     const int ks = -(kx + kw);
-    float* const xch = f43_lds;                    // [8 waves][2 values][2 mt][4 register quads][64 lanes][4 floats] = 128 KB
-    f32x16 mine[2][2];                             // [value][mt]: what this wave keeps; acc[0], acc[1] are overwritten with what it sends
+    float* const xch = f43_lds;                    // [4 waves][2 mt][2 nt][4 register quads][2 values][64 lanes][4 floats] = 128 KB
+    // phase 1: what the partner wave (same channels, other group) needs of every accumulator element
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float m0 = __builtin_ldexpf(acc[0][mt][r], ks), m1 = __builtin_ldexpf(acc[1][mt][r], ks), m2 = __builtin_ldexpf(acc[2][mt][r], ks);
-            if (grp == 0) {
-                mine[0][mt][r] = (m0 + m1) + m2;       // a0
-                mine[1][mt][r] = m1 - m2;              // a1
-                acc[0][mt][r] = m1 + m2;               // a2 -> group 1's Y2
-                acc[1][mt][r] = m1 - m2;               // a1 -> group 1's Y3
-            } else {
-                const float s = m0 + m1, d = m0 - m1;  // (m3 + m4), (m3 - m4)
-                mine[0][mt][r] = 4.f * s;              // b2
-                mine[1][mt][r] = 8.f * d + m2;         // b3
-                acc[0][mt][r] = s;                     // b0 -> group 0's Y0
-                acc[1][mt][r] = 2.f * d;               // b1 -> group 0's Y1
-            }
-        }
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-    for (int v = 0; v < 2; ++v)
+            for (int rq = 0; rq < 4; ++rq) {
+                f32x4 s0, s1;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq)
-                *reinterpret_cast<f32x4*>(&xch[((((wave * 2 + v) * 2 + mt) * 4 + rq) * 64 + lane) * 4]) =
-                    f32x4{acc[v][mt][4 * rq], acc[v][mt][4 * rq + 1], acc[v][mt][4 * rq + 2], acc[v][mt][4 * rq + 3]};
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    {
-        const int other = wave ^ 4;
-#pragma unroll
-        for (int v = 0; v < 2; ++v)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(&xch[((((other * 2 + v) * 2 + mt) * 4 + rq) * 64 + lane) * 4]);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) acc[v][mt][4 * rq + k] = (mine[v][mt][4 * rq + k] + t[k]) + bias;
+                for (int k = 0; k < 4; ++k) {
+                    const int r = 4 * rq + k;
+                    const float m1 = __builtin_ldexpf(acc[1][mt][nt][r], ks);
+                    if (grp == 0) {
+                        const float m2 = __builtin_ldexpf(acc[2][mt][nt][r], ks);
+                        s0[k] = m1 + m2;               // a2 -> group 1's Y2
+                        s1[k] = m1 - m2;               // a1 -> group 1's Y3
+                    } else {
+                        const float m0 = __builtin_ldexpf(acc[0][mt][nt][r], ks);
+                        s0[k] = m0 + m1;               // b0 -> group 0's Y0
+                        s1[k] = 2.f * (m0 - m1);       // b1 -> group 0's Y1
+                    }
                 }
-    }
-    // acc[e][mt][r], e = 0, 1: pixel 4 quad + 2 grp + e of row 4 mt + (r & 3), quad = 2 (r >> 2) + lh
+                float* o = &xch[(((((wave * 2 + mt) * 2 + nt) * 4 + rq) * 2) * 64 + lane) * 4];
+                *reinterpret_cast<f32x4*>(o) = s0;
+                *reinterpret_cast<f32x4*>(o + 256) = s1;
+            }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const bool relu = p.relu != 0;
     float amax = 0.f;
     const unsigned peeked = p.ymax != nullptr ? ccst_absmax_peek(p.ymax, blockIdx.x) : 0u;
     const bool interior = (oy0 + G_TH <= p.H) && (ox0 + G_TW <= p.W) && (co0 + G_BN <= p.Cout);
-    const bool cok = co < p.Cout;
-    if (!POOL) {
-        float* const tile = p.y + (long long)n * p.ysN + (long long)oy0 * p.ysH + (long long)(ox0 + 2 * grp) * p.ysW + co0 + wn * 32;
-        const unsigned lane_off = (unsigned)(4 * lh * p.ysW + li);
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile, 0, 0x7fffffff, 0x00020000);
-        float s1 = 0.f, cnt = 0.f;
+    const int other = wave ^ 2;
+    // phase 2, one 32-channel tile at a time: fin[e][mt][r], e = 0, 1 = pixel 4 quad + 2 grp + e of row 4 mt + (r & 3), quad = 2 (r >> 2) + lh
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+    for (int nt = 0; nt < 2; ++nt) {
+        const int co = co0 + wh * 64 + nt * 32 + li;
+        const bool cok = co < p.Cout;
+        const float bias = (p.bias != nullptr && cok) ? p.bias[co] : 0.f;
+        f32x16 fin[2][2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int dy = 4 * mt + (r & 3);
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    float v = acc[e][mt][r];
-                    if (relu) v = fmaxf(v, 0.f);
-                    const int dx = 8 * (r >> 2) + e;               // + 4 lh (lane_off) + 2 grp (tile)
-                    if (interior) {
-                        amax = fmaxf(amax, fabsf(v));
-                        s1 += v;
-                        cnt += 1.f;
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, lane_off * 4, (dy * p.ysH + dx * p.ysW) * 4, 0);
-                    } else if (cok && oy0 + dy < p.H && ox0 + 2 * grp + dx + 4 * lh < p.W) {
-                        amax = fmaxf(amax, fabsf(v));
-                        s1 += v;
-                        cnt += 1.f;
-                        tile[(long long)dy * p.ysH + (long long)dx * p.ysW + lane_off] = v;
+            for (int rq = 0; rq < 4; ++rq) {
+                const float* o = &xch[(((((other * 2 + mt) * 2 + nt) * 4 + rq) * 2) * 64 + lane) * 4];
+                const f32x4 t0 = *reinterpret_cast<const f32x4*>(o), t1 = *reinterpret_cast<const f32x4*>(o + 256);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = 4 * rq + k;
+                    const float m0 = __builtin_ldexpf(acc[0][mt][nt][r], ks), m1 = __builtin_ldexpf(acc[1][mt][nt][r], ks),
+                                m2 = __builtin_ldexpf(acc[2][mt][nt][r], ks);
+                    if (grp == 0) {
+                        fin[0][mt][r] = (((m0 + m1) + m2) + t0[k]) + bias;                  // Y0 = a0 + b0
+                        fin[1][mt][r] = ((m1 - m2) + t1[k]) + bias;                         // Y1 = a1 + b1
+                    } else {
+                        fin[0][mt][r] = (4.f * (m0 + m1) + t0[k]) + bias;                   // Y2 = b2 + a2
+                        fin[1][mt][r] = ((8.f * (m0 - m1) + m2) + t1[k]) + bias;            // Y3 = b3 + a1
                     }
                 }
             }
-        }
-        if (p.stats != nullptr) {
-            // per-(tile, position group) channel statistics (sum, M2 about the slab's own mean, count): see conv3x3_f23.hip
-            s1 += __shfl_xor(s1, 32, 64);
-            cnt += __shfl_xor(cnt, 32, 64);
-            const float mu = s1 / fmaxf(cnt, 1.f);
-            float m2 = 0.f;
+        if (!POOL) {
+            float* const tile = p.y + (long long)n * p.ysN + (long long)oy0 * p.ysH + (long long)(ox0 + 2 * grp) * p.ysW + co0 + wh * 64 + nt * 32;
+            const unsigned lane_off = (unsigned)(4 * lh * p.ysW + li);
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile, 0, 0x7fffffff, 0x00020000);
+            float s1 = 0.f, cnt = 0.f;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int dy = 4 * mt + (r & 3);
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        float v = acc[e][mt][r];
+                        float v = fin[e][mt][r];
                         if (relu) v = fmaxf(v, 0.f);
-                        const float dv = v - mu;
-                        if (interior || (cok && oy0 + dy < p.H && ox0 + 2 * grp + 8 * (r >> 2) + e + 4 * lh < p.W)) m2 += dv * dv;
+                        const int dx = 8 * (r >> 2) + e;               // + 4 lh (lane_off) + 2 grp (tile)
+                        if (interior) {
+                            amax = fmaxf(amax, fabsf(v));
+                            s1 += v;
+                            cnt += 1.f;
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, lane_off * 4, (dy * p.ysH + dx * p.ysW) * 4, 0);
+                        } else if (cok && oy0 + dy < p.H && ox0 + 2 * grp + dx + 4 * lh < p.W) {
+                            amax = fmaxf(amax, fabsf(v));
+                            s1 += v;
+                            cnt += 1.f;
+                            tile[(long long)dy * p.ysH + (long long)dx * p.ysW + lane_off] = v;
+                        }
                     }
                 }
-            m2 += __shfl_xor(m2, 32, 64);
-            if (lh == 0 && cok)
-                *reinterpret_cast<f32x4*>(p.stats + ((long long)((((n * p.tilesY + ty) * p.tilesX + tx) * 2 + grp)) * p.Cout + co) * 4) = f32x4{s1, m2, cnt, 0.f};
-        }
-    } else {
-        // a pooling window = rows (2 k, 2 k + 1) x pixels (4 quad + 2 grp, + 1) = four values of one lane: registers (r & 3) = 0, 1 | 2, 3
-        const int Hp = (p.H + 1) >> 1, Wp = (p.W + 1) >> 1;
-        const int py0 = oy0 >> 1, px0 = (ox0 >> 1) + grp;
-        float* const tile = p.y + (long long)n * p.ysN + (long long)py0 * p.ysH + (long long)px0 * p.ysW + co0 + wn * 32;
-        const unsigned lane_off = (unsigned)(2 * lh * p.ysW + li);
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile, 0, 0x7fffffff, 0x00020000);
+            }
+            if (p.stats != nullptr) {
+                // per-(tile, position group) channel statistics (sum, M2 about the slab's own mean, count): see conv3x3_f23.hip
+                s1 += __shfl_xor(s1, 32, 64);
+                cnt += __shfl_xor(cnt, 32, 64);
+                const float mu = s1 / fmaxf(cnt, 1.f);
+                float m2 = 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {                      // registers 2 g, 2 g + 1: rows 4 mt + 2 (g & 1), + 1 of quad 2 (g >> 1) + lh
-                const int dyp = 2 * mt + (g & 1), xpu = 4 * (g >> 1);          // pooled row; pooled column 4 (g >> 1) + 2 lh + grp
-                if (interior) {
-                    float v = fmaxf(fmaxf(acc[0][mt][2 * g], acc[1][mt][2 * g]), fmaxf(acc[0][mt][2 * g + 1], acc[1][mt][2 * g + 1]));
-                    if (relu) v = fmaxf(v, 0.f);
-                    amax = fmaxf(amax, fabsf(v));
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, lane_off * 4, (dyp * p.ysH + xpu * p.ysW) * 4, 0);
-                } else {
-                    const int pyp = py0 + dyp, pxp = px0 + xpu + 2 * lh;
-                    if (cok && pyp < Hp && pxp < Wp) {
-                        const bool okx = (2 * pxp + 1 < p.W), oky = (2 * pyp + 1 < p.H);
-                        float v = acc[0][mt][2 * g];
-                        if (okx) v = fmaxf(v, acc[1][mt][2 * g]);
-                        if (oky) v = fmaxf(v, acc[0][mt][2 * g + 1]);
-                        if (okx && oky) v = fmaxf(v, acc[1][mt][2 * g + 1]);
+                    for (int r = 0; r < 16; ++r) {
+                        const int dy = 4 * mt + (r & 3);
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            float v = fin[e][mt][r];
+                            if (relu) v = fmaxf(v, 0.f);
+                            const float dv = v - mu;
+                            if (interior || (cok && oy0 + dy < p.H && ox0 + 2 * grp + 8 * (r >> 2) + e + 4 * lh < p.W)) m2 += dv * dv;
+                        }
+                    }
+                m2 += __shfl_xor(m2, 32, 64);
+                if (lh == 0 && cok)
+                    *reinterpret_cast<f32x4*>(p.stats + ((long long)((((n * p.tilesY + ty) * p.tilesX + tx) * 2 + grp)) * p.Cout + co) * 4) =
+                        f32x4{s1, m2, cnt, 0.f};
+            }
+        } else {
+            // a pooling window = rows (2 k, 2 k + 1) x pixels (4 quad + 2 grp, + 1) = four values of one lane: registers (r & 3) = 0, 1 | 2, 3
+            const int Hp = (p.H + 1) >> 1, Wp = (p.W + 1) >> 1;
+            const int py0 = oy0 >> 1, px0 = (ox0 >> 1) + grp;
+            float* const tile = p.y + (long long)n * p.ysN + (long long)py0 * p.ysH + (long long)px0 * p.ysW + co0 + wh * 64 + nt * 32;
+            const unsigned lane_off = (unsigned)(2 * lh * p.ysW + li);
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {                      // registers 2 g, 2 g + 1: rows 4 mt + 2 (g & 1), + 1 of quad 2 (g >> 1) + lh
+                    const int dyp = 2 * mt + (g & 1), xpu = 4 * (g >> 1);          // pooled row; pooled column 4 (g >> 1) + 2 lh + grp
+                    if (interior) {
+                        float v = fmaxf(fmaxf(fin[0][mt][2 * g], fin[1][mt][2 * g]), fmaxf(fin[0][mt][2 * g + 1], fin[1][mt][2 * g + 1]));
                         if (relu) v = fmaxf(v, 0.f);
                         amax = fmaxf(amax, fabsf(v));
-                        tile[(long long)dyp * p.ysH + (long long)xpu * p.ysW + lane_off] = v;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, lane_off * 4, (dyp * p.ysH + xpu * p.ysW) * 4, 0);
+                    } else {
+                        const int pyp = py0 + dyp, pxp = px0 + xpu + 2 * lh;
+                        if (cok && pyp < Hp && pxp < Wp) {
+                            const bool okx = (2 * pxp + 1 < p.W), oky = (2 * pyp + 1 < p.H);
+                            float v = fin[0][mt][2 * g];
+                            if (okx) v = fmaxf(v, fin[1][mt][2 * g]);
+                            if (oky) v = fmaxf(v, fin[0][mt][2 * g + 1]);
+                            if (okx && oky) v = fmaxf(v, fin[1][mt][2 * g + 1]);
+                            if (relu) v = fmaxf(v, 0.f);
+                            amax = fmaxf(amax, fabsf(v));
+                            tile[(long long)dyp * p.ysH + (long long)xpu * p.ysW + lane_off] = v;
+                        }
                     }
                 }
             }
@@ -465,21 +491,27 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
     if (p.ymax != nullptr) ccst_absmax_publish(p.ymax, amax, blockIdx.x, peeked);
 }
 
-// OIHW 3x3 -> [m = 2 t + group][Cin/16][cout_pad][16 words], t = ky * 3 + j, position q = 3 group + j: words 0..7 = the chunk's 16 input
-// channels of U_q[ky] = (G g[ky][.])_q as half(u * 2^kw), two per word; words 8..15 = half(u * 2^kw - hi).  G g in double (packed once).
+// OIHW 3x3 -> [m = 2 t + group][Cin/16][cout_pad/32][piece][32 channels][8 words], t = ky * 3 + j, position q = 3 group + j: piece 0 = the
+// chunk's 16 input channels of U_q[ky] = (G g[ky][.])_q as half(u * 2^kw), two per word; piece 1 = half(u * 2^kw - hi): the order in which a
+// wave's B fragments are loaded (lane (channel, k half) -> 16 bytes, 1 KiB per load).  G g in double (the weights are packed once).
 __global__ void pack_weight_f43_kernel(const float* __restrict__ w, unsigned* __restrict__ out, int cout, int cin, int cout_pad,
                                        const unsigned* __restrict__ wmax) {
     const int kw = ccst_scale_exp(ccst_absmax_read(wmax), F43_W_TARGET);
     const int nch = cin / 16;
     const long long total = 18LL * nch * cout_pad * 16;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int word = (int)(i & 15);
-        long long jj = i >> 4;
-        const int co = (int)(jj % cout_pad);
-        jj /= cout_pad;
+        const int word = (int)(i & 7);
+        long long jj = i >> 3;
+        const int row = (int)(jj & 31);
+        jj >>= 5;
+        const int piece = (int)(jj & 1);
+        jj >>= 1;
+        const int cg = (int)(jj % (cout_pad >> 5));
+        jj /= (cout_pad >> 5);
         const int chunk = (int)(jj % nch), m = (int)(jj / nch);
+        const int co = cg * 32 + row;
         const int t = m >> 1, ky = t / 3, q = 3 * (m & 1) + t % 3;
-        const int piece = word >> 3, k0 = chunk * 16 + 2 * (word & 7);
+        const int k0 = chunk * 16 + 2 * word;
         unsigned r = 0;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -534,6 +566,8 @@ extern "C" int ccst_conv3x3_f43_f32(const float* x, const uint32_t* x_absmax, co
     const int oh = pool ? (H + 1) / 2 : H, ow = pool ? (W + 1) / 2 : W;
     CCST_REQUIRE((long long)N * oh * ow * Cout < 0x7fffffffLL, "conv3x3_f43: output must have < 2^31 elements");
     a.ysW = Cout; a.ysH = ow * Cout; a.ysN = (long long)oh * ow * Cout;
+    CCST_REQUIRE(18LL * Cin * cout_pad * 4 < 0x7fffffffLL, "conv3x3_f43: packed weights must be < 2^31 bytes");
+    a.ubytes = (int)(18LL * Cin * cout_pad * 4);
     a.tilesN = (Cout + G_BN - 1) / G_BN;
     a.tilesY = (H + G_TH - 1) / G_TH;
     a.tilesX = (W + G_TW - 1) / G_TW;
