@@ -10,18 +10,19 @@
 // i.e. 18 k-steps per 16-channel chunk and pixel quad instead of F(2,3)'s 24 (direct: 36): 1.5 executed MFMA FLOPs per algorithmic FLOP.
 // The price is rounding (interpolation points +-2: ~3x F(2,3)'s error per layer, 1-5e-6 of max |y|; test) and six accumulator sets.
 //
-// Version 1 of this kernel kept the F(2,3) kernel's structure (eight waves, weights through an LDS ring) and was bound by LDS bandwidth:
-// 755 KB per chunk through a 128 B/clock port = 5900 clocks next to 6912 clocks of MFMA, overlapping badly under a barrier per k-step
-// (timing ablation: everything but the MFMAs took 152 of the 217 us of a 256 -> 256 layer).  This version moves two thirds of it away:
-//   * workgroup = 8 rows x 32 pixels (= 64 GEMM rows: (row, pixel quad)) x 128 output channels, FOUR waves of up to 512 registers (one
-//     per SIMD) = 2 POSITION GROUPS (q = 0..2, q = 3..5) x 2 channel halves: a wave holds 64 rows x 64 channels x 3 positions = 12
-//     accumulators (192 registers) and runs 9 k-steps of 12 MFMAs per chunk on 4 A fragments (LDS) and 4 B fragments;
-//   * the WEIGHTS NEVER TOUCH LDS: every wave loads its own B fragments (64 channels x 16 k x hi | lo = 4 KB per k-step, packed in
+// Version 1 of this kernel kept the F(2,3) kernel's structure (weights through an LDS ring, a barrier per k-step) and was bound by LDS
+// bandwidth: 755 KB per chunk through the CU's 128 B/clock port, overlapping badly with the MFMAs (timing ablation: everything but the
+// MFMAs took 152 of the 217 us of a 256 -> 256 layer, the MFMAs alone 137).  Version 2 (four waves of 512 registers, 64 x 64 wave
+// tiles) cut the traffic to a third but lost the second wave per SIMD that hides LDS latency: slower.  This version keeps eight waves:
+//   * workgroup = 8 rows x 32 pixels (= 64 GEMM rows: (row, pixel quad)) x 128 output channels, EIGHT waves = 2 POSITION GROUPS (q = 0..2,
+//     q = 3..5) x 4 channel quarters: a wave holds 64 rows x 32 channels x 3 positions = 6 accumulators and runs 9 k-steps of 6 MFMAs
+//     per chunk; the group is a template parameter of the main loop (every LDS offset is an immediate);
+//   * the WEIGHTS NEVER TOUCH LDS: every wave loads its own B fragments (32 channels x 16 k x hi | lo = 2 KB per k-step, packed in
 //     fragment order) straight into a ring of NINE register sets, one per k-step of a chunk, each refilled for the next chunk right
-//     after its last MFMA: a whole chunk (~2.5 us) of prefetch distance, no barrier for the weights;
-//   * LDS holds the transformed halo (double buffered) and the raw fp32 halo of the next chunk (LDS-DMA): two barriers per chunk;
+//     after its last MFMA: a whole chunk of prefetch distance, no barrier for the weights (LDS: 755 -> 415 KB per chunk);
+//   * LDS holds the transformed halo (double buffered) and the raw fp32 halo of the next chunk (LDS-DMA): TWO barriers per chunk;
 //   * the transform works on PAIRS of positions that share their pixels -- (1,2) and (3,4): four 16-byte reads for two positions,
-//     (0,5): six -- 960 items per chunk, four per thread; the scale 2^kx rides in the coefficients;
+//     (0,5): six -- 960 items per chunk, two per thread; the scale 2^kx rides in the coefficients;
 //   * the output transform needs all six positions: after the last chunk the groups exchange two partial sums per accumulator
 //     element through LDS -- group 0 finishes pixels 4p, 4p + 1, group 1 pixels 4p + 2, 4p + 3;
 //   * epilogue as in conv3x3_f23.hip: scale back, A^T, bias, ReLU, the 2x2 ceil max-pool, NHWC stores, max |y|, per-tile statistics.
@@ -50,7 +51,7 @@ typedef ccst_u32x2 u32x2g;
 typedef _Float16 f16x8g __attribute__((ext_vector_type(8)));
 typedef float f32x2g __attribute__((ext_vector_type(2)));
 
-constexpr int G_TH = 8, G_TW = 32, G_XQ = G_TW / 4, G_HH = G_TH + 2, G_BN = 128, G_NT = 256;
+constexpr int G_TH = 8, G_TW = 32, G_XQ = G_TW / 4, G_HH = G_TH + 2, G_BN = 128, G_NT = 512;
 constexpr int G_QW = 16;                          // words per (quad, position): 16 channels hi (8 words) | 16 channels lo (8 words)
 constexpr int G_XQW = 6 * G_QW + 4;               // 100 words = 25 sixteen-byte units per quad (9 modulo 16)
 constexpr int G_ROWW = G_XQ * G_XQW + 16;         // 816 words = 204 units per halo row (12 modulo 16): the 16 lanes of a fragment read pass
@@ -89,7 +90,7 @@ struct GroupTag {
 };
 
 template <bool POOL>
-__global__ __launch_bounds__(G_NT, 1) void conv3x3_f43_kernel(const F43Args p) {
+__global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
     extern __shared__ __attribute__((aligned(16))) float f43_lds[];
     float* const Vs = f43_lds;                     // [2][G_VW]             transformed halo, double buffered
     float* const Raw = f43_lds + G_RAW0;           // [G_RAW_PIECES * 256]  raw fp32 halo pixels of the NEXT chunk
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(G_NT, 1) void conv3x3_f43_kernel(const F43Args p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 1, wh = wave & 1;
+    const int grp = wave >> 2, wn = wave & 3;
     const int li = lane & 31, lh = lane >> 5;
 
     int bid = ccst_xcd_remap(blockIdx.x, gridDim.x);
@@ -114,14 +115,14 @@ __global__ __launch_bounds__(G_NT, 1) void conv3x3_f43_kernel(const F43Args p) {
     const int nchunks = p.Cin / 16;
 
     const float* const ximg = p.x + (long long)n * p.Hs * p.Ws * p.Cin;
-    // raw pieces g = wave + 4 i (i = 0..6) of the 10 x 42-slot halo image (piece 27 does not exist: wave 3 fetches piece 26 a second time
-    // so that every wave issues the same number of pieces -- the vmcnt at k-step 2 counts on it); lane -> slot 16 g + (lane >> 2), part
+    // raw pieces g = wave + 8 i (i = 0..3) of the 10 x 42-slot halo image (pieces 27..31 do not exist: those waves fetch piece 26 again so
+    // that every wave issues the same number of pieces -- the vmcnt at k-step 2 counts on it); lane -> slot 16 g + (lane >> 2), part
     // lane & 3; reflection / zero padding (the value is zeroed at the transform) / nearest-x2 upsample on the address
-    unsigned rsrc_[7];
-    int rpiece[7];
+    unsigned rsrc_[4];
+    int rpiece[4];
 #pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        rpiece[i] = min(wave + 4 * i, G_RAW_PIECES - 1);
+    for (int i = 0; i < 4; ++i) {
+        rpiece[i] = min(wave + 8 * i, G_RAW_PIECES - 1);
         const int S = min(rpiece[i] * 16 + (lane >> 2), G_HH * G_RSLOTS - 1);
         const int hy = S / G_RSLOTS, sx = S - hy * G_RSLOTS, hx = min(sx - sx / 5, G_RW - 1);
         int gy = oy0 + hy - 1, gx = ox0 + hx - 1;
@@ -134,21 +135,23 @@ __global__ __launch_bounds__(G_NT, 1) void conv3x3_f43_kernel(const F43Args p) {
         }
         rsrc_[i] = (unsigned)((((gy >> p.ups) * p.Ws + (gx >> p.ups)) * p.Cin + (lane & 3) * 4) * 4);
     }
-    auto dma_raw = [&](int c_, int i) {         // raw piece wave + 4 i of chunk c_
+    auto dma_raw = [&](int c_, int i) {         // raw piece wave + 8 i of chunk c_
         const int cc = min(c_, nchunks - 1);
         glds16g(ximg + cc * 16, rsrc_[i], (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(G_RAW0 * 4 + rpiece[i] * 1024))));
     };
 
-    // ---- transform items: 3 position pairs x 10 halo rows x 8 quads x 4 channel parts = 960 = (up to) FOUR per thread: inside an item
-    // lane -> (row + (lane >> 5), quad (lane >> 2) & 7, part lane & 3); items 0..2: pair i of rows 2 wave, 2 wave + 1 (the pair is a compile-
-    // time constant and the row sits in the thread's base address: every LDS offset of the loop is an instruction immediate -- with
-    // run-time rows hipcc hoisted a vector add per access out of the loop and spilled 340 registers); item 3: pair `wave` of rows 8, 9
-    // (wave 3 idle).
+    // ---- transform items: 3 position pairs x 10 halo rows x 8 quads x 4 channel parts = 960 = (up to) TWO per thread.  Half-wave
+    // 16 i + 2 wave + (lane >> 5) of item slot i takes (pair, row) task number h = that (30, 31: idle): pair = h / 10, row = h % 10;
+    // inside a task lane -> (quad (lane >> 2) & 7, part lane & 3).  The pair is wave-uniform (the boundaries are even) and selects a code
+    // path in which it is a compile-time constant; the row sits in the thread's base addresses: every LDS offset of the loop is an
+    // instruction immediate (with run-time rows hipcc hoisted a vector add per access out of the loop and spilled 340 registers).
+    //     slot 0: waves 0-4 pair 0 rows 2 w + lh; waves 5-7 pair 1 rows 2 w + lh - 10;   slot 1: waves 0-1 pair 1 rows 6 + 2 w + lh; waves 2-6 pair 2 rows 2 w + lh - 4
     const int xq_t = (lane >> 2) & 7, part_t = lane & 3;
-    const int tsrcW = ((2 * wave + lh) * G_RSLOTS + 5 * xq_t) * 16 + part_t * 4, tsrc8 = ((8 + lh) * G_RSLOTS + 5 * xq_t) * 16 + part_t * 4;
-    const int tdstW = (2 * wave + lh) * G_ROWW + xq_t * G_XQW + part_t * 2, tdst8 = (8 + lh) * G_ROWW + xq_t * G_XQW + part_t * 2;
+    const int trow0 = 2 * wave + lh - (wave < 5 ? 0 : 10), trow1 = wave < 2 ? 6 + 2 * wave + lh : min(2 * wave + lh - 4, 9);
+    const int tsrcA = (trow0 * G_RSLOTS + 5 * xq_t) * 16 + part_t * 4, tsrcB = (trow1 * G_RSLOTS + 5 * xq_t) * 16 + part_t * 4;
+    const int tdstA = trow0 * G_ROWW + xq_t * G_XQW + part_t * 2, tdstB = trow1 * G_ROWW + xq_t * G_XQW + part_t * 2;
     unsigned tokx = 0x3fu;       // zero padding: validity of the quad's six pixels;
-    bool okyW = true, oky8 = true;   // ... of the rows of items 0..2, of item 3
+    bool okyA = true, okyB = true;   // ... of the rows of item 0, of item 1
     if (!p.reflect) {
         tokx = 0;
 #pragma unroll
@@ -156,9 +159,9 @@ __global__ __launch_bounds__(G_NT, 1) void conv3x3_f43_kernel(const F43Args p) {
             const int gx = ox0 + 4 * xq_t - 1 + d;
             tokx |= (((gx >= 0) & (gx < p.W)) ? 1u : 0u) << d;
         }
-        const int gyW = oy0 + 2 * wave + lh - 1, gy8 = oy0 + 8 + lh - 1;
-        okyW = (gyW >= 0) & (gyW < p.H);
-        oky8 = (gy8 >= 0) & (gy8 < p.H);
+        const int gyA = oy0 + trow0 - 1, gyB = oy0 + trow1 - 1;
+        okyA = (gyA >= 0) & (gyA < p.H);
+        okyB = (gyB >= 0) & (gyB < p.H);
     }
     float xs = 1.f;          // 2^kx (set in the prologue)
     auto put = [&](float* o, f32x4 v) {          // four scaled fp32 values -> (hi, lo) half pieces -> V
@@ -203,15 +206,14 @@ __global__ __launch_bounds__(G_NT, 1) void conv3x3_f43_kernel(const F43Args p) {
             put(o + 5 * G_QW, d1 * c4 + (d3 * c5 + d5 * xs));
         }
     };
-    // (dW, d8: the thread's destination in the V buffer being filled -- tdstW / tdst8 of buffer 0 or 1; the loop swaps them per chunk)
-    auto xform = [&](int dW, int d8, int i) __attribute__((always_inline)) {
-        if (i == 0) xpair(GroupTag<0>{}, &Raw[tsrcW], &Vs[dW], okyW);
-        if (i == 1) xpair(GroupTag<1>{}, &Raw[tsrcW], &Vs[dW], okyW);
-        if (i == 2) xpair(GroupTag<2>{}, &Raw[tsrcW], &Vs[dW], okyW);
-        if (i == 3) {
-            if (wave == 0) xpair(GroupTag<0>{}, &Raw[tsrc8], &Vs[d8], oky8);
-            else if (wave == 1) xpair(GroupTag<1>{}, &Raw[tsrc8], &Vs[d8], oky8);
-            else if (wave == 2) xpair(GroupTag<2>{}, &Raw[tsrc8], &Vs[d8], oky8);
+    // (dA, dB: the thread's destinations in the V buffer being filled -- tdstA / tdstB of buffer 0 or 1; the loop swaps them per chunk)
+    auto xform = [&](int dA, int dB, int i) __attribute__((always_inline)) {
+        if (i == 0) {
+            if (wave < 5) xpair(GroupTag<0>{}, &Raw[tsrcA], &Vs[dA], okyA);
+            else xpair(GroupTag<1>{}, &Raw[tsrcA], &Vs[dA], okyA);
+        } else {
+            if (wave < 2) xpair(GroupTag<1>{}, &Raw[tsrcB], &Vs[dB], okyB);
+            else if (wave < 7) xpair(GroupTag<2>{}, &Raw[tsrcB], &Vs[dB], okyB);
         }
     };
 
@@ -219,24 +221,22 @@ __global__ __launch_bounds__(G_NT, 1) void conv3x3_f43_kernel(const F43Args p) {
     // buffer load per (piece, 32-channel tile) reads 1 KiB contiguous; beyond the array (the prefetch of the chunk after the last) it returns 0
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.u), 0, p.ubytes, 0x00020000);
     const int bvoff = li * 32 + lh * 16;
-    const int wgroups = p.CoutPad >> 5, wg0 = (co0 >> 5) + 2 * wh;
+    const int wgroups = p.CoutPad >> 5, wg0 = (co0 >> 5) + wn;
 
-    f32x16 acc[3][2][2];         // [position of the group][M tile][N tile]
+    f32x16 acc[3][2];            // [position of the group][M tile]
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[q][mt][nt][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[q][mt][r] = 0.f;
 
     // A fragment base: GEMM row li of M tile mt is (row 4 mt + (li & 3), quad li >> 2)
     const int aBase = (li & 3) * G_ROWW + (li >> 2) * G_XQW + lh * 4;
 
     // ---- prologue: raw pixels of chunk 0, transform, raw pixels of chunk 1 ------------------------------------------------------------
 #pragma unroll
-    for (int i = 0; i < 7; ++i) dma_raw(0, i);
+    for (int i = 0; i < 4; ++i) dma_raw(0, i);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     asm volatile("" : "+v"(xword), "+v"(wword));
     const int kx = ccst_scale_exp(ccst_absmax_reduce(xword), F43_X_TARGET);
@@ -248,16 +248,13 @@ __global__ __launch_bounds__(G_NT, 1) void conv3x3_f43_kernel(const F43Args p) {
     // chunk: the thread's bases into "this chunk's" and "the next chunk's" buffer are swapped at the end of a chunk (ONE loop body).
     auto run = [&](auto gtag) __attribute__((always_inline)) {
         constexpr int G_ = decltype(gtag)::value;
-        f16x8g bq[9][2][2];          // [k-step][piece][N tile]: the weight ring
+        f16x8g bq[9][2];             // [k-step][piece]: the weight ring
         const int tstride = 2 * nchunks * wgroups * 2048, cstride = wgroups * 2048;
         int sbase = (G_ * nchunks * wgroups + wg0) * 2048;          // slab (t = 0, group G_) of the chunk being LOADED
         auto load_b = [&](int t_) {
             const int soff = sbase + t_ * tstride;        // uniform
 #pragma unroll
-            for (int pc = 0; pc < 2; ++pc)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    bq[t_][pc][nt] = __builtin_bit_cast(f16x8g, __builtin_amdgcn_raw_buffer_load_b128(wrs, bvoff + nt * 2048 + pc * 1024, soff, 0));
+            for (int pc = 0; pc < 2; ++pc) bq[t_][pc] = __builtin_bit_cast(f16x8g, __builtin_amdgcn_raw_buffer_load_b128(wrs, bvoff + pc * 1024, soff, 0));
         };
         f16x8g a[2][2];              // [piece][M tile]: ONE set -- the lo pieces of the next k-step are read as soon as this k-step's first
                                      // MFMA group (their only reader) is issued, the hi pieces after its last group
@@ -270,11 +267,11 @@ __global__ __launch_bounds__(G_NT, 1) void conv3x3_f43_kernel(const F43Args p) {
         for (int t = 0; t < 9; ++t) load_b(t);
         sbase += cstride;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xform(tdstW, tdst8, i);
+        for (int i = 0; i < 2; ++i) xform(tdstA, tdstB, i);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-        for (int i = 0; i < 7; ++i) dma_raw(1, i);
-        int aCur = aBase, aNxt = aBase + G_VW, dWn = tdstW + G_VW, d8n = tdst8 + G_VW, dWc = tdstW, d8c = tdst8;
+        for (int i = 0; i < 4; ++i) dma_raw(1, i);
+        int aCur = aBase, aNxt = aBase + G_VW, dWn = tdstA + G_VW, d8n = tdstB + G_VW, dWc = tdstA, d8c = tdstB;
         read_a(1, aCur, 0);
         read_a(0, aCur, 0);
 
@@ -284,44 +281,36 @@ __global__ __launch_bounds__(G_NT, 1) void conv3x3_f43_kernel(const F43Args p) {
                 const int j = t % 3;
                 const int nbase = t == 8 ? aNxt : aCur, nt_ = (t + 1) % 9;          // the next k-step's V buffer (of the next chunk: complete since the barrier of k-step 6)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        acc[j][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][mt], bq[t][0][nt], acc[j][mt][nt], 0, 0, 0);   // a_lo b_hi
+                for (int mt = 0; mt < 2; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][mt], bq[t][0], acc[j][mt], 0, 0, 0);   // a_lo b_hi
                 __builtin_amdgcn_sched_barrier(0);
                 read_a(1, nbase, nt_);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        acc[j][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mt], bq[t][1][nt], acc[j][mt][nt], 0, 0, 0);   // a_hi b_lo
+                for (int mt = 0; mt < 2; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mt], bq[t][1], acc[j][mt], 0, 0, 0);   // a_hi b_lo
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        acc[j][mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mt], bq[t][0][nt], acc[j][mt][nt], 0, 0, 0);   // a_hi b_hi
+                for (int mt = 0; mt < 2; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mt], bq[t][0], acc[j][mt], 0, 0, 0);   // a_hi b_hi
                 __builtin_amdgcn_sched_barrier(0);
                 read_a(0, nbase, nt_);
                 // staging.  The raw buffer holds chunk c + 1 (every wave waits for its own pieces, then the barrier, at k-step 2); it is
-                // transformed into the other V buffer at k-steps 3-6, one item per thread and k-step, and after the barrier of k-step 6
-                // refilled with chunk c + 2 (k-steps 7, 8).  The weights of k-step t of the NEXT chunk replace this k-step's.
+                // transformed into the other V buffer at k-steps 3 and 5, one item per thread, and after the barrier of k-step 6 refilled
+                // with chunk c + 2 (k-steps 7, 8).  The weights of k-step t of the NEXT chunk replace this k-step's.
                 if (t == 7) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) dma_raw(c + 2, i);
+                    dma_raw(c + 2, 0);
+                    dma_raw(c + 2, 1);
                 }
                 if (t == 8) {
-#pragma unroll
-                    for (int i = 4; i < 7; ++i) dma_raw(c + 2, i);
+                    dma_raw(c + 2, 2);
+                    dma_raw(c + 2, 3);
                 }
                 load_b(t);
-                if (t >= 3 && t <= 6) xform(dWn, d8n, t - 3);
+                if (t == 3) xform(dWn, d8n, 0);
+                if (t == 5) xform(dWn, d8n, 1);
                 __builtin_amdgcn_sched_barrier(0);
-                // k-step 2: the raw pieces (issued before the weights of k-step 8: the 16 loads issued since -- 12 after the prologue's --
+                // k-step 2: the raw pieces (issued before the weights of k-step 8: the 8 loads issued since -- 6 after the prologue's --
                 // may stay in flight) have landed, and every wave is done with the fragments of the previous chunk's V;  k-step 6: the
                 // other V buffer is complete and the raw buffer is free
-                if (t == 2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (t == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 if (t == 6) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
             sbase += cstride;
@@ -339,45 +328,43 @@ __global__ __launch_bounds__(G_NT, 1) void conv3x3_f43_kernel(const F43Args p) {
     // ---- epilogue: scale back, the groups' halves of A^T, exchange, bias ---------------------------------------------------------
     //   group 0 (m0 m1 m2): a0 = m0 + m1 + m2, a1 = m1 - m2, a2 = m1 + m2;     group 1 (m3 m4 m5): b0 = m3 + m4, b1 = 2 (m3 - m4), b2 = 4 b0, b3 = 4 b1 + m5
     //   Y0 = a0 + b0, Y1 = a1 + b1 (finished by group 0: it receives b0, b1);   Y2 = a2 + b2, Y3 = a1 + b3 (group 1: receives a2, a1)
-    // (in two phases over the accumulators, which stay where they are: nothing but one 32-channel tile of results is live beside them)
+    // (in two phases over the accumulators, which stay where they are)
     const int ks = -(kx + kw);
-    float* const xch = f43_lds;                    // [4 waves][2 mt][2 nt][4 register quads][2 values][64 lanes][4 floats] = 128 KB
+    float* const xch = f43_lds;                    // [8 waves][2 mt][4 register quads][2 values][64 lanes][4 floats] = 128 KB
     // phase 1: what the partner wave (same channels, other group) needs of every accumulator element
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+    for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 f32x4 s0, s1;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int r = 4 * rq + k;
-                    const float m1 = __builtin_ldexpf(acc[1][mt][nt][r], ks);
+                    const float m1 = __builtin_ldexpf(acc[1][mt][r], ks);
                     if (grp == 0) {
-                        const float m2 = __builtin_ldexpf(acc[2][mt][nt][r], ks);
+                        const float m2 = __builtin_ldexpf(acc[2][mt][r], ks);
                         s0[k] = m1 + m2;               // a2 -> group 1's Y2
                         s1[k] = m1 - m2;               // a1 -> group 1's Y3
                     } else {
-                        const float m0 = __builtin_ldexpf(acc[0][mt][nt][r], ks);
+                        const float m0 = __builtin_ldexpf(acc[0][mt][r], ks);
                         s0[k] = m0 + m1;               // b0 -> group 0's Y0
                         s1[k] = 2.f * (m0 - m1);       // b1 -> group 0's Y1
                     }
                 }
-                float* o = &xch[(((((wave * 2 + mt) * 2 + nt) * 4 + rq) * 2) * 64 + lane) * 4];
+                float* o = &xch[((((wave * 2 + mt) * 4 + rq) * 2) * 64 + lane) * 4];
                 *reinterpret_cast<f32x4*>(o) = s0;
                 *reinterpret_cast<f32x4*>(o + 256) = s1;
             }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const bool relu = p.relu != 0;
     float amax = 0.f;
     const unsigned peeked = p.ymax != nullptr ? ccst_absmax_peek(p.ymax, blockIdx.x) : 0u;
     const bool interior = (oy0 + G_TH <= p.H) && (ox0 + G_TW <= p.W) && (co0 + G_BN <= p.Cout);
-    const int other = wave ^ 2;
-    // phase 2, one 32-channel tile at a time: fin[e][mt][r], e = 0, 1 = pixel 4 quad + 2 grp + e of row 4 mt + (r & 3), quad = 2 (r >> 2) + lh
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int co = co0 + wh * 64 + nt * 32 + li;
+    const int other = wave ^ 4;
+    // phase 2: fin[e][mt][r], e = 0, 1 = pixel 4 quad + 2 grp + e of row 4 mt + (r & 3), quad = 2 (r >> 2) + lh
+    {
+        const int co = co0 + wn * 32 + li;
         const bool cok = co < p.Cout;
         const float bias = (p.bias != nullptr && cok) ? p.bias[co] : 0.f;
         f32x16 fin[2][2];
@@ -385,13 +372,13 @@ __global__ __launch_bounds__(G_NT, 1) void conv3x3_f43_kernel(const F43Args p) {
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
-                const float* o = &xch[(((((other * 2 + mt) * 2 + nt) * 4 + rq) * 2) * 64 + lane) * 4];
+                const float* o = &xch[((((other * 2 + mt) * 4 + rq) * 2) * 64 + lane) * 4];
                 const f32x4 t0 = *reinterpret_cast<const f32x4*>(o), t1 = *reinterpret_cast<const f32x4*>(o + 256);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int r = 4 * rq + k;
-                    const float m0 = __builtin_ldexpf(acc[0][mt][nt][r], ks), m1 = __builtin_ldexpf(acc[1][mt][nt][r], ks),
-                                m2 = __builtin_ldexpf(acc[2][mt][nt][r], ks);
+                    const float m0 = __builtin_ldexpf(acc[0][mt][r], ks), m1 = __builtin_ldexpf(acc[1][mt][r], ks),
+                                m2 = __builtin_ldexpf(acc[2][mt][r], ks);
                     if (grp == 0) {
                         fin[0][mt][r] = (((m0 + m1) + m2) + t0[k]) + bias;                  // Y0 = a0 + b0
                         fin[1][mt][r] = ((m1 - m2) + t1[k]) + bias;                         // Y1 = a1 + b1
@@ -402,7 +389,7 @@ __global__ __launch_bounds__(G_NT, 1) void conv3x3_f43_kernel(const F43Args p) {
                 }
             }
         if (!POOL) {
-            float* const tile = p.y + (long long)n * p.ysN + (long long)oy0 * p.ysH + (long long)(ox0 + 2 * grp) * p.ysW + co0 + wh * 64 + nt * 32;
+            float* const tile = p.y + (long long)n * p.ysN + (long long)oy0 * p.ysH + (long long)(ox0 + 2 * grp) * p.ysW + co0 + wn * 32;
             const unsigned lane_off = (unsigned)(4 * lh * p.ysW + li);
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile, 0, 0x7fffffff, 0x00020000);
             float s1 = 0.f, cnt = 0.f;
@@ -458,7 +445,7 @@ __global__ __launch_bounds__(G_NT, 1) void conv3x3_f43_kernel(const F43Args p) {
             // a pooling window = rows (2 k, 2 k + 1) x pixels (4 quad + 2 grp, + 1) = four values of one lane: registers (r & 3) = 0, 1 | 2, 3
             const int Hp = (p.H + 1) >> 1, Wp = (p.W + 1) >> 1;
             const int py0 = oy0 >> 1, px0 = (ox0 >> 1) + grp;
-            float* const tile = p.y + (long long)n * p.ysN + (long long)py0 * p.ysH + (long long)px0 * p.ysW + co0 + wh * 64 + nt * 32;
+            float* const tile = p.y + (long long)n * p.ysN + (long long)py0 * p.ysH + (long long)px0 * p.ysW + co0 + wn * 32;
             const unsigned lane_off = (unsigned)(2 * lh * p.ysW + li);
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(tile, 0, 0x7fffffff, 0x00020000);
 #pragma unroll
