@@ -55,6 +55,8 @@ def traffic_keys(dom, tj):
                 and k.rstrip(">").split(",")[3].strip() == pooled]
     if base == "conv3x3_f23_kernel":              # rocprofv3: conv3x3_f23_kernel<POOL>
         return [k for k in tj if k.startswith("void conv3x3_f23_kernel<") and k.rstrip(">").split("<")[1].strip() == pooled]
+    if base == "conv3x3_f43_kernel":              # rocprofv3: conv3x3_f43_kernel<POOL, ZP>
+        return [k for k in tj if k.startswith("void conv3x3_f43_kernel<") and k.rstrip(">").split("<")[1].split(",")[0].strip() == pooled]
     if base == "conv_igemm_kernel":
         return ["void conv_igemm_kernel<%s, %s, 2, 16>" % (nums, pooled)]
     # rocprofv3 prints every template argument: <WM, WN, NT, POOL, TRAIN>
@@ -404,14 +406,17 @@ def main():
         bound_wino = bound_w4 if wfac == 4.0 else bound_w2
         executed = alg / wfac
         # the direct kernel's SPLIT form executes three half-precision MFMA products per fp32 product: its pipe is the 16-bit MFMA
-        f23 = dom.startswith("conv3x3_f23")
+        f43 = dom.startswith("conv3x3_f43")
+        f23 = dom.startswith("conv3x3_f23") or f43          # (one of the two Winograd-along-x forms)
         split = dom.startswith("conv3x3_halo_split") or f23
-        issue_factor = 2.0 if f23 else 3.0      # executed 16-bit MFMA FLOPs per algorithmic FLOP: 3 half-piece products, x 12/18 k-steps for F(2,3)
+        # executed 16-bit MFMA FLOPs per algorithmic FLOP: 3 half-piece products, x 12/18 k-steps for F(2,3), x 18/36 for F(4,3)
+        issue_factor = 1.5 if f43 else 2.0 if f23 else 3.0
         peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
         if split:
             executed = alg * issue_factor
         bound_split = PEAK_F16_MFMA_TFLOPS / 3.0 * 1e3 / (GFLOP_PER_IMAGE_512 * scale)
         bound_f23 = PEAK_F16_MFMA_TFLOPS / 2.0 * 1e3 / (GFLOP_PER_IMAGE_512 * scale)
+        bound_f43 = PEAK_F16_MFMA_TFLOPS / 1.5 * 1e3 / (GFLOP_PER_IMAGE_512 * scale)
         traffic, traffic_src, tsrc = None, None, os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tsrc):      # HBM bytes/launch from the separate rocprofv3 --pmc passes (tools/profile_bench.sh)
             with open(tsrc) as fh:
@@ -440,18 +445,22 @@ def main():
                                   "frac are the ALGORITHMIC rate (SURVEY 8d)" % ("4x4" if wfac == 4.0 else "2x2", wfac) if wino else
                                   "winograd F(2,3) along x, every fp32 product as three half-precision MFMA products (fp32 accumulate): 12 instead of "
                                   "18 k-steps per pixel pair; achieved and frac are the ALGORITHMIC rate against the dense 16-bit MFMA peak (SURVEY "
-                                  "8d); mfma_issue_* = 2 x that, what the pipe issues" if f23 else
+                                  "8d); mfma_issue_* = 2 x that, what the pipe issues" if f23 and not f43 else
+                                  "winograd F(4,3) along x, every fp32 product as three half-precision MFMA products (fp32 accumulate): 18 instead of "
+                                  "36 k-steps per pixel quad; achieved and frac are the ALGORITHMIC rate against the dense 16-bit MFMA peak (SURVEY "
+                                  "8d); mfma_issue_* = 1.5 x that, what the pipe issues" if f43 else
                                   "direct, every fp32 product as three half-precision MFMA products (fp32 accumulate): achieved and frac are the "
                                   "ALGORITHMIC rate against the dense 16-bit MFMA peak (SURVEY 8d); mfma_issue_* = 3 x that, what the pipe issues"
                                   if split else "direct"),
                     "executed_gflop_per_launch": round(fl / cnt / 1e9 * (issue_factor if split else 1.0 / wfac), 3),
                     "bound_images_per_s": {"direct": round(bound_direct, 1), "winograd_f2x2": round(bound_w2, 1), "winograd_f4x4": round(bound_w4, 1),
-                                           "direct_split_f16x3": round(bound_split, 1), "winograd_f23_split_f16x3": round(bound_f23, 1)},
-                    "path_frac_of_bound": round(value / n_ranks_seen / (bound_wino if wino else bound_f23 if f23 else bound_split if split else bound_direct), 4)}
+                                           "direct_split_f16x3": round(bound_split, 1), "winograd_f23_split_f16x3": round(bound_f23, 1),
+                                           "winograd_f43_split_f16x3": round(bound_f43, 1)},
+                    "path_frac_of_bound": round(value / n_ranks_seen / (bound_wino if wino else bound_f43 if f43 else bound_f23 if f23 else bound_split if split else bound_direct), 4)}
         if split:       # measured context for `frac` (it stays priced against the nominal peak)
-            roofline["frac_note"] = ("the fp32-exact product costs three 16-bit MFMAs (two per algorithmic product with F(2,3)), so frac <= 1/%d for "
-                                     "this form; the fp32-MFMA bound of SURVEY 8d (157.3 TFLOP/s) is retired: achieved is %.2f x it"
-                                     % (2 if f23 else 3, alg / PEAK_F32_MFMA_TFLOPS))
+            roofline["frac_note"] = ("the fp32-exact product costs three 16-bit MFMAs (two per algorithmic product with F(2,3), 1.5 with F(4,3)), so "
+                                     "frac <= %s for this form; the fp32-MFMA bound of SURVEY 8d (157.3 TFLOP/s) is retired: achieved is %.2f x it"
+                                     % ("2/3" if f43 else "1/2" if f23 else "1/3", alg / PEAK_F32_MFMA_TFLOPS))
             roofline["pipe_sustained_on_random_operands"] = {
                 "tflops": [1062.4, 1592.2], "source": "profiles/r03_bf16x3_microbench.txt part 3 (tools/micro/bf16x3.hip)",
                 "note": "a bare stream of v_mfma_f32_32x32x16_f16 on random half operands sustains 1.06-1.59 PFLOP/s on this GPU (the clock "
@@ -494,7 +503,7 @@ def main():
         "warmup": args.warmup, "init_passes": INIT_PASSES, "ms_per_step": round(ms_per_step, 3),
         "median_ms_per_step": round(median_ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("f32 (3xf16 split products, f32 accumulate)" if any(k.startswith(("conv3x3_halo_split", "conv3x3_f23")) for k in per_kernel) else "f32"),
+        "dtype": ("f32 (3xf16 split products, f32 accumulate)" if any(k.startswith(("conv3x3_halo_split", "conv3x3_f23", "conv3x3_f43")) for k in per_kernel) else "f32"),
         "data": "synthetic",
         "config": {"workload": "CCST_OverallStyleTransfer PACS %dx%d batch=%d (encoder->AdaIN->decoder)" % (S, S, B),
                    "batch_per_gpu": B, "image_size": S, "sharding": "content batches per rank, no collective"},

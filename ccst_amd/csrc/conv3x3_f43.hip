@@ -89,7 +89,8 @@ struct GroupTag {
     static constexpr int value = V;
 };
 
-template <bool POOL>
+// ZP: zero padding (the masks cost 16-24 vector instructions per transform item: the reflecting AdaIN layers run the kernel without them)
+template <bool POOL, bool ZP>
 __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
     extern __shared__ __attribute__((aligned(16))) float f43_lds[];
     float* const Vs = f43_lds;                     // [2][G_VW]             transformed halo, double buffered
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
         const int S = min(rpiece[i] * 16 + (lane >> 2), G_HH * G_RSLOTS - 1);
         const int hy = S / G_RSLOTS, sx = S - hy * G_RSLOTS, hx = min(sx - sx / 5, G_RW - 1);
         int gy = oy0 + hy - 1, gx = ox0 + hx - 1;
-        if (p.reflect) {
+        if (!ZP) {
             gy = reflect_g(gy, p.H);
             gx = reflect_g(gx, p.W);
         } else {
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
     const int tdstA = trow0 * G_ROWW + xq_t * G_XQW + part_t * 2, tdstB = trow1 * G_ROWW + xq_t * G_XQW + part_t * 2;
     unsigned tokx = 0x3fu;       // zero padding: validity of the quad's six pixels;
     bool okyA = true, okyB = true;   // ... of the rows of item 0, of item 1
-    if (!p.reflect) {
+    if (ZP) {
         tokx = 0;
 #pragma unroll
         for (int d = 0; d < 6; ++d) {
@@ -181,10 +182,9 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
     auto xpair = [&](auto ptag, const float* r0, float* o, bool oky) __attribute__((always_inline)) {
         constexpr int PAIR = decltype(ptag)::value;
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-        const bool zp = !p.reflect;
         auto px = [&](int d) {                   // pixel d of the quad (0..5)
             f32x4 v = *reinterpret_cast<const f32x4*>(r0 + (d < 4 ? d : d + 1) * 16);
-            if (zp && !(oky && ((tokx >> d) & 1u))) v = z;
+            if (ZP && !(oky && ((tokx >> d) & 1u))) v = z;
             return v;
         };
         if (PAIR < 2) {
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
                 __builtin_amdgcn_sched_barrier(0);
                 read_a(0, nbase, nt_);
                 // staging.  The raw buffer holds chunk c + 1 (every wave waits for its own pieces, then the barrier, at k-step 2); it is
-                // transformed into the other V buffer at k-steps 3 and 5, one item per thread, and after the barrier of k-step 6 refilled
+                // transformed into the other V buffer at k-steps 3, 4 (group 0) / 5, 6 (group 1), one item per thread and k-step, and after the barrier of k-step 6 refilled
                 // with chunk c + 2 (k-steps 7, 8).  The weights of k-step t of the NEXT chunk replace this k-step's.
                 if (t == 7) {
                     dma_raw(c + 2, 0);
@@ -304,8 +304,8 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
                     dma_raw(c + 2, 3);
                 }
                 load_b(t);
-                if (t == 3) xform(dWn, d8n, 0);
-                if (t == 5) xform(dWn, d8n, 1);
+                if (t == 3 + 2 * G_) xform(dWn, d8n, 0);          // (the two waves of a SIMD belong to different groups: staggered, one of them
+                if (t == 4 + 2 * G_) xform(dWn, d8n, 1);          //  keeps the MFMA pipe busy while the other transforms)
                 __builtin_amdgcn_sched_barrier(0);
                 // k-step 2: the raw pieces (issued before the weights of k-step 8: the 8 loads issued since -- 6 after the prologue's --
                 // may stay in flight) have landed, and every wave is done with the fragments of the previous chunk's V;  k-step 6: the
@@ -560,14 +560,15 @@ extern "C" int ccst_conv3x3_f43_f32(const float* x, const uint32_t* x_absmax, co
     a.tilesX = (W + G_TW - 1) / G_TW;
     const long long grid = (long long)N * a.tilesY * a.tilesX * a.tilesN;
     CCST_REQUIRE(grid > 0 && grid <= 0x7fffffffLL, "conv3x3_f43: bad grid");
-    const void* kfn = pool ? reinterpret_cast<const void*>(&conv3x3_f43_kernel<true>) : reinterpret_cast<const void*>(&conv3x3_f43_kernel<false>);
-    hipError_t e1 = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES);
+    const bool zp = !a.reflect;
+    void (*kern)(const F43Args) = pool ? (zp ? conv3x3_f43_kernel<true, true> : conv3x3_f43_kernel<true, false>)
+                                       : (zp ? conv3x3_f43_kernel<false, true> : conv3x3_f43_kernel<false, false>);
+    // (the opt-in above the 64 KB default is per device and idempotent: set for the current device on every launch)
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES);
     if (e1 != hipSuccess) {
         ccst_set_error("conv3x3_f43: cannot reserve %d bytes of LDS: %s", G_LDS_BYTES, hipGetErrorString(e1));
         return (int)e1;
     }
-    hipStream_t s = (hipStream_t)stream;
-    if (pool) hipLaunchKernelGGL((conv3x3_f43_kernel<true>), dim3((unsigned)grid), dim3(G_NT), G_LDS_BYTES, s, a);
-    else hipLaunchKernelGGL((conv3x3_f43_kernel<false>), dim3((unsigned)grid), dim3(G_NT), G_LDS_BYTES, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G_NT), G_LDS_BYTES, (hipStream_t)stream, a);
     return ccst_launch_status("conv3x3_f43");
 }

@@ -1062,12 +1062,15 @@ def test_plan_passes_absmax_between_layers(dev, nets, A):
                                   (3, 50, 84, 64, 128, False, False), (1, 64, 64, 512, 256, False, True), (2, 33, 17, 32, 200, True, False),
                                   (1, 8, 32, 16, 128, False, False), (1, 2, 2, 16, 128, True, False)])
 @pytest.mark.parametrize("reflect", [True, False])
-def test_conv3x3_f23_vs_fp64(dev, case, reflect):
-    """ops.conv3x3_f23 (F(2,3) along x, products on half pieces) against an fp64 convolution: reflection / zero padding, extents that are
-    not multiples of the 8 x 32 tile (odd widths: the last pixel pair is half outside), Cout not a multiple of 128, fused ceil pool with
-    odd extents, upsampled source, the smallest legal image.  Gate: 6e-6 of max |y| (the direct half-piece kernel: 4e-6; F(2,3) adds
-    one fp32 addition on each operand and two on the result).  The epilogue's max |y| words must hold exactly the largest stored value."""
+@pytest.mark.parametrize("form", [2, 4])
+def test_conv3x3_f23_vs_fp64(dev, case, reflect, form):
+    """ops.conv3x3_f23 / ops.conv3x3_f43 (F(2,3) / F(4,3) along x, products on half pieces) against an fp64 convolution: reflection / zero
+    padding, extents that are not multiples of the 8 x 32 tile (odd widths: the last pixel pair / quad is partly outside), Cout not a
+    multiple of 128, fused ceil pool with odd extents, upsampled source, the smallest legal image.  Gate: 6e-6 of max |y| for F(2,3)
+    (the direct half-piece kernel: 4e-6; F(2,3) adds one fp32 addition on each operand and two on the result); 1e-5 for F(4,3)
+    (interpolation points +-2: measured 0.2-4.8e-6).  The epilogue's max |y| words must hold exactly the largest stored value."""
     from ccst_amd import ops
+    conv, gate = (ops.conv3x3_f43, 1e-5) if form == 4 else (ops.conv3x3_f23, 6e-6)
     N, H, W, Cin, Cout, pool, ups = case
     g = torch.Generator().manual_seed(31)
     Hs, Ws = (H // 2, W // 2) if ups else (H, W)
@@ -1077,7 +1080,7 @@ def test_conv3x3_f23_vs_fp64(dev, case, reflect):
     pc = ops.pack_conv_weight(w, b, wino=4)
     flags = 1 | (2 if pool else 0) | (4 if ups else 0) | (8 if reflect else 0)
     ymax = ops.absmax_words(dev)
-    out = ops.conv3x3_f23(x, pc, flags, y_absmax=ymax)
+    out = conv(x, pc, flags, y_absmax=ymax)
     xr = x.permute(0, 3, 1, 2).double()
     if ups:
         xr = F.interpolate(xr, scale_factor=2, mode="nearest")
@@ -1088,21 +1091,22 @@ def test_conv3x3_f23_vs_fp64(dev, case, reflect):
     ref = ref.permute(0, 2, 3, 1)
     assert out.shape == ref.shape
     err = float((out.double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
-    assert err < 6e-6, err
+    assert err < gate, err
     assert _absmax_value(ymax) == float(out.abs().max())
-    assert torch.equal(out, ops.conv3x3_f23(x, pc, flags))
+    assert torch.equal(out, conv(x, pc, flags))
     # and against the direct half-piece kernel on the same operands
-    assert float((out - ops.conv3x3_halo_split(x, pc, flags)).abs().max()) < 6e-6 * max(1.0, float(ref.abs().max()))
+    assert float((out - ops.conv3x3_halo_split(x, pc, flags)).abs().max()) < gate * max(1.0, float(ref.abs().max()))
     if not pool:       # the per-tile channel sums of the epilogue add up to the sums of the output, per image
-        out2, part = ops.conv3x3_f23(x, pc, flags, sums=True)
+        out2, part = conv(x, pc, flags, sums=True)
         assert torch.equal(out2, out) and part.shape[0] % N == 0 and tuple(part.shape[1:]) == (Cout, 4)
         _check_centred_partials(part, out, N)
 
 
 @pytest.mark.parametrize("xscale", [1e-30, 1e-4, 3e4, 1e5, 1e30])
-def test_conv3x3_f23_any_magnitude(dev, xscale):
-    """The F(2,3) kernel takes its operand scales from the same |max| words as the direct half-piece kernel (one bit of head room more:
-    a transform position is the sum of two pixels): any finite fp32 magnitude."""
+@pytest.mark.parametrize("form", [2, 4])
+def test_conv3x3_f23_any_magnitude(dev, xscale, form):
+    """The F(2,3) / F(4,3) kernels take their operand scales from the same |max| words as the direct half-piece kernel (one / four bits of
+    head room more: a transform position is the sum of two pixels / up to ten times a pixel): any finite fp32 magnitude."""
     from ccst_amd import ops
     g = torch.Generator().manual_seed(37)
     N, H, W, Cin, Cout = 1, 24, 64, 64, 128
@@ -1110,19 +1114,20 @@ def test_conv3x3_f23_any_magnitude(dev, xscale):
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05).to(dev)
     b = (torch.randn(Cout, generator=g) * 0.1 * xscale).to(dev)
     pc = ops.pack_conv_weight(w, b, wino=4)
-    out = ops.conv3x3_f23(x, pc, 1 | 8)
+    out = (ops.conv3x3_f43 if form == 4 else ops.conv3x3_f23)(x, pc, 1 | 8)
     ref = _conv_ref64(x, w, b)
     assert bool(torch.isfinite(out).all())
-    assert float((out.double().cpu() - ref).abs().max()) < 6e-6 * float(ref.abs().max())
+    assert float((out.double().cpu() - ref).abs().max()) < (1e-5 if form == 4 else 6e-6) * float(ref.abs().max())
 
 
-def test_style_transfer_goldens_on_f23(dev, nets, A, golden):
-    """The golden images are too small for the plan to pick the F(2,3) kernel by itself (it wants whole rounds of 256 workgroups); forced
-    on every Cout >= 128 layer, the reference-made fixtures must still come out inside the 1e-3 contract."""
+@pytest.mark.parametrize("form", [2, 4])
+def test_style_transfer_goldens_on_f23(dev, nets, A, golden, form):
+    """The golden images are too small for the plan to pick the F(2,3) / F(4,3) kernel by itself (it wants whole rounds of 256 workgroups);
+    forced on every Cout >= 128 layer, the reference-made fixtures must still come out inside the 1e-3 contract."""
     from ccst_amd import ops, style
     vgg31, dec, _, _ = nets
-    old = ops.F23_FORCE
-    ops.F23_FORCE = True
+    old, old43 = ops.F23_FORCE, ops.F43
+    ops.F23_FORCE, ops.F43 = True, form == 4
     try:
         stat7 = [t.to(dev) for t in A.synth_style_stat(512, seed=7)]
         g = golden("style_transfer_64")
@@ -1143,10 +1148,10 @@ def test_style_transfer_goldens_on_f23(dev, nets, A, golden):
         ref = A.style_transfer(nets[2], nets[3], content, stat, 1.0)
         assert maxdiff(out, ref) < TOL
     finally:
-        ops.F23_FORCE = old
+        ops.F23_FORCE, ops.F43 = old, old43
 
 
-@pytest.mark.parametrize("kernel", ["f23", "split"])
+@pytest.mark.parametrize("kernel", ["f23", "f43", "split"])
 def test_adain_tile_sums_with_large_channel_means(dev, kernel):
     """the AdaIN step takes the content variance from the conv epilogue's per-tile sums; as raw fp32 (sum, sum of squares)
     pairs the variance was lost once mean^2 >> var (relative error ~1e-7 mean^2 / var, clamped at zero).  The half-piece conv kernels
@@ -1160,7 +1165,7 @@ def test_adain_tile_sums_with_large_channel_means(dev, kernel):
     b = torch.full((Cout,), 1000.0)
     b[::2] = 0.5                                   # every other channel ordinary
     pc = ops.pack_conv_weight(w, b.to(dev), wino=4)
-    fn = ops.conv3x3_f23 if kernel == "f23" else ops.conv3x3_halo_split
+    fn = ops.conv3x3_f23 if kernel == "f23" else ops.conv3x3_f43 if kernel == "f43" else ops.conv3x3_halo_split
     y, part = fn(x, pc, 1 | 8, sums=True)
     feat = ops.to_api(y)
     assert ops.adain_tile_sums_ok(feat, part)
@@ -1182,7 +1187,7 @@ def test_adain_tile_sums_with_large_channel_means(dev, kernel):
     assert float((q1.double().reshape(-1) - (f64 ** 2).sum(dim=(0, 2, 3))).abs().max()) < 1e-5 * float((f64 ** 2).sum(dim=(0, 2, 3)).abs().max())
 
 
-@pytest.mark.parametrize("kernel", ["f23", "split", "zform", "stem3"])
+@pytest.mark.parametrize("kernel", ["f23", "f43", "split", "zform", "stem3"])
 @pytest.mark.parametrize("k", [-40, 7, 60])
 def test_half_piece_kernels_are_exactly_homogeneous_in_powers_of_two(dev, kernel, k):
     """A size-independent property at the BENCH shapes (B=6; 128x128x256 / 256x256 / 512x512): the half-piece kernels scale their operands
@@ -1192,11 +1197,12 @@ def test_half_piece_kernels_are_exactly_homogeneous_in_powers_of_two(dev, kernel
     from ccst_amd import ops
     g = torch.Generator().manual_seed(43)
     s = 2.0 ** k
-    if kernel in ("f23", "split"):
+    if kernel in ("f23", "f43", "split"):
         x = torch.randn(6, 128, 128, 256, generator=g).to(dev)
         w = (torch.randn(256, 256, 3, 3, generator=g) * 0.02).to(dev)
         pc = ops.pack_conv_weight(w, None, wino=4)
-        fn = (lambda t: ops.conv3x3_f23(t, pc, 1 | 8)) if kernel == "f23" else (lambda t: ops.conv3x3_halo_split(t, pc, 1 | 8))
+        conv = {"f23": ops.conv3x3_f23, "f43": ops.conv3x3_f43, "split": ops.conv3x3_halo_split}[kernel]
+        fn = lambda t: conv(t, pc, 1 | 8)
     elif kernel == "zform":
         x = torch.randn(6, 512, 512, 64, generator=g).to(dev)
         wt = (torch.randn(3, 64, 3, 3, generator=g) * 0.05).to(dev).permute(2, 3, 0, 1).contiguous()
