@@ -136,9 +136,8 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
         }
         rsrc_[i] = (unsigned)((((gy >> p.ups) * p.Ws + (gx >> p.ups)) * p.Cin + (lane & 3) * 4) * 4);
     }
-    auto dma_raw = [&](int c_, int i) {         // raw piece wave + 8 i of chunk c_
-        const int cc = min(c_, nchunks - 1);
-        glds16g(ximg + cc * 16, rsrc_[i], (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(G_RAW0 * 4 + rpiece[i] * 1024))));
+    auto dma_raw = [&](int c_, int i) {         // raw piece wave + 8 i of chunk c_ (clamped: the second-to-last chunk fetches the last once more)
+        glds16g(ximg + min(c_, nchunks - 1) * 16, rsrc_[i], (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)(G_RAW0 * 4 + rpiece[i] * 1024))));
     };
 
     // ---- transform items: 3 position pairs x 10 halo rows x 8 quads x 4 channel parts = 960 = (up to) TWO per thread.  Half-wave
@@ -234,14 +233,10 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
     // A fragment base: GEMM row li of M tile mt is (row 4 mt + (li & 3), quad li >> 2)
     const int aBase = (li & 3) * G_ROWW + (li >> 2) * G_XQW + lh * 4;
 
-    // ---- prologue: raw pixels of chunk 0, transform, raw pixels of chunk 1 ------------------------------------------------------------
+    // ---- prologue: the raw pixels of chunk 0 first, the weights of chunk 0 behind them (their latencies overlap) ----------------------
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma_raw(0, i);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    asm volatile("" : "+v"(xword), "+v"(wword));
-    const int kx = ccst_scale_exp(ccst_absmax_reduce(xword), F43_X_TARGET);
-    const int kw = ccst_scale_exp(ccst_absmax_reduce(wword), F43_W_TARGET);
-    xs = __uint_as_float((unsigned)(127 + kx) << 23);
+    int kx = 0, kw = 0;
 
     // The main loop of position group G_ (a compile-time constant: positions are instruction immediates).  k-step t = ky * 3 + j of a
     // chunk: group G_ multiplies position q = 3 G_ + j of halo rows ky .. ky + 7 by slab m = 2 t + G_.  The two V buffers alternate per
@@ -266,16 +261,25 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) load_b(t);
         sbase += cstride;
+        asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");          // the raw pieces (older than the 18 weight loads) have landed
+        asm volatile("" : "+v"(xword), "+v"(wword));
+        kx = ccst_scale_exp(ccst_absmax_reduce(xword), F43_X_TARGET);
+        kw = ccst_scale_exp(ccst_absmax_reduce(wword), F43_W_TARGET);
+        xs = __uint_as_float((unsigned)(127 + kx) << 23);
 #pragma unroll
         for (int i = 0; i < 2; ++i) xform(tdstA, tdstB, i);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (nchunks > 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dma_raw(1, i);
+            for (int i = 0; i < 4; ++i) dma_raw(1, i);
+        }
         int aCur = aBase, aNxt = aBase + G_VW, dWn = tdstA + G_VW, d8n = tdstB + G_VW, dWc = tdstA, d8c = tdstB;
         read_a(1, aCur, 0);
         read_a(0, aCur, 0);
 
-        for (int c = 0; c < nchunks; ++c) {
+        // one chunk; LAST (compile time): nothing to prepare behind it -- no weight loads, no raw pieces, no transform
+        auto chunk = [&](const int c, auto lasttag) __attribute__((always_inline)) {
+            constexpr bool LAST = decltype(lasttag)::value != 0;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int j = t % 3;
@@ -295,17 +299,17 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
                 // staging.  The raw buffer holds chunk c + 1 (every wave waits for its own pieces, then the barrier, at k-step 2); it is
                 // transformed into the other V buffer at k-steps 3, 4 (group 0) / 5, 6 (group 1), one item per thread and k-step, and after the barrier of k-step 6 refilled
                 // with chunk c + 2 (k-steps 7, 8).  The weights of k-step t of the NEXT chunk replace this k-step's.
-                if (t == 7) {
+                if (t == 7 && !LAST) {
                     dma_raw(c + 2, 0);
                     dma_raw(c + 2, 1);
                 }
-                if (t == 8) {
+                if (t == 8 && !LAST) {
                     dma_raw(c + 2, 2);
                     dma_raw(c + 2, 3);
                 }
-                load_b(t);
-                if (t == 3 + 2 * G_) xform(dWn, d8n, 0);          // (the two waves of a SIMD belong to different groups: staggered, one of them
-                if (t == 4 + 2 * G_) xform(dWn, d8n, 1);          //  keeps the MFMA pipe busy while the other transforms)
+                if (!LAST) load_b(t);
+                if (t == 3 + 2 * G_ && !LAST) xform(dWn, d8n, 0);          // (the two waves of a SIMD belong to different groups: staggered, one of
+                if (t == 4 + 2 * G_ && !LAST) xform(dWn, d8n, 1);          //  them keeps the MFMA pipe busy while the other transforms)
                 __builtin_amdgcn_sched_barrier(0);
                 // k-step 2: the raw pieces (issued before the weights of k-step 8: the 8 loads issued since -- 6 after the prologue's --
                 // may stay in flight) have landed, and every wave is done with the fragments of the previous chunk's V;  k-step 6: the
@@ -317,12 +321,14 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
             int tmp = aCur; aCur = aNxt; aNxt = tmp;
             tmp = dWc; dWc = dWn; dWn = tmp;
             tmp = d8c; d8c = d8n; d8n = tmp;
-        }
+        };
+        for (int c = 0; c + 1 < nchunks; ++c) chunk(c, GroupTag<0>{});
+        chunk(nchunks - 1, GroupTag<1>{});
     };
     if (grp == 0) run(GroupTag<0>{});
     else run(GroupTag<1>{});
-    // the clamped prefetches of the last k-steps must land, and every wave must be past its last fragment read, before the exchange
-    // below overwrites the operand images
+    // every wave must be past its last fragment read before the exchange below overwrites the operand images (nothing is in flight: the
+    // last chunk fetches nothing)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     // ---- epilogue: scale back, the groups' halves of A^T, exchange, bias ---------------------------------------------------------
