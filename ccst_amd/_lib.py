@@ -60,6 +60,7 @@ _SIGNATURES = {
     "ccst_conv3x3_f23_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P, _P],
     "ccst_pack_conv_weight_f43_f32": [_P, _P, c_int, c_int, c_int, _P, _P],
     "ccst_conv3x3_f43_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P, _P],
+    "ccst_conv3x3_f43_workgroups": [c_int, c_int, c_int, c_int],
     "ccst_conv3x3_f23_workgroups": [c_int, c_int, c_int, c_int],
     "ccst_conv3x3_f23_tiles": [c_int, c_int, c_int],
     "ccst_conv3x3_halo_split_tiles": [c_int, c_int, c_int],

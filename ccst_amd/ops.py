@@ -457,6 +457,7 @@ F23_MIN_COUT = 128      # (the Cout = 64 layers padded to its 128-channel tile m
 F23_FORCE = os.environ.get("CCST_CONV_F23", "1") == "2"       # every Cout >= 128 layer whatever its grid (tests: small images)
 # ... and F(4,3) along x (conv3x3_f43.hip: 1.5 executed FLOPs per algorithmic one) in the F(2,3) kernel's place.  CCST_CONV_F43=0: F(2,3).
 F43 = os.environ.get("CCST_CONV_F43", "1") != "0"
+F43_MIN_COUT = int(os.environ.get("CCST_F43_MIN_COUT", "64"))      # (128: the Cout = 64 layers stay on the direct half-piece kernel)
 _N_CU = {}
 
 
@@ -468,13 +469,15 @@ def num_cus(device):
 
 
 def f23_wanted(pc, N, H, W, device):
-    """Run this 3x3 layer (conv extent H x W) on the F(2,3) kernel?"""
-    if not (F23 and halo_split_wanted(pc)) or pc.cout < F23_MIN_COUT or H * W * pc.cin >= 2 ** 30:
+    """Run this 3x3 layer (conv extent H x W) on the F(2,3) / F(4,3) kernel?  (F(4,3) has a 64-channel tile: the Cout = 64 layers too.)"""
+    min_cout = F43_MIN_COUT if F43 else F23_MIN_COUT
+    if not (F23 and halo_split_wanted(pc)) or pc.cout < min_cout or H * W * pc.cin >= 2 ** 30:
         return False
     if F23_FORCE:
         return True
     # (one workgroup per CU: measured faster than the direct kernel down to 0.75 rounds of the chip -- 64^2 512->256 at B=6, x1.16)
-    wgs = int(_lib.load().ccst_conv3x3_f23_workgroups(N, H, W, pc.cout))
+    lib = _lib.load()
+    wgs = int((lib.ccst_conv3x3_f43_workgroups if F43 else lib.ccst_conv3x3_f23_workgroups)(N, H, W, pc.cout))
     return wgs >= F23_MIN_FILL * num_cus(device)
 
 

@@ -13,6 +13,7 @@ LAYERS = [  # H (= W, conv extent), Cin, Cout, pool, ups
     (256, 64, 128, False, False), (256, 128, 128, True, False), (128, 128, 256, False, False), (128, 256, 256, False, False),
     (128, 256, 256, True, False), (64, 256, 512, False, False), (64, 512, 256, False, False), (128, 256, 256, False, True),
     (128, 256, 128, False, False), (256, 128, 128, False, True),
+    (512, 64, 64, True, False), (256, 128, 64, False, False), (512, 64, 64, False, True),        # the Cout = 64 layers (F(4,3)'s 64-channel tile; no F(2,3) form)
 ]
 
 
@@ -31,7 +32,8 @@ def main():
         pc = ops.pack_conv_weight(w, b, wino=4)
         flags = 1 | 8 | (2 if pool else 0) | (4 if ups else 0)
         xmax = ops.absmax(x)
-        fns = (lambda: ops.conv3x3_halo_split(x, pc, flags, x_absmax=xmax), lambda: ops.conv3x3_f23(x, pc, flags, x_absmax=xmax),
+        fns = (lambda: ops.conv3x3_halo_split(x, pc, flags, x_absmax=xmax),
+               (lambda: ops.conv3x3_f23(x, pc, flags, x_absmax=xmax)) if Cout >= 128 else (lambda: ops.conv3x3_halo_split(x, pc, flags, x_absmax=xmax)),
                lambda: ops.conv3x3_f43(x, pc, flags, x_absmax=xmax))
         res = []
         for fn in fns:
@@ -55,7 +57,7 @@ def main():
         ref = ref.permute(0, 2, 3, 1)
         errs = [float((r[1][:1].double() - ref).abs().max()) / float(ref.abs().max()) for r in res]
         fl = 2.0 * B * H * H * Cout * Cin * 9
-        wgs = B * ((H + 7) // 8) * ((H + 31) // 32) * ((Cout + 127) // 128)
+        wgs = B * ((H + 7) // 8) * ((H + 31) // 32) * ((Cout + 127) // 128) if Cout >= 128 else B * ((H + 15) // 16) * ((H + 31) // 32)
         print("%4d^2 %3d->%3d %s%s  split %7.1f us %6.1f TF err %.2e | f23 %7.1f us %6.1f TF err %.2e | f43 %7.1f us %6.1f TF err %.2e | f43/f23 x%.2f  (%d workgroups = %.2f rounds)" % (
             H, Cin, Cout, "pool " if pool else "     ", "ups" if ups else "   ", res[0][0], fl / res[0][0] / 1e6, errs[0], res[1][0], fl / res[1][0] / 1e6, errs[1],
             res[2][0], fl / res[2][0] / 1e6, errs[2], res[1][0] / res[2][0], wgs, wgs / 256.0))
