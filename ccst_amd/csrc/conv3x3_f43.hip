@@ -375,7 +375,8 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
     // last chunk fetches nothing)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-    // ---- epilogue: scale back, the groups' halves of A^T, exchange, bias ---------------------------------------------------------
+    // ---- epilogue: the groups' halves of A^T on the scaled accumulators, exchange, scale back (one v_ldexp per OUTPUT: powers of two commute
+    // with every rounding here), bias ---------------------------------------------------------
     //   group 0 (m0 m1 m2): a0 = m0 + m1 + m2, a1 = m1 - m2, a2 = m1 + m2;     group 1 (m3 m4 m5): b0 = m3 + m4, b1 = 2 (m3 - m4), b2 = 4 b0, b3 = 4 b1 + m5
     //   Y0 = a0 + b0, Y1 = a1 + b1 (finished by group 0: it receives b0, b1);   Y2 = a2 + b2, Y3 = a1 + b3 (group 1: receives a2, a1)
     // (in two phases over the accumulators, which stay where they are)
@@ -390,13 +391,13 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int r = 4 * rq + k;
-                    const float m1 = __builtin_ldexpf(acc[1][mt][r], ks);
+                    const float m1 = acc[1][mt][r];
                     if (grp == 0) {
-                        const float m2 = __builtin_ldexpf(acc[2][mt][r], ks);
+                        const float m2 = acc[2][mt][r];
                         s0[k] = m1 + m2;               // a2 -> group 1's Y2
                         s1[k] = m1 - m2;               // a1 -> group 1's Y3
                     } else {
-                        const float m0 = __builtin_ldexpf(acc[0][mt][r], ks);
+                        const float m0 = acc[0][mt][r];
                         s0[k] = m0 + m1;               // b0 -> group 0's Y0
                         s1[k] = 2.f * (m0 - m1);       // b1 -> group 0's Y1
                     }
@@ -427,14 +428,13 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int r = 4 * rq + k;
-                    const float m0 = __builtin_ldexpf(acc[0][mt][r], ks), m1 = __builtin_ldexpf(acc[1][mt][r], ks),
-                                m2 = __builtin_ldexpf(acc[2][mt][r], ks);
+                    const float m0 = acc[0][mt][r], m1 = acc[1][mt][r], m2 = acc[2][mt][r];
                     if (grp == 0) {
-                        fin[0][mt][r] = (((m0 + m1) + m2) + t0[k]) + bias;                  // Y0 = a0 + b0
-                        fin[1][mt][r] = ((m1 - m2) + t1[k]) + bias;                         // Y1 = a1 + b1
+                        fin[0][mt][r] = __builtin_ldexpf(((m0 + m1) + m2) + t0[k], ks) + bias;                  // Y0 = a0 + b0
+                        fin[1][mt][r] = __builtin_ldexpf((m1 - m2) + t1[k], ks) + bias;                         // Y1 = a1 + b1
                     } else {
-                        fin[0][mt][r] = (4.f * (m0 + m1) + t0[k]) + bias;                   // Y2 = b2 + a2
-                        fin[1][mt][r] = ((8.f * (m0 - m1) + m2) + t1[k]) + bias;            // Y3 = b3 + a1
+                        fin[0][mt][r] = __builtin_ldexpf(4.f * (m0 + m1) + t0[k], ks) + bias;                   // Y2 = b2 + a2
+                        fin[1][mt][r] = __builtin_ldexpf((8.f * (m0 - m1) + m2) + t1[k], ks) + bias;            // Y3 = b3 + a1
                     }
                 }
             }

@@ -511,7 +511,8 @@ def conv3x3_f23(x, pc, flags, sums=False, x_absmax=None, y_absmax=None, form=2):
         e0.record()
         check(fn(*args), name)
         e1.record()
-        TIMING.append(("%s_kernel<%s>" % (name, "pool" if pool else "nopool"), 2.0 * N * Hi * Wi * pc.cout * pc.cin * 9, e0, e1,
+        # (the kernel buckets of bench.py = rocprofv3's kernel names: F(4,3)'s 64-channel tile is an instantiation of its own)
+        TIMING.append(("%s_kernel<%s%s>" % (name, "pool" if pool else "nopool", ",tall" if form == 4 and pc.cout <= 64 else ""), 2.0 * N * Hi * Wi * pc.cout * pc.cin * 9, e0, e1,
                        "n%d %dx%d cin%d cout%d taps3x3 flags%d" % (N, Hi, Wi, pc.cin, pc.cout, flags)))
     return (out, part) if sums else out
 
