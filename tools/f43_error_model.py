@@ -1,4 +1,5 @@
-"""Emulates the rounding of the half-piece Winograd forms along x (F(2,3) as shipped, F(4,3) as priced) against fp64 on VGG-like data."""
+"""Emulates the rounding of the half-piece Winograd forms along x (F(2,3), F(4,3)) against fp64 on VGG-like data: fp32 transform chain,
+half-piece split, three products, fp32 accumulation per 16-channel chunk.  python tools/f43_error_model.py (CPU, ~2 min)."""
 import numpy as np
 rng = np.random.default_rng(0)
 def split(v):           # v float32 already scaled -> hi, lo halves (as float32 values)
@@ -8,8 +9,7 @@ def split(v):           # v float32 already scaled -> hi, lo halves (as float32 
 def scale_exp(m, target):
     return target - int(np.floor(np.log2(m)))  # 2^k * m in [2^target, 2^(target+1))
 def run(F, Cin=256, Cout=32, H=16, W=32, relu_in=True, mean=0.0):
-    x = rng.standard_normal((H + 2, W + 2, Cin)).astype(np.float32) + mean
-    if relu_in: x = np.maximum(x, 0)
+    x = rng.random((H + 2, W + 2, Cin)).astype(np.float32) if mean else np.maximum(rng.standard_normal((H + 2, W + 2, Cin)).astype(np.float32), 0)
     x[0] = 0; x[-1] = 0; x[:, 0] = 0; x[:, -1] = 0
     w = (rng.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32)
     # fp64 reference
@@ -42,12 +42,14 @@ def run(F, Cin=256, Cout=32, H=16, W=32, relu_in=True, mean=0.0):
                 if BT[q, j] != 0: acc = (acc + BT[q, j] * d[:, j]).astype(np.float32)
             V[:, q] = acc
         Vh, Vl = split(V)
-        M = np.zeros((a, H, Cout), np.float64)
-        for ky in range(3):
+        M = np.zeros((a, H, Cout), np.float32)
+        for c0 in range(0, Cin, 16):
+          for ky in range(3):
             for q in range(a):
-                A_h, A_l = Vh[ky:ky + H, q].astype(np.float64), Vl[ky:ky + H, q].astype(np.float64)
-                B_h, B_l = Uh[ky, q].astype(np.float64).T, Ul[ky, q].astype(np.float64).T
-                M[q] += A_l @ B_h + A_h @ B_l + A_h @ B_h
+                A_h, A_l = Vh[ky:ky + H, q, c0:c0+16].astype(np.float64), Vl[ky:ky + H, q, c0:c0+16].astype(np.float64)
+                B_h, B_l = Uh[ky, q][:, c0:c0+16].astype(np.float64).T, Ul[ky, q][:, c0:c0+16].astype(np.float64).T
+                for P in (A_l @ B_h, A_h @ B_l, A_h @ B_h):
+                    M[q] = (M[q] + P.astype(np.float32)).astype(np.float32)
         M = (M.astype(np.float32) * np.float32(2.0 ** -(kx_ + kw_))).astype(np.float32)    # (fp32 accumulators: rounding of the final value only, an under-estimate)
         for e in range(m):
             acc = np.zeros((H, Cout), np.float32)
