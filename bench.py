@@ -47,7 +47,7 @@ def traffic_keys(dom, tj):
     'conv3x3_halo_split_kernel<nopool>'): a bucket may hold several template instantiations."""
     base, targs = dom[:-1].split("<")
     targs = targs.split(",")
-    nums, pooled = ", ".join(a for a in targs if a not in ("pool", "nopool", "tall")), ("true" if "pool" in targs else "false")
+    nums, pooled = ", ".join(a for a in targs if a not in ("pool", "nopool", "half")), ("true" if "pool" in targs else "false")
     if base in ("conv3x3_wino_kernel", "conv3x3_wino4_kernel", "conv3x3_wino4w_kernel"):
         return [k for k in tj if k.startswith("void %s<" % base) and k.rstrip(">").split("<")[1].split(",")[0].strip() == pooled]
     if base == "conv3x3_halo_split_kernel":       # rocprofv3: conv3x3_halo_kernel<WM, WN, NT, POOL, TRAIN, SPLIT>
@@ -55,10 +55,10 @@ def traffic_keys(dom, tj):
                 and k.rstrip(">").split(",")[3].strip() == pooled]
     if base == "conv3x3_f23_kernel":              # rocprofv3: conv3x3_f23_kernel<POOL>
         return [k for k in tj if k.startswith("void conv3x3_f23_kernel<") and k.rstrip(">").split("<")[1].strip() == pooled]
-    if base == "conv3x3_f43_kernel":              # rocprofv3: conv3x3_f43_kernel<POOL, ZP, TALL>
-        tall = "true" if "tall" in targs else "false"
+    if base == "conv3x3_f43_kernel":              # rocprofv3: conv3x3_f43_kernel<POOL, ZP, HALF>
+        half = "true" if "half" in targs else "false"
         return [k for k in tj if k.startswith("void conv3x3_f43_kernel<") and k.rstrip(">").split("<")[1].split(",")[0].strip() == pooled
-                and k.rstrip(">").split(",")[-1].strip() == tall]
+                and k.rstrip(">").split(",")[-1].strip() == half]
     if base == "conv_igemm_kernel":
         return ["void conv_igemm_kernel<%s, %s, 2, 16>" % (nums, pooled)]
     # rocprofv3 prints every template argument: <WM, WN, NT, POOL, TRAIN>

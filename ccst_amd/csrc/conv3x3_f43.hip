@@ -51,31 +51,35 @@ typedef ccst_u32x2 u32x2g;
 typedef _Float16 f16x8g __attribute__((ext_vector_type(8)));
 typedef float f32x2g __attribute__((ext_vector_type(2)));
 
-constexpr int G_TW = 32, G_XQ = G_TW / 4, G_NT = 512;
-// the tile: 8 rows x 32 pixels x 128 output channels, or TALL (the layers with Cout <= 64): 16 rows x 32 pixels x 64 output channels --
-// the four waves of a position group are then 2 row halves x 2 channel halves instead of 4 channel quarters
-template <bool TALL>
+constexpr int G_TW = 32, G_XQ = G_TW / 4;
+// the tile: 8 rows x 32 pixels x 128 output channels, eight waves (two position groups x four channel quarters), one workgroup per CU; or
+// HALF (the layers with Cout <= 64): 8 rows x 32 pixels x 64 output channels, FOUR waves (two groups x two channel halves) and 64 KB of
+// LDS: TWO workgroups per CU with barriers of their own -- one's prologue / epilogue runs under the other's k-loop (a four-chunk tile
+// spends 40 % of its time there).  ONE V buffer: a chunk's nine k-steps, then the transform of the next chunk (the other workgroup has
+// the MFMA pipe meanwhile).  (A 16-row x 64-channel tile of eight waves, one per CU, measured 5 % slower on those layers.)
+template <bool HALF>
 struct Tile {
-    static constexpr int TH = TALL ? 16 : 8, HH = TH + 2, BN = TALL ? 64 : 128;
+    static constexpr int NT = HALF ? 256 : 512, WAVES = NT / 64;
+    static constexpr int TH = 8, HH = TH + 2, BN = HALF ? 64 : 128;
     static constexpr int VW = HH * (G_XQ * (6 * 16 + 4) + 16);                  // words per V buffer (HH * G_ROWW)
-    // raw halo image, 64 B per pixel.  8-row tile: ONE PAD SLOT after every four pixels -- pixel hx sits in slot hx + (hx >> 2), a quad's
-    // six pixels at slots 5 xq + {0, 1, 2, 3, 5, 6}: constant offsets, and the four consecutive quads of a 16-lane LDS pass 320 B apart
-    // = on four different 64-byte bank groups.  TALL: no pads (they would not fit), 35 slots per row: the 16 lanes of a pass are four
-    // consecutive ROWS of one quad, 2240 B = 192 (mod 256) apart.
-    static constexpr int RSLOTS = TALL ? 35 : 42;
-    static constexpr int RAW_PIECES = TALL ? 40 : 27;                           // 1 KiB LDS-DMA pieces (16 slots each)
-    static constexpr int RAW_PER_WAVE = TALL ? 5 : 4;
-    static constexpr int RAW0 = 2 * VW;
-    static constexpr int OPERAND_BYTES = (RAW0 + RAW_PIECES * 256) * 4;         // 92 928 / 158 464 B
-    static constexpr int LDS_BYTES = OPERAND_BYTES > 131072 ? OPERAND_BYTES : 131072;      // the epilogue's exchange: 8 waves x 16 KB
-    static_assert(LDS_BYTES <= 163840, "LDS layout");
+    // raw halo image, 64 B per pixel, ONE PAD SLOT after every four pixels -- pixel hx sits in slot hx + (hx >> 2), a quad's six pixels
+    // at slots 5 xq + {0, 1, 2, 3, 5, 6}: constant offsets, and the four consecutive quads of a 16-lane LDS pass 320 B apart = on four
+    // different 64-byte bank groups
+    static constexpr int RSLOTS = 42;
+    static constexpr int RAW_PIECES = 27;                                       // 1 KiB LDS-DMA pieces (16 slots each): 10 x 42 slots = 26.25
+    static constexpr int RAW_PER_WAVE = (RAW_PIECES + WAVES - 1) / WAVES;       // 4 / 7
+    static constexpr int RAW0 = (HALF ? 1 : 2) * VW;
+    static constexpr int OPERAND_BYTES = (RAW0 + RAW_PIECES * 256) * 4;         // 92 928 / 60 288 B
+    static constexpr int XCH_BYTES = WAVES * 16384;                             // the epilogue's exchange
+    static constexpr int LDS_BYTES = OPERAND_BYTES > XCH_BYTES ? OPERAND_BYTES : XCH_BYTES;
+    static_assert(LDS_BYTES <= (HALF ? 81856 : 163840), "LDS layout");
 };
 constexpr int G_QW = 16;                          // words per (quad, position): 16 channels hi (8 words) | 16 channels lo (8 words)
 constexpr int G_XQW = 6 * G_QW + 4;               // 100 words = 25 sixteen-byte units per quad (9 modulo 16)
 constexpr int G_ROWW = G_XQ * G_XQW + 16;         // 816 words = 204 units per halo row (12 modulo 16): the 16 lanes of a fragment read pass
                                                   // -- rows 0..3 x quads 0..3 -- land on 16 different 16-byte bank groups
 constexpr int G_RW = G_TW + 2;                    // raw halo pixels per row (34)
-static_assert(Tile<false>::VW == 10 * G_ROWW && Tile<true>::VW == 18 * G_ROWW, "V layout");
+static_assert(Tile<false>::VW == 10 * G_ROWW, "V layout");
 // operand scale targets (common.h): a position is up to 10 x the largest pixel (|4| + |-5| + |1|); a transformed weight at most 1 x
 constexpr int F43_X_TARGET = CCST_SPLIT_X_TARGET - 4, F43_W_TARGET = CCST_SPLIT_W_TARGET - 1;
 
@@ -101,9 +105,9 @@ struct GroupTag {
 };
 
 // ZP: zero padding (the masks cost 16-24 vector instructions per transform item: the reflecting AdaIN layers run the kernel without them)
-template <bool POOL, bool ZP, bool TALL>
-__global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
-    typedef Tile<TALL> T;
+template <bool POOL, bool ZP, bool HALF>
+__global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F43Args p) {
+    typedef Tile<HALF> T;
     constexpr int G_TH = T::TH, G_HH = T::HH, G_BN = T::BN, G_VW = T::VW, G_RSLOTS = T::RSLOTS, G_RAW_PIECES = T::RAW_PIECES, G_RAW0 = T::RAW0,
                   NRAW = T::RAW_PER_WAVE;
     extern __shared__ __attribute__((aligned(16))) float f43_lds[];
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, wn = TALL ? (wave & 1) : (wave & 3), mh = TALL ? ((wave >> 1) & 1) : 0;      // position group, channel part, row half
+    const int grp = HALF ? wave >> 1 : wave >> 2, wn = HALF ? (wave & 1) : (wave & 3);      // position group, channel part
     const int li = lane & 31, lh = lane >> 5;
 
     int bid = ccst_xcd_remap(blockIdx.x, gridDim.x);
@@ -137,9 +141,9 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
     int rpiece[NRAW];
 #pragma unroll
     for (int i = 0; i < NRAW; ++i) {
-        rpiece[i] = min(wave + 8 * i, G_RAW_PIECES - 1);
+        rpiece[i] = min(wave + T::WAVES * i, G_RAW_PIECES - 1);
         const int S = min(rpiece[i] * 16 + (lane >> 2), G_HH * G_RSLOTS - 1);
-        const int hy = S / G_RSLOTS, sx = S - hy * G_RSLOTS, hx = min(TALL ? sx : sx - sx / 5, G_RW - 1);
+        const int hy = S / G_RSLOTS, sx = S - hy * G_RSLOTS, hx = min(sx - sx / 5, G_RW - 1);
         int gy = oy0 + hy - 1, gx = ox0 + hx - 1;
         if (!ZP) {
             gy = reflect_g(gy, p.H);
@@ -160,19 +164,16 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
     // path in which it is a compile-time constant; the row sits in the thread's base addresses: every LDS offset of the loop is an
     // instruction immediate (with run-time rows hipcc hoisted a vector add per access out of the loop and spilled 340 registers).
     //     slot 0: waves 0-4 pair 0 rows 2 w + lh; waves 5-7 pair 1 rows 2 w + lh - 10;   slot 1: waves 0-1 pair 1 rows 6 + 2 w + lh; waves 2-6 pair 2 rows 2 w + lh - 4
-    //   TALL (18 halo rows: 1728 items, up to FOUR per thread, two per call): a half-wave takes (pair, group of four rows, pair of quads)
-    //   number 16 s + 2 wave + (lane >> 5) of item slot s (60 .. 63: idle), i.e. with u = 4 s + (wave >> 1): pair u / 5, rows 4 (u % 5) ..
-    //   + 3, quads 2 ((2 wave + (lane >> 5)) & 3), + 1; inside it lane -> (quad (lane >> 4) & 1, row (lane >> 2) & 3, part lane & 3): the 16
-    //   lanes of an LDS pass are four rows of one quad.  The row group is wave-uniform but not a constant: one scalar-plus-vector add per
-    //   item and side, kept inside the loop (laundered: hoisted out they would cost eight registers this kernel does not have).
     const int part_t = lane & 3;
-    const int xq_t = TALL ? 2 * ((2 * wave + lh) & 3) + ((lane >> 4) & 1) : (lane >> 2) & 7;
-    const int rr_t = (lane >> 2) & 3;                    // (TALL) row inside the group of four
-    const int trow0 = TALL ? rr_t : 2 * wave + lh - (wave < 5 ? 0 : 10), trow1 = TALL ? rr_t : (wave < 2 ? 6 + 2 * wave + lh : min(2 * wave + lh - 4, 9));
-    const int tsrcA = (trow0 * G_RSLOTS + (TALL ? 4 : 5) * xq_t) * 16 + part_t * 4, tsrcB = (trow1 * G_RSLOTS + (TALL ? 4 : 5) * xq_t) * 16 + part_t * 4;
+    const int xq_t = (lane >> 2) & 7;
+    //   HALF (four waves: up to FOUR items per thread, between two chunks): half-wave 8 s + 2 wave + (lane >> 5) of item slot s takes (pair,
+    //   row) task number h = that (30, 31: idle), pair = h / 10, row = h % 10.  The even part of the row is wave-uniform but not a
+    //   constant: one scalar-plus-vector add per item and side, kept inside the loop (laundered: hoisted out they would cost registers).
+    const int trow0 = HALF ? lh : 2 * wave + lh - (wave < 5 ? 0 : 10), trow1 = HALF ? lh : (wave < 2 ? 6 + 2 * wave + lh : min(2 * wave + lh - 4, 9));
+    const int tsrcA = (trow0 * G_RSLOTS + 5 * xq_t) * 16 + part_t * 4, tsrcB = (trow1 * G_RSLOTS + 5 * xq_t) * 16 + part_t * 4;
     const int tdstA = trow0 * G_ROWW + xq_t * G_XQW + part_t * 2, tdstB = trow1 * G_ROWW + xq_t * G_XQW + part_t * 2;
     unsigned tokx = 0x3fu;       // zero padding: validity of the quad's six pixels;
-    bool okyA = true, okyB = true;   // ... of the rows of item 0, of item 1 (TALL: computed per item)
+    bool okyA = true, okyB = true;   // ... of the rows of item 0, of item 1 (HALF: computed per item)
     if (ZP) {
         tokx = 0;
 #pragma unroll
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
         constexpr int PAIR = decltype(ptag)::value;
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
         auto px = [&](int d) {                   // pixel d of the quad (0..5)
-            f32x4 v = *reinterpret_cast<const f32x4*>(r0 + (TALL || d < 4 ? d : d + 1) * 16);
+            f32x4 v = *reinterpret_cast<const f32x4*>(r0 + (d < 4 ? d : d + 1) * 16);
             if (ZP && !(oky && ((tokx >> d) & 1u))) v = z;
             return v;
         };
@@ -228,25 +229,21 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
     };
     // (dA, dB: the thread's destinations in the V buffer being filled -- tdstA / tdstB of buffer 0 or 1; the loop swaps them per chunk)
     auto xform = [&](int dA, int dB, int i) __attribute__((always_inline)) {
-        if (TALL) {
+        if (HALF) {           // all four slots in one call (i unused)
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const int sl = 2 * i + s2, u = 4 * sl + (wave >> 1);
-                if (u >= 15) continue;
-                const int pair = u / 5;
-                int rg = u - 5 * pair;                       // wave-uniform
-                asm volatile("" : "+s"(rg));
-                const int row = 4 * rg + rr_t;
-                if (row < G_HH) {
-                    const float* r0 = &Raw[tsrcA + rg * (4 * G_RSLOTS * 16)];
-                    float* o = &Vs[dA + rg * (4 * G_ROWW)];
-                    const int gy = oy0 + row - 1;
-                    const bool oky = !ZP || ((gy >= 0) & (gy < p.H));
-                    // (slot 0: pair 0; slot 1: 0 or 1; slot 2: 1 or 2; slot 3: 2)
-                    if (sl <= 1 && pair == 0) xpair(GroupTag<0>{}, r0, o, oky);
-                    if ((sl == 1 || sl == 2) && pair == 1) xpair(GroupTag<1>{}, r0, o, oky);
-                    if (sl >= 2 && pair == 2) xpair(GroupTag<2>{}, r0, o, oky);
-                }
+            for (int sl = 0; sl < 4; ++sl) {
+                const int u = 8 * sl + 2 * wave;
+                if (u >= 30) continue;
+                const int pair = u / 10;
+                int re = u - 10 * pair;                      // wave-uniform even row; + lh in the thread's bases
+                asm volatile("" : "+s"(re));
+                const float* r0 = &Raw[tsrcA + re * (G_RSLOTS * 16)];
+                float* o = &Vs[dA + re * G_ROWW];
+                const int gy = oy0 + re + lh - 1;
+                const bool oky = !ZP || ((gy >= 0) & (gy < p.H));
+                if (sl <= 1 && pair == 0) xpair(GroupTag<0>{}, r0, o, oky);
+                if ((sl == 1 || sl == 2) && pair == 1) xpair(GroupTag<1>{}, r0, o, oky);
+                if (sl >= 2 && pair == 2) xpair(GroupTag<2>{}, r0, o, oky);
             }
             return;
         }
@@ -273,8 +270,8 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][mt][r] = 0.f;
 
-    // A fragment base: GEMM row li of M tile mt is (row 8 mh + 4 mt + (li & 3), quad li >> 2)
-    const int aBase = ((li & 3) + 8 * mh) * G_ROWW + (li >> 2) * G_XQW + lh * 4;
+    // A fragment base: GEMM row li of M tile mt is (row 4 mt + (li & 3), quad li >> 2)
+    const int aBase = (li & 3) * G_ROWW + (li >> 2) * G_XQW + lh * 4;
 
     // ---- prologue: the raw pixels of chunk 0 first, the weights of chunk 0 behind them (their latencies overlap) ----------------------
 #pragma unroll
@@ -310,8 +307,52 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
         kw = ccst_scale_exp(ccst_absmax_reduce(wword), F43_W_TARGET);
         xs = __uint_as_float((unsigned)(127 + kx) << 23);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) xform(tdstA, tdstB, i);
+        for (int i = 0; i < (HALF ? 1 : 2); ++i) xform(tdstA, tdstB, i);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (HALF) {
+            // ---- four waves, ONE V buffer: the nine k-steps of a chunk (raw pieces of the next chunk requested at its first k-step, the
+            // weights of k-step t of the next chunk behind k-step t), then -- every wave waits for its own pieces, barrier -- the transform
+            // of the next chunk into the same buffer, barrier.  The CU's other workgroup has the MFMA pipe meanwhile.
+            read_a(1, aBase, 0);
+            read_a(0, aBase, 0);
+            auto hchunk = [&](const int c, auto lasttag) __attribute__((always_inline)) {
+                constexpr bool LAST = decltype(lasttag)::value != 0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int j = t % 3;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][mt], bq[t][0], acc[j][mt], 0, 0, 0);   // a_lo b_hi
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t < 8) read_a(1, aBase, t + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mt], bq[t][1], acc[j][mt], 0, 0, 0);   // a_hi b_lo
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mt], bq[t][0], acc[j][mt], 0, 0, 0);   // a_hi b_hi
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t < 8) read_a(0, aBase, t + 1);
+                    if (t == 0 && !LAST) {
+#pragma unroll
+                        for (int i = 0; i < NRAW; ++i) dma_raw(c + 1, i);
+                    }
+                    if (!LAST) load_b(t);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (!LAST) {
+                    // the raw pieces are older than the 18 weight loads of this chunk; every wave is past its last fragment read
+                    asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    xform(tdstA, tdstB, 0);
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    read_a(1, aBase, 0);
+                    read_a(0, aBase, 0);
+                    sbase += cstride;
+                }
+            };
+            for (int c = 0; c + 1 < nchunks; ++c) hchunk(c, GroupTag<0>{});
+            hchunk(nchunks - 1, GroupTag<1>{});
+            return;
+        }
         if (nchunks > 1) {
 #pragma unroll
             for (int i = 0; i < NRAW; ++i) dma_raw(1, i);
@@ -345,7 +386,6 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
                 if (t == 7 && !LAST) {
                     dma_raw(c + 2, 0);
                     dma_raw(c + 2, 1);
-                    if (NRAW > 4) dma_raw(c + 2, 4);
                 }
                 if (t == 8 && !LAST) {
                     dma_raw(c + 2, 2);
@@ -381,7 +421,7 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
     //   Y0 = a0 + b0, Y1 = a1 + b1 (finished by group 0: it receives b0, b1);   Y2 = a2 + b2, Y3 = a1 + b3 (group 1: receives a2, a1)
     // (in two phases over the accumulators, which stay where they are)
     const int ks = -(kx + kw);
-    float* const xch = f43_lds;                    // [8 waves][2 mt][4 register quads][2 values][64 lanes][4 floats] = 128 KB
+    float* const xch = f43_lds;                    // [waves][2 mt][4 register quads][2 values][64 lanes][4 floats] = 128 KB
     // phase 1: what the partner wave (same channels, other group) needs of every accumulator element
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -412,7 +452,7 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
     float amax = 0.f;
     const unsigned peeked = p.ymax != nullptr ? ccst_absmax_peek(p.ymax, blockIdx.x) : 0u;
     const bool interior = (oy0 + G_TH <= p.H) && (ox0 + G_TW <= p.W) && (co0 + G_BN <= p.Cout);
-    const int other = wave ^ 4;
+    const int other = wave ^ (HALF ? 2 : 4);
     // phase 2: fin[e][mt][r], e = 0, 1 = pixel 4 quad + 2 grp + e of row 4 mt + (r & 3), quad = 2 (r >> 2) + lh
     {
         const int co = co0 + wn * 32 + li;
@@ -447,7 +487,7 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
             for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int dy = 8 * mh + 4 * mt + (r & 3);
+                    const int dy = 4 * mt + (r & 3);
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         float v = fin[e][mt][r];
@@ -477,7 +517,7 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int dy = 8 * mh + 4 * mt + (r & 3);
+                        const int dy = 4 * mt + (r & 3);
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
                             float v = fin[e][mt][r];
@@ -502,7 +542,7 @@ __global__ __launch_bounds__(G_NT, 2) void conv3x3_f43_kernel(const F43Args p) {
             for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {                      // registers 2 g, 2 g + 1: rows 4 mt + 2 (g & 1), + 1 of quad 2 (g >> 1) + lh
-                    const int dyp = 4 * mh + 2 * mt + (g & 1), xpu = 4 * (g >> 1);          // pooled row; pooled column 4 (g >> 1) + 2 lh + grp
+                    const int dyp = 2 * mt + (g & 1), xpu = 4 * (g >> 1);          // pooled row; pooled column 4 (g >> 1) + 2 lh + grp
                     if (interior) {
                         float v = fmaxf(fmaxf(fin[0][mt][2 * g], fin[1][mt][2 * g]), fmaxf(fin[0][mt][2 * g + 1], fin[1][mt][2 * g + 1]));
                         if (relu) v = fmaxf(v, 0.f);
@@ -583,41 +623,40 @@ extern "C" int ccst_pack_conv_weight_f43_f32(const float* w_oihw, float* u, int 
     return ccst_launch_status("pack_weight_f43");
 }
 
-// Workgroups the kernel launches for a layer (8 x 32 pixels x 128 channels each; Cout <= 64: 16 x 32 pixels x 64 channels).
+// Workgroups the kernel launches for a layer (8 x 32 pixels x 128 channels each, one per CU; Cout <= 64: x 64 channels, two per CU).
 extern "C" int ccst_conv3x3_f43_workgroups(int N, int H, int W, int Cout) {
-    const int th = Cout <= 64 ? 16 : 8, bn = Cout <= 64 ? 64 : 128;
-    return N * ((H + th - 1) / th) * ((W + G_TW - 1) / G_TW) * ((Cout + bn - 1) / bn);
+    const int bn = Cout <= 64 ? 64 : 128;
+    return N * ((H + 7) / 8) * ((W + G_TW - 1) / G_TW) * ((Cout + bn - 1) / bn);
 }
 
-template <bool POOL, bool ZP, bool TALL>
+template <bool POOL, bool ZP, bool HALF>
 static int launch_f43(F43Args& a, int N, int H, int W, int Cout, hipStream_t s) {
-    typedef Tile<TALL> T;
+    typedef Tile<HALF> T;
     a.tilesN = (Cout + T::BN - 1) / T::BN;
     a.tilesY = (H + T::TH - 1) / T::TH;
     a.tilesX = (W + G_TW - 1) / G_TW;
     const long long grid = (long long)N * a.tilesY * a.tilesX * a.tilesN;
     CCST_REQUIRE(grid > 0 && grid <= 0x7fffffffLL, "conv3x3_f43: bad grid");
-    void (*kern)(const F43Args) = conv3x3_f43_kernel<POOL, ZP, TALL>;
+    void (*kern)(const F43Args) = conv3x3_f43_kernel<POOL, ZP, HALF>;
     // (the opt-in above the 64 KB default is per device and idempotent: set for the current device on every launch)
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
     if (e1 != hipSuccess) {
         ccst_set_error("conv3x3_f43: cannot reserve %d bytes of LDS: %s", T::LDS_BYTES, hipGetErrorString(e1));
         return (int)e1;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(G_NT), T::LDS_BYTES, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(T::NT), T::LDS_BYTES, s, a);
     return ccst_launch_status("conv3x3_f43");
 }
 
 // Same contract and statistics rows as ccst_conv3x3_f23_f32; the tile is 8 rows x 32 pixels x 128 channels, or for Cout <= 64 (no statistics)
-// 16 rows x 32 pixels x 64 channels (ccst_conv3x3_f43_workgroups).
+// 8 rows x 32 pixels x 64 channels, four waves, two workgroups per CU (ccst_conv3x3_f43_workgroups).
 extern "C" int ccst_conv3x3_f43_f32(const float* x, const uint32_t* x_absmax, const float* u, const uint32_t* w_absmax, const float* bias,
                                     float* y, uint32_t* y_absmax, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags,
                                     float* chan_sum_partials, void* stream) {
     CCST_REQUIRE(x && u && y && x_absmax && w_absmax, "conv3x3_f43: null pointer (the |max| words of x and w are required)");
     CCST_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0, "conv3x3_f43: bad shape");
-    const bool tall = Cout <= 64;
-    CCST_REQUIRE(cout_pad >= Cout && cout_pad % (tall ? 64 : 128) == 0, "conv3x3_f43: cout_pad must be a multiple of 128 (Cout <= 64: of 64) >= cout");
-    CCST_REQUIRE(!(tall && chan_sum_partials), "conv3x3_f43: no statistics epilogue in the 64-channel tile");
+    const bool half = Cout <= 64;
+    CCST_REQUIRE(cout_pad >= Cout && cout_pad % (half ? 64 : 128) == 0, "conv3x3_f43: cout_pad must be a multiple of 128 (Cout <= 64: of 64) >= cout");
     const bool pool = (flags & CCST_CONV_POOL2) != 0, ups = (flags & CCST_CONV_UPS2) != 0;
     CCST_REQUIRE(!(chan_sum_partials && pool), "conv3x3_f43: channel sums are of the un-pooled output");
     if (ups) CCST_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv3x3_f43: upsampled extent must be even");
@@ -635,7 +674,7 @@ extern "C" int ccst_conv3x3_f43_f32(const float* x, const uint32_t* x_absmax, co
     a.ubytes = (int)(18LL * Cin * cout_pad * 4);
     const bool zp = !a.reflect;
     hipStream_t st = (hipStream_t)stream;
-#define F43_GO(P_, Z_) (tall ? launch_f43<P_, Z_, true>(a, N, H, W, Cout, st) : launch_f43<P_, Z_, false>(a, N, H, W, Cout, st))
+#define F43_GO(P_, Z_) (half ? launch_f43<P_, Z_, true>(a, N, H, W, Cout, st) : launch_f43<P_, Z_, false>(a, N, H, W, Cout, st))
     return pool ? (zp ? F43_GO(true, true) : F43_GO(true, false)) : (zp ? F43_GO(false, true) : F43_GO(false, false));
 #undef F43_GO
 }

@@ -452,7 +452,7 @@ def halo_split_wanted(pc):
 # layers of the plan with Cout >= 128 whose grid of 8x32-pixel x 128-channel workgroups (ONE per CU: 120 KB of LDS) fills whole rounds
 # of the chip; the others stay on the direct kernel.  CCST_CONV_F23=0: direct everywhere.
 F23 = os.environ.get("CCST_CONV_F23", "1") != "0"
-F23_MIN_FILL = float(os.environ.get("CCST_F23_MIN_FILL", "0.5"))
+F23_MIN_TILES = int(os.environ.get("CCST_F23_MIN_TILES", "30"))      # per image (8 x 32 pixels x 128 / 64 channels each)
 F23_MIN_COUT = 128      # (the Cout = 64 layers padded to its 128-channel tile measured slower than the direct half-piece kernel)
 F23_FORCE = os.environ.get("CCST_CONV_F23", "1") == "2"       # every Cout >= 128 layer whatever its grid (tests: small images)
 # ... and F(4,3) along x (conv3x3_f43.hip: 1.5 executed FLOPs per algorithmic one) in the F(2,3) kernel's place.  CCST_CONV_F43=0: F(2,3).
@@ -469,16 +469,17 @@ def num_cus(device):
 
 
 def f23_wanted(pc, N, H, W, device):
-    """Run this 3x3 layer (conv extent H x W) on the F(2,3) / F(4,3) kernel?  (F(4,3) has a 64-channel tile: the Cout = 64 layers too.)"""
+    """Run this 3x3 layer (conv extent H x W) on the F(2,3) / F(4,3) kernel?  (F(4,3) has a 64-channel tile: the Cout = 64 layers too.)
+    The rule looks at ONE image's tiles, never at the batch size: a sample must not change kernels (and with them its rounding, at the
+    1e-5 level after sixteen layers) with the number of its batch-mates."""
     min_cout = F43_MIN_COUT if F43 else F23_MIN_COUT
     if not (F23 and halo_split_wanted(pc)) or pc.cout < min_cout or H * W * pc.cin >= 2 ** 30:
         return False
     if F23_FORCE:
         return True
-    # (one workgroup per CU: measured faster than the direct kernel down to 0.75 rounds of the chip -- 64^2 512->256 at B=6, x1.16)
+    # (the bench's smallest layer -- 64 x 64, 512 -> 256: 32 tiles per image, 0.75 rounds of the chip at B = 6 -- is x1.3 the direct kernel)
     lib = _lib.load()
-    wgs = int((lib.ccst_conv3x3_f43_workgroups if F43 else lib.ccst_conv3x3_f23_workgroups)(N, H, W, pc.cout))
-    return wgs >= F23_MIN_FILL * num_cus(device)
+    return int((lib.ccst_conv3x3_f43_workgroups if F43 else lib.ccst_conv3x3_f23_workgroups)(1, H, W, pc.cout)) >= F23_MIN_TILES
 
 
 def conv3x3_f43(x, pc, flags, sums=False, x_absmax=None, y_absmax=None):
@@ -512,7 +513,7 @@ def conv3x3_f23(x, pc, flags, sums=False, x_absmax=None, y_absmax=None, form=2):
         check(fn(*args), name)
         e1.record()
         # (the kernel buckets of bench.py = rocprofv3's kernel names: F(4,3)'s 64-channel tile is an instantiation of its own)
-        TIMING.append(("%s_kernel<%s%s>" % (name, "pool" if pool else "nopool", ",tall" if form == 4 and pc.cout <= 64 else ""), 2.0 * N * Hi * Wi * pc.cout * pc.cin * 9, e0, e1,
+        TIMING.append(("%s_kernel<%s%s>" % (name, "pool" if pool else "nopool", ",half" if form == 4 and pc.cout <= 64 else ""), 2.0 * N * Hi * Wi * pc.cout * pc.cin * 9, e0, e1,
                        "n%d %dx%d cin%d cout%d taps3x3 flags%d" % (N, Hi, Wi, pc.cin, pc.cout, flags)))
     return (out, part) if sums else out
 

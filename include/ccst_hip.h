@@ -175,7 +175,8 @@ int ccst_pack_conv_weight_f43_f32(const float* w_oihw, float* u, int cout, int c
 int ccst_conv3x3_f43_f32(const float* x, const uint32_t* x_absmax, const float* u, const uint32_t* w_absmax, const float* bias, float* y,
                          uint32_t* y_absmax, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags, float* chan_sum_partials,
                          void* stream);
-/* Layers with Cout <= 64 run a 16 x 32-pixel x 64-channel tile (cout_pad a multiple of 64; no chan_sum_partials): workgroups per launch */
+/* Layers with Cout <= 64 run an 8 x 32-pixel x 64-channel tile of four waves, two workgroups per CU (cout_pad a multiple of 64):
+ * workgroups per launch */
 int ccst_conv3x3_f43_workgroups(int N, int H, int W, int Cout);
 /* chan_sum_partials (may be NULL; not with POOL2): [ccst_conv3x3_halo_split_tiles(N,H,W)][Cout][4] per-(8x16-pixel tile, wave row)
  * (sum, M2, count, 0) of the output after bias / ReLU, M2 = the sum of squares about the slab's OWN mean (no E[x^2] - mean^2

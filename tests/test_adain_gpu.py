@@ -1061,7 +1061,7 @@ def test_plan_passes_absmax_between_layers(dev, nets, A):
                                   (1, 22, 38, 64, 256, False, True), (1, 16, 32, 256, 512, False, False), (1, 9, 7, 16, 160, True, False),
                                   (3, 50, 84, 64, 128, False, False), (1, 64, 64, 512, 256, False, True), (2, 33, 17, 32, 200, True, False),
                                   (1, 8, 32, 16, 128, False, False), (1, 2, 2, 16, 128, True, False),
-                                  # Cout <= 64: F(4,3)'s 16 x 32-pixel x 64-channel tile (F(2,3) has none)
+                                  # Cout <= 64: F(4,3)'s 64-channel tile of four waves (F(2,3) has none)
                                   (2, 40, 70, 64, 64, True, False), (1, 33, 47, 128, 64, False, False), (2, 48, 64, 64, 64, False, True),
                                   (1, 16, 32, 16, 48, False, False), (1, 5, 9, 32, 64, True, False)])
 @pytest.mark.parametrize("reflect", [True, False])
@@ -1101,7 +1101,7 @@ def test_conv3x3_f23_vs_fp64(dev, case, reflect, form):
     assert torch.equal(out, conv(x, pc, flags))
     # and against the direct half-piece kernel on the same operands
     assert float((out - ops.conv3x3_halo_split(x, pc, flags)).abs().max()) < gate * max(1.0, float(ref.abs().max()))
-    if not pool and Cout > 64:       # the per-tile channel sums of the epilogue add up to the sums of the output, per image
+    if not pool:       # the per-tile channel sums of the epilogue add up to the sums of the output, per image
         out2, part = conv(x, pc, flags, sums=True)
         assert torch.equal(out2, out) and part.shape[0] % N == 0 and tuple(part.shape[1:]) == (Cout, 4)
         _check_centred_partials(part, out, N)

@@ -57,7 +57,7 @@ def main():
         ref = ref.permute(0, 2, 3, 1)
         errs = [float((r[1][:1].double() - ref).abs().max()) / float(ref.abs().max()) for r in res]
         fl = 2.0 * B * H * H * Cout * Cin * 9
-        wgs = B * ((H + 7) // 8) * ((H + 31) // 32) * ((Cout + 127) // 128) if Cout >= 128 else B * ((H + 15) // 16) * ((H + 31) // 32)
+        wgs = B * ((H + 7) // 8) * ((H + 31) // 32) * ((Cout + 127) // 128) if Cout >= 128 else B * ((H + 7) // 8) * ((H + 31) // 32)
         print("%4d^2 %3d->%3d %s%s  split %7.1f us %6.1f TF err %.2e | f23 %7.1f us %6.1f TF err %.2e | f43 %7.1f us %6.1f TF err %.2e | f43/f23 x%.2f  (%d workgroups = %.2f rounds)" % (
             H, Cin, Cout, "pool " if pool else "     ", "ups" if ups else "   ", res[0][0], fl / res[0][0] / 1e6, errs[0], res[1][0], fl / res[1][0] / 1e6, errs[1],
             res[2][0], fl / res[2][0] / 1e6, errs[2], res[1][0] / res[2][0], wgs, wgs / 256.0))
