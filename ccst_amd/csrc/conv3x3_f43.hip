@@ -105,7 +105,8 @@ struct GroupTag {
 };
 
 // ZP: zero padding (the masks cost 16-24 vector instructions per transform item: the reflecting AdaIN layers run the kernel without them)
-template <bool POOL, bool ZP, bool HALF>
+// NT: non-temporal output stores -- for outputs the caches cannot hold until the next layer reads them (>= 256 MB: the host decides)
+template <bool POOL, bool ZP, bool HALF, bool NT>
 __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F43Args p) {
     typedef Tile<HALF> T;
     constexpr int G_TH = T::TH, G_HH = T::HH, G_BN = T::BN, G_VW = T::VW, G_RSLOTS = T::RSLOTS, G_RAW_PIECES = T::RAW_PIECES, G_RAW0 = T::RAW0,
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
                             amax = fmaxf(amax, fabsf(v));
                             s1 += v;
                             cnt += 1.f;
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, lane_off * 4, (dy * p.ysH + dx * p.ysW) * 4, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, lane_off * 4, (dy * p.ysH + dx * p.ysW) * 4, NT ? 2 : 0);
                         } else if (cok && oy0 + dy < p.H && ox0 + 2 * grp + dx + 4 * lh < p.W) {
                             amax = fmaxf(amax, fabsf(v));
                             s1 += v;
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
                         float v = fmaxf(fmaxf(fin[0][mt][2 * g], fin[1][mt][2 * g]), fmaxf(fin[0][mt][2 * g + 1], fin[1][mt][2 * g + 1]));
                         if (relu) v = fmaxf(v, 0.f);
                         amax = fmaxf(amax, fabsf(v));
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, lane_off * 4, (dyp * p.ysH + xpu * p.ysW) * 4, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, lane_off * 4, (dyp * p.ysH + xpu * p.ysW) * 4, NT ? 2 : 0);
                     } else {
                         const int pyp = py0 + dyp, pxp = px0 + xpu + 2 * lh;
                         if (cok && pyp < Hp && pxp < Wp) {
@@ -629,7 +630,7 @@ extern "C" int ccst_conv3x3_f43_workgroups(int N, int H, int W, int Cout) {
     return N * ((H + 7) / 8) * ((W + G_TW - 1) / G_TW) * ((Cout + bn - 1) / bn);
 }
 
-template <bool POOL, bool ZP, bool HALF>
+template <bool POOL, bool ZP, bool HALF, bool NT>
 static int launch_f43(F43Args& a, int N, int H, int W, int Cout, hipStream_t s) {
     typedef Tile<HALF> T;
     a.tilesN = (Cout + T::BN - 1) / T::BN;
@@ -637,7 +638,7 @@ static int launch_f43(F43Args& a, int N, int H, int W, int Cout, hipStream_t s) 
     a.tilesX = (W + G_TW - 1) / G_TW;
     const long long grid = (long long)N * a.tilesY * a.tilesX * a.tilesN;
     CCST_REQUIRE(grid > 0 && grid <= 0x7fffffffLL, "conv3x3_f43: bad grid");
-    void (*kern)(const F43Args) = conv3x3_f43_kernel<POOL, ZP, HALF>;
+    void (*kern)(const F43Args) = conv3x3_f43_kernel<POOL, ZP, HALF, NT>;
     // (the opt-in above the 64 KB default is per device and idempotent: set for the current device on every launch)
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
     if (e1 != hipSuccess) {
@@ -674,7 +675,14 @@ extern "C" int ccst_conv3x3_f43_f32(const float* x, const uint32_t* x_absmax, co
     a.ubytes = (int)(18LL * Cin * cout_pad * 4);
     const bool zp = !a.reflect;
     hipStream_t st = (hipStream_t)stream;
-#define F43_GO(P_, Z_) (half ? launch_f43<P_, Z_, true>(a, N, H, W, Cout, st) : launch_f43<P_, Z_, false>(a, N, H, W, Cout, st))
+    // outputs the Infinity Cache (256 MB) cannot hold leave with non-temporal stores (the bench's 512^2 x 64-channel map: 403 MB; the stem's
+    // likewise): cached, they only push the next launch's weights and halos out (-7 % on the kernel that reads them, +1 % on the step);
+    // smaller ones are read back from the caches, and non-temporal stores cost the step 2 % (measured at 100 / 200 / 400 MB thresholds)
+    const long long nt_bytes = 256LL << 20;
+    const bool nt = (long long)N * oh * ow * Cout * 4 >= nt_bytes;
+#define F43_GO2(P_, Z_, H_) (nt ? launch_f43<P_, Z_, H_, true>(a, N, H, W, Cout, st) : launch_f43<P_, Z_, H_, false>(a, N, H, W, Cout, st))
+#define F43_GO(P_, Z_) (half ? F43_GO2(P_, Z_, true) : F43_GO2(P_, Z_, false))
     return pool ? (zp ? F43_GO(true, true) : F43_GO(true, false)) : (zp ? F43_GO(false, true) : F43_GO(false, false));
 #undef F43_GO
+#undef F43_GO2
 }

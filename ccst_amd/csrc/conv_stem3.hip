@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STEM_WAVES,
             for (int i = 0; i < 4; ++i) asm("v_max_f32 %0, %1, %2" : "=v"(o[i]) : "v"(o[i]), "v"(floor_));   // (fmaxf would canonicalise first)
             amax = fmaxf(fmaxf(amax, fabsf(o[0])), fabsf(o[1]));
             amax = fmaxf(fmaxf(amax, fabsf(o[2])), fabsf(o[3]));
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, o), yrs, ybase + (unsigned)(pixs * 256 + q * 16), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, o), yrs, ybase + (unsigned)(pixs * 256 + q * 16), 0, 2);      // (non-temporal: 403 MB that the L2 cannot hold; -7 us here, -8 us in conv1_2)
         }
     };
     // Two register sets, no copies: the taps of block i + 1 are requested before block i is computed.  (With one set refilled through
