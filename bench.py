@@ -55,10 +55,10 @@ def traffic_keys(dom, tj):
                 and k.rstrip(">").split(",")[3].strip() == pooled]
     if base == "conv3x3_f23_kernel":              # rocprofv3: conv3x3_f23_kernel<POOL>
         return [k for k in tj if k.startswith("void conv3x3_f23_kernel<") and k.rstrip(">").split("<")[1].strip() == pooled]
-    if base == "conv3x3_f43_kernel":              # rocprofv3: conv3x3_f43_kernel<POOL, ZP, HALF>
+    if base == "conv3x3_f43_kernel":              # rocprofv3: conv3x3_f43_kernel<POOL, ZP, HALF, NT> (a bucket holds both store policies)
         half = "true" if "half" in targs else "false"
         return [k for k in tj if k.startswith("void conv3x3_f43_kernel<") and k.rstrip(">").split("<")[1].split(",")[0].strip() == pooled
-                and k.rstrip(">").split(",")[-1].strip() == half]
+                and k.rstrip(">").split("<")[1].split(",")[2].strip() == half]
     if base == "conv_igemm_kernel":
         return ["void conv_igemm_kernel<%s, %s, 2, 16>" % (nums, pooled)]
     # rocprofv3 prints every template argument: <WM, WN, NT, POOL, TRAIN>
