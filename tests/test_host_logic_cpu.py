@@ -116,12 +116,19 @@ def test_bench_traffic_keys_find_the_committed_profile():
     with open(os.path.join(root, "profiles", "traffic.json")) as fh:
         tj = json.load(fh)
     assert tj["_source"]["build_stamp"] and tj["_source"]["profile"].startswith("profiles/")
-    keys = bench.traffic_keys("conv3x3_halo_split_kernel<nopool>", tj)
-    assert keys and all(k.startswith("void conv3x3_halo_kernel<") and k.endswith("false, false, true>") for k in keys)
-    pooled = bench.traffic_keys("conv3x3_halo_split_kernel<pool>", tj)
-    assert pooled and all(k.endswith("true, false, true>") for k in pooled) and not set(pooled) & set(keys)
-    for k in keys + pooled:
+    # the buckets of the round-5 path: F(4,3) along x, <POOL, ZP, HALF, NT> in the kernel trace
+    keys = bench.traffic_keys("conv3x3_f43_kernel<nopool>", tj)
+    assert keys and all(k.startswith("void conv3x3_f43_kernel<false, ") and k.split(",")[2].strip() == "false" for k in keys)
+    pooled = bench.traffic_keys("conv3x3_f43_kernel<pool>", tj)
+    assert pooled and all(k.startswith("void conv3x3_f43_kernel<true, ") for k in pooled) and not set(pooled) & set(keys)
+    half = bench.traffic_keys("conv3x3_f43_kernel<nopool,half>", tj)       # (both store policies of the 64-channel tile in one bucket)
+    assert half and all(k.split(",")[2].strip() == "true" for k in half) and not set(half) & set(keys)
+    for k in keys + pooled + half:
         assert tj[k]["total_bytes_per_launch"] > 0 and tj[k]["launches"] > 0
+    # ... and of the kernels behind the switches (names only: the committed profile does not run them)
+    assert bench.traffic_keys("conv3x3_halo_split_kernel<nopool>", {"void conv3x3_halo_kernel<4, 1, 2, false, false, true>": 1}) == \
+        ["void conv3x3_halo_kernel<4, 1, 2, false, false, true>"]
+    assert bench.traffic_keys("conv3x3_f23_kernel<pool>", {"void conv3x3_f23_kernel<true>": 1, "void conv3x3_f23_kernel<false>": 1}) == ["void conv3x3_f23_kernel<true>"]
     assert bench.traffic_keys("conv_igemm_kernel<2,2,1>", tj) == ["void conv_igemm_kernel<2, 2, 1, false, 2, 16>"]
 
 
