@@ -245,7 +245,7 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__
         for (; i + (BN_UNROLL - 1) * stride < total4; i += BN_UNROLL * stride) {
             f32x4 v[BN_UNROLL], r[BN_UNROLL];
 #pragma unroll
-            for (int u = 0; u < BN_UNROLL; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + (i + u * stride) * 4);
+            for (int u = 0; u < BN_UNROLL; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + (i + u * stride) * 4));
 #pragma unroll
             for (int u = 0; u < BN_UNROLL; ++u) r[u] = residual ? *reinterpret_cast<const f32x4*>(residual + (i + u * stride) * 4) : z4;
 #pragma unroll
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
         for (; i + stride < total4; i += 2 * stride) {
             const long long i1 = i + stride;
             const f32x4 g0 = *reinterpret_cast<const f32x4*>(dy + i * 4), g1 = *reinterpret_cast<const f32x4*>(dy + i1 * 4);
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(x + i * 4), v1 = *reinterpret_cast<const f32x4*>(x + i1 * 4);
+            const f32x4 v0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + i * 4)), v1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(x + i1 * 4));
             const f32x4 o0 = MASK == 1 ? *reinterpret_cast<const f32x4*>(y + i * 4) : z4, o1 = MASK == 1 ? *reinterpret_cast<const f32x4*>(y + i1 * 4) : z4;
             const unsigned b0 = MASK == 3 ? (unsigned)rmask[i] : 0u, b1 = MASK == 3 ? (unsigned)rmask[i1] : 0u;
             finish(g0, v0, o0, b0, k, i);
