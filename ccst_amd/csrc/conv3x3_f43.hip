@@ -18,8 +18,9 @@
 //     q = 3..5) x 4 channel quarters: a wave holds 64 rows x 32 channels x 3 positions = 6 accumulators and runs 9 k-steps of 6 MFMAs
 //     per chunk; the group is a template parameter of the main loop (every LDS offset is an immediate);
 //   * the WEIGHTS NEVER TOUCH LDS: every wave loads its own B fragments (32 channels x 16 k x hi | lo = 2 KB per k-step, packed in
-//     fragment order) straight into a ring of NINE register sets, one per k-step of a chunk, each refilled for the next chunk right
-//     after its last MFMA: a whole chunk of prefetch distance, no barrier for the weights (LDS: 755 -> 415 KB per chunk);
+//     fragment order) straight into a ring of THREE register sets, each refilled with the slab of three k-steps ahead right after its
+//     last MFMA: no barrier for the weights (LDS: 755 -> 415 KB per chunk).  (Nine sets -- a whole chunk ahead -- were no faster and
+//     cost the 40 registers the transform's prefetch now uses; the four-wave tile, which transforms between two chunks, keeps nine);
 //   * LDS holds the transformed halo (double buffered) and the raw fp32 halo of the next chunk (LDS-DMA): TWO barriers per chunk;
 //   * the transform works on PAIRS of positions that share their pixels -- (1,2) and (3,4): four 16-byte reads for two positions,
 //     (0,5): six -- 960 items per chunk, two per thread; the scale 2^kx rides in the coefficients;
@@ -228,6 +229,51 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
             put(o + 5 * G_QW, d1 * c4 + (d3 * c5 + d5 * xs));
         }
     };
+    // The same in two halves for the eight-wave loop: the item's pixels are requested one k-step before they are used (xr), so that the
+    // LDS latency passes under that k-step's MFMAs instead of in front of the transform.
+    f32x4 xr[6];
+    auto xl = [&](auto ptag, const float* r0, bool oky) __attribute__((always_inline)) {
+        constexpr int PAIR = decltype(ptag)::value;
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = (PAIR < 2 ? 1 : 0); d < (PAIR < 2 ? 5 : 6); ++d) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(r0 + (d < 4 ? d : d + 1) * 16);
+            if (ZP && !(oky && ((tokx >> d) & 1u))) v = z;
+            xr[d] = v;
+        }
+    };
+    auto xc = [&](auto ptag, float* o) __attribute__((always_inline)) {
+        constexpr int PAIR = decltype(ptag)::value;
+        if (PAIR < 2) {
+            const float c1 = PAIR == 0 ? -4.f * xs : -xs, c2 = PAIR == 0 ? 4.f * xs : 2.f * xs, c3 = PAIR == 0 ? xs : 2.f * xs;
+            const f32x4 sc = xr[2] * c1 + xr[4] * xs;
+            const f32x4 va = xr[1] * (-c2) + (xr[3] * c3 + sc), vb = xr[1] * c2 + (sc - xr[3] * c3);
+            put(o + (PAIR == 0 ? 1 : 3) * G_QW, va);
+            put(o + (PAIR == 0 ? 2 : 4) * G_QW, vb);
+        } else {
+            const float c4 = 4.f * xs, c5 = -5.f * xs;
+            put(o, xr[0] * c4 + (xr[2] * c5 + xr[4] * xs));
+            put(o + 5 * G_QW, xr[1] * c4 + (xr[3] * c5 + xr[5] * xs));
+        }
+    };
+    auto xload = [&](int i) __attribute__((always_inline)) {
+        if (i == 0) {
+            if (wave < 5) xl(GroupTag<0>{}, &Raw[tsrcA], okyA);
+            else xl(GroupTag<1>{}, &Raw[tsrcA], okyA);
+        } else {
+            if (wave < 2) xl(GroupTag<1>{}, &Raw[tsrcB], okyB);
+            else if (wave < 7) xl(GroupTag<2>{}, &Raw[tsrcB], okyB);
+        }
+    };
+    auto xcomp = [&](int dA, int dB, int i) __attribute__((always_inline)) {
+        if (i == 0) {
+            if (wave < 5) xc(GroupTag<0>{}, &Vs[dA]);
+            else xc(GroupTag<1>{}, &Vs[dA]);
+        } else {
+            if (wave < 2) xc(GroupTag<1>{}, &Vs[dB]);
+            else if (wave < 7) xc(GroupTag<2>{}, &Vs[dB]);
+        }
+    };
     // (dA, dB: the thread's destinations in the V buffer being filled -- tdstA / tdstB of buffer 0 or 1; the loop swaps them per chunk)
     auto xform = [&](int dA, int dB, int i) __attribute__((always_inline)) {
         if (HALF) {           // all four slots in one call (i unused)
@@ -284,13 +330,14 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
     // chunk: the thread's bases into "this chunk's" and "the next chunk's" buffer are swapped at the end of a chunk (ONE loop body).
     auto run = [&](auto gtag) __attribute__((always_inline)) {
         constexpr int G_ = decltype(gtag)::value;
-        f16x8g bq[9][2];             // [k-step][piece]: the weight ring
+        constexpr int RING = HALF ? 9 : 3;      // register sets of the weight ring: k-step t's slab lives in set t % RING
+        f16x8g bq[RING][2];          // [set][piece]
         const int tstride = 2 * nchunks * wgroups * 2048, cstride = wgroups * 2048;
         int sbase = (G_ * nchunks * wgroups + wg0) * 2048;          // slab (t = 0, group G_) of the chunk being LOADED
         auto load_b = [&](int t_) {
             const int soff = sbase + t_ * tstride;        // uniform
 #pragma unroll
-            for (int pc = 0; pc < 2; ++pc) bq[t_][pc] = __builtin_bit_cast(f16x8g, __builtin_amdgcn_raw_buffer_load_b128(wrs, bvoff + pc * 1024, soff, 0));
+            for (int pc = 0; pc < 2; ++pc) bq[t_ % RING][pc] = __builtin_bit_cast(f16x8g, __builtin_amdgcn_raw_buffer_load_b128(wrs, bvoff + pc * 1024, soff, 0));
         };
         f16x8g a[2][2];              // [piece][M tile]: ONE set -- the lo pieces of the next k-step are read as soon as this k-step's first
                                      // MFMA group (their only reader) is issued, the hi pieces after its last group
@@ -300,9 +347,10 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
             for (int mt = 0; mt < 2; ++mt) a[pc][mt] = __builtin_bit_cast(f16x8g, *reinterpret_cast<const f32x4*>(vb + mt * 4 * G_ROWW));
         };
 #pragma unroll
-        for (int t = 0; t < 9; ++t) load_b(t);
-        sbase += cstride;
-        asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");          // the raw pieces (older than the 18 weight loads) have landed
+        for (int t = 0; t < RING; ++t) load_b(t);
+        if (HALF) sbase += cstride;
+        if (HALF) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");          // the raw pieces (older than the 18 weight loads) have landed
         asm volatile("" : "+v"(xword), "+v"(wword));
         kx = ccst_scale_exp(ccst_absmax_reduce(xword), F43_X_TARGET);
         kw = ccst_scale_exp(ccst_absmax_reduce(wword), F43_W_TARGET);
@@ -370,15 +418,15 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
                 const int j = t % 3;
                 const int nbase = t == 8 ? aNxt : aCur, nt_ = (t + 1) % 9;          // the next k-step's V buffer (of the next chunk: complete since the barrier of k-step 6)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][mt], bq[t][0], acc[j][mt], 0, 0, 0);   // a_lo b_hi
+                for (int mt = 0; mt < 2; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][mt], bq[t % RING][0], acc[j][mt], 0, 0, 0);   // a_lo b_hi
                 __builtin_amdgcn_sched_barrier(0);
                 read_a(1, nbase, nt_);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mt], bq[t][1], acc[j][mt], 0, 0, 0);   // a_hi b_lo
+                for (int mt = 0; mt < 2; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mt], bq[t % RING][1], acc[j][mt], 0, 0, 0);   // a_hi b_lo
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mt], bq[t][0], acc[j][mt], 0, 0, 0);   // a_hi b_hi
+                for (int mt = 0; mt < 2; ++mt) acc[j][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][mt], bq[t % RING][0], acc[j][mt], 0, 0, 0);   // a_hi b_hi
                 __builtin_amdgcn_sched_barrier(0);
                 read_a(0, nbase, nt_);
                 // staging.  The raw buffer holds chunk c + 1 (every wave waits for its own pieces, then the barrier, at k-step 2); it is
@@ -392,14 +440,28 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
                     dma_raw(c + 2, 2);
                     dma_raw(c + 2, 3);
                 }
-                if (!LAST) load_b(t);
-                if (t == 3 + 2 * G_ && !LAST) xform(dWn, d8n, 0);          // (the two waves of a SIMD belong to different groups: staggered, one of
-                if (t == 4 + 2 * G_ && !LAST) xform(dWn, d8n, 1);          //  them keeps the MFMA pipe busy while the other transforms)
+                if (t + RING < 9) load_b(t + RING);
+                else if (!LAST) {
+                    sbase += cstride;
+                    load_b(t + RING - 9);
+                    sbase -= cstride;
+                }
+                // (the two waves of a SIMD belong to different groups: staggered, one of them keeps the MFMA pipe busy while the other
+                //  transforms; an item's pixels are requested one k-step ahead)
+                if (G_ == 1 && t == 4 && !LAST) xload(0);
+                if (t == 3 + 2 * G_ && !LAST) {
+                    xcomp(dWn, d8n, 0);
+                    xload(1);
+                }
+                if (t == 4 + 2 * G_ && !LAST) xcomp(dWn, d8n, 1);
                 __builtin_amdgcn_sched_barrier(0);
                 // k-step 2: the raw pieces (issued before the weights of k-step 8: the 8 loads issued since -- 6 after the prologue's --
                 // may stay in flight) have landed, and every wave is done with the fragments of the previous chunk's V;  k-step 6: the
                 // other V buffer is complete and the raw buffer is free
-                if (t == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                if (t == 2) {
+                    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    if (G_ == 0 && !LAST) xload(0);
+                }
                 if (t == 6) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
             sbase += cstride;
