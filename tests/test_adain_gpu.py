@@ -1107,6 +1107,28 @@ def test_conv3x3_f23_vs_fp64(dev, case, reflect, form):
         _check_centred_partials(part, out, N)
 
 
+def test_conv3x3_f43_random_shapes_are_reproducible(dev):
+    """tools/f43_stress.py in small: random shapes / flags through both tiles of the F(4,3) kernel, every launch three times -- the same bits
+    (hand-counted waits, two barriers per chunk: a race would show as a difference) -- and within 1e-5 of max |y| of the direct kernel."""
+    from ccst_amd import ops
+    g = torch.Generator().manual_seed(5)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    for _ in range(24):
+        N, Cin, Cout = ri(1, 3), 16 * ri(1, 12), [48, 64, 128, 160, 256][ri(0, 4)]
+        pool, ups, reflect = bool(ri(0, 1)), bool(ri(0, 1)), bool(ri(0, 1))
+        H, W = ri(2, 60), ri(2, 100)
+        if ups:
+            H, W = 2 * max(1, H // 2), 2 * max(1, W // 2)
+        x = torch.randn(N, H // 2 if ups else H, W // 2 if ups else W, Cin, generator=g).to(dev)
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(dev)
+        pc = ops.pack_conv_weight(w, (torch.randn(Cout, generator=g) * 0.1).to(dev), wino=4)
+        flags = 1 | (2 if pool else 0) | (4 if ups else 0) | (8 if reflect else 0)
+        y0 = ops.conv3x3_f43(x, pc, flags)
+        assert torch.equal(y0, ops.conv3x3_f43(x, pc, flags)) and torch.equal(y0, ops.conv3x3_f43(x, pc, flags)), (N, H, W, Cin, Cout, flags)
+        ref = ops.conv3x3_halo_split(x, pc, flags)
+        assert float((y0 - ref).abs().max()) < 1e-5 * max(1.0, float(ref.abs().max())), (N, H, W, Cin, Cout, flags)
+
+
 @pytest.mark.parametrize("xscale", [1e-30, 1e-4, 3e4, 1e5, 1e30])
 @pytest.mark.parametrize("form", [2, 4])
 def test_conv3x3_f23_any_magnitude(dev, xscale, form):
