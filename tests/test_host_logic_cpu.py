@@ -236,3 +236,21 @@ def test_conv_kernel_selection_does_not_depend_on_the_batch_size():
         picks = {ops.f23_wanted(PC(cin, cout), n, h, w, dev) for n in (1, 2, 3, 6, 32)}
         assert len(picks) == 1, (h, w, cin, cout, picks)
     assert ops.f23_wanted(PC(64, 64), 1, 512, 512, dev) and not ops.f23_wanted(PC(512, 512), 32, 8, 8, dev)
+
+
+def test_timing_experiment_patches_apply_to_the_shipped_sources(tmp_path):
+    """The timing-experiment branches live outside the product sources as tools/variants/<file>.patch (tools/build_variant.sh applies them to a
+    scratch copy): every patch must still apply to the file it is named after."""
+    import glob
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    patches = sorted(glob.glob(os.path.join(root, "tools", "variants", "*.patch")))
+    assert patches
+    for pf in patches:
+        scratch = tmp_path / os.path.basename(pf)
+        shutil.copytree(os.path.join(root, "ccst_amd", "csrc"), scratch / "ccst_amd" / "csrc", ignore=shutil.ignore_patterns("*.o", "*.so"))
+        with open(pf) as fh:
+            r = subprocess.run(["patch", "-s", "-p1", "--dry-run", "-d", str(scratch)], stdin=fh, capture_output=True, text=True)
+        assert r.returncode == 0, (os.path.basename(pf), r.stdout[-400:])
