@@ -542,11 +542,11 @@ def main():
         cpu_legs = world == 1 and not args.no_cpu_baseline
         # (no empty_cache(): the freed AdaIN blocks stay in the caching allocator -- returning them makes the first train steps
         #  re-hipMalloc their workspaces inside the timed region: 2870 instead of 3190 images/s over 25 steps)
-        sec = [bench_resnet.run(dev, world, steps=max(3, args.steps // 2), warmup=5, graph="auto", cpu_baseline=cpu_legs)]      # config 4 (metric, 2nd half)
+        sec = [bench_resnet.run(dev, world, steps=max(30, args.steps), warmup=5, graph="auto", cpu_baseline=cpu_legs)]      # config 4 (metric, 2nd half)
         if not args.no_extra:
             sec.append(bench_extra.stage1(dev, vgg31, A, world, rank, cpu=cpu_legs, vgg_w=vgg_w))                  # configs 0 / 1
             sec.append(bench_extra.single_mode(dev, vgg31, dec, A, world, rank))                                   # config 3
-            sec.append(bench_resnet.run(dev, world, steps=max(6, args.steps // 2), warmup=5, batch=32, arch="resnet18", classes=2,
+            sec.append(bench_resnet.run(dev, world, steps=max(60, args.steps), warmup=5, batch=32, arch="resnet18", classes=2,
                                         graph="auto", cpu_baseline=cpu_legs))                                     # config 5
             sec.append(bench_extra.eval_forward(dev, world, rank))                                                 # a12: test()
             if rank == 0:

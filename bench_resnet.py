@@ -23,7 +23,14 @@ if ROOT not in sys.path:
 
 GFLOP_PER_IMAGE = {"resnet50": 24.51, "resnet18": 10.87}      # SURVEY.md 8d (fwd + bwd-data + bwd-weight), 222x222
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_F16_MFMA_TFLOPS = 2516.6                               # the pipe the hot GEMMs run on (three half-piece products per fp32 product)
 PEAK_HBM_GBPS = 8000.0                                      # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+# ALGORITHMIC HBM bytes of a train step (SURVEY.md 8d "Roofline 2"): every conv output (fp32, 44.40 MB per image for ResNet50 at 222 x 222,
+# 9.88 MB for ResNet18: the sum over the convs of Cout x Ho x Wo x 4 B) touched ~8.8 times per step by a fully fused schedule (written by the
+# conv, read by the BatchNorm apply, written normalised, read by the next conv and by its weight gradient, and the backward's gradient
+# passes) => 25 GB per B=64 ResNet50 step.  The step is HBM-bound: 3.1 ms at 8 TB/s against 1.9 ms of MFMA time on the 16-bit pipe.
+CONV_OUT_MB_PER_IMAGE = {"resnet50": 44.40, "resnet18": 9.88}
+TOUCHES_PER_STEP = 8.8
 
 
 def host_cores():
@@ -56,18 +63,24 @@ def build(dev, arch="resnet50", classes=7, batch=64, size=222, lr=0.001, seed=1)
 
 
 def make_step(model, opt, loss_fun, x, y, join_side=False):
-    from ccst_amd import fed
+    """join_side=True: the form that is captured into a HIP graph -- ROTATED as fed._GraphedTrainStep: the re-pack of the weights
+    the previous step's SGD wrote opens the step (side stream, joined where the forward first reads a packed weight), so that the
+    capture ends with every stream joined without serialising the re-pack behind the optimiser step."""
+    from ccst_amd import fed, nn_ops
 
     window = fed.StepWindow() if (x.is_cuda and not join_side) else None      # as fed.train(): the host stays <= 2 steps ahead
 
     def step():
+        if join_side:
+            nn_ops.prepack_on_side(model)
         opt.zero_grad()
         loss = loss_fun(model(x), y)
         fed.backward(loss) if x.is_cuda else loss.backward()
-        opt.step()
-        if join_side:         # graph capture: every forked stream must re-join before the capture ends
-            from ccst_amd import nn_ops
+        if join_side:
+            opt.step(prepack=False)
             nn_ops.join_prepack(x.device)
+        else:
+            opt.step()
         if window is not None:
             window.tick()
         return loss
@@ -152,34 +165,63 @@ def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False
     if layers:
         layer_table(step)
     graph_choice = None
+
+    def capture():
+        gstep = make_step(model, opt, loss_fun, x, y, join_side=True)
+        for _ in range(2):
+            gstep()
+        sync()
+        from ccst_amd import ops
+        g = torch.cuda.CUDAGraph()
+        ops.reset_absmax_pool()             # as fed._GraphedTrainStep: the step's |max| word rows come from a block zero-filled INSIDE the graph
+        with torch.cuda.graph(g):
+            l = gstep()
+        ops.reset_absmax_pool()
+        sync()
+        return g, l
     if auto_graph:
-        # launch-bound or GPU-bound?  Issue a few eager steps without waiting: if the host needs longer to issue a step than the GPU to
-        # run it, the HIP-graph replay is the faster loop (fed.train(..., args.hip_graph) makes the same choice available to the CLI)
-        probe = 6
+        # Eager or replayed?  Both loops give the same bits; which is faster depends on the host (the eager loop issues ~590 launches per
+        # step) -- so MEASURE: `probe` steps of each, bracketed by synchronisation, and run the timed region on the faster one.
+        probe = max(30, int(os.environ.get("CCST_BENCH_LOOP_PROBE", "30")))
+
+        def timed(fn):
+            sync()
+            h0 = time.perf_counter()
+            for _ in range(probe):
+                fn()
+            sync()
+            return (time.perf_counter() - h0) * 1e3 / probe
+        # host issue time of the eager loop alone (no window, no waiting): what a slower host would be bound by
         sync()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         h0 = time.perf_counter()
         e0.record()
-        for _ in range(probe):
+        for _ in range(6):
             step()
         e1.record()
-        issue_ms = (time.perf_counter() - h0) * 1e3 / probe
+        issue_ms = (time.perf_counter() - h0) * 1e3 / 6
         sync()
-        device_ms = e0.elapsed_time(e1) / probe
-        graph = issue_ms > 0.9 * device_ms
-        graph_choice = {"host_issue_ms_per_step": round(issue_ms, 3), "device_ms_per_step_eager": round(device_ms, 3),
-                        "rule": "HIP graph when the host needs > 0.9 x the device time to issue a step", "hip_graph": bool(graph)}
+        eager_ms = timed(step)
+        g, gloss = capture()
+        for _ in range(3):
+            g.replay()
+        graph_ms = timed(g.replay)
+        graph = graph_ms < eager_ms
+        graph_choice = {"host_issue_ms_per_step": round(issue_ms, 3), "eager_ms_per_step": round(eager_ms, 3),
+                        "graph_ms_per_step": round(graph_ms, 3), "probe_steps": probe,
+                        "rule": "both loops timed over probe_steps, the faster one runs the timed region", "hip_graph": bool(graph)}
         if graph:
-            # (capture needs every forked stream re-joined inside the step)
-            step = make_step(model, opt, loss_fun, x, y, join_side=True)
+            loss, run_step = gloss, g.replay
+        else:
+            del g
+            from ccst_amd import ops
+            ops.bump_weights_epoch()        # the replays moved the weights behind the host-side pack keys
+            run_step = step
             for _ in range(2):
                 step()
             sync()
-    if graph:
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            loss = step()
-        sync()
+    elif graph:
+        g, loss = capture()
         run_step = g.replay
     else:
         run_step = step
@@ -247,6 +289,7 @@ def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False
     gflop = GFLOP_PER_IMAGE.get(arch, 0.0) * batch
     tf = gflop / dt / 1e3
     traffic, traffic_src = hbm_traffic_per_step(arch, batch)
+    alg_bytes = CONV_OUT_MB_PER_IMAGE.get(arch, 0.0) * 1e6 * batch * TOUCHES_PER_STEP
     out = {"metric": "%s train images/sec @222x222 B=%d" % (arch, batch), "value": round(n_ranks_seen * batch / dt, 2), "unit": "images/sec",
            "n_gpus": world, "n_ranks_seen": n_ranks_seen, "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup, "dtype": "f32",
            "hip_graph": bool(graph), "scaling": "weak",
@@ -255,14 +298,21 @@ def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False
            "device_ms_per_step": round(dev_ev[0].elapsed_time(dev_ev[1]) / steps, 3) if dev_ev is not None else None,
            "config": {"workload": "fed_run.py train() body, %s classes=%d, SGD lr 0.001, one client per GPU%s"
                       % (arch, classes, ", + 1 FedAvg all-reduce (RCCL) per %d steps" % steps if distributed else "")},
-           "tflops_per_gpu": round(tf, 2), "frac_of_f32_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
-           # the step is bounded by the fp32 MFMA time of its 3 GEMMs per conv (SURVEY 8d "Roofline 2"); the BN / element-wise
-           # kernels are HBM work on top: traffic = measured HBM bytes per step (PMC), hbm_frac = traffic / step time / 8 TB/s
-           "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "bound_images_per_s": round(PEAK_F32_MFMA_TFLOPS * 1e3 / GFLOP_PER_IMAGE.get(arch, 1.0), 1),
+           "tflops_per_gpu": round(tf, 2),
+           # The step is HBM-bound: its GEMMs run on the 16-bit MFMA pipe (3 products per fp32 product => 839 TFLOP/s, 1.9 ms
+           # for ResNet50 at B=64) while a fully fused schedule moves ~25 GB (3.1 ms at 8 TB/s).  achieved = ALGORITHMIC bytes / step time;
+           # traffic = the measured HBM bytes per step (committed --pmc passes of this build); mfma = the same step against the pipe it uses.
+           "roofline": {"bound": "hbm", "achieved": round(alg_bytes / dt / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                        "frac": round(alg_bytes / dt / 1e9 / PEAK_HBM_GBPS, 4), "algorithmic_bytes_per_step": int(alg_bytes),
+                        "bound_images_per_s": round(batch / (alg_bytes / (PEAK_HBM_GBPS * 1e9)), 1),
                         "traffic": traffic, "traffic_source": traffic_src,
-                        "achieved_GBps": round(traffic / dt / 1e9, 1) if traffic else None,
-                        "hbm_frac": round(traffic / dt / 1e9 / PEAK_HBM_GBPS, 4) if traffic else None},
+                        "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
+                        "measured_GBps": round(traffic / dt / 1e9, 1) if traffic else None,
+                        "measured_hbm_frac": round(traffic / dt / 1e9 / PEAK_HBM_GBPS, 4) if traffic else None,
+                        "mfma": {"achieved": round(tf, 2), "peak": round(PEAK_F16_MFMA_TFLOPS / 3.0, 1), "unit": "TFLOP/s",
+                                 "frac": round(tf / (PEAK_F16_MFMA_TFLOPS / 3.0), 4),
+                                 "note": "fp32 products as three half-piece products on the 16-bit MFMA: bound = 2516.6 / 3",
+                                 "frac_of_f32_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}},
            "final_loss": round(float(loss.detach()), 5)}
     if graph_choice is not None:
         out["graph_choice"] = graph_choice
@@ -314,9 +364,9 @@ if __name__ == "__main__":
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--arch", default="resnet50")
-    ap.add_argument("--graph", action="store_true")
+    ap.add_argument("--graph", nargs="?", const="1", default="0", help="replay a HIP graph of the step; 'auto': time both loops, run the faster")
     ap.add_argument("--cpu-baseline", action="store_true")
     ap.add_argument("--layers", action="store_true")
     a = ap.parse_args()
-    print(json.dumps(run(torch.device("cuda:0"), steps=a.steps, warmup=a.warmup, batch=a.batch, arch=a.arch, graph=a.graph,
+    print(json.dumps(run(torch.device("cuda:0"), steps=a.steps, warmup=a.warmup, batch=a.batch, arch=a.arch, graph=("auto" if a.graph == "auto" else a.graph == "1"),
                          cpu_baseline=a.cpu_baseline, layers=a.layers)))

@@ -161,12 +161,15 @@ class SGD(object):
     def zero_grad(self, set_to_none=False):
         self.arena.zero_grad()
 
-    def step(self):
+    def step(self, prepack=True):
+        """prepack=False: the caller refreshes the packed weights itself (a captured train step does so at the HEAD of the next replay,
+        see _GraphedTrainStep)."""
         a = self.arena
         a.require_cuda("SGD.step")
         check(_lib.load().ccst_sgd_f32(ptr(a.flat), ptr(a.grad), float(self.param_groups[0]["lr"]), a.n_param, stream_ptr()), "sgd")
         ops.bump_weights_epoch()
-        nn_ops.prepack_on_side(a.model)
+        if prepack:
+            nn_ops.prepack_on_side(a.model)
 
 
 _ONES = {}
@@ -223,13 +226,15 @@ def _dg(args):
 
 
 class _GraphedTrainStep(object):
-    """One train iteration (zero_grad, forward, loss, running loss / accuracy sums, backward, SGD step, weight
-    re-pack) captured into a HIP graph and replayed per batch.  Insurance against a slow or contended host for
-    launch-bound configurations: ResNet18 at B=32 issues ~250 short kernels per 5.7 ms step; eager measured 5.7 ms
-    per iteration on one MI355X box and 8.7-10.7 ms on another (host-bound), replayed 5.9-6.2 ms on both.  ResNet50
-    at B=64 is GPU-bound (13 ms to issue, 23 ms to run) and its two-stream eager schedule beats the graph (23.0
-    vs 25.2 ms), so this is opt-in (args.hip_graph / --hip_graph / CCST_TRAIN_GRAPH=1).  Results are bit-identical
-    to the eager loop (tests/test_resnet_gpu.py::test_train_hip_graph_matches_eager)."""
+    """One train iteration captured into a HIP graph and replayed per batch -- ROTATED: the replay starts with the re-pack of
+    the weights the PREVIOUS step's SGD wrote (forked to the side stream, joined where the forward first reads a packed weight:
+    it runs under zero_grad / stem conv / stem BatchNorm + pool exactly as in the eager loop), then zero_grad, forward, loss,
+    running loss / accuracy sums, backward, SGD step.  A capture must end with every forked stream re-joined; with the re-pack
+    at the TAIL of the step (round 5) that join serialised it behind the optimiser step -- 16.3 ms replayed against 14.9 ms
+    of eager device time for ResNet50 at B=64 (BENCH_r05).  Weights rewritten outside the graph (FedAvg, load_state_dict, an
+    eager step) are picked up by the next replay's own re-pack.  Results are bit-identical to the eager loop
+    (tests/test_resnet_gpu.py::test_train_hip_graph_matches_eager).  Opt-in: args.hip_graph / --hip_graph / CCST_TRAIN_GRAPH=1,
+    or "auto" (train() times both loops and keeps the faster)."""
 
     def __init__(self, model, optimizer, loss_fun, img, class_l, loss_all, correct_all):
         self.model, self.shape = model, (tuple(img.shape), tuple(class_l.shape))
@@ -242,14 +247,16 @@ class _GraphedTrainStep(object):
         self.graph = torch.cuda.CUDAGraph()
         ops.reset_absmax_pool()                 # the step's |max| word rows: from a block zero-filled INSIDE the graph
         with torch.cuda.graph(self.graph):
+            nn_ops.prepack_on_side(model)       # head of the replay: the packs of the weights as they are NOW (joined in the forward)
             optimizer.zero_grad()
             loss = loss_fun(model(self.x), self.y)
             self.loss_all += loss.detach()
             self.correct_all += loss_fun.correct[0]
             backward(loss)
-            optimizer.step()
-            nn_ops.join_prepack(dev)            # every forked stream re-joins before the capture ends
+            optimizer.step(prepack=False)
+            nn_ops.join_prepack(dev)            # (a model without packed convs never joined in its forward)
         ops.reset_absmax_pool()
+        nn_ops.restamp_packs(model)             # host-side keys: the packs are as current as the next replay needs them
 
     def run(self, img, class_l):
         self.x.copy_(img, non_blocking=True)
@@ -261,9 +268,51 @@ class _GraphedTrainStep(object):
         # keys; the caller bumps ops.WEIGHTS_EPOCH before anything eager reads a packed weight again (train()).
 
 
-def _graph_wanted(args):
+def _graph_mode(args):
+    """'on' (args.hip_graph true / --hip_graph / CCST_TRAIN_GRAPH=1), 'auto' (args.hip_graph == 'auto' / CCST_TRAIN_GRAPH=auto:
+    train() times AUTO_PROBE iterations of the eager loop and of the replayed one per batch shape and keeps the faster -- both give
+    the same bits, so the choice is free), else 'off'."""
     import os
-    return bool(getattr(args, "hip_graph", False)) or os.environ.get("CCST_TRAIN_GRAPH", "0") == "1"
+    v = getattr(args, "hip_graph", None)
+    if v is None or v is False:
+        v = os.environ.get("CCST_TRAIN_GRAPH", "0")
+    if isinstance(v, str):
+        v = v.strip().lower()
+        return "auto" if v == "auto" else ("on" if v in ("1", "true", "yes", "on") else "off")
+    return "on" if v else "off"
+
+
+def _graph_wanted(args):
+    return _graph_mode(args) != "off"
+
+
+AUTO_PROBE = 10
+
+
+class _LoopTimer(object):
+    """Times P consecutive iterations of one loop form with two events on the compute stream (they see host-bound gaps as well as
+    device time): `before_iteration()` is called ahead of each iteration and returns ms per iteration once, after the P-th."""
+
+    def __init__(self, P, skip=0):
+        self.P, self.n, self.e0, self.skip = P, 0, None, skip
+
+    def before_iteration(self):
+        if self.skip > 0:
+            self.skip -= 1
+            return None
+        if self.e0 is None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+            self.n = 0
+            return None
+        self.n += 1
+        if self.n < self.P:
+            return None
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        e1.synchronize()
+        ms, self.e0 = self.e0.elapsed_time(e1) / self.P, None
+        return ms
 
 
 def train(model, train_loader, optimizer, loss_fun, client_num, device, args, iter_idx, logger):
@@ -277,6 +326,7 @@ def train(model, train_loader, optimizer, loss_fun, client_num, device, args, it
     it = -1
     fused_acc = isinstance(loss_fun, CrossEntropyLoss)
     use_graph = _graph_wanted(args) and fused_acc and logger is None and isinstance(optimizer, SGD)
+    auto = use_graph and _graph_mode(args) == "auto"
     if use_graph:
         # Captured steps hold raw addresses of the parameter arena.  model.to() above (args.offload_models moves the model to the
         # CPU and back every epoch), a load-by-assignment or any model.cpu() by the caller re-homes the tensors: re-resolve the
@@ -293,6 +343,7 @@ def train(model, train_loader, optimizer, loss_fun, client_num, device, args, it
         correct_all.zero_()
     eager_iters, stale_keys = 0, False
     window = StepWindow() if torch.device(device).type == "cuda" else None
+    timers = {}             # auto: per batch shape, the timer of the loop form being measured in THIS call (a measurement never spans calls)
     for it, data in enumerate(train_loader):
         img, class_l = data
         img, class_l = img.to(device, non_blocking=True), class_l.to(device, non_blocking=True)
@@ -300,7 +351,19 @@ def train(model, train_loader, optimizer, loss_fun, client_num, device, args, it
         if use_graph:
             key = (tuple(img.shape), tuple(class_l.shape), float(optimizer.lr), id(loss_fun))
             gs = steps.get(key)
-            if gs is None and eager_iters >= 2 and len(steps) < 5:     # capture once caches / workspaces are warm (<= 4 shapes)
+            st = steps.setdefault("_auto", {}).setdefault(key, {"eager_ms": None, "graph_ms": None}) if auto else None
+            ready = True
+            if st is not None:
+                if st["eager_ms"] is None:              # phase 0: time the eager loop first (these ARE training iterations)
+                    ready = False
+                    if eager_iters >= 2:
+                        st["eager_ms"] = timers.setdefault((key, 0), _LoopTimer(AUTO_PROBE)).before_iteration()
+                        ready = st["eager_ms"] is not None
+                elif gs is not None and st["graph_ms"] is None:         # phase 1: ... then the replayed one (not its first replay)
+                    st["graph_ms"] = timers.setdefault((key, 1), _LoopTimer(AUTO_PROBE, skip=1)).before_iteration()
+                if st["graph_ms"] is not None and st["graph_ms"] > st["eager_ms"]:
+                    gs, ready = None, False             # decided: the eager loop is the faster one for this shape
+            if gs is None and ready and eager_iters >= 2 and len([k for k in steps if k not in ("_sums", "_auto")]) < 4:     # capture once caches / workspaces are warm (<= 4 shapes)
                 nn_ops.join_prepack(device)
                 torch.cuda.current_stream(device).synchronize()
                 gs = steps[key] = _GraphedTrainStep(model, optimizer, loss_fun, img, class_l, loss_all, correct_all)

@@ -92,17 +92,18 @@ class GradWords(object):
     gives it to its ConvFn; the BatchNorm that reads that output gives it to its own Function, whose backward fills it (`put`); the
     conv's backward `take`s it -- only for the very tensor it was filled for (autograd may hand over a different one: a hook, an
     accumulation of several consumers' gradients)."""
-    __slots__ = ("words", "ptr", "shape")
+    __slots__ = ("words", "ptr", "shape", "version")
 
     def __init__(self):
-        self.words = self.ptr = self.shape = None
+        self.words = self.ptr = self.shape = self.version = None
 
     def put(self, t, words):
-        self.words, self.ptr, self.shape = words, t.data_ptr(), tuple(t.shape)
+        self.words, self.ptr, self.shape, self.version = words, t.data_ptr(), tuple(t.shape), t._version
 
     def take(self, t):
-        words, ok = self.words, self.words is not None and self.ptr == t.data_ptr() and self.shape == tuple(t.shape)
-        self.words = self.ptr = self.shape = None
+        # (same storage, same shape AND unmodified since: a hook that rescales the gradient in place bumps its version counter)
+        words, ok = self.words, self.words is not None and self.ptr == t.data_ptr() and self.shape == tuple(t.shape) and self.version == t._version
+        self.words = self.ptr = self.shape = self.version = None
         return words if ok else None
 
 
@@ -221,6 +222,24 @@ def prepack_on_side(model):
     for i, m in enumerate(j["mslots"]):
         w = m.weight
         m.__dict__["_ccst_wmax"] = ((w._version, w.data_ptr(), ops.WEIGHTS_EPOCH), j["mwords"][i])
+
+
+def restamp_packs(model):
+    """Stamp every packed copy the batched re-pack covers as current for the weights' present (version, address, epoch).  For a
+    captured train step whose replay starts with that re-pack (fed._GraphedTrainStep): the step's own SGD bumped the epoch after
+    the head re-pack stamped the slots, and the per-replay `prepack()` key compares must not re-pack eagerly what the replay
+    re-packs itself."""
+    convs = model.__dict__.get("_ccst_convs") or []
+    if not convs:
+        return
+    j = _prepack_jobs(model, convs)
+    for m, name, pk, _t in j["slots"] + j["wslots"] + j["hslots"] + j["h3slots"]:
+        w = m.weight
+        m.__dict__[name] = ((w._version, w.data_ptr(), ops.WEIGHTS_EPOCH), pk)
+    if j["mwords"] is not None:
+        for i, m in enumerate(j["mslots"]):
+            w = m.weight
+            m.__dict__["_ccst_wmax"] = ((w._version, w.data_ptr(), ops.WEIGHTS_EPOCH), j["mwords"][i])
 
 
 def join_prepack(device):
@@ -356,7 +375,8 @@ def conv_bwd_weight(d, x, dy, weight_grad_oihw, accumulate=True, x_absmax=None, 
     lib = _lib.load()
     M = d.n * d.ho * d.wo
     ntap = d.nky * d.nkx
-    half = x_absmax is not None and dy_absmax is not None
+    # (the half-piece kernel addresses x and dy with 32-bit byte offsets: operands of 2 GiB or more take the fp32-MFMA kernel)
+    half = x_absmax is not None and dy_absmax is not None and x.numel() * 4 < 2 ** 31 and dy.numel() * 4 < 2 ** 31
     splits = (lib.ccst_conv2d_bwd_weight_split_splits if half else lib.ccst_conv2d_bwd_weight_splits)(M, d.cin, d.cout, ntap)
     need = splits * ntap * d.cin * d.cout * 4
     ws = _workspace(need, x.device)
@@ -492,7 +512,9 @@ class ConvFn(torch.autograd.Function):
             g = _grad_slot(weight)
             xmax = ctx.xmax if dymax is not None else None
             if SIDE_STREAM:
-                _on_side_stream(x.device, (x, dy), lambda: conv_bwd_weight(d, x, dy, g, x_absmax=xmax, dy_absmax=dymax))
+                # (the |max| word rows are views of pool blocks allocated on the main stream: they must outlive the side-stream kernel too)
+                keep = (x, dy) + tuple(t for t in (xmax, dymax) if t is not None)
+                _on_side_stream(x.device, keep, lambda: conv_bwd_weight(d, x, dy, g, x_absmax=xmax, dy_absmax=dymax))
             else:
                 conv_bwd_weight(d, x, dy, g, x_absmax=xmax, dy_absmax=dymax)
         dx = None

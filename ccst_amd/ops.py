@@ -263,7 +263,7 @@ class _PackOrder(object):
     """Cross-stream ordering of lazily packed layouts: a layout is packed by a kernel on the stream that is current at its
     first use; the Python slot is set at once, so a use on ANOTHER stream (style._style_transfer_two_streams: the side half finds the
     slot filled by the main half) could launch its conv before that pack kernel has run.  `packed(slot)` records an event behind the
-    pack launch; `use(slot)` makes any other stream wait for it, once per (slot, stream) -- a dictionary lookup per use after that."""
+    pack launch; `use(slot)` makes any other stream wait for it (a completed event costs next to nothing)."""
     __slots__ = ("ev",)
 
     def __init__(self):
@@ -272,15 +272,16 @@ class _PackOrder(object):
     def packed(self, slot):
         e = torch.cuda.Event()
         e.record()
-        self.ev[slot] = (e, {_lib.raw_stream()})
+        self.ev[slot] = (e, torch.cuda.current_stream())
 
     def use(self, slot):
+        # (a use on the packing stream is ordered by the stream itself; any other stream waits for the event EVERY time -- remembering
+        #  "this stream has waited" by raw handle would skip the wait for a new stream that recycled a destroyed one's handle)
         ent = self.ev.get(slot)
         if ent is not None:
-            st = _lib.raw_stream()
-            if st not in ent[1]:
-                torch.cuda.current_stream().wait_event(ent[0])
-                ent[1].add(st)
+            cur = torch.cuda.current_stream()
+            if cur != ent[1]:
+                cur.wait_event(ent[0])
 
 
 class PackedConv(object):

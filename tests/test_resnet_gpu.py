@@ -837,7 +837,7 @@ def test_test_fedbn_merge_and_eval(dev):
     assert abs(got[0] - ref[0]) < 1e-3 and got[1] == ref[1]
 
 
-def test_train_hip_graph_matches_eager(dev):
+def test_train_hip_graph_matches_eager(dev, monkeypatch):
     """fed.train(..., args.hip_graph=True): iterations 3.. are HIP-graph replays; same losses, accuracies and -- bit for
     bit -- the same weights / BN statistics as the eager loop, across two calls with a FedAvg-style weight rewrite between."""
     import types
@@ -847,7 +847,8 @@ def test_train_hip_graph_matches_eager(dev):
     xs = [R.synth_batch(4, 222, 7, seed=300 + i) for i in range(5)] + [R.synth_batch(3, 222, 7, seed=400)]   # ragged last batch
     loader = [(x, y) for x, y in xs]
     out = {}
-    for mode in (False, True):
+    monkeypatch.setattr(fed, "AUTO_PROBE", 1)      # "auto": 2 warm + 1 timed eager iterations, capture, 1 + 1 timed replays (spans both calls)
+    for mode in (False, True, "auto"):
         args = types.SimpleNamespace(mode="fedavg", dg_method="no_DG", hip_graph=mode)
         model = models.get_network("resnet18")(args, pretrained=False, classes=7)
         model.load_state_dict(R.seeded_state_dict(R.resnet18(7), 11))
@@ -860,12 +861,16 @@ def test_train_hip_graph_matches_eager(dev):
         r2 = fed.train(model, loader, fed.SGD(model, lr=0.01), ce, 1, dev, args, 1, None)
         r3 = fed.test(model, loader, ce, dev, args)
         out[mode] = (r1, r2, r3, {k: v.detach().clone() for k, v in model.state_dict().items()})
-        if mode:
-            assert len([k for k in model.__dict__["_ccst_graph_steps"] if k != "_sums"]) == 2        # full batch + the ragged last batch
-    for a, b in zip(out[False][:3], out[True][:3]):
-        assert abs(a[0] - b[0]) < 1e-6 * abs(a[0]) and a[1] == b[1], (a, b)      # the running loss is summed per graph, then added
-    for k, v in out[False][3].items():
-        assert torch.equal(v, out[True][3][k]), k
+        if mode is True:
+            assert len([k for k in model.__dict__["_ccst_graph_steps"] if k not in ("_sums", "_auto")]) == 2        # full batch + the ragged last batch
+        if mode == "auto":          # both loops were timed for the full-batch shape, and a decision exists
+            st = [v for v in model.__dict__["_ccst_graph_steps"]["_auto"].values() if v["graph_ms"] is not None]
+            assert len(st) == 1 and st[0]["eager_ms"] > 0 and st[0]["graph_ms"] > 0, model.__dict__["_ccst_graph_steps"]["_auto"]
+    for mode in (True, "auto"):
+        for a, b in zip(out[False][:3], out[mode][:3]):
+            assert abs(a[0] - b[0]) < 1e-6 * abs(a[0]) and a[1] == b[1], (mode, a, b)      # the running loss is summed per graph, then added
+        for k, v in out[False][3].items():
+            assert torch.equal(v, out[mode][3][k]), (mode, k)
 
 
 def test_fed_run_cli_checkpoint_resume_test(dev, tmp_path):
