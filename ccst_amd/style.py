@@ -171,13 +171,16 @@ class StylePipeline(object):
         for u8, meta in pipe.run(((batch, fpaths) for ...), style_stat, alpha): ...      # u8: [N,H,W,3] uint8 numpy, valid until the next item
     """
 
-    def __init__(self, vgg, decoder, device, output_size=-1, depth=3, u8=True):
+    def __init__(self, vgg, decoder, device, output_size=-1, depth=3, u8=True, no_h2d=False, no_d2h=False, one_stream=False):
         # depth 3: before batch k+1 can be staged its slot's previous result (batch k-2) is handed out -- finished long ago -- so the
         # host queues batch k's kernels while the GPU still runs batch k-1 (with 2 slots it would first wait for batch k-1 itself)
         self.vgg, self.decoder, self.device = vgg, decoder, torch.device(device)
         self.output_size, self.depth, self.u8 = output_size, max(2, int(depth)), u8
-        self.h2d = torch.cuda.Stream(device=self.device)
-        self.d2h = torch.cuda.Stream(device=self.device)
+        # (diagnosis switches, tools/pipeline_diag.py: no_h2d / no_d2h skip that edge's copy, one_stream puts both on the compute stream)
+        self.no_h2d, self.no_d2h = bool(no_h2d), bool(no_d2h)
+        self.h2d = torch.cuda.current_stream(self.device) if one_stream else torch.cuda.Stream(device=self.device)
+        self.d2h = torch.cuda.current_stream(self.device) if one_stream else torch.cuda.Stream(device=self.device)
+        self.trace = None               # a list: per batch (host seconds, timing events) for tools/pipeline_diag.py
         self.slots = [dict(pin_in=None, dev_in=None, pin_out=None, ev_in=torch.cuda.Event(), ev_c=torch.cuda.Event(),
                            ev_out=torch.cuda.Event(), meta=None, busy=False) for _ in range(self.depth)]
 
@@ -194,7 +197,15 @@ class StylePipeline(object):
             src = slot["pin_in"]
         with torch.cuda.stream(self.h2d):
             self.h2d.wait_event(slot["ev_c"])      # the slot's previous batch has been consumed by its kernels
-            slot["dev_in"].copy_(src, non_blocking=True)
+            if self.trace is not None:
+                slot["t_h2d0"] = torch.cuda.Event(enable_timing=True)
+                slot["t_h2d0"].record(self.h2d)
+            if not (self.no_h2d and slot.get("filled")):
+                slot["dev_in"].copy_(src, non_blocking=True)
+                slot["filled"] = True
+            if self.trace is not None:
+                slot["t_h2d1"] = torch.cuda.Event(enable_timing=True)
+                slot["t_h2d1"].record(self.h2d)
             slot["ev_in"].record(self.h2d)
         # dev_in was allocated in the compute stream's order but is written on the copy stream: tell the caching allocator, so that a
         # buffer dropped on a shape change (the short last batch of a list) is not handed out again before this copy has run
@@ -205,19 +216,51 @@ class StylePipeline(object):
         from . import data as cdata
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(slot["ev_in"])
+        if self.trace is not None:
+            import time
+            h0 = time.perf_counter()
+            tc0, tc1, td0, td1 = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            tc0.record(cur)
         with torch.no_grad():
             out = style_transfer(self.vgg, self.decoder, slot["dev_in"], style_stat, alpha)
             if self.output_size and self.output_size > 0:
                 out = cdata.resize_tensor(out, self.output_size)
             res = cdata.quantize_u8(out) if self.u8 else out
         slot["ev_c"].record(cur)
+        if self.trace is not None:
+            tc1.record(cur)
         if slot["pin_out"] is None or slot["pin_out"].shape != res.shape or slot["pin_out"].dtype != res.dtype:
             slot["pin_out"] = torch.empty(res.shape, dtype=res.dtype).pin_memory()
         with torch.cuda.stream(self.d2h):
             self.d2h.wait_event(slot["ev_c"])
-            slot["pin_out"].copy_(res, non_blocking=True)
+            if self.trace is not None:
+                td0.record(self.d2h)
+            if not self.no_d2h:
+                slot["pin_out"].copy_(res, non_blocking=True)
+            if self.trace is not None:
+                td1.record(self.d2h)
             slot["ev_out"].record(self.d2h)
         res.record_stream(self.d2h)            # the allocator must not hand `res` out again before the copy has read it
+        if self.trace is not None:
+            self.trace.append({"issue_ms": (time.perf_counter() - h0) * 1e3, "h0": h0, "h2d": (slot.get("t_h2d0"), slot.get("t_h2d1")),
+                               "c": (tc0, tc1), "d2h": (td0, td1)})
+
+    def trace_rows(self):
+        """Text rows of the recorded trace: per batch, host issue ms and, relative to the first batch's compute start, when its H2D,
+        compute and D2H started / ended on the device (ms)."""
+        t = self.trace or []
+        if not t:
+            return []
+        z = t[0]["c"][0]
+        rows = ["batch  host_issue  host_gap |  h2d start-end  |  compute start-end (dur)  |  d2h start-end"]
+        for i, r in enumerate(t):
+            def rel(e):
+                return z.elapsed_time(e) if e is not None else float("nan")
+            gap = (r["h0"] - t[i - 1]["h0"]) * 1e3 if i else 0.0
+            rows.append("%5d  %9.2f  %8.2f | %7.2f-%7.2f | %7.2f-%7.2f (%5.2f) | %7.2f-%7.2f" % (
+                i, r["issue_ms"], gap, rel(r["h2d"][0]), rel(r["h2d"][1]), rel(r["c"][0]), rel(r["c"][1]), r["c"][0].elapsed_time(r["c"][1]),
+                rel(r["d2h"][0]), rel(r["d2h"][1])))
+        return rows
 
     def run(self, batches, style_stat, alpha=1.0):
         """batches: iterable of (CPU tensor [N,3,H,W], meta).  Yields (numpy view of the pinned result, meta) in order; a view is

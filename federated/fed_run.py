@@ -38,6 +38,8 @@ def parse():
     parser = argparse.ArgumentParser()
     parser.add_argument('--log', action='store_true', help='whether to make a log')
     parser.add_argument('--test', action='store_true', help='test the pretrained model')
+    parser.add_argument('--tent_test', action='store_true', help='test the pretrained model with the Tent test-time optimization')
+    parser.add_argument('--tent_test_on-the-fly', action='store_true', help='test the pretrained model with the Tent test-time optimization one by one')
     parser.add_argument('--IN_test', action='store_true', help='test the pretrained model using IN with affine')
     parser.add_argument('--batch', type=int, default=32, help='batch size')
     parser.add_argument('--iters', type=int, default=500, help='iterations for communication')
@@ -67,11 +69,18 @@ def parse():
     parser.add_argument('--gpu', type=int, default=0, help='gpu device number')
     parser.add_argument('--seed', type=int, default=1, help='random seed number')
     parser.add_argument('--save_freq', type=int, default=1)
+    # Jigsaw / FedDG hyper-parameters (fed_run.py:498-502): parsed with the reference's defaults; the methods that read them
+    # (--dg_method Jigsaw / feddg) are outside the hot path and refuse in main()
+    parser.add_argument("--bias_whole_image", default=0.9, type=float, help="If set, will bias the training procedure to show more often the whole image")
+    parser.add_argument("--jig_weight", type=float, default=0.7, help="Weight for the jigsaw puzzle loss")
+    parser.add_argument('--meta_step_size', type=float, default=1e-3, help='meta learning rate')
+    parser.add_argument('--clip_value', type=float, default=1.0, help='gradient clip')
     # additions
     parser.add_argument('--synthetic', type=int, default=0, help='N seeded synthetic images per client instead of the list files')
     parser.add_argument('--txt_root', type=str, default='data/txt_lists')
-    parser.add_argument('--hip_graph', action='store_true',
-                        help='capture the train iteration into a HIP graph and replay it per batch (launch-bound models: ResNet18, small batches)')
+    parser.add_argument('--hip_graph', nargs='?', const=True, default=False,
+                        help='capture the train iteration into a HIP graph and replay it per batch (launch-bound models: ResNet18, small batches); '
+                             '"--hip_graph auto": time both loops during the first epoch and keep the faster')
     parser.add_argument('--pretrained', action='store_true',
                         help='ImageNet initialisation from $CCST_PRETRAINED_DIR/<network>.pth (the reference downloads it, nets/resnet.py:364-369; '
                              'there is no network here, so it is opt-in and fails loudly when the file is missing)')
@@ -91,6 +100,8 @@ def restore(checkpoint, server_model, models, fedbn):
 
 def main():
     args = parse()
+    if args.tent_test or getattr(args, 'tent_test_on-the-fly', False) or getattr(args, 'tent_test_on_the_fly', False):
+        raise NotImplementedError("--tent_test / --tent_test_on-the-fly (Tent test-time optimisation, fed_run.py:591-624) are outside the hot path")
     if args.mode.lower() not in ('fedavg', 'fedbn', 'deepall') or args.dg_method not in ('no_DG',):
         raise NotImplementedError("only --mode fedavg/fedbn/deepall with --dg_method no_DG is on the hot path")
     if not torch.cuda.is_available():

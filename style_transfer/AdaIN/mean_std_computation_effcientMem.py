@@ -15,6 +15,7 @@ import torch
 from ccst_amd import data, style
 
 parser = base_parser(image_size_default=222)      # :48 default 222
+parser.set_defaults(output_name=None)              # :49-50: this script declares --output_name without a default
 args = parser.parse_args()
 device = device_or_die()
 os.makedirs(args.output, exist_ok=True)            # :72-73

@@ -479,4 +479,36 @@ if wanted("data_lists"):
         sys.modules["pdb"] = real_pdb
     else:
         del sys.modules["pdb"]
+# ---------------------------------------------------------------------------------------------------------------------------------
+# cli_flags: the LIVE add_argument calls of the four scripts the drop-in CLIs mirror: option strings, default, action.
+# Commented-out flags are not in the AST.  Data only (names and literal defaults).
+if wanted("cli_flags"):
+    import json
+
+    def flags_of(path):
+        with open(path) as f:
+            tree = ast.parse(f.read(), filename=path)
+        out = []
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == "add_argument":
+                names = [a.value for a in node.args if isinstance(a, ast.Constant) and isinstance(a.value, str)]
+                kw = {}
+                for k in node.keywords:
+                    if k.arg in ("default", "action", "nargs"):
+                        try:
+                            kw[k.arg] = ast.literal_eval(k.value)
+                        except ValueError:
+                            kw[k.arg] = None
+                    elif k.arg == "type" and isinstance(k.value, ast.Name):
+                        kw["type"] = k.value.id
+                out.append({"names": names, **kw})
+        return out
+    scripts = {"mean_std_computation_effcientMem.py": "style_transfer/AdaIN/mean_std_computation_effcientMem.py",
+               "CCST_OverallStyleTransfer.py": "style_transfer/AdaIN/CCST_OverallStyleTransfer.py",
+               "CCST_SingleStyleTransfer.py": "style_transfer/AdaIN/CCST_SingleStyleTransfer.py",
+               "fed_run.py": "federated/fed_run.py"}
+    blob = json.dumps({k: flags_of(os.path.join(REF, v)) for k, v in scripts.items()}, indent=1, sort_keys=True)
+    with open(os.path.join(OUT, "cli_flags.json"), "w") as f:
+        f.write(blob + "\n")
+    print("wrote cli_flags.json")
 print("done")
