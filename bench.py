@@ -48,13 +48,11 @@ def traffic_keys(dom, tj):
     base, targs = dom[:-1].split("<")
     targs = targs.split(",")
     nums, pooled = ", ".join(a for a in targs if a not in ("pool", "nopool", "half")), ("true" if "pool" in targs else "false")
-    if base in ("conv3x3_wino_kernel", "conv3x3_wino4_kernel", "conv3x3_wino4w_kernel"):
+    if base == "conv3x3_wino_kernel":
         return [k for k in tj if k.startswith("void %s<" % base) and k.rstrip(">").split("<")[1].split(",")[0].strip() == pooled]
     if base == "conv3x3_halo_split_kernel":       # rocprofv3: conv3x3_halo_kernel<WM, WN, NT, POOL, TRAIN, SPLIT>
         return [k for k in tj if k.startswith("void conv3x3_halo_kernel<") and k.rstrip(">").split(",")[-1].strip() == "true"
                 and k.rstrip(">").split(",")[3].strip() == pooled]
-    if base == "conv3x3_f23_kernel":              # rocprofv3: conv3x3_f23_kernel<POOL>
-        return [k for k in tj if k.startswith("void conv3x3_f23_kernel<") and k.rstrip(">").split("<")[1].strip() == pooled]
     if base == "conv3x3_f43_kernel":              # rocprofv3: conv3x3_f43_kernel<POOL, ZP, HALF, NT> (a bucket holds both store policies)
         half = "true" if "half" in targs else "false"
         return [k for k in tj if k.startswith("void conv3x3_f43_kernel<") and k.rstrip(">").split("<")[1].split(",")[0].strip() == pooled
@@ -253,6 +251,7 @@ def main():
     # timed steps run 2-25 % slow while they ramp back (6.46 5.90 5.66 5.48 5.33 5.28 ms against 5.19 steady).  So: collect first,
     # then warm up straight into the timed region.
     gc.collect()
+    gc.freeze()         # ... and everything alive now (torch, the plans) leaves the collector's generations: later passes scan new objects only
     w0 = time.perf_counter()
     for _ in range(args.warmup):
         out = step()
@@ -353,17 +352,27 @@ def main():
         # the same loop with its edges overlapped (style.StylePipeline, what the stage-2 CLI runs): H2D of batch k+1 and the quantise +
         # D2H of batch k-1 on their own streams under the compute of batch k
         pipe = style.StylePipeline(vgg31, dec, dev)
-        nb = 4 * reps
+        # >= 2 s of batches.  The interpreter's cyclic GC is parked for the timed loop: by now the process holds a few
+        # hundred thousand live objects (torch, the per-launch event list of the timed region above) and ONE generation-2 pass -- which
+        # the loop's own event / tensor allocations trigger -- stalls the issuing thread for 60-80 ms: a quarter of the 0.24 s the 80
+        # batches of round 5 took (1494 images/s in BENCH_r05 against 1978 for the same loop in a fresh process,
+        # tools/pipeline_diag.py).  The stage-2 CLIs do the same after set-up (gc.freeze(), style_transfer/AdaIN/_common.py).
+        nb = max(4 * reps, int(np.ceil(2.0 / max(ms_per_step * 1e-3, 1e-4))))
 
         def feed(n):
             for _ in range(n):
                 yield host_in, None
         for _u8, _m in pipe.run(feed(3), stat, 1.0):
             pass
-        c0 = time.perf_counter()
-        for _u8, _m in pipe.run(feed(nb), stat, 1.0):
-            pass
-        rate_pipe = nb * B / (time.perf_counter() - c0)
+        gc.collect()
+        gc.disable()
+        try:
+            c0 = time.perf_counter()
+            for _u8, _m in pipe.run(feed(nb), stat, 1.0):
+                pass
+            rate_pipe = nb * B / (time.perf_counter() - c0)
+        finally:
+            gc.enable()
         e2e = {"images_per_s": round(rates[0], 2), "images_per_s_u8_output": round(rates[1], 2), "batches": reps,
                "images_per_s_overlapped_u8": round(rate_pipe, 2), "overlapped_batches": nb,
                "overlapped_note": "style.StylePipeline: pinned H2D of batch k+1 and quantise + D2H of batch k-1 on their own HIP streams under "
@@ -403,21 +412,19 @@ def main():
         dom = max(per_kernel, key=lambda n: per_kernel[n][2])
         cnt, fl, sec = per_kernel[dom]
         alg = fl / sec / 1e12
-        wfac = 4.0 if dom.startswith("conv3x3_wino4") else 2.25 if dom.startswith("conv3x3_wino_kernel") else 1.0
+        wfac = 2.25 if dom.startswith("conv3x3_wino_kernel") else 1.0
         wino = wfac != 1.0
         bound_wino = bound_w4 if wfac == 4.0 else bound_w2
         executed = alg / wfac
         # the direct kernel's SPLIT form executes three half-precision MFMA products per fp32 product: its pipe is the 16-bit MFMA
         f43 = dom.startswith("conv3x3_f43")
-        f23 = dom.startswith("conv3x3_f23") or f43          # (one of the two Winograd-along-x forms)
-        split = dom.startswith("conv3x3_halo_split") or f23
-        # executed 16-bit MFMA FLOPs per algorithmic FLOP: 3 half-piece products, x 12/18 k-steps for F(2,3), x 18/36 for F(4,3)
-        issue_factor = 1.5 if f43 else 2.0 if f23 else 3.0
+        split = dom.startswith("conv3x3_halo_split") or f43
+        # executed 16-bit MFMA FLOPs per algorithmic FLOP: 3 half-piece products, x 18/36 k-steps for F(4,3) along x
+        issue_factor = 1.5 if f43 else 3.0
         peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
         if split:
             executed = alg * issue_factor
         bound_split = PEAK_F16_MFMA_TFLOPS / 3.0 * 1e3 / (GFLOP_PER_IMAGE_512 * scale)
-        bound_f23 = PEAK_F16_MFMA_TFLOPS / 2.0 * 1e3 / (GFLOP_PER_IMAGE_512 * scale)
         bound_f43 = PEAK_F16_MFMA_TFLOPS / 1.5 * 1e3 / (GFLOP_PER_IMAGE_512 * scale)
         traffic, traffic_src, tsrc = None, None, os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tsrc):      # HBM bytes/launch from the separate rocprofv3 --pmc passes (tools/profile_bench.sh)
@@ -445,9 +452,6 @@ def main():
                     "gflop_per_launch": round(fl / cnt / 1e9, 3), "algorithmic_tflops": round(alg, 2),
                     "algorithm": ("winograd F(%s,3x3) on the fp32 MFMA: the pipe executes gflop_per_launch / %.4g (mfma_issue_*); achieved and "
                                   "frac are the ALGORITHMIC rate (SURVEY 8d)" % ("4x4" if wfac == 4.0 else "2x2", wfac) if wino else
-                                  "winograd F(2,3) along x, every fp32 product as three half-precision MFMA products (fp32 accumulate): 12 instead of "
-                                  "18 k-steps per pixel pair; achieved and frac are the ALGORITHMIC rate against the dense 16-bit MFMA peak (SURVEY "
-                                  "8d); mfma_issue_* = 2 x that, what the pipe issues" if f23 and not f43 else
                                   "winograd F(4,3) along x, every fp32 product as three half-precision MFMA products (fp32 accumulate): 18 instead of "
                                   "36 k-steps per pixel quad; achieved and frac are the ALGORITHMIC rate against the dense 16-bit MFMA peak (SURVEY "
                                   "8d); mfma_issue_* = 1.5 x that, what the pipe issues" if f43 else
@@ -456,13 +460,13 @@ def main():
                                   if split else "direct"),
                     "executed_gflop_per_launch": round(fl / cnt / 1e9 * (issue_factor if split else 1.0 / wfac), 3),
                     "bound_images_per_s": {"direct": round(bound_direct, 1), "winograd_f2x2": round(bound_w2, 1), "winograd_f4x4": round(bound_w4, 1),
-                                           "direct_split_f16x3": round(bound_split, 1), "winograd_f23_split_f16x3": round(bound_f23, 1),
+                                           "direct_split_f16x3": round(bound_split, 1),
                                            "winograd_f43_split_f16x3": round(bound_f43, 1)},
-                    "path_frac_of_bound": round(value / n_ranks_seen / (bound_wino if wino else bound_f43 if f43 else bound_f23 if f23 else bound_split if split else bound_direct), 4)}
+                    "path_frac_of_bound": round(value / n_ranks_seen / (bound_wino if wino else bound_f43 if f43 else bound_split if split else bound_direct), 4)}
         if split:       # measured context for `frac` (it stays priced against the nominal peak)
-            roofline["frac_note"] = ("the fp32-exact product costs three 16-bit MFMAs (two per algorithmic product with F(2,3), 1.5 with F(4,3)), so "
+            roofline["frac_note"] = ("the fp32-exact product costs three 16-bit MFMAs (1.5 per algorithmic product with F(4,3) along x), so "
                                      "frac <= %s for this form; the fp32-MFMA bound of SURVEY 8d (157.3 TFLOP/s) is retired: achieved is %.2f x it"
-                                     % ("2/3" if f43 else "1/2" if f23 else "1/3", alg / PEAK_F32_MFMA_TFLOPS))
+                                     % ("2/3" if f43 else "1/3", alg / PEAK_F32_MFMA_TFLOPS))
             roofline["pipe_sustained_on_random_operands"] = {
                 "tflops": [1062.4, 1592.2], "source": "profiles/r03_bf16x3_microbench.txt part 3 (tools/micro/bf16x3.hip)",
                 "note": "a bare stream of v_mfma_f32_32x32x16_f16 on random half operands sustains 1.06-1.59 PFLOP/s on this GPU (the clock "
@@ -476,7 +480,7 @@ def main():
                       "kernels": "tile_stats_fold_kernel + adain_stream_nhwc_kernel: content statistics folded ONCE from the per-tile centred records "
                                  "that conv4_1's epilogue left (no statistics pass), then normalise + blend streamed once: one read, one write (HIP "
                                  "events around both launches of ccst_adain_tile_sums_f32; the streaming launch alone is ~22 us; "
-                                 "CCST_ADAIN_TILE_SUMS=0: the two-pass register-resident kernel of ccst_adain_f32)"}
+                                 "the stand-alone entry ccst_adain_f32 is the two-pass register-resident kernel)"}
 
     # ---- the same step with the two halves of the batch on two HIP streams (CCST_ADAIN_STREAMS=2, style._style_transfer_two_streams):
     # one half's tails, partly filled rounds and HBM-bound edge layers run under the other half's MFMA work.  Reported beside `value`,
@@ -505,7 +509,7 @@ def main():
         "warmup": args.warmup, "init_passes": INIT_PASSES, "ms_per_step": round(ms_per_step, 3),
         "median_ms_per_step": round(median_ms, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("f32 (3xf16 split products, f32 accumulate)" if any(k.startswith(("conv3x3_halo_split", "conv3x3_f23", "conv3x3_f43")) for k in per_kernel) else "f32"),
+        "dtype": ("f32 (3xf16 split products, f32 accumulate)" if any(k.startswith(("conv3x3_halo_split", "conv3x3_f43")) for k in per_kernel) else "f32"),
         "data": "synthetic",
         "config": {"workload": "CCST_OverallStyleTransfer PACS %dx%d batch=%d (encoder->AdaIN->decoder)" % (S, S, B),
                    "batch_per_gpu": B, "image_size": S, "sharding": "content batches per rank, no collective"},
@@ -542,11 +546,11 @@ def main():
         cpu_legs = world == 1 and not args.no_cpu_baseline
         # (no empty_cache(): the freed AdaIN blocks stay in the caching allocator -- returning them makes the first train steps
         #  re-hipMalloc their workspaces inside the timed region: 2870 instead of 3190 images/s over 25 steps)
-        sec = [bench_resnet.run(dev, world, steps=max(30, args.steps), warmup=5, graph="auto", cpu_baseline=cpu_legs)]      # config 4 (metric, 2nd half)
+        sec = [bench_resnet.run(dev, world, steps=max(30, steps_requested), warmup=5, graph="auto", cpu_baseline=cpu_legs)]      # config 4 (metric, 2nd half)
         if not args.no_extra:
             sec.append(bench_extra.stage1(dev, vgg31, A, world, rank, cpu=cpu_legs, vgg_w=vgg_w))                  # configs 0 / 1
             sec.append(bench_extra.single_mode(dev, vgg31, dec, A, world, rank))                                   # config 3
-            sec.append(bench_resnet.run(dev, world, steps=max(60, args.steps), warmup=5, batch=32, arch="resnet18", classes=2,
+            sec.append(bench_resnet.run(dev, world, steps=max(60, steps_requested), warmup=5, batch=32, arch="resnet18", classes=2,
                                         graph="auto", cpu_baseline=cpu_legs))                                     # config 5
             sec.append(bench_extra.eval_forward(dev, world, rank))                                                 # a12: test()
             if rank == 0:

@@ -157,6 +157,7 @@ def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False
     args = types.SimpleNamespace(mode="fedavg")
     comm_kw = {"scale_fn": scale_fn} if scale_fn is not None else {}
     gc.collect()        # before the warm-up, see below
+    gc.freeze()         # (what is alive now leaves the collector's generations: later passes scan new objects only)
     for _ in range(warmup):
         loss = step()
     if distributed:

@@ -56,13 +56,10 @@ _SIGNATURES = {
     "ccst_absmax_f32": [_P, c_int64, _P, _P],
     "ccst_absmax_batch_f32": [_P, c_int, _P, _P],
     "ccst_conv3x3_halo_split_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P, _P],
-    "ccst_pack_conv_weight_f23_f32": [_P, _P, c_int, c_int, c_int, _P, _P],
-    "ccst_conv3x3_f23_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P, _P],
     "ccst_pack_conv_weight_f43_f32": [_P, _P, c_int, c_int, c_int, _P, _P],
     "ccst_conv3x3_f43_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P, _P],
     "ccst_conv3x3_f43_workgroups": [c_int, c_int, c_int, c_int],
-    "ccst_conv3x3_f23_workgroups": [c_int, c_int, c_int, c_int],
-    "ccst_conv3x3_f23_tiles": [c_int, c_int, c_int],
+    "ccst_conv3x3_f43_tiles": [c_int, c_int, c_int],
     "ccst_conv3x3_halo_split_tiles": [c_int, c_int, c_int],
     "ccst_pack_conv_weight_halo_split_f32": [_P, _P, c_int, c_int, c_int, _P, c_int, _P],
     "ccst_pack_conv_weights_halo_split_batch_f32": [_P, c_int, _P],
@@ -70,10 +67,6 @@ _SIGNATURES = {
     "ccst_conv3x3_halo_narrow": [c_int, c_int, c_int, c_int],
     "ccst_wino_weight_floats": [c_int, c_int],
     "ccst_pack_conv_weight_wino_f32": [_P, _P, c_int, c_int, c_int, _P],
-    "ccst_wino4_weight_floats": [c_int, c_int],
-    "ccst_pack_conv_weight_wino4w_f32": [_P, _P, c_int, c_int, c_int, _P],
-    "ccst_conv3x3_wino4w_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P, _P],
-    "ccst_wino4w_spatial_tiles": [c_int, c_int, c_int],
     "ccst_pack_stem3_weight_f32": [_P, _P, _P, c_int, _P],
     "ccst_conv3x3_stem3_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P],
     "ccst_chan_sums_finalize_f32": [_P, c_int, c_int, c_int, _P, _P, _P],
@@ -85,7 +78,6 @@ _SIGNATURES = {
     "ccst_conv3x3_halo_stats_groups": [c_int, c_int, c_int],
     "ccst_conv2d_igemm_tile": [c_int, c_int, c_int, c_int, c_int],
     "ccst_pack_conv_weights_batch_f32": [_P, c_int, _P],
-    "ccst_conv3x3_smallco_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
     "ccst_conv3x3_zform_weight_floats": [c_int],
     "ccst_pack_conv_weight_zform_f32": [_P, _P, _P, c_int, c_int, _P],
     "ccst_conv3x3_zform_f32": [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P],
@@ -108,9 +100,7 @@ _SIGNATURES = {
     "ccst_adain_f32": [_P, _P, _P, c_int, c_float, _P, c_int, c_int, c_int, c_int, c_float, _P, c_int64, _P, _P],
     "ccst_chan_sums_f32": [_P, _P, _P, c_int, c_int, c_int, c_int, _P, c_int64, _P],
     "ccst_stats_workspace_bytes": [c_int, c_int, c_int],
-    "ccst_bn_train_fwd_f32": [_P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P, _P, _P, c_int64, c_int, _P, c_int, _P, c_int64, _P],
     "ccst_bn_eval_fwd_f32": [_P, _P, _P, _P, _P, c_float, _P, c_int, _P, c_int64, c_int, _P, _P],
-    "ccst_bn_train_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int64, c_int, _P, c_int64, _P],
     "ccst_bn_train_fwd_mask_f32": [_P, _P, _P, _P, _P, c_float, c_float, _P, c_int, _P, _P, _P, _P, c_int64, c_int, _P, c_int, _P, c_int64, _P, _P],
     "ccst_bn_train_bwd_mask_f32": [_P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int64, c_int, _P, c_int64, _P, _P],
     "ccst_bn_workspace_bytes": [c_int64, c_int],
@@ -131,7 +121,7 @@ _SIGNATURES = {
 }
 _RESTYPES = {"ccst_last_error": c_char_p, "ccst_stats_workspace_bytes": c_int64, "ccst_bn_workspace_bytes": c_int64,
              "ccst_wino_weight_floats": c_int64, "ccst_image_plan": c_int64,
-             "ccst_wino4_weight_floats": c_int64, "ccst_conv3x3_zform_weight_floats": c_int64}
+             "ccst_conv3x3_zform_weight_floats": c_int64}
 EXPORTS = tuple(_SIGNATURES)
 
 _lib = None
@@ -151,7 +141,7 @@ def load():
         fn = getattr(lib, name)   # AttributeError if the .so lacks a declared symbol
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, c_int)
-    if lib.ccst_abi_version() != 1:
+    if lib.ccst_abi_version() != 2:
         raise RuntimeError("ccst_amd: ABI version mismatch")
     _lib = lib
     return lib

@@ -411,7 +411,7 @@ int check_common(const void* x, int N, int C, int HW, int layout) {
 //   records: CENTRED (the half-piece conv kernels): (S, M2 about the slab's own mean, count, 0) per (tile, channel); the fold keeps
 //   s = sum of (x - pivot) and q = sum of (x - pivot)^2 about a pivot (the first slab's mean), assembled in fp64 from slab quantities
 //   that carry no cancellation: the variance is sum M2_i + sum n_i (mean_i - mean)^2 up to fp64 rounding however large |mean| / sigma.
-//   Raw (sum, sum of squares) pairs (ccst_conv3x3_wino4w_f32): mean = S / HW, unbiased variance = (Q - S mean) / (HW - 1) in fp64.
+//   Raw (sum, sum of squares) pairs (a caller's own fp32 producer; round 3's F(4x4) kernel wrote them): mean = S / HW, unbiased variance = (Q - S mean) / (HW - 1) in fp64.
 // (a workgroup = 16 channels of one image x 16 record lanes: lane kl folds records kl, kl + 16, ...; the lanes are then summed in
 //  fixed order through LDS -- one memory round trip and one barrier deep, bitwise reproducible)
 template <bool CENTRED>
@@ -573,7 +573,8 @@ extern "C" int ccst_adain_f32(const float* x, const float* style_mean, const flo
 
 // function.py:26-33 (+ the alpha blend) on an NHWC tensor x [N][HW][C] whose producer left per-tile channel sums: partials
 // [N * tiles_per_image][C][2] = (sum, sum of squares) of x over the pixels of spatial tile t, tiles of image n contiguous
-// (ccst_conv3x3_wino4w_f32's chan_sum_partials).  C a multiple of 64.  mean_out / std_out: NULL or [N*C] (the content statistics).
+// -- or [..][C][4] centred records (ccst_conv3x3_f43_f32's / ccst_conv3x3_halo_split_f32's chan_sum_partials).  C a multiple of 64.
+// mean_out / std_out: [N*C] each, REQUIRED: the content statistics, handed from the fold launch to the streaming launch.
 extern "C" int ccst_adain_tile_sums_f32(const float* x, const float* partials, int partial_floats, int tiles_per_image, const float* style_mean,
                                         const float* style_std, int style_per_n, float alpha, float* y, int N, int C, int HW, float eps,
                                         float* mean_out, float* std_out, uint32_t* y_absmax, void* stream) {
@@ -608,7 +609,7 @@ extern "C" int ccst_interp_blend_f32(const float* base, const float* content0, c
     return ccst_launch_status("interp_blend");
 }
 
-// Fold K per-tile (sum, sum of squares) pairs [K][C][2] (the statistics epilogue of ccst_conv3x3_wino4w_f32) into the per-channel totals.
+// Fold K per-tile records -- (sum, sum of squares) pairs [K][C][2] or the conv epilogues' centred quadruples [K][C][4] -- into the per-channel totals.
 extern "C" int ccst_chan_sums_finalize_f32(const float* partials, int partial_floats, int K, int C, float* sum, float* sqsum, void* stream) {
     CCST_REQUIRE(partials && sum && sqsum && K > 0 && C > 0, "chan_sums_finalize: bad args");
     CCST_REQUIRE(partial_floats == 2 || partial_floats == 4, "chan_sums_finalize: partials are [K][C][2] (sum, sum^2) or [K][C][4] (sum, M2, count, 0)");

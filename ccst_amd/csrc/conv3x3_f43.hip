@@ -1,8 +1,8 @@
 // 3x3 stride-1 "same" convolution as Winograd F(4,3) ALONG X ONLY, on half pieces on the 16-bit MFMA (round 5) -- the AdaIN encoder /
 // decoder layers with Cout >= 128 (style_transfer/AdaIN/net.py:6-36,38-69).
 //
-// Why this form.  The F(2,3) kernel (conv3x3_f23.hip) runs the MFMA pipe under the board's power limit: what moves it is fewer executed
-// MFMAs per output.  F(4,3) along x takes SIX transform positions per QUAD of output pixels where F(2,3) takes four per pair:
+// Why this form.  Round 4's F(2,3)-along-x kernel (retired in round 6; JOURNAL.md 3.11) ran the MFMA pipe under the board's power limit: what
+// moves it is fewer executed MFMAs per output.  F(4,3) along x takes SIX transform positions per QUAD of output pixels where F(2,3) takes four per pair:
 //     Y[y][4p + e] = sum_ky sum_q A[e][q] * ( V_q[y + ky][p] . U_q[ky] ),   V = B^T d (d = the six input pixels 4p-1 .. 4p+4),  U = G g
 //     B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
 //     G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
@@ -26,7 +26,7 @@
 //     (0,5): six -- 960 items per chunk, two per thread; the scale 2^kx rides in the coefficients;
 //   * the output transform needs all six positions: after the last chunk the groups exchange two partial sums per accumulator
 //     element through LDS -- group 0 finishes pixels 4p, 4p + 1, group 1 pixels 4p + 2, 4p + 3;
-//   * epilogue as in conv3x3_f23.hip: scale back, A^T, bias, ReLU, the 2x2 ceil max-pool, NHWC stores, max |y|, per-tile statistics.
+//   * epilogue: scale back, A^T, bias, ReLU, the 2x2 ceil max-pool, NHWC stores, max |y|, per-tile statistics.
 #include "common.h"
 
 namespace {
@@ -39,7 +39,7 @@ struct F43Args {
     const unsigned* xmax;
     const unsigned* wmax;
     unsigned* ymax;
-    float* stats;        // nullptr, or [ccst_conv3x3_f23_tiles(N,H,W)][Cout][4] per-(8x32-pixel tile, position group) (sum, M2 about the slab's own mean, count, 0)
+    float* stats;        // nullptr, or [ccst_conv3x3_f43_tiles(N,H,W)][Cout][4] per-(8x32-pixel tile, position group) (sum, M2 about the slab's own mean, count, 0)
     int N, H, W, Hs, Ws, Cin, Cout, CoutPad;
     int reflect, ups, relu;
     long long ysN;
@@ -90,8 +90,9 @@ __device__ __forceinline__ int reflect_g(int i, int n) {
     return min(max(i, 0), n - 1);
 }
 
-// One LDS-DMA piece (see conv3x3_f23.hip): 64 lanes x 16 bytes -> 1 KiB of LDS at the wave-uniform byte address lds_addr.  hipcc neither
-// counts it in its s_waitcnt bookkeeping nor waits for it: the loop's barrier at k-step 2 carries a hand-counted vmcnt.
+// One LDS-DMA piece: 64 lanes x 16 bytes from (uniform base + per-lane byte offset) to 1 KiB of LDS at the wave-uniform byte address
+// lds_addr (lane i lands at + 16 i).  hipcc neither counts it in its s_waitcnt bookkeeping nor waits for it: the loop's barrier at k-step
+// 2 carries a hand-counted vmcnt (cdna_hip_programming.md 5.7).
 __device__ __forceinline__ void glds16g(const void* sbase, unsigned voff, unsigned lds_addr) {
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -571,7 +572,10 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
                 }
             }
             if (p.stats != nullptr) {
-                // per-(tile, position group) channel statistics (sum, M2 about the slab's own mean, count): see conv3x3_f23.hip
+                // The per-(tile, position group) channel statistics the AdaIN step and stage 1 take instead of a pass over the features: (sum,
+                // M2, count) with M2 = the sum of squares ABOUT THE SLAB'S OWN MEAN -- a second pass over the values still in registers -- so
+                // that the consumer's variance (Chan's merge, fp64) has no E[x^2] - mean^2 cancellation however large |mean| / sigma is (raw
+                // fp32 sums of x^2 lose the variance once mean^2 >> var)
                 s1 += __shfl_xor(s1, 32, 64);
                 cnt += __shfl_xor(cnt, 32, 64);
                 const float mu = s1 / fmaxf(cnt, 1.f);
@@ -686,6 +690,9 @@ extern "C" int ccst_pack_conv_weight_f43_f32(const float* w_oihw, float* u, int 
     return ccst_launch_status("pack_weight_f43");
 }
 
+// Rows of chan_sum_partials: one per (image, 8x32-pixel tile, position group), an image's rows contiguous.
+extern "C" int ccst_conv3x3_f43_tiles(int N, int H, int W) { return N * ((H + 7) / 8) * ((W + G_TW - 1) / G_TW) * 2; }
+
 // Workgroups the kernel launches for a layer (8 x 32 pixels x 128 channels each, one per CU; Cout <= 64: x 64 channels, two per CU).
 extern "C" int ccst_conv3x3_f43_workgroups(int N, int H, int W, int Cout) {
     const int bn = Cout <= 64 ? 64 : 128;
@@ -711,7 +718,7 @@ static int launch_f43(F43Args& a, int N, int H, int W, int Cout, hipStream_t s) 
     return ccst_launch_status("conv3x3_f43");
 }
 
-// Same contract and statistics rows as ccst_conv3x3_f23_f32; the tile is 8 rows x 32 pixels x 128 channels, or for Cout <= 64 (no statistics)
+// Contract in include/ccst_hip.h; the tile is 8 rows x 32 pixels x 128 channels, or for Cout <= 64 (no statistics)
 // 8 rows x 32 pixels x 64 channels, four waves, two workgroups per CU (ccst_conv3x3_f43_workgroups).
 extern "C" int ccst_conv3x3_f43_f32(const float* x, const uint32_t* x_absmax, const float* u, const uint32_t* w_absmax, const float* bias,
                                     float* y, uint32_t* y_absmax, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags,

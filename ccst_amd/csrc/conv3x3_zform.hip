@@ -4,7 +4,7 @@
 //     y[co][p] = b[co] + sum_tap z[tap * Cout + co][p + tap],      z[j][q] = sum_c x[q][c] w[tap(j)][co(j)][c]
 //
 // Why this form.  The layer is 0.9 GFLOP per image against 67 MB of input: HBM-bound at 13 FLOP/B, and padding Cout = 3 to an MFMA tile
-// wastes 5-10x the math -- so the first kernel (conv_small.hip) is a VALU kernel, and measured 129 us for 403 MB (693 MB fetched: it
+// wastes 5-10x the math -- so the first kernel (a direct packed-fp32 VALU kernel, retired in round 6) measured 129 us for 403 MB (693 MB fetched: it
 // stages the halo 16 channels at a time, so every 128-byte line of the input is fetched in two passes that L2 does not hold together).
 // z has 27 rows for Cout = 3: padded to 32 it IS an MFMA shape with 16 % waste (v_mfma_f32_16x16x32_f16: M = 16 tap planes, N = 16
 // pixels, K = 32 channels), z of a pixel needs no neighbours -- every pixel's 256-byte record is read ONCE, whole, straight into the B
@@ -18,7 +18,7 @@
 //   * z planes in LDS [27 + 1][356] (the planes past 9 Cout of the padded M tile land in a plane nobody reads, so the stores carry no
 //     predicate; every address of the loop is an instruction immediate), then each thread sums 9 taps x Cout for one pixel: lanes
 //     along x, 128-byte NCHW row stores; the power-of-two scale comes off after the sum.
-//   Measured (B=6, 512x512, 64 -> 3): 93-96 us against 133-137 for conv_small.hip on the same boxes; a plain linear read of the same
+//   Measured (B=6, 512x512, 64 -> 3): 93-96 us against 133-137 for that VALU kernel on the same boxes; a plain linear read of the same
 //   403 MB (absmax_kernel) takes 81 us there, a fill 60.  History / timing experiments: one workgroup per tile 98-101 us (2 / 3 / 4
 //   groups of loads in flight 99 / 100 / 98; 16-row tiles at two workgroups per CU 115; without the MFMAs and the splits 94; without
 //   the shifted sum 97; without both and with every load instruction 1 KB contiguous (wrong data) 90); persistent workgroups -5 us,
@@ -271,7 +271,7 @@ __global__ void pack_weight_zform_kernel(const float* __restrict__ w, const unsi
 // Floats of the packed weight of ccst_conv3x3_zform_f32.
 extern "C" int64_t ccst_conv3x3_zform_weight_floats(int Cin) { return Cin % 32 == 0 && Cin > 0 ? (int64_t)2 * (Cin / 32) * 2 * 64 * 4 : 0; }
 
-// w_tap_co_ci: [3][3][Cout][Cin] (the layout ccst_conv3x3_smallco_f32 takes); w_absmax: its |max| words (ccst_absmax_f32).
+// w_tap_co_ci: [3][3][Cout][Cin]; w_absmax: its |max| words (ccst_absmax_f32).
 extern "C" int ccst_pack_conv_weight_zform_f32(const float* w_tap_co_ci, const unsigned* w_absmax, float* packed, int Cin, int Cout,
                                                void* stream) {
     CCST_REQUIRE(w_tap_co_ci && w_absmax && packed, "pack_conv_weight_zform: null pointer");
@@ -282,8 +282,8 @@ extern "C" int ccst_pack_conv_weight_zform_f32(const float* w_tap_co_ci, const u
     return ccst_launch_status("pack_conv_weight_zform");
 }
 
-// x: NHWC [N,H,W,Cin], Cin 32 or 64, with its |max| words; y: NCHW [N,Cout,H,W], Cout 1..3.  Same result contract as
-// ccst_conv3x3_smallco_f32 (fp32 products to 2^-22 relative, fp32 accumulation).
+// x: NHWC [N,H,W,Cin], Cin 32 or 64, with its |max| words; y: NCHW [N,Cout,H,W], Cout 1..3.  Result contract:
+// fp32 products to 2^-22 relative, fp32 accumulation.
 extern "C" int ccst_conv3x3_zform_f32(const float* x, const unsigned* x_absmax, const float* w_packed, const unsigned* w_absmax,
                                       const float* bias, float* y, int N, int H, int W, int Cin, int Cout, int reflect, int relu,
                                       void* stream) {

@@ -833,14 +833,6 @@ extern "C" int ccst_bn_train_fwd_mask_f32(const float* x, const float* gamma, co
     return ccst_launch_status("bn_train_fwd");
 }
 
-extern "C" int ccst_bn_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                     float momentum, float eps, const float* residual, int relu, float* y, float* save_mean,
-                                     float* save_invstd, int64_t M, int C, const float* stats_in, int stats_groups, void* ws,
-                                     int64_t ws_bytes, void* stream) {
-    return ccst_bn_train_fwd_mask_f32(x, gamma, beta, running_mean, running_var, momentum, eps, residual, relu, y, nullptr, save_mean,
-                                      save_invstd, M, C, stats_in, stats_groups, ws, ws_bytes, nullptr, stream);
-}
-
 extern "C" int ccst_bn_eval_fwd_f32(const float* x, const float* gamma, const float* beta, const float* running_mean,
                                     const float* running_var, float eps, const float* residual, int relu, float* y, int64_t M, int C,
                                     uint32_t* y_absmax, void* stream) {
@@ -913,14 +905,6 @@ extern "C" int ccst_bn_train_bwd_partials_f32(const float* dy, const float* x, c
     hipLaunchKernelGGL((bn_bwd_apply_kernel<0>), dim3(bn_grid(total4, C, 2)), dim3(TPB), 0, st, dy, x, nullptr, gamma, nullptr, save_mean, save_invstd,
                        sums, 0, dx, nullptr, total4, C, 1.f / (float)M, nullptr, dx_absmax);
     return ccst_launch_status("bn_train_bwd_partials");
-}
-
-extern "C" int ccst_bn_train_bwd_f32(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
-                                     const float* save_mean, const float* save_invstd, int relu, float* dx, float* d_residual,
-                                     float* dgamma, float* dbeta, int accumulate, int64_t M, int C, void* ws, int64_t ws_bytes,
-                                     void* stream) {
-    return ccst_bn_train_bwd_mask_f32(dy, x, y, nullptr, gamma, beta, save_mean, save_invstd, relu, dx, d_residual, dgamma, dbeta, accumulate,
-                                      M, C, ws, ws_bytes, nullptr, stream);
 }
 
 extern "C" int ccst_bn_relu_maxpool_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean,

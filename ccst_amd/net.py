@@ -118,11 +118,10 @@ def _compile(mods):
             elif conv.in_channels <= 4:
                 wv, kwp = ops.stem_virtual_weight(conv.weight.detach())
                 steps.append(_Step("stem", pc=ops.pack_conv_weight(wv, conv.bias), kw=3, kwp=kwp, pad=1, reflect=True, relu=relu))
-            elif conv.out_channels <= 4 and conv.in_channels % 16 == 0 and not pending_up:
-                # image edge of the decoder (net.py:35): direct VALU kernel writing NCHW
+            elif ops.zform_wanted(conv.in_channels, conv.out_channels) and not pending_up:
+                # image edge of the decoder (net.py:35): tap planes on the 16-bit MFMA, NCHW out (conv3x3_zform.hip)
                 w_small = conv.weight.detach().permute(2, 3, 0, 1).contiguous()
-                steps.append(_Step("smallco", w_small=w_small,
-                                   pz=ops.PackedZform(w_small) if ops.zform_wanted(conv.in_channels, conv.out_channels) else None,
+                steps.append(_Step("smallco", w_small=w_small, pz=ops.PackedZform(w_small),
                                    b_small=None if conv.bias is None else conv.bias.detach().contiguous(),
                                    cout=conv.out_channels, reflect=True, relu=relu))
             else:
@@ -281,10 +280,9 @@ def _run_steps(steps, x, sums_box):
         if s.kind == "smallco":
             if cur.shape[-1] % 16 != 0:
                 cur = ops.from_api(ops.to_api(cur[..., :C]), cpad=16)
-            if s.pz is not None and cur.shape[-1] == s.w_small.shape[-1]:
-                out = ops.conv3x3_zform_nchw(cur, s.pz, s.b_small, s.cout, reflect=s.reflect, relu=s.relu, x_absmax=amax)
-            else:
-                out = ops.conv3x3_smallco_nchw(cur, s.w_small, s.b_small, s.cout, reflect=s.reflect, relu=s.relu)
+            if cur.shape[-1] != s.w_small.shape[-1]:
+                raise RuntimeError("ccst_amd.net: the image-edge conv expects %d channels, got %d" % (s.w_small.shape[-1], cur.shape[-1]))
+            out = ops.conv3x3_zform_nchw(cur, s.pz, s.b_small, s.cout, reflect=s.reflect, relu=s.relu, x_absmax=amax)
             cur, api, C, amax = None, out, s.cout, None
             continue
         if s.kind == "conv":
@@ -292,7 +290,7 @@ def _run_steps(steps, x, sums_box):
                 cur = ops.from_api(ops.to_api(cur[..., :C]), cpad=16)
             split = s.stride == 1 and s.pad == 1 and not s.out_nchw and ops.halo_split_wanted(s.pc) and cur.shape[-1] == s.pc.cin
             ymax = ops.absmax_words(x.device) if split and split_next(si) else None
-            if sums_box is not None and s is steps[-1] and ops.wino4w_sums_ok(s.pc, s.stride, s.pad, s.pool, s.out_nchw):
+            if sums_box is not None and s is steps[-1] and ops.conv_sums_ok(s.pc, s.stride, s.pad, s.pool, s.out_nchw):
                 out, part = ops.conv2d_nhwc(cur, s.pc, stride=s.stride, pad=s.pad, reflect=s.reflect, relu=s.relu, pool=s.pool,
                                             ups=s.ups, chan_sums=True, x_absmax=amax, y_absmax=ymax)
                 sums_box.append(part)

@@ -180,8 +180,8 @@ def conv_bn(conv, bn, x, residual=None, relu=False, sink_in=None, sink_out=None,
     return bn(conv(x), residual=residual, relu=relu)
 
 
-USE_GRAD_SINK = os.environ.get("CCST_GRAD_SINK", "1") != "0"
-FUSED_STEM = os.environ.get("CCST_FUSED_STEM", "1") != "0"      # bn1 + relu + maxpool of the stem as one op in training
+USE_GRAD_SINK = True
+FUSED_STEM = True      # bn1 + relu + maxpool of the stem as one op in training
 
 
 def _plain_reader(x):

@@ -15,7 +15,7 @@ from ._lib import CcstConvDesc, check, ptr, stream_ptr
 
 _WS = {}
 import os as _os
-BN_BYTE_MASK = _os.environ.get("CCST_BN_BYTE_MASK", "1") != "0"      # ReLU mask of the residual BNs as bytes (0: read the saved output)
+BN_BYTE_MASK = True      # ReLU mask of the residual BNs as bytes (0: read the saved output)
 
 
 def _workspace(nbytes, device):
@@ -416,8 +416,8 @@ class MaskLink(object):
         self.bn_x, self.bn_save, self.partials = bn_x, bn_save, None
 
 
-MASK_LINK = _os.environ.get("CCST_MASK_LINK", "1") != "0"
-MASK_LINK_STATS = _os.environ.get("CCST_MASK_LINK_STATS", "1") != "0"      # BN-backward partial sums from that epilogue too
+MASK_LINK = True
+MASK_LINK_STATS = True      # BN-backward partial sums from that epilogue too
 
 
 def lib_groups(M, cout, cin):

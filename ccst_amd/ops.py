@@ -26,14 +26,14 @@ def bump_weights_epoch():
     WEIGHTS_EPOCH += 1
 
 
-# 3x3 reflect-pad convs go through the halo-in-LDS kernel (conv3x3_halo.hip); CCST_CONV_HALO=0 keeps the gather kernel.
-USE_HALO = os.environ.get("CCST_CONV_HALO", "1") != "0"
+# 3x3 reflect-pad convs go through the halo-in-LDS kernel (conv3x3_halo.hip); False keeps the gather kernel (a test compares the two).
+USE_HALO = True
 # The zero-padded 3x3 stride-1 convs of the ResNet trunk (forward with BN statistics, backward-data with flipped taps, y +=)
 # CAN run on the halo kernel too (ccst_conv3x3_halo_train_f32) when its 8x16-pixel tiles cover the map well enough (56x56:
 # 88 %, 28x28 / 14x14: 77 %; 7x7 would be 38 %).  Measured: per layer 97-105 TF vs 90-100 TF on the gather kernel, but
 # the same step time (ResNet50 2837 vs 2839 img/s, ResNet18 within noise) -- short K loops and tile waste eat the
-# advantage -- so the gather kernel stays the default; CCST_CONV_HALO_ZERO=1 switches.
-HALO_ZERO_PAD = os.environ.get("CCST_CONV_HALO_ZERO", "0") != "0"
+# advantage -- so the gather kernel stays the default (the fp32 train form remains the tests' reference of the half-piece one).
+HALO_ZERO_PAD = False
 HALO_MIN_COVER = 0.7
 
 
@@ -44,8 +44,8 @@ def halo_train_ok(H, W, cin, cout):
 
 
 # ResNet trunk: 3x3 stride-1 convs (forward with BN statistics, backward-data) on the Winograd kernel when its 8x16-pixel tiles
-# cover the map well enough; CCST_RESNET_WINO=0 keeps the gather kernel.
-RESNET_WINO = os.environ.get("CCST_RESNET_WINO", "1") != "0"
+# cover the map well enough (False: the gather kernel).
+RESNET_WINO = True
 RESNET_WINO_COVER = 0.7
 
 
@@ -287,30 +287,24 @@ class _PackOrder(object):
 class PackedConv(object):
     """A conv weight in the layouts the kernels read (+ optional bias).  `w`: [kh*kw][K/4][n_pad][4] for the implicit-GEMM kernels.
     A weight packed with wino=... (the 3x3 layers of the AdaIN plan) keeps the OIHW source and builds each kernel's layout ON FIRST USE
-    -- `u4` (F(4x4), 64-channel workgroups), `wsplit` (direct kernel on half pieces), `uf23` (F(2,3) on half pieces), `wabsmax` (the weight's |max| words: the half-piece kernels derive their power-of-two weight scale from them on the
-    device) -- so a plan holds ONE packed copy per layer, that of the kernel it runs (all four were built before).
-    The can_* predicates say which layouts exist for this weight without building anything."""
+    -- `uf43` (F(4,3) along x on half pieces), `wsplit` (direct kernel on half pieces), `wabsmax` (the weight's |max| words: the
+    half-piece kernels derive their power-of-two weight scale from them on the device), `w` (the fp32-MFMA kernels' layout) -- so a
+    plan holds ONE packed copy per layer, that of the kernel it runs.  can_split() says whether the half-piece layouts exist for
+    this weight without building anything."""
 
     def __init__(self, w, bias, cin, cout, kh, kw, k_pad, n_pad, transpose, src=None, wino=False):
         self._w, self.bias, self.cin, self.cout, self.kh, self.kw = w, bias, cin, cout, kh, kw
         self.k_pad, self.n_pad, self.transpose = k_pad, n_pad, transpose
         self.src, self.wino = src, wino          # OIHW source (kept only for lazily packed weights) and the wino= argument
-        self.u4_pad = round_up(cout, 64)
-        self._u4 = self._wsplit = self._wabsmax = self._uf23 = self._uf43 = None
+        self._wsplit = self._wabsmax = self._uf43 = None
         self._order = _PackOrder()
 
     # ---- which layouts exist (no packing) ----
     def lazy3x3(self):             # a 3x3 forward weight packed with wino=...: its kernel's layout is built on first use
         return self.src is not None and bool(self.wino) and self.kh == 3 and self.kw == 3 and not self.transpose
 
-    def can_wino4(self):
-        return self.lazy3x3() and (self.wino == 4 or (WINO_F4 and self.cin >= WINO_F4_MIN_CIN))
-
-    def can_wino4w(self):          # the 64-channel kernel peels a first and a last 16-channel chunk
-        return self.can_wino4() and self.cin >= 32
-
     def can_split(self):
-        return self.can_wino4() and HALO_SPLIT != "0" and self.cin % 16 == 0
+        return self.lazy3x3() and HALO_SPLIT != "0" and self.cin % 16 == 0
 
     # ---- the layouts, built on first use ----
     def _lazy(self, slot, nfloats, fn, what, *tail):
@@ -336,12 +330,6 @@ class PackedConv(object):
         return self._w
 
     @property
-    def u4(self):
-        lib = _lib.load()
-        return self._lazy("_u4", lib.ccst_wino4_weight_floats(self.cin, self.u4_pad), lib.ccst_pack_conv_weight_wino4w_f32,
-                          "pack_conv_weight_wino4w", self.u4_pad) if self.can_wino4w() else None
-
-    @property
     def wabsmax(self):
         if self._wabsmax is None and self.can_split():
             self._wabsmax = absmax(self.src)
@@ -356,24 +344,16 @@ class PackedConv(object):
                           self.n_pad, ptr(self.wabsmax), 0) if self.can_split() else None
 
     @property
-    def uf23(self):
-        return self._lazy("_uf23", 12 * self.cin * self.n_pad, _lib.load().ccst_pack_conv_weight_f23_f32, "pack_conv_weight_f23",
-                          self.n_pad, ptr(self.wabsmax)) if self.can_split() else None
-
-    @property
     def uf43(self):
         return self._lazy("_uf43", 18 * self.cin * self.n_pad, _lib.load().ccst_pack_conv_weight_f43_f32, "pack_conv_weight_f43",
                           self.n_pad, ptr(self.wabsmax)) if self.can_split() else None
 
 
 # The 3x3 stride-1 layers of the AdaIN encoder / decoder keep their OIHW weight and pack the layout of the kernel they run on first
-# use (PackedConv).  CCST_CONV_WINO = 4 (default): the half-piece kernels (CCST_HALO_SPLIT / CCST_CONV_F23 below), or with
-# CCST_HALO_SPLIT=0 the fp32-MFMA F(4x4,3x3) kernel (conv3x3_wino4w.hip, 2.25 multiplies per output); 0: the direct fp32-MFMA halo
-# kernel everywhere (9 per output).  (The F(2x2) AdaIN form and the 32-channel F(4x4) kernel of rounds 1-2 were retired in round 5.)
-_WINO_MODE = os.environ.get("CCST_CONV_WINO", "4")
-USE_WINO = _WINO_MODE != "0"
-WINO_F4 = _WINO_MODE == "4"
-WINO_F4_MIN_CIN = 16
+# use (PackedConv): the half-piece kernels (CCST_HALO_SPLIT below), or with CCST_HALO_SPLIT=0 the direct fp32-MFMA halo kernel (the
+# fp32 reference of the tests).  (Retired: F(2x2) / 32-channel F(4x4) in round 5; the 64-channel F(4x4) fp32 kernel and F(2,3) along x in
+# round 6 -- no default path selected them; JOURNAL.md 3.06-3.07, 3.11 keep their measurements.)
+USE_WINO = True          # pack_conv_weight(..., wino=USE_WINO): the AdaIN plan's 3x3 weights are packed lazily
 # The direct 3x3 kernel with every fp32 product as three products of IEEE-half pieces on the 16-bit MFMA (conv3x3_halo.hip SPLIT form:
 # x = hi + lo, 22 significant bits, fp32 accumulation; 5.3x the fp32 MFMA's rate at about its accuracy -- 1e-6 of max |y| per layer, 5x
 # tighter than F(4x4) Winograd in fp32) runs every 3x3 layer of the AdaIN plan by default (CCST_HALO_SPLIT=2).  Measured per layer at B=6
@@ -383,7 +363,7 @@ WINO_F4_MIN_CIN = 16
 # (CCST_HALO_SPLIT=1: SPLIT where Cin != Cout) 1369-1428 -- the F(4x4) launches run 2-6 % slower between SPLIT launches on some boxes.
 # Range: both operands are scaled by powers of two derived ON THE DEVICE from per-tensor |max| words (absmax_words / absmax below): the
 # producing kernel's epilogue leaves max |y| (conv3x3_halo_split, conv3x3_stem3_nchw, the AdaIN kernels), the consumer reads it -- any
-# finite fp32 magnitude is safe, nothing synchronises.  CCST_HALO_SPLIT=0: F(4x4) everywhere.
+# finite fp32 magnitude is safe, nothing synchronises.  CCST_HALO_SPLIT=0: the direct fp32-MFMA kernel everywhere.
 HALO_SPLIT = os.environ.get("CCST_HALO_SPLIT", "2")
 ABSMAX_WORDS = 64        # CCST_ABSMAX_WORDS of include/ccst_hip.h
 
@@ -449,16 +429,13 @@ def halo_split_wanted(pc):
     return HALO_SPLIT == "2" or pc.cin != pc.cout
 
 
-# Winograd F(2,3) along x on the half pieces (conv3x3_f23.hip): 2.0 instead of 3.0 executed MFMA FLOPs per algorithmic FLOP, for the
-# layers of the plan with Cout >= 128 whose grid of 8x32-pixel x 128-channel workgroups (ONE per CU: 120 KB of LDS) fills whole rounds
-# of the chip; the others stay on the direct kernel.  CCST_CONV_F23=0: direct everywhere.
-F23 = os.environ.get("CCST_CONV_F23", "1") != "0"
-F23_MIN_TILES = int(os.environ.get("CCST_F23_MIN_TILES", "30"))      # per image (8 x 32 pixels x 128 / 64 channels each)
-F23_MIN_COUT = 128      # (the Cout = 64 layers padded to its 128-channel tile measured slower than the direct half-piece kernel)
-F23_FORCE = os.environ.get("CCST_CONV_F23", "1") == "2"       # every Cout >= 128 layer whatever its grid (tests: small images)
-# ... and F(4,3) along x (conv3x3_f43.hip: 1.5 executed FLOPs per algorithmic one) in the F(2,3) kernel's place.  CCST_CONV_F43=0: F(2,3).
+# Winograd F(4,3) along x on the half pieces (conv3x3_f43.hip: 1.5 instead of 3.0 executed MFMA FLOPs per algorithmic FLOP) for the layers
+# of the plan whose grid of 8x32-pixel workgroups (x 128 channels, ONE per CU; Cout <= 64: x 64 channels, two per CU) is worth a launch;
+# the others stay on the direct half-piece kernel.  CCST_CONV_F43=0: direct everywhere; 2: F(4,3) whatever the grid (tests: small images).
 F43 = os.environ.get("CCST_CONV_F43", "1") != "0"
-F43_MIN_COUT = int(os.environ.get("CCST_F43_MIN_COUT", "64"))      # (128: the Cout = 64 layers stay on the direct half-piece kernel)
+F43_FORCE = os.environ.get("CCST_CONV_F43", "1") == "2"
+F43_MIN_TILES = 30      # per image
+F43_MIN_COUT = 64       # (128 would leave the Cout = 64 layers on the direct half-piece kernel: 852 against 674 us for the three)
 _N_CU = {}
 
 
@@ -469,27 +446,21 @@ def num_cus(device):
     return _N_CU[idx]
 
 
-def f23_wanted(pc, N, H, W, device):
-    """Run this 3x3 layer (conv extent H x W) on the F(2,3) / F(4,3) kernel?  (F(4,3) has a 64-channel tile: the Cout = 64 layers too.)
-    The rule looks at ONE image's tiles, never at the batch size: a sample must not change kernels (and with them its rounding, at the
-    1e-5 level after sixteen layers) with the number of its batch-mates."""
-    min_cout = F43_MIN_COUT if F43 else F23_MIN_COUT
-    if not (F23 and halo_split_wanted(pc)) or pc.cout < min_cout or H * W * pc.cin >= 2 ** 30:
+def f43_wanted(pc, N, H, W, device):
+    """Run this 3x3 layer (conv extent H x W) on the F(4,3) kernel?  The rule looks at ONE image's tiles, never at the batch size: a
+    sample must not change kernels (and with them its rounding, at the 1e-5 level after sixteen layers) with the number of its
+    batch-mates."""
+    if not (F43 and halo_split_wanted(pc)) or pc.cout < F43_MIN_COUT or H * W * pc.cin >= 2 ** 30:
         return False
-    if F23_FORCE:
+    if F43_FORCE:
         return True
     # (the bench's smallest layer -- 64 x 64, 512 -> 256: 32 tiles per image, 0.75 rounds of the chip at B = 6 -- is x1.3 the direct kernel)
-    lib = _lib.load()
-    return int((lib.ccst_conv3x3_f43_workgroups if F43 else lib.ccst_conv3x3_f23_workgroups)(1, H, W, pc.cout)) >= F23_MIN_TILES
+    return int(_lib.load().ccst_conv3x3_f43_workgroups(1, H, W, pc.cout)) >= F43_MIN_TILES
 
 
 def conv3x3_f43(x, pc, flags, sums=False, x_absmax=None, y_absmax=None):
-    """3x3 stride-1 pad-1 conv as Winograd F(4,3) along x on half pieces (conv3x3_f43.hip); same arguments and results as conv3x3_f23."""
-    return conv3x3_f23(x, pc, flags, sums=sums, x_absmax=x_absmax, y_absmax=y_absmax, form=4)
-
-
-def conv3x3_f23(x, pc, flags, sums=False, x_absmax=None, y_absmax=None, form=2):
-    """3x3 stride-1 pad-1 conv as Winograd F(2,3) (form=4: F(4,3)) along x on half pieces; same arguments and results as conv3x3_halo_split."""
+    """3x3 stride-1 pad-1 conv as Winograd F(4,3) along x on half pieces (conv3x3_f43.hip); same arguments and results as
+    conv3x3_halo_split (sums: per-(tile, position group) centred records [ccst_conv3x3_f43_tiles, Cout, 4])."""
     N, Hs, Ws, Cx = x.shape
     if x_absmax is None:
         x_absmax = absmax(x)
@@ -502,19 +473,18 @@ def conv3x3_f23(x, pc, flags, sums=False, x_absmax=None, y_absmax=None, form=2):
     if sums:
         if pool:
             raise ValueError("ccst_amd.ops: the statistics epilogue is of the un-pooled output")
-        part = torch.empty((int(lib.ccst_conv3x3_f23_tiles(N, Hi, Wi)), pc.cout, 4), device=x.device, dtype=torch.float32)
-    fn, name = (lib.ccst_conv3x3_f43_f32, "conv3x3_f43") if form == 4 else (lib.ccst_conv3x3_f23_f32, "conv3x3_f23")
-    args = (ptr(x), ptr(x_absmax), ptr(pc.uf43 if form == 4 else pc.uf23), ptr(pc.wabsmax), ptr(pc.bias), ptr(out), ptr(y_absmax), N, Hi, Wi, Cx,
+        part = torch.empty((int(lib.ccst_conv3x3_f43_tiles(N, Hi, Wi)), pc.cout, 4), device=x.device, dtype=torch.float32)
+    args = (ptr(x), ptr(x_absmax), ptr(pc.uf43), ptr(pc.wabsmax), ptr(pc.bias), ptr(out), ptr(y_absmax), N, Hi, Wi, Cx,
             pc.cout, pc.n_pad, flags, ptr(part), stream_ptr())
     if TIMING is None:
-        check(fn(*args), name)
+        check(lib.ccst_conv3x3_f43_f32(*args), "conv3x3_f43")
     else:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(fn(*args), name)
+        check(lib.ccst_conv3x3_f43_f32(*args), "conv3x3_f43")
         e1.record()
-        # (the kernel buckets of bench.py = rocprofv3's kernel names: F(4,3)'s 64-channel tile is an instantiation of its own)
-        TIMING.append(("%s_kernel<%s%s>" % (name, "pool" if pool else "nopool", ",half" if form == 4 and pc.cout <= 64 else ""), 2.0 * N * Hi * Wi * pc.cout * pc.cin * 9, e0, e1,
+        # (the kernel buckets of bench.py = rocprofv3's kernel names: the 64-channel tile is an instantiation of its own)
+        TIMING.append(("conv3x3_f43_kernel<%s%s>" % ("pool" if pool else "nopool", ",half" if pc.cout <= 64 else ""), 2.0 * N * Hi * Wi * pc.cout * pc.cin * 9, e0, e1,
                        "n%d %dx%d cin%d cout%d taps3x3 flags%d" % (N, Hi, Wi, pc.cin, pc.cout, flags)))
     return (out, part) if sums else out
 
@@ -551,14 +521,10 @@ def conv3x3_halo_split(x, pc, flags, sums=False, x_absmax=None, y_absmax=None):
     return (out, part) if sums else out
 
 
-def wino4_ok(cin, cout, H, W):
-    return WINO_F4 and cin % 16 == 0 and cin >= WINO_F4_MIN_CIN
-
-
 def pack_conv_weight(w_oihw, bias=None, transpose=False, out=None, wino=False):
     """OIHW checkpoint tensor -> PackedConv.  transpose=True builds the backward-data operand.  wino (True or 4; 3x3 weights):
     nothing is packed here -- the PackedConv keeps the source and builds the layout of whichever kernel ends up running the layer
-    (the implicit-GEMM one, F(2x2), F(4x4), the half-piece direct kernel, F(2,3) on half pieces) on first use."""
+    (the fp32-MFMA one, the half-piece direct kernel, F(4,3) on half pieces) on first use."""
     _require_cuda(w_oihw, "weight")
     w = w_oihw.contiguous()
     cout, cin, kh, kw = w.shape
@@ -592,37 +558,6 @@ def pack_conv_weight_split(w_oihw, w_absmax, transpose=False, out=None):
     return out
 
 
-def conv3x3_wino4(x, pc, flags=0, sums=False):
-    """3x3 stride-1 pad-1 conv on the F(4x4,3x3) kernel (64 output channels per workgroup); x NHWC [N,Hs,Ws,Cin], pc packed with
-    wino=4, Cin >= 32.  flags: CONV_* bits.  sums=True (no pool): also returns the per-tile (sum, sum of squares) partials
-    [tiles, Cout, 2] of the output from the conv epilogue -- fold them with chan_sums_finalize()."""
-    N, Hs, Ws, Cx = x.shape
-    ups, pool = bool(flags & CONV_UPS2), bool(flags & CONV_POOL2)
-    Hi, Wi = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
-    oh, ow = ((Hi + 1) // 2, (Wi + 1) // 2) if pool else (Hi, Wi)
-    out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
-    if not pc.can_wino4w():
-        raise ValueError("ccst_amd.ops: the F(4x4) kernel needs a 3x3 weight packed with wino=4 and Cin >= 32")
-    lib = _lib.load()
-    part = None
-    if sums:
-        if pool:
-            raise ValueError("ccst_amd.ops: the statistics epilogue is that of the un-pooled output")
-        part = torch.empty((int(lib.ccst_wino4w_spatial_tiles(N, Hi, Wi)), pc.cout, 2), device=x.device, dtype=torch.float32)
-    fn, args = lib.ccst_conv3x3_wino4w_f32, (ptr(x), ptr(pc.u4), ptr(pc.bias), ptr(out), N, Hi, Wi, Cx, pc.cout, pc.u4_pad, flags, ptr(part),
-                                             stream_ptr())
-    if TIMING is None:
-        check(fn(*args), "conv3x3_wino4")
-    else:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(fn(*args), "conv3x3_wino4")
-        e1.record()
-        TIMING.append(("conv3x3_wino4w_kernel<%s>" % ("pool" if pool else "nopool"), 2.0 * N * Hi * Wi * pc.cout * pc.cin * 9, e0, e1,
-                       "n%d %dx%d cin%d cout%d taps3x3 flags%d" % (N, Hi, Wi, pc.cin, pc.cout, flags)))
-    return (out, part) if sums else out
-
-
 def chan_sums_finalize(partials):
     """[K, C, 2] per-tile (sum, sum of squares) pairs -> ([1,C,1,1] sum, [1,C,1,1] sqsum), folded in fp64 in a fixed order."""
     K, C, F = partials.shape
@@ -639,12 +574,11 @@ def chan_sums_finalize(partials):
     return s, q
 
 
-def wino4w_sums_ok(pc, stride, pad, pool, out_nchw):
-    """Can this conv leave the per-channel sums of its output in its epilogue (the 64-channel F(4x4) kernel or the direct kernel's
-    SPLIT form, un-pooled)?"""
+def conv_sums_ok(pc, stride, pad, pool, out_nchw):
+    """Can this conv leave the per-channel records of its output in its epilogue (the half-piece kernels, un-pooled)?"""
     if stride != 1 or pad != 1 or pool or out_nchw or pc.kh != 3 or pc.kw != 3:
         return False
-    return halo_split_wanted(pc) or (pc.can_wino4w() and wino4_ok(pc.cin, pc.cout, 0, 0))
+    return halo_split_wanted(pc)
 
 
 def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, ups=False, out_nchw=False, out=None,
@@ -684,19 +618,16 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
     if not reflect and pc.kh == 3 and pc.kw == 3 and stride == 1 and pad == 1 and not (relu or pool or ups or out_nchw) \
             and out is None and pc.bias is None and halo_train_ok(Hi, Wi, Cx, pc.cout):
         return conv3x3_halo_train(x, pc, want_stats=want_stats)
-    if chan_sums:       # (the caller checked wino4w_sums_ok)
-        if halo_split_wanted(pc) and Cx == pc.cin and not pool:
-            if f23_wanted(pc, N, Hi, Wi, x.device):
-                return conv3x3_f23(x, pc, flags, sums=True, x_absmax=x_absmax, y_absmax=y_absmax, form=4 if F43 else 2)
-            return conv3x3_halo_split(x, pc, flags, sums=True, x_absmax=x_absmax, y_absmax=y_absmax)
-        return conv3x3_wino4(x, pc, flags, sums=True)
+    if chan_sums:       # (the caller checked conv_sums_ok)
+        if not (halo_split_wanted(pc) and Cx == pc.cin and not pool):
+            raise ValueError("ccst_amd.ops: this conv cannot leave channel records (conv_sums_ok)")
+        if f43_wanted(pc, N, Hi, Wi, x.device):
+            return conv3x3_f43(x, pc, flags, sums=True, x_absmax=x_absmax, y_absmax=y_absmax)
+        return conv3x3_halo_split(x, pc, flags, sums=True, x_absmax=x_absmax, y_absmax=y_absmax)
     if halo_split_wanted(pc) and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats and Cx == pc.cin:
-        if f23_wanted(pc, N, Hi, Wi, x.device):
-            return conv3x3_f23(x, pc, flags, x_absmax=x_absmax, y_absmax=y_absmax, form=4 if F43 else 2)
+        if f43_wanted(pc, N, Hi, Wi, x.device):
+            return conv3x3_f43(x, pc, flags, x_absmax=x_absmax, y_absmax=y_absmax)
         return conv3x3_halo_split(x, pc, flags, x_absmax=x_absmax, y_absmax=y_absmax)
-    if pc.can_wino4w() and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats \
-            and wino4_ok(pc.cin, pc.cout, Hi, Wi):
-        return conv3x3_wino4(x, pc, flags)
     if USE_HALO and reflect and pc.kh == 3 and pc.kw == 3 and stride == 1 and pad == 1 and not out_nchw \
             and out is None and not want_stats:
         out = torch.empty((N, oh, ow, pc.cout), device=x.device, dtype=torch.float32)
@@ -733,33 +664,10 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
     return (out, stats) if want_stats else out
 
 
-def conv3x3_smallco_nchw(x, w_tap_co_ci, bias, cout, reflect=True, relu=False):
-    """Direct 3x3 conv with <= 4 output channels: NHWC in, contiguous NCHW out (decoder's last layer)."""
-    _require_cuda(x, "activation")
-    assert x.is_contiguous() and x.dim() == 4
-    N, H, W, Cin = x.shape
-    out = torch.empty((N, cout, H, W), device=x.device, dtype=torch.float32)
-    lib = _lib.load()
-    args = (ptr(x), ptr(w_tap_co_ci), ptr(bias), ptr(out), N, H, W, Cin, cout, int(reflect), int(relu), stream_ptr())
-    if TIMING is None:
-        check(lib.ccst_conv3x3_smallco_f32(*args), "conv3x3_smallco")
-    else:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(lib.ccst_conv3x3_smallco_f32(*args), "conv3x3_smallco")
-        e1.record()
-        TIMING.append(("conv3x3_smallco_kernel<%d>" % cout, 2.0 * N * H * W * cout * Cin * 9, e0, e1,
-                       "n%d %dx%d cin%d cout%d taps3x3" % (N, H, W, Cin, cout)))
-    return out
-
-
-# The same layer as a 1x1 convolution to 9 * Cout tap planes on the 16-bit MFMA + nine shifted adds (conv3x3_zform.hip): the default for
-# Cin 32 / 64, Cout <= 3; CCST_CONV_ZFORM=0: the VALU kernel above.
-ZFORM = os.environ.get("CCST_CONV_ZFORM", "1") != "0"
-
-
+# The decoder's image edge (64 -> 3, NHWC in, NCHW out) as a 1x1 convolution to 9 * Cout tap planes on the 16-bit MFMA + nine shifted adds
+# (conv3x3_zform.hip): Cin 32 / 64, Cout <= 3.
 def zform_wanted(cin, cout):
-    return ZFORM and cin in (32, 64) and 1 <= cout <= 3
+    return cin in (32, 64) and 1 <= cout <= 3
 
 
 class PackedZform:
@@ -786,7 +694,8 @@ class PackedZform:
 
 
 def conv3x3_zform_nchw(x, pz, bias, cout, reflect=True, relu=False, x_absmax=None):
-    """conv3x3_smallco_nchw's layer through ccst_conv3x3_zform_f32; x_absmax: the |max| words of x (one extra pass if None)."""
+    """3x3 stride-1 conv with <= 3 output channels, NHWC in, contiguous NCHW out (ccst_conv3x3_zform_f32); x_absmax: the |max| words of x
+    (one extra pass if None)."""
     _require_cuda(x, "activation")
     assert x.is_contiguous() and x.dim() == 4
     N, H, W, Cin = x.shape
@@ -850,7 +759,7 @@ def conv2d_stem_nchw(x_nchw, pc_virtual, kwp, kw, stride=1, pad=0, reflect=False
     return out
 
 
-STEM3 = os.environ.get("CCST_STEM3", "1") != "0"      # the dedicated first-layer kernel (conv_stem3.hip); 0: the generic stem path
+STEM3 = True      # the dedicated first-layer kernel (conv_stem3.hip); False: the generic stem path
 
 
 def pack_stem3(w_oihw, bias=None):
@@ -1022,8 +931,8 @@ def adain_tile_sums_ok(feat, partials):
 
 
 def adain_from_tile_sums(feat, partials, style_mean, style_std, alpha=1.0, eps=1e-5):
-    """function.py:26-33 + the alpha blend where the conv that produced feat left per-tile channel sums (conv3x3_wino4 with sums=True:
-    partials [N * tiles, C, 2]): one streaming launch, no statistics pass.  feat: logical NCHW view of an NHWC buffer."""
+    """function.py:26-33 + the alpha blend where the conv that produced feat left per-tile channel records (conv3x3_f43 /
+    conv3x3_halo_split with sums=True: partials [N * tiles, C, 4]): one fold + one streaming launch, no statistics pass.  feat: logical NCHW view of an NHWC buffer."""
     N, C, H, W = feat.shape
     buf = feat.permute(0, 2, 3, 1)
     assert buf.is_contiguous() and partials.is_contiguous() and partials.shape[0] % N == 0 and partials.shape[1] == C

@@ -22,8 +22,8 @@ _SIDE = {}
 
 # The AdaIN statistics of the content features come out of the encoder's last conv (per-tile channel sums in its epilogue,
 # net.Sequential.forward_with_tile_sums) where that conv can produce them: the AdaIN step is then ONE streaming launch over the
-# features (ops.adain_from_tile_sums) instead of load-everything / two-pass / store.  CCST_ADAIN_TILE_SUMS=0: always ops.adain.
-TILE_SUM_ADAIN = os.environ.get("CCST_ADAIN_TILE_SUMS", "1") != "0"
+# features (ops.adain_from_tile_sums) instead of load-everything / two-pass / store.  TILE_SUM_ADAIN = False: always ops.adain (the stand-alone two-pass kernel).
+TILE_SUM_ADAIN = True
 
 
 def _encode_and_adain(vgg, content, style_stat, alpha):

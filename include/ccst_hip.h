@@ -33,7 +33,7 @@ extern "C" {
 #define CCST_EINVAL (-1)   /* bad argument / unsupported shape */
 #define CCST_EWORKSPACE (-2) /* workspace too small */
 
-#define CCST_ABI_VERSION 1
+#define CCST_ABI_VERSION 2
 int ccst_abi_version(void);
 /* Human-readable text for the last non-zero return on this thread. */
 const char* ccst_last_error(void);
@@ -150,39 +150,28 @@ int ccst_pack_conv_weights_halo_split_batch_f32(const int64_t* jobs_device, int 
 int ccst_conv3x3_halo_split_f32(const float* x, const uint32_t* x_absmax, const float* w_split, const uint32_t* w_absmax, const float* bias,
                                 float* y, uint32_t* y_absmax, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags,
                                 float* chan_sum_partials, void* stream);
-/* The same convolution (same x / y / flags / |max|-words contract as ccst_conv3x3_halo_split_f32) as Winograd F(2,3) along x on the half
- * pieces: four transform positions per pair of output pixels replace the three kx taps -- 12 instead of 18 k-steps per pixel pair, 2.0
- * instead of 3.0 executed 16-bit MFMA FLOPs per algorithmic FLOP (conv3x3_f23.hip).  u from ccst_pack_conv_weight_f23_f32 (12 * cin *
- * cout_pad floats' worth of [ky * 4 + q][cin/16][cout_pad][16 k hi | lo] rows of G g scaled by the power of two derived from w_absmax).
- * One 512-thread workgroup per CU (all of its LDS: transformed halo, raw halo and a six-stage weight ring, everything staged by LDS-DMA)
- * covers 8 x 32 pixels x 128 output channels; ccst_conv3x3_f23_workgroups tells a caller how many a layer launches.  One image must
- * have < 2^30 elements. */
-int ccst_pack_conv_weight_f23_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, const uint32_t* w_absmax, void* stream);
-int ccst_conv3x3_f23_f32(const float* x, const uint32_t* x_absmax, const float* u, const uint32_t* w_absmax, const float* bias, float* y,
-                         uint32_t* y_absmax, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags,
-                         float* chan_sum_partials /* NULL, or [ccst_conv3x3_f23_tiles(N,H,W)][Cout][4] (sum, M2, count, 0) of the un-pooled
-                                                     output per (8x32-pixel tile, wave row), an image's rows contiguous */,
-                         void* stream);
-int ccst_conv3x3_f23_workgroups(int N, int H, int W, int Cout);
-int ccst_conv3x3_f23_tiles(int N, int H, int W);
-/* The same convolution once more (same contract, tile, grid and statistics rows as ccst_conv3x3_f23_f32) as Winograd F(4,3) along x on the
- * half pieces: SIX transform positions per QUAD of output pixels -- 18 instead of 24 k-steps per pixel quad, 1.5 executed 16-bit MFMA
- * FLOPs per algorithmic FLOP (conv3x3_f43.hip); ~3x the rounding of F(2,3) (1-2e-6 of max |y| per layer).  u from
+/* The same convolution (same x / y / flags / |max|-words contract as ccst_conv3x3_halo_split_f32) as Winograd F(4,3) along x on the half
+ * pieces: SIX transform positions per QUAD of output pixels replace the three kx taps -- 18 instead of 36 k-steps per pixel quad, 1.5
+ * instead of 3.0 executed 16-bit MFMA FLOPs per algorithmic FLOP (conv3x3_f43.hip); rounding 1-5e-6 of max |y| per layer.  u from
  * ccst_pack_conv_weight_f43_f32: 18 * cin * cout_pad floats' worth of [2 (ky * 3 + j) + group][cin/16][cout_pad][16 k hi | lo] rows of G g
- * (position q = 3 group + j), scaled by the power of two derived from w_absmax.  Replaces nn.Conv2d(.., (3, 3)) after ReflectionPad2d in
- * style_transfer/AdaIN/net.py:6-36 (decoder) and :38-69 (vgg) for the layers with Cout >= 128. */
+ * (position q = 3 group + j), scaled by the power of two derived from w_absmax.  One 512-thread workgroup per CU covers 8 x 32 pixels x
+ * 128 output channels (cout_pad a multiple of 128); layers with Cout <= 64 run an 8 x 32-pixel x 64-channel tile of four waves, two
+ * workgroups per CU (cout_pad a multiple of 64); ccst_conv3x3_f43_workgroups tells a caller how many a layer launches.  One image must
+ * have < 2^30 elements.  chan_sum_partials: NULL, or [ccst_conv3x3_f43_tiles(N,H,W)][Cout][4] (sum, M2, count, 0) of the un-pooled output
+ * per (8x32-pixel tile, position group), an image's rows contiguous (see ccst_conv3x3_halo_split_tiles below).  Replaces
+ * nn.Conv2d(.., (3, 3)) after ReflectionPad2d in style_transfer/AdaIN/net.py:6-36 (decoder) and :38-69 (vgg).
+ * (Round 4's F(2,3) form, ccst_conv3x3_f23_f32, was retired in round 6 -- ABI version 2.) */
 int ccst_pack_conv_weight_f43_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, const uint32_t* w_absmax, void* stream);
 int ccst_conv3x3_f43_f32(const float* x, const uint32_t* x_absmax, const float* u, const uint32_t* w_absmax, const float* bias, float* y,
                          uint32_t* y_absmax, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags, float* chan_sum_partials,
                          void* stream);
-/* Layers with Cout <= 64 run an 8 x 32-pixel x 64-channel tile of four waves, two workgroups per CU (cout_pad a multiple of 64):
- * workgroups per launch */
 int ccst_conv3x3_f43_workgroups(int N, int H, int W, int Cout);
+int ccst_conv3x3_f43_tiles(int N, int H, int W);
 /* chan_sum_partials (may be NULL; not with POOL2): [ccst_conv3x3_halo_split_tiles(N,H,W)][Cout][4] per-(8x16-pixel tile, wave row)
  * (sum, M2, count, 0) of the output after bias / ReLU, M2 = the sum of squares about the slab's OWN mean (no E[x^2] - mean^2
  * cancellation however large |mean| / sigma is), an image's rows contiguous -- the statistics ccst_adain_tile_sums_f32 and
- * ccst_chan_sums_finalize_f32 (partial_floats = 4) take instead of a pass over the tensor.  ccst_conv3x3_f23_f32 writes the same
- * quadruples; ccst_conv3x3_wino4w_f32 writes (sum, sum of squares) pairs (partial_floats = 2). */
+ * ccst_chan_sums_finalize_f32 (partial_floats = 4) take instead of a pass over the tensor.  ccst_conv3x3_f43_f32 writes the same
+ * quadruples (its own row count: ccst_conv3x3_f43_tiles). */
 int ccst_conv3x3_halo_split_tiles(int N, int H, int W);
 /* Fused Winograd F(2x2,3x3) (16 multiplies per 2x2 output tile and input channel instead of 36) for the ResNet trunk's 3x3 stride-1
  * layers (ccst_conv3x3_wino_train_f32 below): transformed weights from ccst_pack_conv_weight_wino_f32 (ccst_wino_weight_floats(cin,
@@ -191,8 +180,6 @@ int ccst_conv3x3_halo_split_tiles(int N, int H, int W);
 int64_t ccst_wino_weight_floats(int cin, int cout_pad);
 int ccst_pack_conv_weight_wino_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, void* stream);
 
-/* Floats of a Winograd F(4x4,3x3) transformed weight ([Cin/16][36][2][cout_pad][8]) for ccst_pack_conv_weight_wino4w_f32. */
-int64_t ccst_wino4_weight_floats(int cin, int cout_pad);
 /* The AdaIN encoder's first layer (net.py:39-42: the 1x1 colour conv folded into ReflectionPad2d(1) + Conv2d(3,64,3x3) + ReLU) from the
  * contiguous NCHW image [N,3,H,W] to the NHWC map [N,H,W,64]; wa = ccst_pack_stem3_weight_f32(w [64,3,3,3], bias [64] or null)
  * (18*2*64 floats: a header with the weights' power-of-two scale, the half-piece fragments of the 16-bit MFMA's A operand and the bias;
@@ -200,21 +187,8 @@ int64_t ccst_wino4_weight_floats(int cin, int cout_pad);
 int ccst_pack_stem3_weight_f32(const float* w_oihw, const float* bias, float* wa, int cout, void* stream);
 int ccst_conv3x3_stem3_f32(const float* x_nchw, const float* wa, float* y_nhwc, int N, int H, int W, int relu,
                            uint32_t* y_absmax /* NULL or zeroed |max| words of y, see CCST_ABSMAX_WORDS */, void* stream);
-/* Fused Winograd F(4x4,3x3) with 64 output channels per workgroup (conv3x3_wino4w.hip): the 3x3 stride-1 "same" conv of net.py:6-36,38-69
- * (reflection or zero padding, fused bias / ReLU / nearest-x2 upsample on read / 2x2 ceil max-pool; flags as ccst_conv3x3_halo_f32), 2.25
- * multiplies per output;
- * every transformed input value feeds two MFMAs and the halo is fetched once per 64 output channels.  cout_pad a multiple of 64, Cin >= 32;
- * u_packed from ccst_pack_conv_weight_wino4w_f32 ([Cin/16][36][4 channel pairs][2][cout_pad/64][32][2][2] floats: a lane's weights
- * of one position and channel pair for both 32-channel groups are one 16-byte load, a wave's load 2 x 512 contiguous bytes;
- * ccst_wino4_weight_floats(cin, cout_pad) floats). */
-int ccst_pack_conv_weight_wino4w_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, void* stream);
-int ccst_conv3x3_wino4w_f32(const float* x, const float* u_packed, const float* bias, float* y, int N, int H, int W, int Cin,
-                            int Cout, int cout_pad, uint32_t flags, float* chan_sum_partials, void* stream);
-/* chan_sum_partials (NULL, or [ccst_wino4w_spatial_tiles(N,H,W)][Cout][2] floats; not with CCST_CONV_POOL2): the epilogue also leaves
- * the per-channel sum and sum of squares of each 16x32-pixel tile of the OUTPUT (bias / ReLU applied) -- calc_sum,
- * mean_std_computation_effcientMem.py:103-115, without a pass over the tensor; ccst_chan_sums_finalize_f32 folds K such pairs
- * [K][C][2] into the [C] totals in fp64 (fixed order: bitwise reproducible). */
-int ccst_wino4w_spatial_tiles(int N, int H, int W);
+/* calc_sum (mean_std_computation_effcientMem.py:103-115) without a pass over the tensor: folds the K per-tile records a conv epilogue
+ * left (chan_sum_partials) into the [C] totals in fp64, fixed order (bitwise reproducible). */
 int ccst_chan_sums_finalize_f32(const float* partials, int partial_floats /* 2: (sum, sum^2) pairs; 4: (sum, M2, count, 0), see
                                 ccst_conv3x3_halo_split_f32 */, int K, int C, float* sum, float* sqsum, void* stream);
 /* The Winograd kernel for the ResNet trunk's 3x3 stride-1 zero-padded bias-free convs (forward with the BatchNorm statistics
@@ -271,18 +245,14 @@ int ccst_conv2d_igemm_bn_relu_bwd_f32(const CcstConvDesc* d, const float* x, con
  * mean / invstd; the epilogue also leaves that BatchNorm's backward partial sums (sum g, sum g*xhat) per 32 rows in
  * bn_partials[2*ceil(M/64)][cout][2], for ccst_bn_train_bwd_partials_f32 -- one pass over (x, g) less. */
 
-/* Direct 3x3 stride-1 conv with 1..4 output channels writing NCHW (the decoder's last layer,
- * net.py:35): x NHWC [N,H,W,Cin] (Cin % 16 == 0), w [3][3][Cout][Cin], y NCHW [N,Cout,H,W].
- * HBM-bound (13 FLOP/B), so it runs on the VALU rather than padding Cout to an MFMA tile. */
-int ccst_conv3x3_smallco_f32(const float* x, const float* w_tap_co_ci, const float* bias, float* y,
-                             int N, int H, int W, int Cin, int Cout, int reflect, int relu, void* stream);
-
-/* The same layer as a 1x1 convolution to 9*Cout "tap planes" on the 16-bit MFMA (fp32 products as three half-piece products,
+/* The decoder's last layer (net.py:34-35: 3x3 stride 1, 64 -> 3 channels; x NHWC [N,H,W,Cin], y NCHW [N,Cout,H,W]; HBM-bound at
+ * 13 FLOP/B) as a 1x1 convolution to 9*Cout "tap planes" on the 16-bit MFMA (fp32 products as three half-piece products,
  * fp32 accumulate; 27 planes padded to 32 for Cout = 3) followed by the nine shifted fp32 adds (conv3x3_zform.hip, round 4): every
  * pixel's record is read once, whole.  Cin 32 or 64, Cout 1..3.  x_absmax / w_absmax: the |max| words of x and of the weight
  * (CCST_ABSMAX_WORDS each: the operands' power-of-two scales are derived from them on the device, any finite fp32 magnitude is safe).
  * w_packed: ccst_pack_conv_weight_zform_f32 of the [3][3][Cout][Cin] weight, ccst_conv3x3_zform_weight_floats(Cin) floats.
- * Replaces the same reference lines as ccst_conv3x3_smallco_f32 (style_transfer/AdaIN/net.py:34-35). */
+ * Replaces ReflectionPad2d + nn.Conv2d(64, 3, (3, 3)) of style_transfer/AdaIN/net.py:34-35.  (The VALU kernel ccst_conv3x3_smallco_f32
+ * was retired in round 6 -- ABI version 2.) */
 int64_t ccst_conv3x3_zform_weight_floats(int Cin);
 int ccst_pack_conv_weight_zform_f32(const float* w_tap_co_ci, const uint32_t* w_absmax, float* packed, int Cin, int Cout, void* stream);
 int ccst_conv3x3_zform_f32(const float* x, const uint32_t* x_absmax, const float* w_packed, const uint32_t* w_absmax,
@@ -407,27 +377,9 @@ int64_t ccst_stats_workspace_bytes(int N, int C, int HW);
 /* BatchNorm2d training forward: batch mean / biased var over the M = N*H*W rows, running-stat update
  * (momentum, unbiased var), y = (x-mean)*invstd*gamma+beta [+ residual] [ReLU].
  * save_mean/save_invstd: [C] for backward.  residual may be NULL.  stats_in (may be NULL): per-channel
- * (sum, sum^2) partials [stats_groups][C][2] from ccst_conv2d_igemm_stats_f32 -- then x is not re-read. */
-int ccst_bn_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
-                          float* running_var, float momentum, float eps, const float* residual, int relu,
-                          float* y, float* save_mean, float* save_invstd, int64_t M, int C,
-                          const float* stats_in, int stats_groups, void* ws, int64_t ws_bytes, void* stream);
-/* BatchNorm2d eval forward with running stats (fed_run.py:216). */
-int ccst_bn_eval_fwd_f32(const float* x, const float* gamma, const float* beta, const float* running_mean,
-                         const float* running_var, float eps, const float* residual, int relu, float* y,
-                         int64_t M, int C, uint32_t* y_absmax /* NULL or zeroed |max| words of y: the eval forward's pointwise convs then run on half pieces too */,
-                        void* stream);
-/* BatchNorm2d backward: dx, dgamma, dbeta (accumulate=1 adds into dgamma/dbeta).  With relu=1 the ReLU mask
- * comes from the saved output y (y > 0), or -- when y == NULL, allowed only if no residual was added in
- * the forward -- is recomputed from x as (x-mean)*invstd*gamma+beta > 0 (one tensor read less per pass).
- * If d_residual != NULL it receives the masked incoming gradient (the skip connection's share). */
-int ccst_bn_train_bwd_f32(const float* dy, const float* x, const float* y, const float* gamma, const float* beta,
-                          const float* save_mean, const float* save_invstd, int relu, float* dx,
-                          float* d_residual, float* dgamma, float* dbeta, int accumulate, int64_t M, int C,
-                          void* ws, int64_t ws_bytes, void* stream);
-/* The same two with a compact ReLU mask between them: the forward writes relu_mask[M*C/4] (bit j of byte i <-> element 4 i + j is
- * positive before the ReLU), the backward reads it instead of the whole saved output y (y may then be NULL even with a residual):
- * 1/16 of a tensor per pass instead of one.  relu_mask == NULL gives the functions above. */
+ * (sum, sum^2) partials [stats_groups][C][2] from ccst_conv2d_igemm_stats_f32 -- then x is not re-read.
+ * relu_mask (may be NULL): [M*C/4] bytes, bit j of byte i <-> element 4 i + j is positive before the ReLU -- the backward then reads
+ * 1/16 of a tensor per pass instead of the whole saved output y. */
 int ccst_bn_train_fwd_mask_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
                                float* running_var, float momentum, float eps, const float* residual, int relu,
                                float* y, uint8_t* relu_mask, float* save_mean, float* save_invstd, int64_t M, int C,
@@ -435,6 +387,15 @@ int ccst_bn_train_fwd_mask_f32(const float* x, const float* gamma, const float* 
                                uint32_t* y_absmax /* NULL, or zeroed |max| words (CCST_ABSMAX_WORDS) receiving max |y|: what the
                                                      half-piece pointwise conv that reads y scales it by */,
                                void* stream);
+/* BatchNorm2d eval forward with running stats (fed_run.py:216). */
+int ccst_bn_eval_fwd_f32(const float* x, const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, const float* residual, int relu, float* y,
+                         int64_t M, int C, uint32_t* y_absmax /* NULL or zeroed |max| words of y: the eval forward's pointwise convs then run on half pieces too */,
+                        void* stream);
+/* BatchNorm2d backward: dx, dgamma, dbeta (accumulate=1 adds into dgamma/dbeta).  With relu=1 the ReLU mask
+ * comes from relu_mask (the forward's byte mask), else from the saved output y (y > 0), or -- when both are NULL, allowed only if no
+ * residual was added in the forward -- is recomputed from x as (x-mean)*invstd*gamma+beta > 0 (one tensor read less per pass).
+ * If d_residual != NULL it receives the masked incoming gradient (the skip connection's share). */
 int ccst_bn_train_bwd_mask_f32(const float* dy, const float* x, const float* y, const uint8_t* relu_mask,
                                const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                                int relu, float* dx, float* d_residual, float* dgamma, float* dbeta, int accumulate,
@@ -454,7 +415,7 @@ int64_t ccst_bn_workspace_bytes(int64_t M, int C);
 /* BatchNorm2d (training) -> ReLU -> MaxPool2d(3, 2, 1), the ResNet stem (nets/resnet.py:138-140), without the full-resolution tensors in
  * between: the forward pools relu(bn(x)) straight from the conv output x [N,H,W,C] into y_pooled [N,Ho,Wo,C] + idx (as
  * ccst_maxpool3s2_fwd_f32); the backward takes the pooled gradient and gathers it through idx inside both BatchNorm-backward passes
- * (ReLU mask recomputed from x).  Same statistics / running-stat semantics as ccst_bn_train_fwd_f32. */
+ * (ReLU mask recomputed from x).  Same statistics / running-stat semantics as ccst_bn_train_fwd_mask_f32. */
 int ccst_bn_relu_maxpool_train_fwd_f32(const float* x, const float* gamma, const float* beta, float* running_mean,
                                        float* running_var, float momentum, float eps, float* y_pooled, uint32_t* idx,
                                        float* save_mean, float* save_invstd, int N, int H, int W, int C, int Ho, int Wo,

@@ -13,7 +13,7 @@ import copy
 import os
 from datetime import datetime
 
-from _common import ALL_CLIENTS, base_parser, device_or_die, load_networks
+from _common import ALL_CLIENTS, base_parser, device_or_die, load_networks, settle_gc
 
 import torch
 
@@ -41,6 +41,7 @@ if world > 1 and args.fuse_stats:
     dist.init_process_group(backend="nccl", device_id=device)       # only the fused statistics need a collective
 
 vgg, decoder = load_networks(args, device)
+settle_gc()
 pipeline = None if args.serial else style.StylePipeline(vgg, decoder, device, output_size=args.output_size)
 data_loader = data.get_train_dataloader(args, args.txt_root, rank, world)      # this rank's shard of the content list
 

@@ -8,7 +8,7 @@ import os
 import random
 from datetime import datetime
 
-from _common import ALL_CLIENTS, base_parser, device_or_die, load_networks
+from _common import ALL_CLIENTS, base_parser, device_or_die, load_networks, settle_gc
 
 import numpy as np
 import torch
@@ -35,6 +35,7 @@ world = int(os.environ.get("WORLD_SIZE", "1"))
 rank = int(os.environ.get("RANK", "0"))
 
 vgg, decoder = load_networks(args, device)
+settle_gc()
 data_loader = data.get_train_dataloader(args, args.txt_root, rank, world)      # this rank's shard of the content list
 
 

@@ -8,7 +8,7 @@ additive (sum, sqsum, count) triple is all-reduced once at the end."""
 import os
 from datetime import datetime
 
-from _common import base_parser, device_or_die, load_networks
+from _common import base_parser, device_or_die, load_networks, settle_gc
 
 import torch
 
@@ -27,6 +27,7 @@ if world > 1:
     dist.init_process_group(backend="nccl", device_id=device)
 
 vgg, decoder = load_networks(args, device)
+settle_gc()
 data_loader = data.get_train_dataloader(args, args.txt_root, rank, world)      # this rank's shard of the list
 start_time = datetime.now()
 (feat_mean, feat_std), acc = style.domain_style_stat(vgg, data_loader, device, world, rank,

@@ -128,7 +128,6 @@ def test_bench_traffic_keys_find_the_committed_profile():
     # ... and of the kernels behind the switches (names only: the committed profile does not run them)
     assert bench.traffic_keys("conv3x3_halo_split_kernel<nopool>", {"void conv3x3_halo_kernel<4, 1, 2, false, false, true>": 1}) == \
         ["void conv3x3_halo_kernel<4, 1, 2, false, false, true>"]
-    assert bench.traffic_keys("conv3x3_f23_kernel<pool>", {"void conv3x3_f23_kernel<true>": 1, "void conv3x3_f23_kernel<false>": 1}) == ["void conv3x3_f23_kernel<true>"]
     assert bench.traffic_keys("conv_igemm_kernel<2,2,1>", tj) == ["void conv_igemm_kernel<2, 2, 1, false, 2, 16>"]
 
 
@@ -215,7 +214,7 @@ def test_resume_restores_every_clients_own_model_under_fedbn():
 
 
 def test_conv_kernel_selection_does_not_depend_on_the_batch_size():
-    """ops.f23_wanted decides from the tiles of ONE image (ccst_conv3x3_f43_workgroups with N = 1): a sample keeps its kernels -- and its
+    """ops.f43_wanted decides from the tiles of ONE image (ccst_conv3x3_f43_workgroups with N = 1): a sample keeps its kernels -- and its
     rounding -- whatever the number of its batch-mates (a rule on the whole launch's workgroups once ran the Cout = 64 layers of a
     96 x 160 image on F(4,3) inside a batch of three and on the direct kernel alone: 2e-5 of the output range apart)."""
     import torch
@@ -228,14 +227,17 @@ def test_conv_kernel_selection_does_not_depend_on_the_batch_size():
         def can_split(self):
             return True
 
+        def lazy3x3(self):
+            return True
+
     dev = torch.device("cpu")
     lib = _lib.load()
     assert int(lib.ccst_conv3x3_f43_workgroups(1, 512, 512, 64)) == 64 * 16           # 8 x 32-pixel x 64-channel tiles
     assert int(lib.ccst_conv3x3_f43_workgroups(6, 64, 64, 256)) == 6 * 8 * 2 * 2      # ... x 128 channels
     for (h, w, cin, cout) in ((512, 512, 64, 64), (64, 64, 512, 256), (96, 160, 64, 64), (48, 80, 64, 128), (24, 40, 128, 256), (8, 8, 512, 512)):
-        picks = {ops.f23_wanted(PC(cin, cout), n, h, w, dev) for n in (1, 2, 3, 6, 32)}
+        picks = {ops.f43_wanted(PC(cin, cout), n, h, w, dev) for n in (1, 2, 3, 6, 32)}
         assert len(picks) == 1, (h, w, cin, cout, picks)
-    assert ops.f23_wanted(PC(64, 64), 1, 512, 512, dev) and not ops.f23_wanted(PC(512, 512), 32, 8, 8, dev)
+    assert ops.f43_wanted(PC(64, 64), 1, 512, 512, dev) and not ops.f43_wanted(PC(512, 512), 32, 8, 8, dev)
 
 
 def test_timing_experiment_patches_apply_to_the_shipped_sources(tmp_path):

@@ -40,7 +40,6 @@ def timed(fn):
 
 out_bytes = B * S * S * 64 * 4
 for name, fn, nbytes in (("stem3", lambda: ops.conv3x3_stem3_nchw(img, wa, relu=True), out_bytes + B * 3 * S * S * 4),
-                         ("smallco", lambda: ops.conv3x3_smallco_nchw(feat, w2t, b2, 3, reflect=True, relu=False), out_bytes + B * 3 * S * S * 4),
                          ("zform", lambda: ops.conv3x3_zform_nchw(feat, pz, b2, 3, reflect=True, relu=False, x_absmax=fwords), out_bytes + B * 3 * S * S * 4),
                          ("absmax", lambda: ops.absmax(feat), out_bytes),
                          ("fill", lambda: feat.fill_(1.0), out_bytes),

@@ -1,5 +1,6 @@
-"""Per-layer time of the AdaIN path's 3x3 layers at B=6, 512x512 on the F(2,3) half-piece kernel (conv3x3_f23.hip) and the F(4,3) kernel (conv3x3_f43.hip) beside the direct
-half-piece kernel (conv3x3_halo.hip SPLIT): python tools/f23_layers.py [reps] -> per layer us, algorithmic TFLOP/s, error vs fp64."""
+"""Per-layer time of the AdaIN path's 3x3 layers at B=6, 512x512 on the F(4,3) kernel (conv3x3_f43.hip) beside the direct half-piece
+kernel (conv3x3_halo.hip SPLIT): python tools/f43_layers.py [reps] -> per layer us, algorithmic TFLOP/s, error vs fp64.
+F43_LAYER=i,j,...: only those rows."""
 import os
 import sys
 
@@ -13,7 +14,7 @@ LAYERS = [  # H (= W, conv extent), Cin, Cout, pool, ups
     (256, 64, 128, False, False), (256, 128, 128, True, False), (128, 128, 256, False, False), (128, 256, 256, False, False),
     (128, 256, 256, True, False), (64, 256, 512, False, False), (64, 512, 256, False, False), (128, 256, 256, False, True),
     (128, 256, 128, False, False), (256, 128, 128, False, True),
-    (512, 64, 64, True, False), (256, 128, 64, False, False), (512, 64, 64, False, True),        # the Cout = 64 layers (F(4,3)'s 64-channel tile; no F(2,3) form)
+    (512, 64, 64, True, False), (256, 128, 64, False, False), (512, 64, 64, False, True),        # the Cout = 64 layers (F(4,3)'s 64-channel tile)
 ]
 
 
@@ -22,8 +23,8 @@ def main():
     dev = torch.device("cuda:0")
     B = 6
     g = torch.Generator().manual_seed(3)
-    tot = [0.0, 0.0, 0.0]
-    sel = os.environ.get("F23_LAYER")
+    tot = [0.0, 0.0]
+    sel = os.environ.get("F43_LAYER", os.environ.get("F23_LAYER"))
     for (H, Cin, Cout, pool, ups) in (LAYERS if sel is None else [LAYERS[int(i)] for i in sel.split(",")]):
         Hs = H // 2 if ups else H
         x = torch.rand(B, Hs, Hs, Cin, generator=g).to(dev)
@@ -32,9 +33,7 @@ def main():
         pc = ops.pack_conv_weight(w, b, wino=4)
         flags = 1 | 8 | (2 if pool else 0) | (4 if ups else 0)
         xmax = ops.absmax(x)
-        fns = (lambda: ops.conv3x3_halo_split(x, pc, flags, x_absmax=xmax),
-               (lambda: ops.conv3x3_f23(x, pc, flags, x_absmax=xmax)) if Cout >= 128 else (lambda: ops.conv3x3_halo_split(x, pc, flags, x_absmax=xmax)),
-               lambda: ops.conv3x3_f43(x, pc, flags, x_absmax=xmax))
+        fns = (lambda: ops.conv3x3_halo_split(x, pc, flags, x_absmax=xmax), lambda: ops.conv3x3_f43(x, pc, flags, x_absmax=xmax))
         res = []
         for fn in fns:
             for _ in range(2):
@@ -58,12 +57,12 @@ def main():
         errs = [float((r[1][:1].double() - ref).abs().max()) / float(ref.abs().max()) for r in res]
         fl = 2.0 * B * H * H * Cout * Cin * 9
         wgs = B * ((H + 7) // 8) * ((H + 31) // 32) * ((Cout + 127) // 128) if Cout >= 128 else B * ((H + 7) // 8) * ((H + 31) // 32)
-        print("%4d^2 %3d->%3d %s%s  split %7.1f us %6.1f TF err %.2e | f23 %7.1f us %6.1f TF err %.2e | f43 %7.1f us %6.1f TF err %.2e | f43/f23 x%.2f  (%d workgroups = %.2f rounds)" % (
+        print("%4d^2 %3d->%3d %s%s  split %7.1f us %6.1f TF err %.2e | f43 %7.1f us %6.1f TF err %.2e | split/f43 x%.2f  (%d workgroups = %.2f rounds)" % (
             H, Cin, Cout, "pool " if pool else "     ", "ups" if ups else "   ", res[0][0], fl / res[0][0] / 1e6, errs[0], res[1][0], fl / res[1][0] / 1e6, errs[1],
-            res[2][0], fl / res[2][0] / 1e6, errs[2], res[1][0] / res[2][0], wgs, wgs / 256.0))
-        for k in range(3):
+            res[0][0] / res[1][0], wgs, wgs / 256.0))
+        for k in range(2):
             tot[k] += res[k][0]
-    print("sum of the layers: split %.1f us, f23 %.1f us, f43 %.1f us" % tuple(tot))
+    print("sum of the layers: split %.1f us, f43 %.1f us" % tuple(tot))
 
 
 if __name__ == "__main__":
