@@ -55,6 +55,7 @@ _SIGNATURES = {
     "ccst_conv3x3_halo_f32": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P],
     "ccst_absmax_f32": [_P, c_int64, _P, _P],
     "ccst_absmax_batch_f32": [_P, c_int, _P, _P],
+    "ccst_absmax_samples_f32": [_P, c_int, c_int64, _P, _P],
     "ccst_conv3x3_halo_split_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P, _P],
     "ccst_pack_conv_weight_f43_f32": [_P, _P, c_int, c_int, c_int, _P, _P],
     "ccst_conv3x3_f43_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P, _P],

@@ -224,14 +224,16 @@ __device__ __forceinline__ float adain_one(float x, float mu, float sd, float sm
 __global__ __launch_bounds__(TPB) void adain_apply_nhwc_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                const float* __restrict__ mean, const float* __restrict__ stdv,
                                                                const float* __restrict__ smean, const float* __restrict__ sstd,
-                                                               int style_per_n, float alpha, long long total4, int HW, int C,
+                                                               int style_per_n, float alpha, long long per_image4, int HW, int C,
                                                                unsigned* __restrict__ ymax) {
+    // (grid: x = blocks over one image's quads, y = image -- the |max| words are per image)
     const int cg = C / 4;
     const bool blend = (alpha != 1.f);
     float amax = 0.f;
-    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total4; i += (long long)gridDim.x * TPB) {
-        const int c = (int)(i % cg) * 4;
-        const int n = (int)(i / ((long long)HW * cg));
+    const int n = blockIdx.y;
+    for (long long j = (long long)blockIdx.x * TPB + threadIdx.x; j < per_image4; j += (long long)gridDim.x * TPB) {
+        const long long i = (long long)n * per_image4 + j;
+        const int c = (int)(j % cg) * 4;
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + i * 4);
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + n * C + c);
         const f32x4 sd = *reinterpret_cast<const f32x4*>(stdv + n * C + c);
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(TPB) void adain_apply_nhwc_kernel(const float* __re
         amax = fmaxf(fmaxf(fmaxf(amax, fabsf(o[0])), fmaxf(fabsf(o[1]), fabsf(o[2]))), fabsf(o[3]));
         *reinterpret_cast<f32x4*>(y + i * 4) = o;
     }
-    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, blockIdx.x);
+    if (ymax != nullptr) ccst_absmax_publish(ymax + n * CCST_ABSMAX_WORDS, amax, blockIdx.x);
 }
 
 __global__ __launch_bounds__(TPB) void adain_apply_nchw_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(TPB) void adain_apply_nchw_kernel(const float* __re
         amax = fmaxf(amax, fabsf(o));
         yb[p] = o;
     }
-    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, blockIdx.y * gridDim.x + blockIdx.x);
+    if (ymax != nullptr) ccst_absmax_publish(ymax + (plane / C) * CCST_ABSMAX_WORDS, amax, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // ---- single-pass AdaIN (NHWC, H*W <= 4096): statistics AND normalise with the tensor read once and written once ------------------
@@ -350,7 +352,8 @@ __global__ __launch_bounds__(FP_T) void adain_fused_nhwc_kernel(const float* __r
     const f32x4 sm = *reinterpret_cast<const f32x4*>(smean + so), ss = *reinterpret_cast<const f32x4*>(sstd + so);
     const bool blend = (alpha != 1.f);
     float amax = 0.f;
-    const unsigned peeked = ymax != nullptr ? ccst_absmax_peek(ymax, blockIdx.y * gridDim.x + blockIdx.x) : 0u;
+    if (ymax != nullptr) ymax += n * CCST_ABSMAX_WORDS;            // per image
+    const unsigned peeked = ymax != nullptr ? ccst_absmax_peek(ymax, blockIdx.x) : 0u;
 #pragma unroll
     for (int i = 0; i < FP_PPT; ++i) {
         const int p = pl + i * FP_PL;
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(FP_T) void adain_fused_nhwc_kernel(const float* __r
             *reinterpret_cast<f32x4*>(yb + (long long)p * C) = o;
         }
     }
-    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, blockIdx.y * gridDim.x + blockIdx.x, peeked);
+    if (ymax != nullptr) ccst_absmax_publish(ymax, amax, blockIdx.x, peeked);
 }
 
 int pick_splits(int N, int C, int HW, int layout) {
@@ -481,7 +484,8 @@ __global__ __launch_bounds__(TPB) void adain_stream_nhwc_kernel(const float* __r
     const f32x4 sm = *reinterpret_cast<const f32x4*>(smean + so), ss = *reinterpret_cast<const f32x4*>(sstd + so);
     const bool blend = (alpha != 1.f);
     float amax = 0.f;
-    const unsigned bid_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const unsigned bid_ = blockIdx.z * gridDim.x + blockIdx.x;
+    if (ymax != nullptr) ymax += n * CCST_ABSMAX_WORDS;            // per image
     const unsigned peeked = ymax != nullptr ? ccst_absmax_peek(ymax, bid_) : 0u;       // (compared after the stores: nobody waits for it)
 #pragma unroll
     for (int i = 0; i < TS_PIX / TS_PL; ++i) {
@@ -559,10 +563,11 @@ extern "C" int ccst_adain_f32(const float* x, const float* style_mean, const flo
     rc = ccst_calc_mean_std_f32(x, mean, stdv, N, C, HW, layout, eps, ws, ws_bytes, stream);
     if (rc) return rc;
     if (layout == 1) {
-        const long long total4 = (long long)N * HW * (C / 4);
-        const int grid = (int)((total4 + TPB - 1) / TPB < 4096 ? (total4 + TPB - 1) / TPB : 4096);
-        hipLaunchKernelGGL(adain_apply_nhwc_kernel, dim3(grid), dim3(TPB), 0, st, x, y, mean, stdv, style_mean, style_std,
-                           style_per_n, alpha, total4, HW, C, y_absmax);
+        CCST_REQUIRE(N <= 65535, "adain: N must be <= 65535");
+        const long long per4 = (long long)HW * (C / 4);
+        const long long want = (per4 + TPB - 1) / TPB, cap = (4096 + N - 1) / N;
+        hipLaunchKernelGGL(adain_apply_nhwc_kernel, dim3((unsigned)(want < cap ? want : cap), N), dim3(TPB), 0, st, x, y, mean, stdv, style_mean, style_std,
+                           style_per_n, alpha, per4, HW, C, y_absmax);
     } else {
         const int gx = (HW + TPB - 1) / TPB < 64 ? (HW + TPB - 1) / TPB : 64;
         hipLaunchKernelGGL(adain_apply_nchw_kernel, dim3(gx, N * C), dim3(TPB), 0, st, x, y, mean, stdv, style_mean, style_std,

@@ -36,9 +36,9 @@ struct F43Args {
     const float* u;
     const float* bias;
     float* y;
-    const unsigned* xmax;
+    const unsigned* xmax;    // [N][CCST_ABSMAX_WORDS]: every image its own words (a sample's scale -- and bits -- do not depend on its batch-mates)
     const unsigned* wmax;
-    unsigned* ymax;
+    unsigned* ymax;          // nullptr, or zeroed [N][CCST_ABSMAX_WORDS]
     float* stats;        // nullptr, or [ccst_conv3x3_f43_tiles(N,H,W)][Cout][4] per-(8x32-pixel tile, position group) (sum, M2 about the slab's own mean, count, 0)
     int N, H, W, Hs, Ws, Cin, Cout, CoutPad;
     int reflect, ups, relu;
@@ -133,7 +133,8 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
     const int co0 = tn * G_BN;
     const int oy0 = ty * G_TH, ox0 = tx * G_TW;
 
-    unsigned xword = ccst_absmax_load(p.xmax), wword = ccst_absmax_load(p.wmax);
+    unsigned xword = ccst_absmax_load(p.xmax + n * CCST_ABSMAX_WORDS), wword = ccst_absmax_load(p.wmax);
+    unsigned* const ymax_n = p.ymax != nullptr ? p.ymax + n * CCST_ABSMAX_WORDS : nullptr;
     const int nchunks = p.Cin / 16;
 
     const float* const ximg = p.x + (long long)n * p.Hs * p.Ws * p.Cin;
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const bool relu = p.relu != 0;
     float amax = 0.f;
-    const unsigned peeked = p.ymax != nullptr ? ccst_absmax_peek(p.ymax, blockIdx.x) : 0u;
+    const unsigned peeked = ymax_n != nullptr ? ccst_absmax_peek(ymax_n, blockIdx.x) : 0u;
     const bool interior = (oy0 + G_TH <= p.H) && (ox0 + G_TW <= p.W) && (co0 + G_BN <= p.Cout);
     const int other = wave ^ (HALF ? 2 : 4);
     // phase 2: fin[e][mt][r], e = 0, 1 = pixel 4 quad + 2 grp + e of row 4 mt + (r & 3), quad = 2 (r >> 2) + lh
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
             }
         }
     }
-    if (p.ymax != nullptr) ccst_absmax_publish(p.ymax, amax, blockIdx.x, peeked);
+    if (ymax_n != nullptr) ccst_absmax_publish(ymax_n, amax, blockIdx.x, peeked);
 }
 
 // OIHW 3x3 -> [m = 2 t + group][Cin/16][cout_pad/32][piece][32 channels][8 words], t = ky * 3 + j, position q = 3 group + j: piece 0 = the

@@ -43,6 +43,8 @@ struct HaloArgs {
     const unsigned* xmax;   // SPLIT: |max| words of x and of the OIHW weight (CCST_ABSMAX_WORDS each): the operands' power-of-two scales
     const unsigned* wmax;   //        are derived from them in the kernel, the accumulators scaled back before the epilogue
     unsigned* ymax;         // SPLIT: nullptr, or zeroed |max| words receiving max |y| of what this launch stores
+    int wpn;                // words per image of xmax / ymax: CCST_ABSMAX_WORDS (the AdaIN entry: every image its own words, [N][64]) or 0
+                            // (the ResNet train form: one set per tensor -- BatchNorm couples the samples of a batch anyway)
     float* stats;        // TRAIN: per-(spatial tile, wave row) (sum, sum^2) partials of the output, or nullptr; SPLIT: (sum, M2 about the slab's own mean, count, 0)
     int flip, accum;     // TRAIN: taps read in reverse order (backward-data); y += conv
     // TRAIN + SPLIT, backward-data whose result is the output gradient of a BatchNorm + ReLU that only this conv reads (bn1 -> conv2):
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
     int kx = 0, kw = 0;
     unsigned xword = 0u, wword = 0u;
     if (SPLIT) {
-        xword = ccst_absmax_load(p.xmax);
+        xword = ccst_absmax_load(p.xmax + n * p.wpn);
         wword = ccst_absmax_load(p.wmax);
     }
     float xs = 1.f;
@@ -407,7 +409,8 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
     // with no vector address arithmetic and no predicate.  Edge tiles keep the predicated pointer path.
     const int cw = wn * (32 * NT);                                            // uniform (wn is)
     float amax = 0.f;                                                         // SPLIT: largest |value| this lane stores (p.ymax)
-    const unsigned peeked = (SPLIT && p.ymax != nullptr) ? ccst_absmax_peek(p.ymax, blockIdx.x) : 0u;     // (compared after the stores)
+    unsigned* const ymax_n = (SPLIT && p.ymax != nullptr) ? p.ymax + n * p.wpn : nullptr;
+    const unsigned peeked = ymax_n != nullptr ? ccst_absmax_peek(ymax_n, blockIdx.x) : 0u;     // (compared after the stores)
     if (!POOL) {
         float* const tile = p.y + (long long)n * p.ysN + (long long)oy0 * p.ysH + (long long)ox0 * p.ysW + co0 + cw;
         const unsigned lane_off = (unsigned)(2 * lh * p.ysW + li);
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(256, (SPLIT && NT == 2) ? 2 : 3) void conv3x3_halo_
             }
         }
     }
-    if (SPLIT && p.ymax != nullptr) ccst_absmax_publish(p.ymax, amax, blockIdx.x, peeked);
+    if (ymax_n != nullptr) ccst_absmax_publish(ymax_n, amax, blockIdx.x, peeked);
 }
 
 template <int WM, int WN, int NT, bool POOL, bool TRAIN = false, bool SPLIT = false>
@@ -721,7 +724,7 @@ static int halo_impl(const float* x, const float* w_packed, const float* bias, f
     a.x = x; a.w = w_packed; a.bias = bias; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Hs = ups ? H / 2 : H; a.Ws = ups ? W / 2 : W; a.Cin = Cin; a.Cout = Cout; a.CoutPad = cout_pad;
     a.reflect = (flags & CCST_CONV_REFLECT) ? 1 : 0; a.ups = ups ? 1 : 0; a.relu = (flags & CCST_CONV_RELU) ? 1 : 0;
-    a.stats = sums; a.flip = 0; a.accum = 0; a.xmax = xmax; a.wmax = wmax; a.ymax = ymax;
+    a.stats = sums; a.flip = 0; a.accum = 0; a.xmax = xmax; a.wmax = wmax; a.ymax = ymax; a.wpn = CCST_ABSMAX_WORDS;
     a.bn_x = a.bn_mean = a.bn_invstd = a.bn_gamma = a.bn_beta = nullptr; a.bn_part = nullptr;
     CCST_REQUIRE((long long)N * a.Hs * a.Ws * Cin < 0x7fffffffLL, "conv3x3_halo: input must have < 2^31 elements");
     const int oh = pool ? (H + 1) / 2 : H, ow = pool ? (W + 1) / 2 : W;
@@ -765,7 +768,7 @@ extern "C" int ccst_conv3x3_halo_train_f32(const float* x, const float* w_packed
     a.N = N; a.H = H; a.W = W; a.Hs = H; a.Ws = W; a.Cin = Cin; a.Cout = Cout; a.CoutPad = cout_pad;
     a.reflect = 0; a.ups = 0; a.relu = 0;
     a.stats = stats; a.flip = (flags & CCST_CONV_FLIP) ? 1 : 0; a.accum = (flags & CCST_CONV_ACCUM) ? 1 : 0;
-    a.xmax = a.wmax = nullptr; a.ymax = nullptr;
+    a.xmax = a.wmax = nullptr; a.ymax = nullptr; a.wpn = 0;
     a.bn_x = a.bn_mean = a.bn_invstd = a.bn_gamma = a.bn_beta = nullptr; a.bn_part = nullptr;
     a.ysW = Cout; a.ysH = W * Cout; a.ysN = (long long)H * W * Cout;
     hipStream_t s = (hipStream_t)stream;
@@ -794,7 +797,7 @@ extern "C" int ccst_conv3x3_halo_train_split_f32(const float* x, const uint32_t*
     a.N = N; a.H = H; a.W = W; a.Hs = H; a.Ws = W; a.Cin = Cin; a.Cout = Cout; a.CoutPad = cout_pad;
     a.reflect = 0; a.ups = 0; a.relu = 0;
     a.stats = stats; a.flip = (flags & CCST_CONV_FLIP) ? 1 : 0; a.accum = (flags & CCST_CONV_ACCUM) ? 1 : 0;
-    a.xmax = x_absmax; a.wmax = w_absmax; a.ymax = nullptr;
+    a.xmax = x_absmax; a.wmax = w_absmax; a.ymax = nullptr; a.wpn = 0;
     a.bn_x = bn_x; a.bn_mean = bn_mean; a.bn_invstd = bn_invstd; a.bn_gamma = bn_gamma; a.bn_beta = bn_beta; a.bn_part = bn_partials;
     a.ysW = Cout; a.ysH = W * Cout; a.ysN = (long long)H * W * Cout;
     hipStream_t s = (hipStream_t)stream;

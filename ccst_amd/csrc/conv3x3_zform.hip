@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256, Z_WGS) void conv3x3_zform_kernel(const ZArgs p
         return (idx < chunk && first + idx < ntiles) ? first + idx : -1;
     };
 
-    unsigned xword = ccst_absmax_load(p.xmax), wword = ccst_absmax_load(p.wmax);
+    unsigned wword = ccst_absmax_load(p.wmax);
 
     // a tile's pixel groups for this wave: float offsets of the lane's pixel (+ its first channel run), and whether the pixel is inside
     // the image (zero padding: an outside pixel has z = 0).  Waves 2 and 3 own five groups; their sixth is a copy of the tile's last
@@ -166,10 +166,11 @@ __global__ __launch_bounds__(256, Z_WGS) void conv3x3_zform_kernel(const ZArgs p
             for (int pc = 0; pc < 2; ++pc)
                 wa[jt][ks][pc] = __builtin_bit_cast(f16x8z, *reinterpret_cast<const f32x4*>(p.wp + ((((jt * NKS + ks) * 2 + pc) * 64 + lane) * 4)));
 
-    const int kx = ccst_scale_exp(ccst_absmax_reduce(xword), CCST_SPLIT_X_TARGET);
+    // x's scale is PER IMAGE (p.xmax: [N][CCST_ABSMAX_WORDS]): read when the walk enters an image (a workgroup's tiles are consecutive
+    // tiles of its XCD's range: the image changes at most a couple of times per workgroup)
     const int kw = ccst_scale_exp(ccst_absmax_reduce(wword), CCST_SPLIT_W_TARGET);
-    const float xs = __uint_as_float((unsigned)(127 + kx) << 23);
-    const int kd = -(kx + kw);
+    int scale_n = -1, kd = 0;
+    float xs = 1.f;
     const int nplanes = 9 * p.Cout;
     // accumulator register r of tile jt of a lane: plane 16 jt + 4 kg + r of pixel 16 g + pn; the planes past 9 Cout go to a
     // plane of their own (never read), so that the stores below carry no predicate
@@ -188,6 +189,12 @@ __global__ __launch_bounds__(256, Z_WGS) void conv3x3_zform_kernel(const ZArgs p
     const int tx = tid & 31, ty = (tid >> 5) * RPT;
 
     for (int k = 0; t >= 0; ++k) {
+        if (cur.n != scale_n) {                 // (workgroup-uniform)
+            scale_n = cur.n;
+            const int kx = ccst_scale_exp(ccst_absmax_read(p.xmax + scale_n * CCST_ABSMAX_WORDS), CCST_SPLIT_X_TARGET);
+            xs = __uint_as_float((unsigned)(127 + kx) << 23);
+            kd = -(kx + kw);
+        }
         const int tn = tile_of(k + 1);
         offsets(tn >= 0 ? tn : t, nxt);         // (past the end the prefetch re-reads this tile: unconditional loads, exact wait counts)
 #pragma unroll

@@ -31,7 +31,7 @@ struct Stem3Args {
     int blocksPerRow;
     int nblocks;
     unsigned long long mBpr, mH;   // ceil(2^40 / blocksPerRow), ceil(2^40 / H): divisions by multiplication (launcher checks the ranges)
-    unsigned* ymax;      // nullptr, or zeroed |max| words (CCST_ABSMAX_WORDS) receiving max |y|: the next layer's half-piece kernel scales by it
+    unsigned* ymax;      // nullptr, or zeroed |max| words [N][CCST_ABSMAX_WORDS] receiving max |y| PER IMAGE: the next layer's half-piece kernel scales by it
 };
 
 typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
@@ -111,11 +111,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STEM_WAVES,
     const float floor_ = p.relu ? 0.f : -__builtin_inff();
     const int stride = (int)gridDim.x * 4;
     int blk = (int)blockIdx.x * 4 + wave;
-    float amax = 0.f;         // largest |output| of this lane (lanes past the row's end hold copies of its last pixel)
+    float amax = 0.f;         // largest |output| of this lane in image amax_n (lanes past the row's end hold copies of its last pixel)
+    int amax_n = 0;           // a wave's blocks are visited in ascending order: when the image changes, the old image's maximum is published
     // one block from its 16 taps
     auto process = [&](int blk, const float (&bv)[16]) __attribute__((always_inline)) {
         const int row = (int)(((unsigned long long)blk * p.mBpr) >> 40);
         const int bx = blk - row * p.blocksPerRow;
+        if (p.ymax != nullptr) {
+            const int n_ = (int)(((unsigned long long)row * p.mH) >> 40);
+            if (n_ != amax_n) {                 // (wave-uniform)
+                ccst_absmax_publish_wave(p.ymax + amax_n * CCST_ABSMAX_WORDS, amax, blockIdx.x * 4 + wave);
+                amax = 0.f;
+                amax_n = n_;
+            }
+        }
         // this pixel's scale: the power of two that puts its largest tap below 2^14 (both lane halves hold taps of the same pixel)
         float m = 0.f;
 #pragma unroll
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STEM_WAVES,
         process(blk, bvb);
         blk += stride;
     }
-    if (p.ymax != nullptr) ccst_absmax_publish(p.ymax, amax, blockIdx.x);
+    if (p.ymax != nullptr) ccst_absmax_publish_wave(p.ymax + amax_n * CCST_ABSMAX_WORDS, amax, blockIdx.x * 4 + wave);
 }
 
 // OIHW [64,3,3,3] (+ bias [64]) -> header | A fragments | bias (Stem3Args::wa).  One workgroup: the weights' largest |value| gives their

@@ -168,6 +168,28 @@ __global__ __launch_bounds__(256) void absmax_batch_kernel(const long long* __re
     ccst_absmax_publish(words + (long long)blockIdx.y * CCST_ABSMAX_WORDS, m, blockIdx.x);
 }
 
+// The |max| words of the N images of a batch in one launch: x [N][per] contiguous, words [N][CCST_ABSMAX_WORDS] zeroed by the caller;
+// blockIdx.y = image.  (The AdaIN-path kernels keep one set of words PER IMAGE: a sample's power-of-two scale -- and with it its bits --
+// must not depend on its batch-mates, function.py:4-13.)  16-byte loads when an image's elements are a multiple of four.
+__global__ __launch_bounds__(256) void absmax_samples_kernel(const float* __restrict__ x, long long per, unsigned* __restrict__ words) {
+    const float* xb = x + (long long)blockIdx.y * per;
+    float m = 0.f;
+    if ((per & 3) == 0) {
+        const long long n4 = per >> 2;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xb + i * 4);
+            m = fmaxf(fmaxf(fmaxf(m, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
+            if (v[0] != v[0] || v[1] != v[1] || v[2] != v[2] || v[3] != v[3]) m = __builtin_nanf("");
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per; i += (long long)gridDim.x * 256) {
+            const float v = xb[i];
+            m = (v != v) ? v : fmaxf(m, fabsf(v));
+        }
+    }
+    ccst_absmax_publish(words + (long long)blockIdx.y * CCST_ABSMAX_WORDS, m, blockIdx.x);
+}
+
 }  // namespace
 
 extern "C" int ccst_absmax_f32(const float* x, int64_t n, uint32_t* absmax, void* stream) {
@@ -178,6 +200,16 @@ extern "C" int ccst_absmax_f32(const float* x, int64_t n, uint32_t* absmax, void
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks < cap ? blocks : cap))), dim3(256), 0, (hipStream_t)stream, x,
                        (long long)n, absmax);
     return ccst_launch_status("absmax");
+}
+
+extern "C" int ccst_absmax_samples_f32(const float* x, int N, int64_t per_sample, uint32_t* absmax, void* stream) {
+    CCST_REQUIRE(x && absmax && N > 0 && N <= 65535 && per_sample > 0, "absmax_samples: bad args");
+    CCST_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "absmax_samples: x must be 16-byte aligned");
+    const long long blocks = (per_sample / 4 + 255) / 256;
+    const long long cap = ((long long)ccst_num_cus() * 8 + N - 1) / N;
+    const long long gx = blocks < 1 ? 1 : (blocks < cap ? blocks : (cap < 1 ? 1 : cap));
+    hipLaunchKernelGGL(absmax_samples_kernel, dim3((unsigned)gx, (unsigned)N), dim3(256), 0, (hipStream_t)stream, x, (long long)per_sample, absmax);
+    return ccst_launch_status("absmax_samples");
 }
 
 extern "C" int ccst_absmax_batch_f32(const int64_t* table, int n, uint32_t* absmax, void* stream) {

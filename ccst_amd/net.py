@@ -242,10 +242,12 @@ def _run_steps(steps, x, sums_box):
     C = x.shape[1]
     cur = None          # NHWC buffer
     api = x             # logical NCHW tensor not yet converted
-    # |max| words of `cur` (ops.absmax_words) where its producer left them: the half-piece (SPLIT) conv kernels scale their input by the
+    # per-image |max| words of `cur` (ops.sample_absmax_words) where its producer left them: the half-piece (SPLIT) conv kernels scale their input by the
     # power of two derived from them, on the device.  ReLU / pad / upsample / pool keep them valid (an upper bound suffices); a tensor
-    # that arrives without them costs ops.conv3x3_halo_split one extra pass (ops.absmax).
+    # that arrives without them costs the first half-piece conv one extra pass (ops.absmax_samples).
     amax = ops.tagged_absmax(x)
+    if amax is not None and amax.numel() != x.shape[0] * ops.ABSMAX_WORDS:
+        amax = None     # (words of another granularity -- a per-tensor set of the ResNet kernels: this plan's kernels take per-image words)
 
     def split_next(i):
         """Does the next conv after step i run on the SPLIT kernel (i.e. is max |out| of step i wanted)?"""
@@ -262,7 +264,7 @@ def _run_steps(steps, x, sums_box):
         if s.kind == "stem3":
             if cur is not None:
                 api = ops.to_api(cur[..., :C]) if cur.shape[-1] != C else ops.to_api(cur)
-            amax = ops.absmax_words(x.device) if split_next(si) else None
+            amax = ops.sample_absmax_words(x.device, api.shape[0]) if split_next(si) else None
             cur = ops.conv3x3_stem3_nchw(ops.as_nchw_contiguous(api), s.wa, relu=s.relu, y_absmax=amax)
             C, api = 64, None
             continue
@@ -289,7 +291,7 @@ def _run_steps(steps, x, sums_box):
             if cur.shape[-1] != s.pc.k_pad:
                 cur = ops.from_api(ops.to_api(cur[..., :C]), cpad=16)
             split = s.stride == 1 and s.pad == 1 and not s.out_nchw and ops.halo_split_wanted(s.pc) and cur.shape[-1] == s.pc.cin
-            ymax = ops.absmax_words(x.device) if split and split_next(si) else None
+            ymax = ops.sample_absmax_words(x.device, cur.shape[0]) if split and split_next(si) else None
             if sums_box is not None and s is steps[-1] and ops.conv_sums_ok(s.pc, s.stride, s.pad, s.pool, s.out_nchw):
                 out, part = ops.conv2d_nhwc(cur, s.pc, stride=s.stride, pad=s.pad, reflect=s.reflect, relu=s.relu, pool=s.pool,
                                             ups=s.ups, chan_sums=True, x_absmax=amax, y_absmax=ymax)

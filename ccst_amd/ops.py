@@ -385,6 +385,43 @@ def absmax_words(device):
     return row
 
 
+def sample_absmax_words(device, n):
+    """n consecutive zeroed |max| word sets ([n, ABSMAX_WORDS] int32, one per IMAGE of a batch) from the same pool: what the AdaIN-path
+    kernels take as x_absmax / y_absmax (include/ccst_hip.h: per image, so that a sample's scale -- and bits -- never depend on its
+    batch-mates)."""
+    n = int(n)
+    key = (torch.cuda.current_device() if device.index is None else device.index, _lib.raw_stream())
+    ent = _ABSMAX_POOL.get(key)
+    if ent is None or ent[1] + n > ent[0].shape[0]:
+        ent = [torch.zeros((max(1024, n), ABSMAX_WORDS), device=device, dtype=torch.int32), 0]
+        _ABSMAX_POOL[key] = ent
+    rows = ent[0][ent[1]:ent[1] + n]
+    ent[1] += n
+    return rows
+
+
+def absmax_samples(t):
+    """The per-image |max| words [N, ABSMAX_WORDS] of a contiguous fp32 CUDA batch t [N, ...] (one streaming pass,
+    ccst_absmax_samples_f32) -- for AdaIN-path tensors whose producer left none."""
+    _require_cuda(t, "tensor")
+    t = t if t.is_contiguous() else t.contiguous()
+    N = int(t.shape[0])
+    out = sample_absmax_words(t.device, N)
+    if t.numel() > 0:
+        check(_lib.load().ccst_absmax_samples_f32(ptr(t), N, t.numel() // N, ptr(out), stream_ptr()), "absmax_samples")
+    return out
+
+
+def _sample_words(x, words):
+    """The per-image words of batch x: `words` if they are [N, ABSMAX_WORDS] (a producer's), else computed by one pass."""
+    if words is not None and words.numel() == x.shape[0] * ABSMAX_WORDS:
+        return words
+    if words is not None:
+        raise ValueError("ccst_amd.ops: the AdaIN-path kernels take PER-IMAGE |max| words [N, %d] (got %d words for a batch of %d)"
+                         % (ABSMAX_WORDS, words.numel(), x.shape[0]))
+    return absmax_samples(x)
+
+
 def reset_absmax_pool():
     """Forget the current blocks: the next absmax_words() zero-fills a fresh one.  fed._GraphedTrainStep calls it on both sides of a
     capture, so that a captured step takes its rows from a block whose zero fill is part of the graph (re-zeroed by every replay:
@@ -462,8 +499,8 @@ def conv3x3_f43(x, pc, flags, sums=False, x_absmax=None, y_absmax=None):
     """3x3 stride-1 pad-1 conv as Winograd F(4,3) along x on half pieces (conv3x3_f43.hip); same arguments and results as
     conv3x3_halo_split (sums: per-(tile, position group) centred records [ccst_conv3x3_f43_tiles, Cout, 4])."""
     N, Hs, Ws, Cx = x.shape
-    if x_absmax is None:
-        x_absmax = absmax(x)
+    x_absmax = _sample_words(x, x_absmax)
+    assert y_absmax is None or y_absmax.numel() == N * ABSMAX_WORDS, "y_absmax: per-image words [N, ABSMAX_WORDS] (sample_absmax_words)"
     ups, pool = bool(flags & CONV_UPS2), bool(flags & CONV_POOL2)
     Hi, Wi = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
     oh, ow = ((Hi + 1) // 2, (Wi + 1) // 2) if pool else (Hi, Wi)
@@ -492,11 +529,11 @@ def conv3x3_f43(x, pc, flags, sums=False, x_absmax=None, y_absmax=None):
 def conv3x3_halo_split(x, pc, flags, sums=False, x_absmax=None, y_absmax=None):
     """3x3 stride-1 pad-1 conv on the direct kernel's SPLIT form; x NHWC [N,Hs,Ws,Cin], pc packed with wino=4 (which also builds
     pc.wsplit).  sums=True (no pool): also the per-tile (sum, sum of squares) partials [tiles, Cout, 2] of the output.
-    x_absmax: the |max| words of x left by its producer (None: one extra pass over x computes them); y_absmax: zeroed words that
-    receive max |out| for the next layer."""
+    x_absmax: the per-image |max| words [N, ABSMAX_WORDS] of x left by its producer (None: one extra pass over x computes them);
+    y_absmax: zeroed per-image words (sample_absmax_words) that receive max |out| for the next layer."""
     N, Hs, Ws, Cx = x.shape
-    if x_absmax is None:
-        x_absmax = absmax(x)
+    x_absmax = _sample_words(x, x_absmax)
+    assert y_absmax is None or y_absmax.numel() == N * ABSMAX_WORDS, "y_absmax: per-image words [N, ABSMAX_WORDS] (sample_absmax_words)"
     ups, pool = bool(flags & CONV_UPS2), bool(flags & CONV_POOL2)
     Hi, Wi = (2 * Hs, 2 * Ws) if ups else (Hs, Ws)
     oh, ow = ((Hi + 1) // 2, (Wi + 1) // 2) if pool else (Hi, Wi)
@@ -701,8 +738,7 @@ def conv3x3_zform_nchw(x, pz, bias, cout, reflect=True, relu=False, x_absmax=Non
     N, H, W, Cin = x.shape
     if x_absmax is None:
         x_absmax = tagged_absmax(x)
-    if x_absmax is None:
-        x_absmax = absmax(x)
+    x_absmax = _sample_words(x, x_absmax)
     packed, words = pz.get()
     out = torch.empty((N, cout, H, W), device=x.device, dtype=torch.float32)
     lib = _lib.load()
@@ -772,19 +808,20 @@ def pack_stem3(w_oihw, bias=None):
 
 
 def conv3x3_stem3_nchw(x_nchw, wa, relu=True, y_absmax=None):
-    """ReflectionPad2d(1) + Conv2d(3,64,3x3) (+ReLU) on a contiguous NCHW image -> NHWC [N,H,W,64].  y_absmax: zeroed |max| words
-    that receive max |out| (absmax_words) for a half-piece conv that follows."""
+    """ReflectionPad2d(1) + Conv2d(3,64,3x3) (+ReLU) on a contiguous NCHW image -> NHWC [N,H,W,64].  y_absmax: zeroed per-image |max|
+    words [N, ABSMAX_WORDS] (sample_absmax_words) that receive max |out| for a half-piece conv that follows."""
     _require_cuda(x_nchw, "image")
     x = as_nchw_contiguous(x_nchw)
     N, C, H, W = x.shape
     assert C == 3
     out = torch.empty((N, H, W, 64), device=x.device, dtype=torch.float32)
+    assert y_absmax is None or y_absmax.numel() == N * ABSMAX_WORDS, "y_absmax: per-image words [N, ABSMAX_WORDS] (sample_absmax_words)"
     # the kernel addresses its output through one 32-bit buffer resource: slices of < 2^31 bytes along the batch
     per = max(1, (2 ** 31 - 1) // (H * W * 64 * 4))
     lib = _lib.load()
     for n0 in range(0, N, per):
         n = min(per, N - n0)
-        args = (ptr(x[n0:]), ptr(wa), ptr(out[n0:]), n, H, W, int(relu), ptr(y_absmax), stream_ptr())
+        args = (ptr(x[n0:]), ptr(wa), ptr(out[n0:]), n, H, W, int(relu), ptr(None if y_absmax is None else y_absmax.reshape(N, ABSMAX_WORDS)[n0:]), stream_ptr())
         if TIMING is None:
             check(lib.ccst_conv3x3_stem3_f32(*args), "conv3x3_stem3")
         else:
@@ -908,7 +945,7 @@ def adain(feat, style_mean, style_std, alpha=1.0, eps=1e-5):
         raise RuntimeError("ccst_amd: style statistics must have C or N*C elements")
     out = torch.empty_like(buf)
     ws, nb = _stats_ws(N, C, H * W, feat.device)
-    amax = absmax_words(feat.device)      # the kernel leaves max |out|: the decoder's first half-piece conv scales by it
+    amax = sample_absmax_words(feat.device, N)      # the kernel leaves max |out| per image: the decoder's first half-piece conv scales by it
     args = (ptr(buf), ptr(sm), ptr(ss), per_n, float(alpha), ptr(out), N, C, H * W, layout, eps, ptr(ws), nb, ptr(amax), stream_ptr())
     if TIMING is None:
         check(_lib.load().ccst_adain_f32(*args), "adain")
@@ -945,7 +982,7 @@ def adain_from_tile_sums(feat, partials, style_mean, style_std, alpha=1.0, eps=1
     else:
         raise RuntimeError("ccst_amd: style statistics must have C or N*C elements")
     out = torch.empty_like(buf)
-    amax = absmax_words(feat.device)      # the kernel leaves max |out|: the decoder's first half-piece conv scales by it
+    amax = sample_absmax_words(feat.device, N)      # the kernel leaves max |out| per image: the decoder's first half-piece conv scales by it
     stat = torch.empty((2, N * C), device=feat.device, dtype=torch.float32)      # the folded content statistics (fold kernel -> stream kernel)
     args = (ptr(buf), ptr(partials), int(partials.shape[2]), int(partials.shape[0] // N), ptr(sm), ptr(ss), per_n, float(alpha), ptr(out), N, C, H * W,
             eps, ptr(stat[0]), ptr(stat[1]), ptr(amax), stream_ptr())

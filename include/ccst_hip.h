@@ -120,13 +120,20 @@ int ccst_conv3x3_halo_f32(const float* x, const float* w_packed, const float* bi
 
 int ccst_conv3x3_halo_narrow(int N, int H, int W, int Cout);   /* 1: the 128x64 tile is dispatched, 0: 128x128 */
 
-/* Per-tensor |max| words: CCST_ABSMAX_WORDS = 64 uint32 (256 bytes) on the device, zeroed by the caller, into which a producing kernel
+/* |max| words: CCST_ABSMAX_WORDS = 64 uint32 (256 bytes) on the device, zeroed by the caller, into which a producing kernel
  * max-accumulates the raw fp32 bits of the largest |value| it wrote (one conditional atomic per workgroup into word id % 64) and from
  * which the half-piece kernels below derive their power-of-two operand scales ON THE DEVICE (one coalesced load per wave) -- no host
  * synchronisation anywhere.  ccst_absmax_f32 is the stand-alone producer (one pass over x) for tensors whose producer did not leave
- * the words. */
+ * the words.
+ *   PER TENSOR for weights and for the ResNet train / eval kernels (BatchNorm couples the samples of a batch anyway);
+ *   PER IMAGE -- [N][CCST_ABSMAX_WORDS], image n's words at + n * CCST_ABSMAX_WORDS -- for the activations of the AdaIN-path kernels
+ *   (ccst_conv3x3_stem3_f32, ccst_conv3x3_f43_f32, ccst_conv3x3_halo_split_f32, ccst_conv3x3_zform_f32, ccst_adain_f32,
+ *   ccst_adain_tile_sums_f32: every x_absmax / y_absmax of theirs), since ABI version 2: the reference is strictly per sample
+ *   (function.py:4-13, net.py), so an image's scale -- and with it its bits -- must not depend on its batch-mates; ccst_absmax_samples_f32
+ *   is their stand-alone producer (x [N][per_sample] contiguous). */
 #define CCST_ABSMAX_WORDS 64
 int ccst_absmax_f32(const float* x, int64_t n, uint32_t* absmax, void* stream);
+int ccst_absmax_samples_f32(const float* x, int N, int64_t per_sample, uint32_t* absmax /* [N][CCST_ABSMAX_WORDS], zeroed */, void* stream);
 /* ... of n tensors in one launch: table [n][2] int64 = (device pointer, 16-byte aligned; element count), absmax [n][CCST_ABSMAX_WORDS]
  * zeroed by the caller (the pointwise conv weights of a ResNet after each optimiser step, nets/resnet.py). */
 int ccst_absmax_batch_f32(const int64_t* table, int n, uint32_t* absmax, void* stream);

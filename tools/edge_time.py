@@ -21,7 +21,7 @@ w2t = w2.permute(2, 3, 0, 1).contiguous()       # [3][3][Cout][Cin], as net.py h
 
 
 pz = ops.PackedZform(w2t) if hasattr(ops, "PackedZform") else None
-fwords = ops.absmax(feat)
+fwords = ops.absmax_samples(feat)
 
 
 def timed(fn):

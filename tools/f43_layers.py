@@ -32,7 +32,7 @@ def main():
         b = (torch.randn(Cout, generator=g) * 0.05).to(dev)
         pc = ops.pack_conv_weight(w, b, wino=4)
         flags = 1 | 8 | (2 if pool else 0) | (4 if ups else 0)
-        xmax = ops.absmax(x)
+        xmax = ops.absmax_samples(x)
         fns = (lambda: ops.conv3x3_halo_split(x, pc, flags, x_absmax=xmax), lambda: ops.conv3x3_f43(x, pc, flags, x_absmax=xmax))
         res = []
         for fn in fns:
