@@ -58,7 +58,8 @@ _SIGNATURES = {
     "ccst_absmax_samples_f32": [_P, c_int, c_int64, _P, _P],
     "ccst_conv3x3_halo_split_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P, _P],
     "ccst_pack_conv_weight_f43_f32": [_P, _P, c_int, c_int, c_int, _P, _P],
-    "ccst_conv3x3_f43_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P, _P],
+    "ccst_conv3x3_f43_f32": [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_uint32, _P, _P, _P, _P],
+    "ccst_adain_fold_affine_f32": [_P, c_int, _P, _P, c_int, c_float, c_int, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P],
     "ccst_conv3x3_f43_workgroups": [c_int, c_int, c_int, c_int],
     "ccst_conv3x3_f43_tiles": [c_int, c_int, c_int],
     "ccst_conv3x3_halo_split_tiles": [c_int, c_int, c_int],

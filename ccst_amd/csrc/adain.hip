@@ -368,6 +368,68 @@ __global__ __launch_bounds__(FP_T) void adain_fused_nhwc_kernel(const float* __r
     if (ymax != nullptr) ccst_absmax_publish(ymax, amax, blockIdx.x, peeked);
 }
 
+// The same fold for the FUSED AdaIN step (round 6): instead of streaming the tensor through (x - mu) / sigma * sigma_s + mu_s and the
+// alpha blend, the step becomes the per-(image, channel) affine map  y = a x + b,
+//     a = alpha sigma_s / sigma + (1 - alpha),     b = alpha (mu_s - mu sigma_s / sigma)        (in fp64, rounded once),
+// which the decoder's first conv applies to x on its way into its input transform (ccst_conv3x3_f43_f32's in_scale / in_shift): the
+// normalised tensor is never written or read -- the step's 100 MB pass is gone.  The conv needs the |max| words of the MAPPED tensor:
+// the records' fourth float is the slab's largest |x|, so  max |a x + b| <= |a| max |x| + |b|  per channel -- or, for x >= 0 (x_nonneg: the
+// producer applied ReLU), exactly max(|b|, |a max x + b|), the map being monotone on [0, max x] -- maximised over the image's channels into
+// y_absmax[n] (an upper bound is a valid scale).  Centred records only (the half-piece conv kernels' epilogues).
+__global__ __launch_bounds__(TPB) void tile_stats_affine_kernel(const float* __restrict__ part, int tpi, int HW, int C, float eps,
+                                                                const float* __restrict__ smean, const float* __restrict__ sstd, int style_per_n,
+                                                                float alpha, int x_nonneg, float* __restrict__ mean_out, float* __restrict__ std_out,
+                                                                float* __restrict__ a_out, float* __restrict__ b_out, unsigned* __restrict__ ymax) {
+    __shared__ double red[2][16][17];
+    __shared__ float redm[16][17];
+    const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + cl;                    // (image, channel); C % 16 == 0, so a workgroup stays inside one image
+    const int n = i / C, c = i - n * C;
+    double s = 0.0, q = 0.0, piv = 0.0;
+    float vm = 0.f;
+    const f32x4* pp = reinterpret_cast<const f32x4*>(part) + (long long)n * tpi * C + c;
+    const f32x4 a0 = pp[0];
+    piv = a0[2] > 0.f ? (double)(a0[0] / a0[2]) : 0.0;
+    for (int k = kl; k < tpi; k += 16) {
+        const f32x4 a = pp[(long long)k * C];
+        if (a[2] > 0.f) {
+            const double tk = (double)a[0] - (double)a[2] * piv;
+            s += tk;
+            q += (double)a[1] + tk * tk / (double)a[2];
+            vm = fmaxf(vm, a[3]);
+        }
+    }
+    red[0][kl][cl] = s;
+    red[1][kl][cl] = q;
+    redm[kl][cl] = vm;
+    __syncthreads();
+    float bound = 0.f;
+    if (kl == 0) {
+        s = red[0][0][cl];
+        q = red[1][0][cl];
+        vm = redm[0][cl];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            s += red[0][k][cl];
+            q += red[1][k][cl];
+            vm = fmaxf(vm, redm[k][cl]);
+        }
+        const double m = s / (double)HW;
+        const double var = fmax(q - s * m, 0.0) / ((double)HW - 1.0);
+        const float mu = (float)(m + piv), sd = sqrtf((float)var + eps);          // the statistics as ccst_adain_tile_sums_f32 rounds them
+        mean_out[i] = mu;
+        std_out[i] = sd;
+        const int so = style_per_n ? i : c;
+        const double r = (double)sstd[so] / (double)sd;
+        const float a = (float)((double)alpha * r + (1.0 - (double)alpha));
+        const float b = (float)((double)alpha * ((double)smean[so] - (double)mu * r));
+        a_out[i] = a;
+        b_out[i] = b;
+        bound = (x_nonneg ? fmaxf(fabsf(b), fabsf(__builtin_fmaf(a, vm, b))) : fabsf(a) * vm + fabsf(b)) * 1.0000005f;   // (rounded up: the words must bound every mapped value)
+    }
+    ccst_absmax_publish(ymax + n * CCST_ABSMAX_WORDS, bound, blockIdx.x);
+}
+
 int pick_splits(int N, int C, int HW, int layout) {
     // aim for ~2048 workgroups (8 per CU, four 16-byte loads in flight per thread), at least ~8 pixels (NHWC) / 1024 elements (NCHW) per split
     long long units = (layout == 1) ? (long long)N * ((C / 4 + 255) / 256) : (long long)N * C;
@@ -599,6 +661,21 @@ extern "C" int ccst_adain_tile_sums_f32(const float* x, const float* partials, i
     hipLaunchKernelGGL(adain_stream_nhwc_kernel, dim3(C / (4 * TS_CQ), N, chunks), dim3(TPB), 0, st, x, y, mean_out, std_out, style_mean, style_std,
                        style_per_n, alpha, HW, C, y_absmax);
     return ccst_launch_status("adain_tile_sums");
+}
+
+// function.py:26-33 + the alpha blend as an affine map for the consumer to apply (see tile_stats_affine_kernel): partials = the centred
+// records [N * tiles_per_image][C][4] (sum, M2, count, max |x|) of ccst_conv3x3_f43_f32's epilogue.  Outputs, [N*C] floats each: the
+// content statistics (mean_out, std_out) and the map (a_out, b_out); y_absmax: zeroed per-image words [N][CCST_ABSMAX_WORDS] that receive
+// a bound of max |a x + b|.  One launch of N*C/16 small workgroups; nothing touches the features.
+extern "C" int ccst_adain_fold_affine_f32(const float* partials, int tiles_per_image, const float* style_mean, const float* style_std,
+                                          int style_per_n, float alpha, int x_nonneg, int N, int C, int HW, float eps, float* mean_out,
+                                          float* std_out, float* a_out, float* b_out, uint32_t* y_absmax, void* stream) {
+    CCST_REQUIRE(partials && style_mean && style_std && mean_out && std_out && a_out && b_out && y_absmax, "adain_fold_affine: null pointer");
+    CCST_REQUIRE(N > 0 && N <= 65535 && C > 0 && C % 16 == 0 && HW >= 2 && tiles_per_image > 0, "adain_fold_affine: bad shape (C %% 16 == 0, HW >= 2)");
+    CCST_REQUIRE(alpha >= 0.f && alpha <= 1.f, "adain_fold_affine: alpha=%f outside [0,1]", (double)alpha);
+    hipLaunchKernelGGL(tile_stats_affine_kernel, dim3(N * C / 16), dim3(TPB), 0, (hipStream_t)stream, partials, tiles_per_image, HW, C, eps,
+                       style_mean, style_std, style_per_n, alpha, x_nonneg, mean_out, std_out, a_out, b_out, y_absmax);
+    return ccst_launch_status("adain_fold_affine");
 }
 
 // style_transfer's interpolation branch (CCST_OverallStyleTransfer.py:36-45): base [K][elems] = the K stylised feature maps of one

@@ -106,14 +106,6 @@ __device__ __forceinline__ void ccst_absmax_publish(unsigned* slots, float lane_
         }
     }
 }
-// The same for ONE WAVE (no LDS, no barrier): kernels whose waves walk several images publish an image's maximum when they leave it.
-__device__ __forceinline__ void ccst_absmax_publish_wave(unsigned* slots, float lane_max, unsigned slot) {
-    const unsigned m = ccst_wave_umax(__float_as_uint(lane_max) & 0x7fffffffu);
-    if ((threadIdx.x & 63) == 0 && m != 0u) {
-        unsigned* const s = slots + slot % CCST_ABSMAX_SLOTS;
-        if (m > __hip_atomic_load(s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) (void)__hip_atomic_fetch_max(s, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
 // the two halves of ccst_absmax_read for kernels that want the load in flight behind other work: every lane loads its word early
 // (ccst_absmax_load), the wave reduces it where the value is first needed (ccst_absmax_reduce)
 __device__ __forceinline__ unsigned ccst_absmax_load(const unsigned* slots) {

@@ -39,7 +39,9 @@ struct F43Args {
     const unsigned* xmax;    // [N][CCST_ABSMAX_WORDS]: every image its own words (a sample's scale -- and bits -- do not depend on its batch-mates)
     const unsigned* wmax;
     unsigned* ymax;          // nullptr, or zeroed [N][CCST_ABSMAX_WORDS]
-    float* stats;        // nullptr, or [ccst_conv3x3_f43_tiles(N,H,W)][Cout][4] per-(8x32-pixel tile, position group) (sum, M2 about the slab's own mean, count, 0)
+    float* stats;        // nullptr, or [ccst_conv3x3_f43_tiles(N,H,W)][Cout][4] per-(8x32-pixel tile, position group) (sum, M2 about the slab's own mean, count, max |y|)
+    const float* aff_a;  // AFF: [N][Cin] per-(image, input channel) scale and shift applied to x ON ITS WAY INTO THE TRANSFORM: the conv of a x + b
+    const float* aff_b;  //      (the AdaIN normalise + alpha blend folded into the decoder's first conv: no pass over the features)
     int N, H, W, Hs, Ws, Cin, Cout, CoutPad;
     int reflect, ups, relu;
     long long ysN;
@@ -108,7 +110,10 @@ struct GroupTag {
 
 // ZP: zero padding (the masks cost 16-24 vector instructions per transform item: the reflecting AdaIN layers run the kernel without them)
 // NT: non-temporal output stores -- for outputs the caches cannot hold until the next layer reads them (>= 256 MB: the host decides)
-template <bool POOL, bool ZP, bool HALF, bool NT>
+// AFF: x is read through the per-(image, channel) affine map p.aff_a x + p.aff_b (one fused multiply-add per loaded value, rounded once --
+//     what storing the normalised tensor would have rounded too); p.xmax are then the words of the MAPPED tensor.  The 2 x Cin
+//     coefficients of the workgroup's image sit in LDS behind the raw halo (inside the allocation the epilogue's exchange needs anyway).
+template <bool POOL, bool ZP, bool HALF, bool NT, bool AFF>
 __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F43Args p) {
     typedef Tile<HALF> T;
     constexpr int G_TH = T::TH, G_HH = T::HH, G_BN = T::BN, G_VW = T::VW, G_RSLOTS = T::RSLOTS, G_RAW_PIECES = T::RAW_PIECES, G_RAW0 = T::RAW0,
@@ -116,6 +121,7 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
     extern __shared__ __attribute__((aligned(16))) float f43_lds[];
     float* const Vs = f43_lds;                     // [2][G_VW]             transformed halo, double buffered
     float* const Raw = f43_lds + G_RAW0;           // [G_RAW_PIECES * 256]  raw fp32 halo pixels of the NEXT chunk
+    float* const Aff = f43_lds + T::OPERAND_BYTES / 4;      // AFF: [2][Cin] scale | shift of this image
     const unsigned lds0 = (unsigned)(size_t)f43_lds;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -190,6 +196,22 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
         okyB = (gyB >= 0) & (gyB < p.H);
     }
     float xs = 1.f;          // 2^kx (set in the prologue)
+    int aff_c = 0;           // AFF: the chunk the transform is working on (its coefficients: Aff[16 aff_c + 4 part ..], Aff[Cin + ..])
+    f32x4 fa = {1.f, 1.f, 1.f, 1.f}, fb = {0.f, 0.f, 0.f, 0.f};
+    auto affine_coef = [&]() __attribute__((always_inline)) {          // once per transform item: the item's four channels of chunk aff_c
+        if (!AFF) return;
+        int co_ = aff_c * 16;
+        asm volatile("" : "+s"(co_));                // (a scalar add per item, not a hoisted vector one)
+        fa = *reinterpret_cast<const f32x4*>(Aff + co_ + part_t * 4);
+        fb = *reinterpret_cast<const f32x4*>(Aff + p.Cin + co_ + part_t * 4);
+    };
+    auto affine = [&](f32x4 v) __attribute__((always_inline)) {
+        if (!AFF) return v;
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = __builtin_fmaf(v[j], fa[j], fb[j]);
+        return o;
+    };
     auto put = [&](float* o, f32x4 v) {          // four scaled fp32 values -> (hi, lo) half pieces -> V
         u32x2g hi, lo;
 #pragma unroll
@@ -207,8 +229,9 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
     auto xpair = [&](auto ptag, const float* r0, float* o, bool oky) __attribute__((always_inline)) {
         constexpr int PAIR = decltype(ptag)::value;
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        affine_coef();
         auto px = [&](int d) {                   // pixel d of the quad (0..5)
-            f32x4 v = *reinterpret_cast<const f32x4*>(r0 + (d < 4 ? d : d + 1) * 16);
+            f32x4 v = affine(*reinterpret_cast<const f32x4*>(r0 + (d < 4 ? d : d + 1) * 16));
             if (ZP && !(oky && ((tokx >> d) & 1u))) v = z;
             return v;
         };
@@ -237,9 +260,10 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
     auto xl = [&](auto ptag, const float* r0, bool oky) __attribute__((always_inline)) {
         constexpr int PAIR = decltype(ptag)::value;
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        affine_coef();
 #pragma unroll
         for (int d = (PAIR < 2 ? 1 : 0); d < (PAIR < 2 ? 5 : 6); ++d) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(r0 + (d < 4 ? d : d + 1) * 16);
+            f32x4 v = affine(*reinterpret_cast<const f32x4*>(r0 + (d < 4 ? d : d + 1) * 16));
             if (ZP && !(oky && ((tokx >> d) & 1u))) v = z;
             xr[d] = v;
         }
@@ -323,6 +347,14 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
     const int aBase = (li & 3) * G_ROWW + (li >> 2) * G_XQW + lh * 4;
 
     // ---- prologue: the raw pixels of chunk 0 first, the weights of chunk 0 behind them (their latencies overlap) ----------------------
+    if (AFF) {          // this image's 2 x Cin coefficients -> LDS (complete before the first barrier: plain loads, the wave's own waits)
+        const float* const sa = p.aff_a + (long long)n * p.Cin;
+        const float* const sb = p.aff_b + (long long)n * p.Cin;
+        for (int i = tid * 4; i < p.Cin; i += T::NT * 4) {
+            *reinterpret_cast<f32x4*>(Aff + i) = *reinterpret_cast<const f32x4*>(sa + i);
+            *reinterpret_cast<f32x4*>(Aff + p.Cin + i) = *reinterpret_cast<const f32x4*>(sb + i);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NRAW; ++i) dma_raw(0, i);
     int kx = 0, kw = 0;
@@ -393,6 +425,7 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
                 if (!LAST) {
                     // the raw pieces are older than the 18 weight loads of this chunk; every wave is past its last fragment read
                     asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    aff_c = c + 1;
                     xform(tdstA, tdstB, 0);
                     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                     read_a(1, aBase, 0);
@@ -415,6 +448,7 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
         // one chunk; LAST (compile time): nothing to prepare behind it -- no weight loads, no raw pieces, no transform
         auto chunk = [&](const int c, auto lasttag) __attribute__((always_inline)) {
             constexpr bool LAST = decltype(lasttag)::value != 0;
+            aff_c = c + 1;              // (the transform items of this chunk's k-steps belong to the next chunk)
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int j = t % 3;
@@ -595,9 +629,12 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
                         }
                     }
                 m2 += __shfl_xor(m2, 32, 64);
+                // (... and the slab's largest |value|: a lane holds ONE channel, so its running maximum is the channel's -- what lets the AdaIN fold
+                //  bound max |a x + b| per image without a pass over the tensor)
+                const float cmax = fmaxf(amax, __shfl_xor(amax, 32, 64));
                 if (lh == 0 && cok)
                     *reinterpret_cast<f32x4*>(p.stats + ((long long)((((n * p.tilesY + ty) * p.tilesX + tx) * 2 + grp)) * p.Cout + co) * 4) =
-                        f32x4{s1, m2, cnt, 0.f};
+                        f32x4{s1, m2, cnt, cmax};
             }
         } else {
             // a pooling window = rows (2 k, 2 k + 1) x pixels (4 quad + 2 grp, + 1) = four values of one lane: registers (r & 3) = 0, 1 | 2, 3
@@ -700,7 +737,7 @@ extern "C" int ccst_conv3x3_f43_workgroups(int N, int H, int W, int Cout) {
     return N * ((H + 7) / 8) * ((W + G_TW - 1) / G_TW) * ((Cout + bn - 1) / bn);
 }
 
-template <bool POOL, bool ZP, bool HALF, bool NT>
+template <bool POOL, bool ZP, bool HALF, bool NT, bool AFF = false>
 static int launch_f43(F43Args& a, int N, int H, int W, int Cout, hipStream_t s) {
     typedef Tile<HALF> T;
     a.tilesN = (Cout + T::BN - 1) / T::BN;
@@ -708,7 +745,9 @@ static int launch_f43(F43Args& a, int N, int H, int W, int Cout, hipStream_t s) 
     a.tilesX = (W + G_TW - 1) / G_TW;
     const long long grid = (long long)N * a.tilesY * a.tilesX * a.tilesN;
     CCST_REQUIRE(grid > 0 && grid <= 0x7fffffffLL, "conv3x3_f43: bad grid");
-    void (*kern)(const F43Args) = conv3x3_f43_kernel<POOL, ZP, HALF, NT>;
+    void (*kern)(const F43Args) = conv3x3_f43_kernel<POOL, ZP, HALF, NT, AFF>;
+    if (AFF) CCST_REQUIRE(T::OPERAND_BYTES + 8LL * a.Cin <= T::LDS_BYTES, "conv3x3_f43: too many input channels for the fused input affine (<= %d)",
+                          (T::LDS_BYTES - T::OPERAND_BYTES) / 8);
     // (the opt-in above the 64 KB default is per device and idempotent: set for the current device on every launch)
     hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
     if (e1 != hipSuccess) {
@@ -723,8 +762,11 @@ static int launch_f43(F43Args& a, int N, int H, int W, int Cout, hipStream_t s) 
 // 8 rows x 32 pixels x 64 channels, four waves, two workgroups per CU (ccst_conv3x3_f43_workgroups).
 extern "C" int ccst_conv3x3_f43_f32(const float* x, const uint32_t* x_absmax, const float* u, const uint32_t* w_absmax, const float* bias,
                                     float* y, uint32_t* y_absmax, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags,
-                                    float* chan_sum_partials, void* stream) {
+                                    float* chan_sum_partials, const float* in_scale, const float* in_shift, void* stream) {
     CCST_REQUIRE(x && u && y && x_absmax && w_absmax, "conv3x3_f43: null pointer (the |max| words of x and w are required)");
+    CCST_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3x3_f43: in_scale and in_shift come together ([N][Cin] each)");
+    const bool aff = in_scale != nullptr;
+    CCST_REQUIRE(!aff || !(flags & (CCST_CONV_POOL2 | CCST_CONV_UPS2)), "conv3x3_f43: the fused input affine goes with a plain conv (no pool, no upsample)");
     CCST_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0, "conv3x3_f43: bad shape");
     const bool half = Cout <= 64;
     CCST_REQUIRE(cout_pad >= Cout && cout_pad % (half ? 64 : 128) == 0, "conv3x3_f43: cout_pad must be a multiple of 128 (Cout <= 64: of 64) >= cout");
@@ -734,6 +776,7 @@ extern "C" int ccst_conv3x3_f43_f32(const float* x, const uint32_t* x_absmax, co
     if (flags & CCST_CONV_REFLECT) CCST_REQUIRE(H >= 2 && W >= 2, "conv3x3_f43: reflection needs extent >= 2");
     F43Args a;
     a.x = x; a.u = u; a.bias = bias; a.y = y; a.xmax = x_absmax; a.wmax = w_absmax; a.ymax = y_absmax; a.stats = chan_sum_partials;
+    a.aff_a = in_scale; a.aff_b = in_shift;
     a.N = N; a.H = H; a.W = W; a.Hs = ups ? H / 2 : H; a.Ws = ups ? W / 2 : W; a.Cin = Cin; a.Cout = Cout; a.CoutPad = cout_pad;
     a.reflect = (flags & CCST_CONV_REFLECT) ? 1 : 0; a.ups = ups ? 1 : 0; a.relu = (flags & CCST_CONV_RELU) ? 1 : 0;
     CCST_REQUIRE((long long)N * a.Hs * a.Ws * Cin < 0x7fffffffLL, "conv3x3_f43: input must have < 2^31 elements");
@@ -750,6 +793,10 @@ extern "C" int ccst_conv3x3_f43_f32(const float* x, const uint32_t* x_absmax, co
     // smaller ones are read back from the caches, and non-temporal stores cost the step 2 % (measured at 100 / 200 / 400 MB thresholds)
     const long long nt_bytes = 256LL << 20;
     const bool nt = (long long)N * oh * ow * Cout * 4 >= nt_bytes;
+    if (aff) {          // (never pooled; its output is small enough for the caches wherever the path uses it: ordinary stores)
+        if (half) return zp ? launch_f43<false, true, true, false, true>(a, N, H, W, Cout, st) : launch_f43<false, false, true, false, true>(a, N, H, W, Cout, st);
+        return zp ? launch_f43<false, true, false, false, true>(a, N, H, W, Cout, st) : launch_f43<false, false, false, false, true>(a, N, H, W, Cout, st);
+    }
 #define F43_GO2(P_, Z_, H_) (nt ? launch_f43<P_, Z_, H_, true>(a, N, H, W, Cout, st) : launch_f43<P_, Z_, H_, false>(a, N, H, W, Cout, st))
 #define F43_GO(P_, Z_) (half ? F43_GO2(P_, Z_, true) : F43_GO2(P_, Z_, false))
     return pool ? (zp ? F43_GO(true, true) : F43_GO(true, false)) : (zp ? F43_GO(false, true) : F43_GO(false, false));

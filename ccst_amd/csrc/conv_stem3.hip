@@ -29,7 +29,7 @@ struct Stem3Args {
     float* y;            // [N,H,W,64]
     int N, H, W, relu;
     int blocksPerRow;
-    int nblocks;
+    int nblocks, blocksPerImage;
     unsigned long long mBpr, mH;   // ceil(2^40 / blocksPerRow), ceil(2^40 / H): divisions by multiplication (launcher checks the ranges)
     unsigned* ymax;      // nullptr, or zeroed |max| words [N][CCST_ABSMAX_WORDS] receiving max |y| PER IMAGE: the next layer's half-piece kernel scales by it
 };
@@ -109,22 +109,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STEM_WAVES,
             bv[8 + i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrs, colo[i % 3] + 2u * HW4, rowo[i / 3], 0));
     };
     const float floor_ = p.relu ? 0.f : -__builtin_inff();
+    // grid = (workgroups per image, images): a workgroup walks the blocks of ONE image, so that its maximum is that image's (the |max|
+    // words are per image) -- with nothing but arithmetic inside the pipelined loop (a publish behind a branch there put a vector-memory
+    // operation on one path and with it a vmcnt(0) at the join: 86 -> 163 us)
     const int stride = (int)gridDim.x * 4;
-    int blk = (int)blockIdx.x * 4 + wave;
-    float amax = 0.f;         // largest |output| of this lane in image amax_n (lanes past the row's end hold copies of its last pixel)
-    int amax_n = 0;           // a wave's blocks are visited in ascending order: when the image changes, the old image's maximum is published
+    const int blk_end = ((int)blockIdx.y + 1) * p.blocksPerImage;
+    int blk = (int)blockIdx.y * p.blocksPerImage + (int)blockIdx.x * 4 + wave;
+    float amax = 0.f;         // largest |output| of this lane (lanes past the row's end hold copies of its last pixel)
     // one block from its 16 taps
     auto process = [&](int blk, const float (&bv)[16]) __attribute__((always_inline)) {
         const int row = (int)(((unsigned long long)blk * p.mBpr) >> 40);
         const int bx = blk - row * p.blocksPerRow;
-        if (p.ymax != nullptr) {
-            const int n_ = (int)(((unsigned long long)row * p.mH) >> 40);
-            if (n_ != amax_n) {                 // (wave-uniform)
-                ccst_absmax_publish_wave(p.ymax + amax_n * CCST_ABSMAX_WORDS, amax, blockIdx.x * 4 + wave);
-                amax = 0.f;
-                amax_n = n_;
-            }
-        }
         // this pixel's scale: the power of two that puts its largest tap below 2^14 (both lane halves hold taps of the same pixel)
         float m = 0.f;
 #pragma unroll
@@ -204,20 +199,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STEM_WAVES,
     float bva[16], bvb[16];
     // The prefetch is UNCONDITIONAL (past the end it re-reads the last block): behind a branch, the wait in front of the current
     // block's taps has to be right for the path that skipped the fetch too, and becomes vmcnt(0).
-    const int last = p.nblocks - 1;
-    if (blk < p.nblocks) fetch(blk, bva);
-    while (blk < p.nblocks) {
+    const int last = blk_end - 1;
+    if (blk < blk_end) fetch(blk, bva);
+    while (blk < blk_end) {
         fetch(min(blk + stride, last), bvb);
         __builtin_amdgcn_sched_barrier(0);
         process(blk, bva);
         blk += stride;
-        if (blk >= p.nblocks) break;
+        if (blk >= blk_end) break;
         fetch(min(blk + stride, last), bva);
         __builtin_amdgcn_sched_barrier(0);
         process(blk, bvb);
         blk += stride;
     }
-    if (p.ymax != nullptr) ccst_absmax_publish_wave(p.ymax + amax_n * CCST_ABSMAX_WORDS, amax, blockIdx.x * 4 + wave);
+    if (p.ymax != nullptr) ccst_absmax_publish(p.ymax + blockIdx.y * CCST_ABSMAX_WORDS, amax, blockIdx.x);
 }
 
 // OIHW [64,3,3,3] (+ bias [64]) -> header | A fragments | bias (Stem3Args::wa).  One workgroup: the weights' largest |value| gives their
@@ -278,9 +273,11 @@ extern "C" int ccst_conv3x3_stem3_f32(const float* x_nchw, const float* wa, floa
     a.nblocks = (int)nblocks;
     a.mBpr = ((1ULL << 40) + a.blocksPerRow - 1) / a.blocksPerRow;
     a.mH = ((1ULL << 40) + H - 1) / H;
-    const long long wgs = (nblocks + 3) / 4;
-    const long long resident = (long long)ccst_num_cus() * STEM_WAVES;                // three workgroups (12 waves) per CU: persistent
-    const unsigned grid = (unsigned)(wgs < resident ? wgs : resident);
-    hipLaunchKernelGGL(conv_stem3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+    a.blocksPerImage = H * a.blocksPerRow;
+    CCST_REQUIRE(N <= 65535, "conv3x3_stem3: N must be <= 65535");
+    const long long wgs = (a.blocksPerImage + 3) / 4;                                 // per image
+    const long long resident = ((long long)ccst_num_cus() * STEM_WAVES + N - 1) / N;  // three workgroups (12 waves) per CU: persistent
+    const unsigned gx = (unsigned)(wgs < resident ? wgs : (resident < 1 ? 1 : resident));
+    hipLaunchKernelGGL(conv_stem3_kernel, dim3(gx, (unsigned)N), dim3(256), 0, (hipStream_t)stream, a);
     return ccst_launch_status("conv3x3_stem3");
 }

@@ -233,8 +233,24 @@ def _run_batch(steps, x, want_sums=False):
     return y, ops.chan_sums(y)
 
 
-def _run_steps(steps, x, sums_box):
-    """sums_box: None, or a list that receives the last conv's per-tile channel-sum partials when that conv can produce them."""
+def affine_ok(steps, x):
+    """Can the plan `steps` take input x ([N,C,H,W], NHWC in memory) through a fused per-(image, channel) affine map -- i.e. is its
+    first step a plain reflect-padded 3x3 conv that runs on the F(4,3) kernel for this extent, and does the batch go through in one
+    piece?  (The decoder of net.py:6-36 at the metric's sizes: yes.)"""
+    if not steps or steps[0].kind != "conv" or not (isinstance(x, torch.Tensor) and x.is_cuda and x.dim() == 4):
+        return False
+    s = steps[0]
+    N, C, H, W = (int(v) for v in x.shape)
+    if not (s.stride == 1 and s.pad == 1 and s.reflect and not s.ups and not s.pool and not s.out_nchw and C == s.pc.cin and C % 16 == 0
+            and ops.halo_split_wanted(s.pc) and ops.f43_wanted(s.pc, N, H, W, x.device) and x.permute(0, 2, 3, 1).is_contiguous()):
+        return False
+    return _peak_elems_per_sample(steps, C, H, W) * N <= MAX_ELEMS
+
+
+def _run_steps(steps, x, sums_box, affine=None, affine_words=None):
+    """sums_box: None, or a list that receives the last conv's per-tile channel-sum partials when that conv can produce them.
+    affine = (a, b) [N, C] + affine_words (the per-image words of a x + b): the first step -- a conv, affine_ok() -- reads x through
+    that map (the fused AdaIN step)."""
     if not (isinstance(x, torch.Tensor) and x.is_cuda):
         raise RuntimeError("ccst_amd.net: input must be a CUDA (ROCm) tensor; the HIP path has no CPU fallback")
     if x.dim() != 4:
@@ -245,7 +261,7 @@ def _run_steps(steps, x, sums_box):
     # per-image |max| words of `cur` (ops.sample_absmax_words) where its producer left them: the half-piece (SPLIT) conv kernels scale their input by the
     # power of two derived from them, on the device.  ReLU / pad / upsample / pool keep them valid (an upper bound suffices); a tensor
     # that arrives without them costs the first half-piece conv one extra pass (ops.absmax_samples).
-    amax = ops.tagged_absmax(x)
+    amax = ops.tagged_absmax(x) if affine is None else affine_words
     if amax is not None and amax.numel() != x.shape[0] * ops.ABSMAX_WORDS:
         amax = None     # (words of another granularity -- a per-tensor set of the ResNet kernels: this plan's kernels take per-image words)
 
@@ -298,7 +314,7 @@ def _run_steps(steps, x, sums_box):
                 sums_box.append(part)
             else:
                 out = ops.conv2d_nhwc(cur, s.pc, stride=s.stride, pad=s.pad, reflect=s.reflect, relu=s.relu, pool=s.pool,
-                                      ups=s.ups, out_nchw=s.out_nchw, x_absmax=amax, y_absmax=ymax)
+                                      ups=s.ups, out_nchw=s.out_nchw, x_absmax=amax, y_absmax=ymax, affine=affine if si == 0 else None)
             amax = ymax
             C = s.pc.cout
             if s.out_nchw:
@@ -399,6 +415,27 @@ def _forward_with_tile_sums(self, input):
 
 
 Sequential.forward_with_tile_sums = _forward_with_tile_sums
+
+
+def _plan_of(self):
+    cache = self.__dict__.get("_ccst_plan")
+    if cache is None:
+        cache = _PlanCache()
+        self.__dict__["_ccst_plan"] = cache
+    return cache.get(list(self.children()))
+
+
+def _forward_affine(self, input, affine, words):
+    """self(a * input + b) with the per-(image, channel) map applied inside the first conv (affine_ok(self, input) must hold): the
+    fused AdaIN step of style.style_transfer.  affine = (a, b) [N, C]; words: per-image |max| words bounding |a x + b|."""
+    steps = _plan_of(self)
+    if not affine_ok(steps, input):
+        raise ValueError("ccst_amd.net: this network / input cannot take a fused input affine (net.affine_ok)")
+    return _run_steps(steps, input, None, affine=affine, affine_words=words)
+
+
+Sequential.forward_affine = _forward_affine
+Sequential.affine_ok = lambda self, x: affine_ok(_plan_of(self), x)
 
 
 class _SingleMixin(object):

@@ -495,10 +495,16 @@ def f43_wanted(pc, N, H, W, device):
     return int(_lib.load().ccst_conv3x3_f43_workgroups(1, H, W, pc.cout)) >= F43_MIN_TILES
 
 
-def conv3x3_f43(x, pc, flags, sums=False, x_absmax=None, y_absmax=None):
+def conv3x3_f43(x, pc, flags, sums=False, x_absmax=None, y_absmax=None, affine=None):
     """3x3 stride-1 pad-1 conv as Winograd F(4,3) along x on half pieces (conv3x3_f43.hip); same arguments and results as
-    conv3x3_halo_split (sums: per-(tile, position group) centred records [ccst_conv3x3_f43_tiles, Cout, 4])."""
+    conv3x3_halo_split (sums: per-(tile, position group) centred records [ccst_conv3x3_f43_tiles, Cout, 4] = (sum, M2, count, max |y|)).
+    affine = (a, b), [N, Cin] each: the conv of a * x + b (the fused AdaIN step, adain_fold_affine); x_absmax must then be the words of
+    the MAPPED tensor."""
     N, Hs, Ws, Cx = x.shape
+    if affine is not None:
+        if x_absmax is None or (flags & (CONV_POOL2 | CONV_UPS2)):
+            raise ValueError("ccst_amd.ops: a fused input affine needs the mapped tensor's words and a plain conv (no pool / upsample)")
+        assert affine[0].numel() == N * Cx and affine[1].numel() == N * Cx and affine[0].is_contiguous() and affine[1].is_contiguous()
     x_absmax = _sample_words(x, x_absmax)
     assert y_absmax is None or y_absmax.numel() == N * ABSMAX_WORDS, "y_absmax: per-image words [N, ABSMAX_WORDS] (sample_absmax_words)"
     ups, pool = bool(flags & CONV_UPS2), bool(flags & CONV_POOL2)
@@ -511,8 +517,10 @@ def conv3x3_f43(x, pc, flags, sums=False, x_absmax=None, y_absmax=None):
         if pool:
             raise ValueError("ccst_amd.ops: the statistics epilogue is of the un-pooled output")
         part = torch.empty((int(lib.ccst_conv3x3_f43_tiles(N, Hi, Wi)), pc.cout, 4), device=x.device, dtype=torch.float32)
+        part._ccst_f43 = True           # (records with the channel maxima: what adain_fold_affine needs, see f43_records)
+        part._ccst_nonneg = bool(flags & CONV_RELU)
     args = (ptr(x), ptr(x_absmax), ptr(pc.uf43), ptr(pc.wabsmax), ptr(pc.bias), ptr(out), ptr(y_absmax), N, Hi, Wi, Cx,
-            pc.cout, pc.n_pad, flags, ptr(part), stream_ptr())
+            pc.cout, pc.n_pad, flags, ptr(part), ptr(None if affine is None else affine[0]), ptr(None if affine is None else affine[1]), stream_ptr())
     if TIMING is None:
         check(lib.ccst_conv3x3_f43_f32(*args), "conv3x3_f43")
     else:
@@ -619,7 +627,7 @@ def conv_sums_ok(pc, stride, pad, pool, out_nchw):
 
 
 def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, ups=False, out_nchw=False, out=None,
-                want_stats=False, chan_sums=False, x_absmax=None, y_absmax=None, w_absmax=None, w_split=None):
+                want_stats=False, chan_sums=False, x_absmax=None, y_absmax=None, w_absmax=None, w_split=None, affine=None):
     """Forward convolution of an NHWC tensor x [N,Hs,Ws,Cin_pad] with PackedConv pc.
 
     ups:  x is read through a nearest x2 upsample (logical input is [2Hs,2Ws]).
@@ -655,6 +663,11 @@ def conv2d_nhwc(x, pc, stride=1, pad=0, reflect=False, relu=False, pool=False, u
     if not reflect and pc.kh == 3 and pc.kw == 3 and stride == 1 and pad == 1 and not (relu or pool or ups or out_nchw) \
             and out is None and pc.bias is None and halo_train_ok(Hi, Wi, Cx, pc.cout):
         return conv3x3_halo_train(x, pc, want_stats=want_stats)
+    if affine is not None:       # (the caller checked affine_ok: the F(4,3) kernel is the one that applies it)
+        if not (halo_split_wanted(pc) and stride == 1 and pad == 1 and not out_nchw and out is None and not want_stats and not chan_sums
+                and Cx == pc.cin and f43_wanted(pc, N, Hi, Wi, x.device)):
+            raise ValueError("ccst_amd.ops: this conv cannot apply a fused input affine (affine_ok)")
+        return conv3x3_f43(x, pc, flags, x_absmax=x_absmax, y_absmax=y_absmax, affine=affine)
     if chan_sums:       # (the caller checked conv_sums_ok)
         if not (halo_split_wanted(pc) and Cx == pc.cin and not pool):
             raise ValueError("ccst_amd.ops: this conv cannot leave channel records (conv_sums_ok)")
@@ -995,6 +1008,42 @@ def adain_from_tile_sums(feat, partials, style_mean, style_std, alpha=1.0, eps=1
         e1.record()
         TIMING.append(("adain_step", 0.0, e0, e1, "n%d c%d hw%d bytes%d" % (N, C, H * W, 2 * 4 * N * C * H * W)))
     return tag_absmax(to_api(out), amax)
+
+
+def f43_records(feat, partials):
+    """Did the F(4,3) kernel write these records (its rows carry the slab's max |y| in the fourth float; the direct kernel's carry 0)?
+    conv3x3_f43 marks the tensor it hands out."""
+    return partials is not None and bool(getattr(partials, "_ccst_f43", False))
+
+
+def adain_fold_affine(feat, partials, style_mean, style_std, alpha=1.0, eps=1e-5):
+    """The AdaIN step as an affine map for the decoder's first conv (ccst_adain_fold_affine_f32): from the centred records the F(4,3)
+    conv that produced feat left, ((a, b) [N, C] each, per-image words bounding |a feat + b|, (mean, std) [N, C, 1, 1]) -- one small
+    launch, no pass over feat."""
+    N, C, H, W = feat.shape
+    assert partials.is_contiguous() and partials.shape[0] % N == 0 and partials.shape[1] == C and partials.shape[2] == 4
+    sm = style_mean.to(device=feat.device, dtype=torch.float32).reshape(-1).contiguous()
+    ss = style_std.to(device=feat.device, dtype=torch.float32).reshape(-1).contiguous()
+    if sm.numel() == C and ss.numel() == C:
+        per_n = 0
+    elif sm.numel() == N * C and ss.numel() == N * C:
+        per_n = 1
+    else:
+        raise RuntimeError("ccst_amd: style statistics must have C or N*C elements")
+    buf = torch.empty((4, N, C), device=feat.device, dtype=torch.float32)       # mean | std | a | b
+    words = sample_absmax_words(feat.device, N)
+    args = (ptr(partials), int(partials.shape[0] // N), ptr(sm), ptr(ss), per_n, float(alpha), int(bool(getattr(partials, "_ccst_nonneg", False))),
+            N, C, H * W, eps, ptr(buf[0]), ptr(buf[1]),
+            ptr(buf[2]), ptr(buf[3]), ptr(words), stream_ptr())
+    if TIMING is None:
+        check(_lib.load().ccst_adain_fold_affine_f32(*args), "adain_fold_affine")
+    else:       # bench.py: what is left of the AdaIN step -- it moves no feature bytes (bytes0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.load().ccst_adain_fold_affine_f32(*args), "adain_fold_affine")
+        e1.record()
+        TIMING.append(("adain_step", 0.0, e0, e1, "n%d c%d hw%d bytes0 fused" % (N, C, H * W)))
+    return (buf[2], buf[3]), words, (buf[0].view(N, C, 1, 1), buf[1].view(N, C, 1, 1))
 
 
 def interp_blend(base, content_f, weights, alpha=1.0):

@@ -26,16 +26,26 @@ _SIDE = {}
 TILE_SUM_ADAIN = True
 
 
-def _encode_and_adain(vgg, content, style_stat, alpha):
-    """vgg(content) -> adaIN_StyleStat_ContentFeat -> alpha blend (CCST_OverallStyleTransfer.py:35,43,45)."""
+# The AdaIN step WITHOUT its pass over the features (round 6): where conv4_1 left centred records with the channel maxima (the F(4,3)
+# kernel) and the decoder's first conv runs on that kernel too, the step is one small launch that turns the statistics into the affine map
+# y = a x + b per (image, channel) (ops.adain_fold_affine), applied by the decoder's first conv on its loads (net.Sequential.forward_affine):
+# the normalised tensor is never written.  FUSE_ADAIN = False: the streaming form (one read + one write of the features).
+FUSE_ADAIN = os.environ.get("CCST_ADAIN_FUSE", "1") != "0"
+
+
+def _encode_adain_decode(vgg, decoder, content, style_stat, alpha):
+    """decoder(alpha-blend(adaIN_StyleStat_ContentFeat(vgg(content), style_stat))) (CCST_OverallStyleTransfer.py:35,43,45-46)."""
     style_mean, style_std = style_stat
     if TILE_SUM_ADAIN and hasattr(vgg, "forward_with_tile_sums"):
         content_f, part = vgg.forward_with_tile_sums(content)
         if ops.adain_tile_sums_ok(content_f, part):
-            return ops.adain_from_tile_sums(content_f, part, style_mean, style_std, alpha=alpha)
+            if FUSE_ADAIN and part.shape[2] == 4 and ops.f43_records(content_f, part) and hasattr(decoder, "affine_ok") and decoder.affine_ok(content_f):
+                affine, words, _stats = ops.adain_fold_affine(content_f, part, style_mean, style_std, alpha=alpha)
+                return decoder.forward_affine(content_f, affine, words)
+            return decoder(ops.adain_from_tile_sums(content_f, part, style_mean, style_std, alpha=alpha))
     else:
         content_f = vgg(content)
-    return ops.adain(content_f, style_mean, style_std, alpha=alpha)   # AdaIN + alpha blend in one pass
+    return decoder(ops.adain(content_f, style_mean, style_std, alpha=alpha))   # AdaIN + alpha blend in one pass
 
 
 def _style_transfer_two_streams(vgg, decoder, content, style_stat, alpha):
@@ -49,7 +59,7 @@ def _style_transfer_two_streams(vgg, decoder, content, style_stat, alpha):
     side.wait_stream(main)
     for i, st in enumerate((main, side)):
         with torch.cuda.stream(st):
-            outs[i] = decoder(_encode_and_adain(vgg, parts[i], style_stat, alpha))
+            outs[i] = _encode_adain_decode(vgg, decoder, parts[i], style_stat, alpha)
     main.wait_stream(side)
     outs[1].record_stream(main)
     return torch.cat(outs, 0)
@@ -67,7 +77,7 @@ def style_transfer(vgg, decoder, content, style_stat, alpha=1.0, interpolation_w
         return decoder(ops.interp_blend(base_feat, content_f, interpolation_weights, alpha))
     if HALF_BATCH_STREAMS and content.shape[0] >= 2 and content.is_cuda:
         return _style_transfer_two_streams(vgg, decoder, content, style_stat, alpha)
-    return decoder(_encode_and_adain(vgg, content, style_stat, alpha))
+    return _encode_adain_decode(vgg, decoder, content, style_stat, alpha)
 
 
 def calc_sum(feat):

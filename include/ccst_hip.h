@@ -171,6 +171,10 @@ int ccst_conv3x3_halo_split_f32(const float* x, const uint32_t* x_absmax, const 
 int ccst_pack_conv_weight_f43_f32(const float* w_oihw, float* u, int cout, int cin, int cout_pad, const uint32_t* w_absmax, void* stream);
 int ccst_conv3x3_f43_f32(const float* x, const uint32_t* x_absmax, const float* u, const uint32_t* w_absmax, const float* bias, float* y,
                          uint32_t* y_absmax, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags, float* chan_sum_partials,
+                         const float* in_scale, const float* in_shift /* both NULL, or [N][Cin] each: the conv of in_scale * x + in_shift per
+                            (image, input channel) -- one fused multiply-add per value on its way into the input transform, x_absmax then being
+                            the words of the MAPPED tensor; not with POOL2 / UPS2.  How the AdaIN step (function.py:26-33 + the alpha blend)
+                            rides in the decoder's first conv: ccst_adain_fold_affine_f32 below */,
                          void* stream);
 int ccst_conv3x3_f43_workgroups(int N, int H, int W, int Cout);
 int ccst_conv3x3_f43_tiles(int N, int H, int W);
@@ -369,6 +373,17 @@ int ccst_adain_tile_sums_f32(const float* x, const float* partials, int partial_
 /* CCST_OverallStyleTransfer.py:36-45, style_transfer's interpolation branch after the AdaIN of the K copies of one content image
  * against K styles: out[elems] = (sum_k weights[k] * base[k][elems], from zero in index order, products and sums rounded separately)
  * * alpha + content0[elems] * one_minus_alpha.  weights: K floats on the device.  Elementwise: any (common) layout. */
+/* The AdaIN step WITHOUT a pass over the features (round 6): function.py:26-33 and the alpha blend of CCST_OverallStyleTransfer.py:45 as
+ * the per-(image, channel) affine map y = a x + b (a = alpha sigma_s / sigma + 1 - alpha, b = alpha (mu_s - mu sigma_s / sigma), fp64,
+ * rounded once) that ccst_conv3x3_f43_f32 applies through in_scale / in_shift.  partials: the centred records [N * tiles_per_image][C][4]
+ * (sum, M2, count, max |x|) the F(4,3) kernel's epilogue left for x; mean_out / std_out / a_out / b_out: [N*C] floats each; y_absmax: zeroed
+ * [N][CCST_ABSMAX_WORDS], receives |a| max |x| + |b| -- with x_nonneg (x >= 0: its producer applied ReLU) the exact max(|b|, |a max x + b|) --
+ * maximised over the image's channels: a bound of max |y|, which is all a scale needs.
+ * One small launch.  Result: within two fp32 roundings of the reference's four separately rounded operations (ccst_adain_tile_sums_f32
+ * reproduces those bit for bit and stays the stand-alone entry). */
+int ccst_adain_fold_affine_f32(const float* partials, int tiles_per_image, const float* style_mean, const float* style_std, int style_per_n,
+                               float alpha, int x_nonneg, int N, int C, int HW, float eps, float* mean_out, float* std_out, float* a_out,
+                               float* b_out, uint32_t* y_absmax, void* stream);
 int ccst_interp_blend_f32(const float* base, const float* content0, const float* weights, int K, int64_t elems, float alpha,
                           float one_minus_alpha, float* out, void* stream);
 /* mean_std_computation_effcientMem.py:103-115 calc_sum: per-channel sum and sum of squares over

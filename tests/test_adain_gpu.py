@@ -41,16 +41,21 @@ def maxdiff(a, b):
     return float((a.detach().cpu().float() - b.detach().cpu().float()).abs().max())
 
 
-def _check_centred_partials(part, out, N):
-    """part [K, C, 4] = (sum, M2 about the slab's own mean, count, 0) per (tile slab, channel) of the NHWC tensor `out`, an image's
-    slabs contiguous: counts add up to the pixels, sums to the sums, M2 + sum^2 / count to the sums of squares -- per image."""
+def _check_centred_partials(part, out, N, chan_max=False):
+    """part [K, C, 4] = (sum, M2 about the slab's own mean, count, 0 -- or with chan_max, the F(4,3) kernel: the slab's max |y|) per
+    (tile slab, channel) of the NHWC tensor `out`, an image's slabs contiguous: counts add up to the pixels, sums to the sums,
+    M2 + sum^2 / count to the sums of squares, the maxima to the channel's max |y| -- per image."""
     K, C, _ = part.shape
     tpi = K // N
     p64, o64 = part.double(), out.double()
     for n in range(N):
         q = p64[n * tpi:(n + 1) * tpi]
         cnt, s1, m2 = q[:, :, 2], q[:, :, 0], q[:, :, 1]
-        assert bool((cnt.sum(0) == out.shape[1] * out.shape[2]).all()) and bool((q[:, :, 3] == 0).all())
+        assert bool((cnt.sum(0) == out.shape[1] * out.shape[2]).all())
+        if chan_max:
+            assert torch.equal(q[:, :, 3].max(dim=0).values.float(), out[n].abs().amax(dim=(0, 1)))
+        else:
+            assert bool((q[:, :, 3] == 0).all())
         s_ref, q_ref = o64[n].sum(dim=(0, 1)), (o64[n] ** 2).sum(dim=(0, 1))
         assert float((s1.sum(0) - s_ref).abs().max()) < 1e-5 * max(1.0, float(s_ref.abs().max()))
         raw = (m2 + torch.where(cnt > 0, s1 * s1 / cnt.clamp_min(1.0), torch.zeros_like(s1))).sum(0)
@@ -897,7 +902,7 @@ def test_conv3x3_f43_vs_fp64(dev, case, reflect):
     if not pool:       # the per-tile channel sums of the epilogue add up to the sums of the output, per image
         out2, part = conv(x, pc, flags, sums=True)
         assert torch.equal(out2, out) and part.shape[0] % N == 0 and tuple(part.shape[1:]) == (Cout, 4)
-        _check_centred_partials(part, out, N)
+        _check_centred_partials(part, out, N, chan_max=True)
 
 
 def test_conv3x3_f43_random_shapes_are_reproducible(dev):
@@ -1059,3 +1064,84 @@ def test_adain_output_statistics_equal_the_style_statistics_at_full_size(dev, ne
     # (1e-5 under the square root, function.py:12: relative effect eps / (2 var) on the result's deviation)
     tol = 2e-4 + 1e-5 / (2.0 * cs[live] ** 2)
     assert bool((((sd - ts).abs() / ts)[live] < tol).all())
+
+
+# ------------------------------------------------------------------ the AdaIN step fused into the decoder's first conv (round 6)
+@pytest.mark.parametrize("case", [(2, 64, 64, 512, 256), (3, 40, 70, 64, 128), (1, 17, 33, 32, 64)])
+@pytest.mark.parametrize("alpha", [1.0, 0.5])
+def test_adain_fused_into_the_next_conv(dev, case, alpha):
+    """ops.adain_fold_affine + conv3x3_f43(..., affine=...) -- AdaIN + alpha blend as a per-(image, channel) map a x + b applied on the
+    conv's loads, the normalised tensor never written (function.py:26-33, CCST_OverallStyleTransfer.py:45, net.py:7-9) -- against the
+    two-launch form (ops.adain_from_tile_sums, then the same conv) and against fp64: the map is rounded once where the reference rounds
+    four times, so the two agree to a few 1e-7 of max |y| per layer, not to the bit.  Per-image style statistics; images that are not
+    multiples of the tile; the published words bound every mapped value of their image."""
+    from ccst_amd import ops
+    N, H, W, C, Cout = case
+    g = torch.Generator().manual_seed(77)
+    x0 = torch.randn(N, H, W, C, generator=g).to(dev)
+    w0 = (torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).to(dev)
+    b0 = (torch.randn(C, generator=g) * 0.3).to(dev)
+    pc0 = ops.pack_conv_weight(w0, b0, wino=4)
+    feat_nhwc, part = ops.conv3x3_f43(x0, pc0, 1 | 8, sums=True)                # relu4_1's form: ReLU + reflection, records with maxima
+    feat = ops.to_api(feat_nhwc)
+    assert ops.f43_records(feat, part)
+    w = (torch.randn(Cout, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).to(dev)
+    b = (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    pc = ops.pack_conv_weight(w, b, wino=4)
+    for per_n in (False, True):
+        sm = torch.randn(N if per_n else 1, C, 1, 1, generator=g).to(dev)
+        ss = (torch.rand(N if per_n else 1, C, 1, 1, generator=g) + 0.5).to(dev)
+        (a, bb), words, (mu, sd) = ops.adain_fold_affine(feat, part, sm, ss, alpha=alpha)
+        two = ops.adain_from_tile_sums(feat, part, sm, ss, alpha=alpha)        # the streaming form: the reference's four roundings
+        f64 = feat.double()
+        mu64 = f64.mean(dim=(2, 3), keepdim=True)
+        sd64 = (f64.var(dim=(2, 3), keepdim=True) + 1e-5).sqrt()
+        assert float((mu.double() - mu64).abs().max()) < 1e-5 * max(1.0, float(mu64.abs().max())) and float((sd.double() / sd64 - 1).abs().max()) < 1e-5
+        t64 = ((f64 - mu64) / sd64 * ss.double() + sm.double()) * alpha + f64 * (1 - alpha)
+        mapped = feat * a.view(N, C, 1, 1) + bb.view(N, C, 1, 1)
+        assert float((mapped.double() - t64).abs().max()) < 2e-6 * max(1.0, float(t64.abs().max()))
+        for n in range(N):                                                      # the words bound the image's mapped values, tightly enough
+            bound = _absmax_value(words[n])
+            big = float(mapped[n].abs().max())
+            assert big <= bound <= 1.01 * big + 1e-6, (n, big, bound)           # (x >= 0: the bound is exact up to the map's own rounding)
+        fused = ops.conv3x3_f43(feat_nhwc, pc, 1 | 8, x_absmax=words, affine=(a, bb))
+        ref = ops.conv3x3_f43(ops.from_api(two), pc, 1 | 8, x_absmax=ops.tagged_absmax(two))
+        r64 = F.relu(F.conv2d(F.pad(t64, (1, 1, 1, 1), mode="reflect"), w.double(), b.double())).permute(0, 2, 3, 1)
+        scale = max(1.0, float(r64.abs().max()))
+        assert float((fused.double() - r64).abs().max()) < 1e-5 * scale
+        assert float((fused - ref).abs().max()) < 1e-5 * scale
+        assert torch.equal(fused, ops.conv3x3_f43(feat_nhwc, pc, 1 | 8, x_absmax=words, affine=(a, bb)))
+
+
+def test_style_transfer_fused_adain_matches_the_streaming_form(dev, nets, A):
+    """style_transfer with the AdaIN step fused into the decoder (style.FUSE_ADAIN, the default where both convs run on F(4,3)) against
+    the streaming form and the oracle; small images fall back by themselves (no F(4,3) tiles to speak of)."""
+    from ccst_amd import net, style
+    vgg31, dec, _, _ = nets
+    net.vgg.load_state_dict(nets[2])
+    net.decoder.load_state_dict(nets[3])
+    stat = A.synth_style_stat(512, seed=7)
+    dstat = [t.to(dev) for t in stat]
+    content = A.synth_content(2, 512, 384, seed=23)
+    old = style.FUSE_ADAIN
+    try:
+        outs = {}
+        for fuse in (True, False):
+            style.FUSE_ADAIN = fuse
+            with torch.no_grad():
+                outs[fuse] = (style.style_transfer(vgg31, dec, content.to(dev), dstat, 1.0), style.style_transfer(vgg31, dec, content.to(dev), dstat, 0.6))
+        style.FUSE_ADAIN = True
+        with torch.no_grad():
+            feat = vgg31(content.to(dev))
+            assert dec.affine_ok(feat) and not dec.affine_ok(vgg31(content[:, :, :64, :64].to(dev)))
+            small = style.style_transfer(vgg31, dec, content[:, :, :64, :64].to(dev), dstat, 1.0)
+    finally:
+        style.FUSE_ADAIN = old
+    ref = A.style_transfer(nets[2], nets[3], content, stat, 1.0)
+    ref06 = A.style_transfer(nets[2], nets[3], content, stat, 0.6)
+    assert maxdiff(outs[True][0], ref) < TOL and maxdiff(outs[True][1], ref06) < TOL
+    for k in (0, 1):
+        d = float((outs[True][k] - outs[False][k]).abs().max())
+        print("fused vs streaming AdaIN step, alpha %s: max |difference| %.2e" % ("1.0" if k == 0 else "0.6", d))
+        assert d < 2e-5 * max(1.0, float(outs[False][k].abs().max()))
+    assert maxdiff(small, A.style_transfer(nets[2], nets[3], content[:, :, :64, :64], stat, 1.0)) < TOL
