@@ -387,10 +387,11 @@ def main():
         for name, flops, e0, e1, info in timing[-per_step:]:
             us = e0.elapsed_time(e1) * 1e3
             print("%-32s %-48s %9.1f us %7.1f TF" % (name, info, us, flops / us / 1e6), file=sys.stderr)
-    adain_us = []
+    adain_us, adain_fused = [], False
     for name, flops, e0, e1, _info in timing:
         if name == "adain_step":
             adain_us.append(e0.elapsed_time(e1) * 1e3)
+            adain_fused = adain_fused or _info.endswith("fused")
             continue
         k = per_kernel.setdefault(name, [0, 0.0, 0.0])
         k[0] += 1
@@ -475,12 +476,37 @@ def main():
     if adain_us:
         nbytes = 2 * 4 * B * 512 * (S // 8) * (S // 8)       # read x once + write y once (SURVEY 8d "AdaIN-step roofline")
         us = sorted(adain_us)[len(adain_us) // 2]
-        adain_step = {"bound": "hbm", "bytes": nbytes, "median_us": round(us, 2), "achieved": round(nbytes / us / 1e3, 1),
-                      "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(nbytes / us / 1e3 / PEAK_HBM_GBPS, 4),
-                      "kernels": "tile_stats_fold_kernel + adain_stream_nhwc_kernel: content statistics folded ONCE from the per-tile centred records "
-                                 "that conv4_1's epilogue left (no statistics pass), then normalise + blend streamed once: one read, one write (HIP "
-                                 "events around both launches of ccst_adain_tile_sums_f32; the streaming launch alone is ~22 us; "
-                                 "the stand-alone entry ccst_adain_f32 is the two-pass register-resident kernel)"}
+        stream_note = ("tile_stats_fold_kernel + adain_stream_nhwc_kernel: content statistics folded ONCE from the per-tile centred records "
+                       "that conv4_1's epilogue left (no statistics pass), then normalise + blend streamed once: one read, one write (HIP "
+                       "events around both launches of ccst_adain_tile_sums_f32; the streaming launch alone is ~22 us; "
+                       "the stand-alone entry ccst_adain_f32 is the two-pass register-resident kernel)")
+        if not adain_fused:
+            adain_step = {"bound": "hbm", "bytes": nbytes, "median_us": round(us, 2), "achieved": round(nbytes / us / 1e3, 1),
+                          "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(nbytes / us / 1e3 / PEAK_HBM_GBPS, 4), "kernels": stream_note}
+        else:
+            # In the timed path the step is FUSED: one small launch (tile_stats_affine_kernel) turns conv4_1's records into the per-(image,
+            # channel) map a x + b, which the decoder's first conv applies on its loads -- no feature bytes move.  The HBM roofline of the
+            # step's own kernel is measured beside it on the same features: the stand-alone streaming form (ccst_adain_tile_sums_f32).
+            with torch.no_grad():
+                feat, part = vgg31.forward_with_tile_sums(content)
+                evs = []
+                for _ in range(25):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    ops.adain_from_tile_sums(feat, part, stat[0], stat[1], alpha=1.0)
+                    e1.record()
+                    evs.append((e0, e1))
+                torch.cuda.synchronize()
+                del feat, part
+            sus = sorted(a.elapsed_time(b) * 1e3 for a, b in evs[5:])
+            sus = sus[len(sus) // 2]
+            adain_step = {"fused": True, "median_us": round(us, 2), "bytes_moved_in_the_timed_path": 0,
+                          "kernels": "tile_stats_affine_kernel (ccst_adain_fold_affine_f32): (x - mu) / sigma * sigma_s + mu_s and the alpha blend as "
+                                     "y = a x + b per (image, channel), applied by the decoder's first conv on its loads (conv3x3_f43_kernel<.., AFF>): "
+                                     "the 100.66 MB pass of the step is gone from the timed path",
+                          "standalone": {"bound": "hbm", "bytes": nbytes, "median_us": round(sus, 2), "achieved": round(nbytes / sus / 1e3, 1),
+                                         "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(nbytes / sus / 1e3 / PEAK_HBM_GBPS, 4),
+                                         "kernels": stream_note + " -- measured outside the timed region, on the same features"}}
 
     # ---- the same step with the two halves of the batch on two HIP streams (CCST_ADAIN_STREAMS=2, style._style_transfer_two_streams):
     # one half's tails, partly filled rounds and HBM-bound edge layers run under the other half's MFMA work.  Reported beside `value`,
