@@ -110,9 +110,12 @@ struct GroupTag {
 
 // ZP: zero padding (the masks cost 16-24 vector instructions per transform item: the reflecting AdaIN layers run the kernel without them)
 // NT: non-temporal output stores -- for outputs the caches cannot hold until the next layer reads them (>= 256 MB: the host decides)
-// AFF: x is read through the per-(image, channel) affine map p.aff_a x + p.aff_b (one fused multiply-add per loaded value, rounded once --
-//     what storing the normalised tensor would have rounded too); p.xmax are then the words of the MAPPED tensor.  The 2 x Cin
-//     coefficients of the workgroup's image sit in LDS behind the raw halo (inside the allocation the epilogue's exchange needs anyway).
+// AFF: the conv of the per-(image, channel) affine map a x + b (p.aff_a, p.aff_b) of x -- applied to the TRANSFORMED values: B^T is linear and
+//     with reflection padding every pixel of a quad is a real one, so  B^T (a d + b 1) = a B^T d + b B^T 1,  B^T 1 = (0, -6, 0, 0, 0, 0): one
+//     multiplication per transformed value and one constant at position 1 -- half the vector work of mapping the 4-6 loaded pixels of an
+//     item (measured: +16 us on the 512 -> 256 layer that way, the whole gain of the removed pass).  Reflecting layers only (zero padding
+//     would have to keep b out of the border).  p.xmax are the words of the MAPPED tensor.  The 2 x Cin coefficients of the workgroup's
+//     image sit in LDS behind the raw halo (inside the allocation the epilogue's exchange needs anyway).
 template <bool POOL, bool ZP, bool HALF, bool NT, bool AFF>
 __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F43Args p) {
     typedef Tile<HALF> T;
@@ -205,13 +208,7 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
         fa = *reinterpret_cast<const f32x4*>(Aff + co_ + part_t * 4);
         fb = *reinterpret_cast<const f32x4*>(Aff + p.Cin + co_ + part_t * 4);
     };
-    auto affine = [&](f32x4 v) __attribute__((always_inline)) {
-        if (!AFF) return v;
-        f32x4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = __builtin_fmaf(v[j], fa[j], fb[j]);
-        return o;
-    };
+    static_assert(!(AFF && ZP), "the fused input affine is applied to transformed values: reflecting layers only");
     auto put = [&](float* o, f32x4 v) {          // four scaled fp32 values -> (hi, lo) half pieces -> V
         u32x2g hi, lo;
 #pragma unroll
@@ -231,7 +228,7 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
         affine_coef();
         auto px = [&](int d) {                   // pixel d of the quad (0..5)
-            f32x4 v = affine(*reinterpret_cast<const f32x4*>(r0 + (d < 4 ? d : d + 1) * 16));
+            f32x4 v = *reinterpret_cast<const f32x4*>(r0 + (d < 4 ? d : d + 1) * 16);
             if (ZP && !(oky && ((tokx >> d) & 1u))) v = z;
             return v;
         };
@@ -242,16 +239,24 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
             const f32x4 d2 = px(2), d4 = px(4);
             const f32x4 sc = d2 * c1 + d4 * xs;
             const f32x4 d1 = px(1), d3 = px(3);
-            const f32x4 va = d1 * (-c2) + (d3 * c3 + sc), vb = d1 * c2 + (sc - d3 * c3);
+            f32x4 va = d1 * (-c2) + (d3 * c3 + sc), vb = d1 * c2 + (sc - d3 * c3);
+            if (AFF) {
+                va = PAIR == 0 ? va * fa + fb * (-6.f * xs) : va * fa;          // (position 1 carries b B^T 1)
+                vb = vb * fa;
+            }
             put(o + (PAIR == 0 ? 1 : 3) * G_QW, va);
             put(o + (PAIR == 0 ? 2 : 4) * G_QW, vb);
         } else {
             // positions 0: 4 d0 - 5 d2 + d4;   5: 4 d1 - 5 d3 + d5
             const float c4 = 4.f * xs, c5 = -5.f * xs;
             const f32x4 d0 = px(0), d2 = px(2), d4 = px(4);
-            put(o, d0 * c4 + (d2 * c5 + d4 * xs));
+            f32x4 v0 = d0 * c4 + (d2 * c5 + d4 * xs);
+            if (AFF) v0 = v0 * fa;
+            put(o, v0);
             const f32x4 d1 = px(1), d3 = px(3), d5 = px(5);
-            put(o + 5 * G_QW, d1 * c4 + (d3 * c5 + d5 * xs));
+            f32x4 v5 = d1 * c4 + (d3 * c5 + d5 * xs);
+            if (AFF) v5 = v5 * fa;
+            put(o + 5 * G_QW, v5);
         }
     };
     // The same in two halves for the eight-wave loop: the item's pixels are requested one k-step before they are used (xr), so that the
@@ -260,26 +265,35 @@ __global__ __launch_bounds__(Tile<HALF>::NT, 2) void conv3x3_f43_kernel(const F4
     auto xl = [&](auto ptag, const float* r0, bool oky) __attribute__((always_inline)) {
         constexpr int PAIR = decltype(ptag)::value;
         const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-        affine_coef();
 #pragma unroll
         for (int d = (PAIR < 2 ? 1 : 0); d < (PAIR < 2 ? 5 : 6); ++d) {
-            f32x4 v = affine(*reinterpret_cast<const f32x4*>(r0 + (d < 4 ? d : d + 1) * 16));
+            f32x4 v = *reinterpret_cast<const f32x4*>(r0 + (d < 4 ? d : d + 1) * 16);
             if (ZP && !(oky && ((tokx >> d) & 1u))) v = z;
             xr[d] = v;
         }
     };
     auto xc = [&](auto ptag, float* o) __attribute__((always_inline)) {
         constexpr int PAIR = decltype(ptag)::value;
+        affine_coef();
         if (PAIR < 2) {
             const float c1 = PAIR == 0 ? -4.f * xs : -xs, c2 = PAIR == 0 ? 4.f * xs : 2.f * xs, c3 = PAIR == 0 ? xs : 2.f * xs;
             const f32x4 sc = xr[2] * c1 + xr[4] * xs;
-            const f32x4 va = xr[1] * (-c2) + (xr[3] * c3 + sc), vb = xr[1] * c2 + (sc - xr[3] * c3);
+            f32x4 va = xr[1] * (-c2) + (xr[3] * c3 + sc), vb = xr[1] * c2 + (sc - xr[3] * c3);
+            if (AFF) {
+                va = PAIR == 0 ? va * fa + fb * (-6.f * xs) : va * fa;
+                vb = vb * fa;
+            }
             put(o + (PAIR == 0 ? 1 : 3) * G_QW, va);
             put(o + (PAIR == 0 ? 2 : 4) * G_QW, vb);
         } else {
             const float c4 = 4.f * xs, c5 = -5.f * xs;
-            put(o, xr[0] * c4 + (xr[2] * c5 + xr[4] * xs));
-            put(o + 5 * G_QW, xr[1] * c4 + (xr[3] * c5 + xr[5] * xs));
+            f32x4 v0 = xr[0] * c4 + (xr[2] * c5 + xr[4] * xs), v5 = xr[1] * c4 + (xr[3] * c5 + xr[5] * xs);
+            if (AFF) {
+                v0 = v0 * fa;
+                v5 = v5 * fa;
+            }
+            put(o, v0);
+            put(o + 5 * G_QW, v5);
         }
     };
     auto xload = [&](int i) __attribute__((always_inline)) {
@@ -766,7 +780,8 @@ extern "C" int ccst_conv3x3_f43_f32(const float* x, const uint32_t* x_absmax, co
     CCST_REQUIRE(x && u && y && x_absmax && w_absmax, "conv3x3_f43: null pointer (the |max| words of x and w are required)");
     CCST_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3x3_f43: in_scale and in_shift come together ([N][Cin] each)");
     const bool aff = in_scale != nullptr;
-    CCST_REQUIRE(!aff || !(flags & (CCST_CONV_POOL2 | CCST_CONV_UPS2)), "conv3x3_f43: the fused input affine goes with a plain conv (no pool, no upsample)");
+    CCST_REQUIRE(!aff || ((flags & CCST_CONV_REFLECT) && !(flags & (CCST_CONV_POOL2 | CCST_CONV_UPS2))),
+                 "conv3x3_f43: the fused input affine goes with a plain reflection-padded conv (no zero padding, no pool, no upsample)");
     CCST_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 16 == 0 && Cout > 0, "conv3x3_f43: bad shape");
     const bool half = Cout <= 64;
     CCST_REQUIRE(cout_pad >= Cout && cout_pad % (half ? 64 : 128) == 0, "conv3x3_f43: cout_pad must be a multiple of 128 (Cout <= 64: of 64) >= cout");
@@ -794,8 +809,7 @@ extern "C" int ccst_conv3x3_f43_f32(const float* x, const uint32_t* x_absmax, co
     const long long nt_bytes = 256LL << 20;
     const bool nt = (long long)N * oh * ow * Cout * 4 >= nt_bytes;
     if (aff) {          // (never pooled; its output is small enough for the caches wherever the path uses it: ordinary stores)
-        if (half) return zp ? launch_f43<false, true, true, false, true>(a, N, H, W, Cout, st) : launch_f43<false, false, true, false, true>(a, N, H, W, Cout, st);
-        return zp ? launch_f43<false, true, false, false, true>(a, N, H, W, Cout, st) : launch_f43<false, false, false, false, true>(a, N, H, W, Cout, st);
+        return half ? launch_f43<false, false, true, false, true>(a, N, H, W, Cout, st) : launch_f43<false, false, false, false, true>(a, N, H, W, Cout, st);
     }
 #define F43_GO2(P_, Z_, H_) (nt ? launch_f43<P_, Z_, H_, true>(a, N, H, W, Cout, st) : launch_f43<P_, Z_, H_, false>(a, N, H, W, Cout, st))
 #define F43_GO(P_, Z_) (half ? F43_GO2(P_, Z_, true) : F43_GO2(P_, Z_, false))

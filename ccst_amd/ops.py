@@ -502,8 +502,8 @@ def conv3x3_f43(x, pc, flags, sums=False, x_absmax=None, y_absmax=None, affine=N
     the MAPPED tensor."""
     N, Hs, Ws, Cx = x.shape
     if affine is not None:
-        if x_absmax is None or (flags & (CONV_POOL2 | CONV_UPS2)):
-            raise ValueError("ccst_amd.ops: a fused input affine needs the mapped tensor's words and a plain conv (no pool / upsample)")
+        if x_absmax is None or (flags & (CONV_POOL2 | CONV_UPS2)) or not (flags & CONV_REFLECT):
+            raise ValueError("ccst_amd.ops: a fused input affine needs the mapped tensor's words and a plain reflection-padded conv (no pool / upsample)")
         assert affine[0].numel() == N * Cx and affine[1].numel() == N * Cx and affine[0].is_contiguous() and affine[1].is_contiguous()
     x_absmax = _sample_words(x, x_absmax)
     assert y_absmax is None or y_absmax.numel() == N * ABSMAX_WORDS, "y_absmax: per-image words [N, ABSMAX_WORDS] (sample_absmax_words)"

@@ -172,8 +172,9 @@ int ccst_pack_conv_weight_f43_f32(const float* w_oihw, float* u, int cout, int c
 int ccst_conv3x3_f43_f32(const float* x, const uint32_t* x_absmax, const float* u, const uint32_t* w_absmax, const float* bias, float* y,
                          uint32_t* y_absmax, int N, int H, int W, int Cin, int Cout, int cout_pad, uint32_t flags, float* chan_sum_partials,
                          const float* in_scale, const float* in_shift /* both NULL, or [N][Cin] each: the conv of in_scale * x + in_shift per
-                            (image, input channel) -- one fused multiply-add per value on its way into the input transform, x_absmax then being
-                            the words of the MAPPED tensor; not with POOL2 / UPS2.  How the AdaIN step (function.py:26-33 + the alpha blend)
+                            (image, input channel) -- applied inside the input transform (B^T is linear: one multiplication per transformed
+                            value and one constant), x_absmax then being the words of the MAPPED tensor; CCST_CONV_REFLECT only, not with
+                            POOL2 / UPS2.  How the AdaIN step (function.py:26-33 + the alpha blend)
                             rides in the decoder's first conv: ccst_adain_fold_affine_f32 below */,
                          void* stream);
 int ccst_conv3x3_f43_workgroups(int N, int H, int W, int Cout);
