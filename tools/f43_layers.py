@@ -21,7 +21,7 @@ LAYERS = [  # H (= W, conv extent), Cin, Cout, pool, ups
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     dev = torch.device("cuda:0")
-    B = 6
+    B = int(os.environ.get("F43_B", "6"))
     g = torch.Generator().manual_seed(3)
     tot = [0.0, 0.0]
     sel = os.environ.get("F43_LAYER", os.environ.get("F23_LAYER"))
