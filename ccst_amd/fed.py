@@ -287,6 +287,7 @@ def _graph_wanted(args):
 
 
 AUTO_PROBE = 10
+AUTO_EAGER_MARGIN = 1.03
 
 
 class _LoopTimer(object):
@@ -361,8 +362,9 @@ def train(model, train_loader, optimizer, loss_fun, client_num, device, args, it
                         ready = st["eager_ms"] is not None
                 elif gs is not None and st["graph_ms"] is None:         # phase 1: ... then the replayed one (not its first replay)
                     st["graph_ms"] = timers.setdefault((key, 1), _LoopTimer(AUTO_PROBE, skip=1)).before_iteration()
-                if st["graph_ms"] is not None and st["graph_ms"] > st["eager_ms"]:
-                    gs, ready = None, False             # decided: the eager loop is the faster one for this shape
+                if st["graph_ms"] is not None and st["graph_ms"] > st["eager_ms"] * AUTO_EAGER_MARGIN:
+                    gs, ready = None, False             # decided: the eager loop is the faster one for this shape (by a margin: its
+                                                        # time depends on the host, the replay's does not)
             if gs is None and ready and eager_iters >= 2 and len([k for k in steps if k not in ("_sums", "_auto")]) < 4:     # capture once caches / workspaces are warm (<= 4 shapes)
                 nn_ops.join_prepack(device)
                 torch.cuda.current_stream(device).synchronize()

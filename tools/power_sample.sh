@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocm-smi power / engine clock sampled beside a long bench.py run (run on the GPU box): tools/power_sample.sh [steps] -> gpurun_out/power_clock.txt
-STEPS=${1:-4000}
+STEPS=${1:-14000}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/power_clock.txt
 cd $ROOT
