@@ -357,7 +357,7 @@ def main():
         # the loop's own event / tensor allocations trigger -- stalls the issuing thread for 60-80 ms: a quarter of the 0.24 s the 80
         # batches of round 5 took (1494 images/s in BENCH_r05 against 1978 for the same loop in a fresh process,
         # tools/pipeline_diag.py).  The stage-2 CLIs do the same after set-up (gc.freeze(), style_transfer/AdaIN/_common.py).
-        nb = max(4 * reps, int(np.ceil(2.0 / max(ms_per_step * 1e-3, 1e-4))))
+        nb = max(4 * reps, int(np.ceil(2.0 / max(ms_per_step * 1e-3, 1e-4)))) if args.min_seconds > 0 else 4 * reps      # (--min-seconds 0: the short profiling runs)
 
         def feed(n):
             for _ in range(n):
