@@ -45,21 +45,53 @@ def _side_stream(device):
     return st
 
 
-def _on_side_stream(device, tensors, fn):
-    """Run fn() on the side stream after everything enqueued so far on the current stream; keep `tensors` alive for it."""
+# While a HIP graph is being CAPTURED, the weight-gradient launches are handed to the side stream in batches of GRAPH_FORK_BATCH: every
+# fork of the side stream becomes a cross-queue dependency of the graph executor (~25 us each: a replay of the ResNet50 step with its 53
+# forks ran 16.5 ms against 15.1 ms of eager device time, the ResNet18 step paid 20 of them in 4.2 ms).  A batch's launches wait for the
+# main stream once; their operands (activations saved by the forward, gradients no later node modifies, |max| word rows) stay referenced
+# by the pending closures until then.  The eager loop forks per conv as before (an event wait there costs nothing, and the earlier a
+# weight gradient starts the more of it hides behind the backward-data chain).
+GRAPH_FORK_BATCH = max(1, int(_os.environ.get("CCST_GRAPH_FORK_BATCH", "8")))
+_DEFERRED = {}
+
+
+def _flush_deferred(device):
+    pend = _DEFERRED.pop(device.index, None)
+    if not pend:
+        return
     main = torch.cuda.current_stream(device)
     side = _side_stream(device)
     side.wait_stream(main)
     with torch.cuda.stream(side):
-        fn()
-    for t in tensors:
-        t.record_stream(side)
+        for _tensors, fn in pend:
+            fn()
+    for tensors, _fn in pend:
+        for t in tensors:
+            t.record_stream(side)
+
+
+def _on_side_stream(device, tensors, fn):
+    """Run fn() on the side stream after everything enqueued so far on the current stream; keep `tensors` alive for it."""
+    if GRAPH_FORK_BATCH > 1 and torch.cuda.is_current_stream_capturing():
+        pend = _DEFERRED.setdefault(device.index, [])
+        pend.append((tensors, fn))
+        if len(pend) >= GRAPH_FORK_BATCH:
+            _flush_deferred(device)
+    else:
+        main = torch.cuda.current_stream(device)
+        side = _side_stream(device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            fn()
+        for t in tensors:
+            t.record_stream(side)
     if device.index not in _JOIN_PENDING:
         _JOIN_PENDING.add(device.index)
 
         def join():
             _JOIN_PENDING.discard(device.index)
-            torch.cuda.current_stream(device).wait_stream(side)
+            _flush_deferred(device)
+            torch.cuda.current_stream(device).wait_stream(_side_stream(device))
         torch.autograd.Variable._execution_engine.queue_callback(join)
 
 
