@@ -173,9 +173,10 @@ def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False
         for _ in range(2):
             gstep()
         sync()
-        from ccst_amd import ops
+        from ccst_amd import nn_ops, ops
         g = torch.cuda.CUDAGraph()
         ops.reset_absmax_pool()             # as fed._GraphedTrainStep: the step's |max| word rows come from a block zero-filled INSIDE the graph
+        nn_ops.reset_deferred()
         with torch.cuda.graph(g):
             l = gstep()
         ops.reset_absmax_pool()

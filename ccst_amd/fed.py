@@ -246,6 +246,7 @@ class _GraphedTrainStep(object):
         self.convs = [m for m in model.modules() if hasattr(m, "prepack")]
         self.graph = torch.cuda.CUDAGraph()
         ops.reset_absmax_pool()                 # the step's |max| word rows: from a block zero-filled INSIDE the graph
+        nn_ops.reset_deferred()
         with torch.cuda.graph(self.graph):
             nn_ops.prepack_on_side(model)       # head of the replay: the packs of the weights as they are NOW (joined in the forward)
             optimizer.zero_grad()

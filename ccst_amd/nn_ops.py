@@ -56,6 +56,11 @@ EAGER_FORK_BATCH = 1           # (measured 2 / 4 / 8 in the eager loop: ResNet50
 _DEFERRED = {}
 
 
+def reset_deferred():
+    """Forget weight-gradient launches a FAILED capture left pending (their tensors belong to an aborted step): called before a capture."""
+    _DEFERRED.clear()
+
+
 def _flush_deferred(device):
     pend = _DEFERRED.pop(device.index, None)
     if not pend:
