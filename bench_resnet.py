@@ -217,16 +217,24 @@ def run(dev, world=1, steps=10, warmup=3, batch=64, arch="resnet50", graph=False
                         "rule": "both loops timed over probe_steps; the eager loop runs the timed region if it is more than %d %% faster than the "
                                 "replay (whose time does not depend on the host), else the replay" % round((EAGER_MARGIN - 1) * 100),
                         "hip_graph": bool(graph)}
+        if not graph:
+            from ccst_amd import ops
+            ops.bump_weights_epoch()        # the replays moved the weights behind the host-side pack keys
+            try:
+                for _ in range(2):
+                    step()
+                sync()
+                run_step = step
+            except RuntimeError as e:       # (seen ONCE in ~30 driver-style runs of round 6: autograd refused the first eager backward after
+                # the capture -- "backward through the graph a second time"; not reproduced in 100 rounds of tools/repro_fork.py.  The
+                # replay gives the same bits: run the timed region on it and say so in the line.)
+                graph_choice["eager_after_capture_error"] = str(e)[:200]
+                graph_choice["hip_graph"] = graph = True
+                sync()
         if graph:
             loss, run_step = gloss, g.replay
         else:
             del g
-            from ccst_amd import ops
-            ops.bump_weights_epoch()        # the replays moved the weights behind the host-side pack keys
-            run_step = step
-            for _ in range(2):
-                step()
-            sync()
     elif graph:
         g, loss = capture()
         run_step = g.replay
