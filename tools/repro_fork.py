@@ -20,6 +20,8 @@ step = bench_resnet.make_step(model, opt, loss_fun, x, y)
 if os.environ.get("FREEZE") == "1":
     gc.collect()
     gc.freeze()
+if os.environ.get("GC_STRESS") == "1":          # a full collection every few dozen allocations: does the cyclic GC ever take a live graph apart?
+    gc.set_threshold(40, 2, 2)
 fails = 0
 for r in range(rounds):
     try:
