@@ -70,7 +70,7 @@ def stage1(dev, vgg31, A, world, rank, steps=6, warmup=2, batch=32, size=512, cp
            "config": {"workload": "mean_std_computation_effcientMem PACS %dx%d batch=%d, one domain's batches per rank + one all-reduce of "
                                   "(sum, sqsum, n) at the end" % (size, size, batch)},
            "statistics": {"path": "fused: per-tile sums from conv4_1's epilogue (%s) + ccst_chan_sums_finalize_f32"
-                                  % ("ccst_conv3x3_halo_split_f32, the default plan's kernel" if ops.HALO_SPLIT != "0" else "ccst_conv3x3_wino4w_f32"),
+                                  % ("ccst_conv3x3_f43_f32, the default plan's kernel" if ops.HALO_SPLIT != "0" else "none: CCST_HALO_SPLIT=0 takes the streaming pass"),
                           "finalize_us": round(fin[0], 2) if fin else None, "tensor_bytes_not_read": nbytes},
            "roofline": {"bound": "hbm", "kernel": "ccst_chan_sums_f32 (the stand-alone pass over relu4_1, what the fused path removes)", "bytes": nbytes,
                         "avg_launch_us": round(us[0], 2) if us else None, "achieved": round(nbytes / us[0] / 1e3, 1) if us else None,

@@ -21,7 +21,7 @@ if pf == 4:
 else:
     part = torch.stack([torch.rand(N * tpi, C, generator=g) * cnt, torch.rand(N * tpi, C, generator=g) * cnt], dim=2).contiguous().to(dev)
 sm, ss = torch.rand(C).to(dev), (torch.rand(C) + 0.5).to(dev)
-words = None if os.environ.get("NO_WORDS") == "1" else torch.zeros(64, dtype=torch.int32, device=dev)
+words = None if os.environ.get("NO_WORDS") == "1" else torch.zeros((N, 64), dtype=torch.int32, device=dev)      # per image (ABI version 2)
 lib = _lib.load()
 stat = torch.empty(2, N * C, device=dev)
 
